@@ -1,0 +1,15 @@
+"""graphs4cfd_amd — MI355X-native implementation of graphs4cfd's message-passing hot path.
+
+Drop-in for the hot-path slice of `import graphs4cfd as gfd`:
+
+    import graphs4cfd_amd as gfd
+    model = gfd.nn.NsThreeScaleGNN(arch=arch, device=torch.device('cuda'))
+    out = model.solve(graph, n_out)          # graph: gfd.Graph with the reference's attribute layout
+
+Compute runs in hand-written HIP kernels (libg4c.so, C-ABI in include/g4c.h); there is no CPU or
+eager-torch fallback.  Out of scope: training loop, datasets, plotting, augmentation.
+"""
+from .graph import Graph
+from . import nn, plan, ops, synthetic
+
+__version__ = "0.1.0"

@@ -1,0 +1,127 @@
+"""ctypes binding of libg4c.so (the C-ABI declared in include/g4c.h).
+
+The product path has no CPU / eager-torch fallback: if the HIP library is missing the import
+of any compute entry point raises, and every op rejects non-HIP tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libg4c.so")
+
+OK, EINVAL, ELAUNCH, EUNSUPPORTED = 0, -1, -2, -3
+ACT_NONE, ACT_SELU, ACT_TANH = 0, 1, 2
+MAX_SRC, MAX_LAYERS = 4, 4
+
+_ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "selu": ACT_SELU, "tanh": ACT_TANH}
+
+
+def act_code(activation) -> Optional[int]:
+    """Map an activation spec to a fused-epilogue code, or None if it cannot be fused
+    (an arbitrary callable is then applied by the caller with torch on the HIP tensor)."""
+    if activation is None or isinstance(activation, str):
+        return _ACT_CODES[activation]
+    if activation is torch.tanh or activation is torch.nn.functional.tanh:
+        return ACT_TANH
+    if activation is torch.nn.functional.selu or activation is torch.selu:
+        return ACT_SELU
+    return None
+
+
+class g4c_src_t(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("idx", C.c_void_p), ("width", C.c_int32), ("ld", C.c_int32),
+                ("col0", C.c_int32), ("pre_act", C.c_int32)]
+
+
+class g4c_mlp_t(C.Structure):
+    _fields_ = [("n_layers", C.c_int32), ("k_pad", C.c_int32 * MAX_LAYERS), ("n_pad", C.c_int32 * MAX_LAYERS),
+                ("w", C.c_void_p * MAX_LAYERS), ("b", C.c_void_p * MAX_LAYERS),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("n_out", C.c_int32)]
+
+
+_SIGNATURES = {
+    "g4c_version": (C.c_int, []),
+    "g4c_last_error": (C.c_char_p, []),
+    "g4c_plan_csr": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "g4c_plan_pool_edge": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
+    "g4c_segment_reduce": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "g4c_weighted_segment_mean": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                            C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "g4c_mlp_pack_layer": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                     C.c_int32, C.c_int32, C.c_void_p]),
+    "g4c_mlp_forward": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_void_p,
+                                  C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "g4c_project_to_edges": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                       C.c_void_p, C.c_int32, C.c_void_p]),
+    "g4c_edge_scalar_to_node_vector": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32,
+                                                 C.c_void_p, C.c_int32, C.c_void_p]),
+    "g4c_rollout_advance": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                      C.c_void_p, C.c_int64, C.c_void_p]),
+    "g4c_activation_inplace": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "g4c_add_cols": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                               C.c_int32, C.c_int64, C.c_void_p]),
+    "g4c_copy_cols": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                C.c_int32, C.c_int64, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libg4c.so (built in-tree by `__graft_entry__.build()` / `make -C graphs4cfd_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"graphs4cfd_amd: HIP library not found at {LIB_PATH}. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(code: int) -> None:
+    if code == OK:
+        return
+    msg = load().g4c_last_error().decode("utf-8", "replace")
+    if code == EINVAL:
+        raise ValueError(msg)
+    if code == EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)
+
+
+def require_hip(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("graphs4cfd_amd kernels run on an MI355X (HIP) device only; got a tensor on "
+                               f"'{t.device}'. Move the model and Graph to 'cuda' (there is no CPU fallback).")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} and {t.device}")
+    return dev
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_handle(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,69 @@
+// Host-side builders of the static mesh plan (run once per mesh, not per step).
+//
+// The reference recomputes all of this inside every forward, with device->host syncs:
+//   * PyG scatter(dim_size=None) -> int(index.max())+1           (call at nn/blocks.py:231)
+//   * pool_edge: idx.max().item(), remove_self_loops (mask compaction), coalesce (sort+unique)
+//                                                                (nn/blocks.py:63-67)
+// Topology is loop-invariant in a rollout, so it is hoisted here.
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+#include "g4c_common.h"
+
+extern "C" int g4c_plan_csr(const int64_t *keys, int64_t n, int64_t n_seg, int32_t *perm, int32_t *off) {
+    G4C_REQUIRE(n >= 0 && n_seg >= 0 && n < (1LL << 31) && n_seg < (1LL << 31), G4C_EINVAL,
+                "g4c_plan_csr: sizes out of int32 range (n=%lld n_seg=%lld)", (long long)n, (long long)n_seg);
+    G4C_REQUIRE((keys || n == 0) && off && (perm || n == 0), G4C_EINVAL, "g4c_plan_csr: null pointer");
+    std::fill(off, off + n_seg + 1, 0);
+    for (int64_t p = 0; p < n; ++p) {
+        const int64_t k = keys[p];
+        G4C_REQUIRE(k >= 0 && k < n_seg, G4C_EINVAL, "g4c_plan_csr: key %lld at %lld outside [0, %lld)",
+                    (long long)k, (long long)p, (long long)n_seg);
+        off[k + 1]++;
+    }
+    for (int64_t s = 0; s < n_seg; ++s) off[s + 1] += off[s];
+    std::vector<int32_t> cur(off, off + n_seg);
+    for (int64_t p = 0; p < n; ++p) perm[cur[keys[p]]++] = (int32_t)p;   // stable
+    return G4C_OK;
+}
+
+extern "C" int64_t g4c_plan_pool_edge(const int64_t *idx_hr_to_lr, int64_t n_hr, const int64_t *edge_index,
+                                      int64_t n_edges, int64_t *coarse_edge_index, int32_t *perm, int32_t *off,
+                                      int64_t *n_kept) {
+    G4C_REQUIRE(n_hr >= 0 && n_edges >= 0 && n_edges < (1LL << 31), G4C_EINVAL, "g4c_plan_pool_edge: bad sizes");
+    G4C_REQUIRE((idx_hr_to_lr || n_hr == 0) && (edge_index || n_edges == 0) && off && n_kept, G4C_EINVAL,
+                "g4c_plan_pool_edge: null pointer");
+    int64_t n_lr = 0;
+    for (int64_t i = 0; i < n_hr; ++i) n_lr = std::max(n_lr, idx_hr_to_lr[i] + 1);
+    struct Item { int64_t key; int32_t e; };
+    std::vector<Item> items;
+    items.reserve((size_t)n_edges);
+    const int64_t *row = edge_index, *col = edge_index + n_edges;
+    for (int64_t e = 0; e < n_edges; ++e) {
+        G4C_REQUIRE(row[e] >= 0 && row[e] < n_hr && col[e] >= 0 && col[e] < n_hr, G4C_EINVAL,
+                    "g4c_plan_pool_edge: edge %lld endpoint outside [0, %lld)", (long long)e, (long long)n_hr);
+        const int64_t r = idx_hr_to_lr[row[e]], c = idx_hr_to_lr[col[e]];
+        if (r != c) items.push_back({r * n_lr + c, (int32_t)e});   // remove_self_loops
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.key < b.key; });
+    const int64_t kept = (int64_t)items.size();
+    *n_kept = kept;
+    // first pass: count coarse edges so the two rows of coarse_edge_index can be written contiguously
+    int64_t n_coarse = 0;
+    for (int64_t p = 0; p < kept; ++p)
+        if (p == 0 || items[p].key != items[p - 1].key) ++n_coarse;
+    int64_t s = -1;
+    for (int64_t p = 0; p < kept; ++p) {
+        if (p == 0 || items[p].key != items[p - 1].key) {
+            ++s;
+            off[s] = (int32_t)p;
+            coarse_edge_index[s] = items[p].key / n_lr;
+            coarse_edge_index[n_coarse + s] = items[p].key % n_lr;
+        }
+        perm[p] = items[p].e;
+    }
+    off[n_coarse] = (int32_t)kept;
+    return n_coarse;
+}

@@ -1,0 +1,147 @@
+// Segmented sum / mean over CSR-by-destination (the "scatter-sum" of the hot path).
+//
+// Replaces torch_geometric.utils.scatter(reduce='sum'|'mean') as called by the reference at
+// graphs4cfd/nn/blocks.py:183 (GNBlock), :231 (DownMP), :330 (EdgeMP), :378 (DownEdgeMP), and the
+// feature reduction of coalesce(reduce='mean') at :67 (pool_edge).  No atomics: the static mesh
+// plan sorts messages by destination once, each destination row is owned by one group of LPR
+// lanes that streams its messages as 16-byte loads and adds them in plan order (so a stable plan
+// reproduces a sequential scatter_add_ bit for bit).
+//
+// HBM-bound.  Algorithmic bytes per call: E*W*4 (messages) + S*W*4 (output) + (S+1)*4 (offsets)
+// [+ E*4 when a permutation is read].  For W = 128 one message row is 512 B = 32 lanes x float4,
+// a wave covers two destination rows per load instruction and keeps up to UNROLL rows in flight.
+#include "g4c_common.h"
+
+namespace {
+
+constexpr int UNROLL = 8;
+
+template <int LPR>
+__global__ __launch_bounds__(256) void segment_reduce_kernel(
+    const float *__restrict__ src, int src_ld, const int *__restrict__ perm,
+    const int *__restrict__ off, int n_seg, int width, int mean, int src_act, int act,
+    float *__restrict__ out, int out_ld) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int seg = (int)(gid / LPR);
+    const int l = (int)(gid % LPR);
+    if (seg >= n_seg) return;
+    const int beg = off[seg], end = off[seg + 1];
+    const float cnt = (float)((end - beg) > 1 ? (end - beg) : 1);
+    for (int c = l * 4; c < width; c += LPR * 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // Loads are issued unconditionally from a clamped row (a per-element "load or not" branch
+        // would serialise them); only the adds are predicated.
+        for (int p = beg; p < end; p += UNROLL) {
+            float4 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int pp = (p + u < end) ? (p + u) : (end - 1);
+                const long long r = perm ? perm[pp] : pp;
+                v[u] = *reinterpret_cast<const float4 *>(src + r * src_ld + c);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const bool on = (p + u < end);
+                if (src_act) {   // wave-uniform
+                    v[u].x = g4c::apply_act(v[u].x, src_act); v[u].y = g4c::apply_act(v[u].y, src_act);
+                    v[u].z = g4c::apply_act(v[u].z, src_act); v[u].w = g4c::apply_act(v[u].w, src_act);
+                }
+                acc.x += on ? v[u].x : 0.f; acc.y += on ? v[u].y : 0.f;
+                acc.z += on ? v[u].z : 0.f; acc.w += on ? v[u].w : 0.f;
+            }
+        }
+        if (mean) { acc.x /= cnt; acc.y /= cnt; acc.z /= cnt; acc.w /= cnt; }
+        acc.x = g4c::apply_act(acc.x, act); acc.y = g4c::apply_act(acc.y, act);
+        acc.z = g4c::apply_act(acc.z, act); acc.w = g4c::apply_act(acc.w, act);
+        *reinterpret_cast<float4 *>(out + (long long)seg * out_ld + c) = acc;
+    }
+}
+
+// generic-width fallback (width or strides not multiples of 4): one lane per column
+__global__ __launch_bounds__(256) void segment_reduce_scalar_kernel(
+    const float *__restrict__ src, int src_ld, const int *__restrict__ perm,
+    const int *__restrict__ off, int n_seg, int width, int mean, int src_act, int act,
+    float *__restrict__ out, int out_ld) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int seg = (int)(gid / width);
+    const int c = (int)(gid % width);
+    if (seg >= n_seg) return;
+    const int beg = off[seg], end = off[seg + 1];
+    float acc = 0.f;
+    for (int p = beg; p < end; ++p) {
+        const long long r = perm ? perm[p] : p;
+        acc += g4c::apply_act(src[r * src_ld + c], src_act);
+    }
+    if (mean) acc /= (float)((end - beg) > 1 ? (end - beg) : 1);
+    out[(long long)seg * out_ld + c] = g4c::apply_act(acc, act);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void weighted_segment_mean_kernel(
+    const float *__restrict__ x, int x_ld, const int *__restrict__ x_idx, const float *__restrict__ w,
+    const int *__restrict__ off, int n_seg, int width, float *__restrict__ out, int out_ld,
+    const int *__restrict__ out_idx) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int seg = (int)(gid / LPR);
+    const int l = (int)(gid % LPR);
+    if (seg >= n_seg) return;
+    const int beg = off[seg], end = off[seg + 1];
+    const long long orow = out_idx ? out_idx[seg] : seg;
+    float den = 0.f;
+    for (int p = beg; p < end; ++p) den += w[p];
+    for (int c = l; c < width; c += LPR) {
+        float num = 0.f;
+        for (int p = beg; p < end; ++p) num += x[(long long)x_idx[p] * x_ld + c] * w[p];
+        out[orow * out_ld + c] = num / den;
+    }
+}
+
+}  // namespace
+
+extern "C" int g4c_segment_reduce(const float *src, int32_t src_ld, const int32_t *perm, const int32_t *off,
+                                  int32_t n_seg, int32_t width, int32_t mean, int32_t src_act, int32_t act,
+                                  float *out, int32_t out_ld, void *stream) {
+    G4C_REQUIRE(n_seg >= 0 && width > 0 && src_ld >= width && out_ld >= width, G4C_EINVAL,
+                "g4c_segment_reduce: bad sizes n_seg=%d width=%d src_ld=%d out_ld=%d", n_seg, width, src_ld, out_ld);
+    G4C_REQUIRE(off != nullptr && out != nullptr && (src != nullptr || n_seg == 0), G4C_EINVAL,
+                "g4c_segment_reduce: null pointer");
+    if (n_seg == 0) return G4C_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = (width % 4 == 0) && (src_ld % 4 == 0) && (out_ld % 4 == 0) &&
+                     ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    if (!vec) {
+        const long long total = (long long)n_seg * width;
+        segment_reduce_scalar_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
+            src, src_ld, perm, off, n_seg, width, mean, src_act, act, out, out_ld);
+        return g4c::check_launch("g4c_segment_reduce");
+    }
+    const int q = width / 4;
+    if (q > 16) {
+        const long long total = (long long)n_seg * 32;
+        segment_reduce_kernel<32><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
+            src, src_ld, perm, off, n_seg, width, mean, src_act, act, out, out_ld);
+    } else if (q > 8) {
+        const long long total = (long long)n_seg * 16;
+        segment_reduce_kernel<16><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
+            src, src_ld, perm, off, n_seg, width, mean, src_act, act, out, out_ld);
+    } else {
+        const long long total = (long long)n_seg * 8;
+        segment_reduce_kernel<8><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
+            src, src_ld, perm, off, n_seg, width, mean, src_act, act, out, out_ld);
+    }
+    return g4c::check_launch("g4c_segment_reduce");
+}
+
+extern "C" int g4c_weighted_segment_mean(const float *x, int32_t x_ld, const int32_t *x_idx, const float *w,
+                                         const int32_t *off, int32_t n_seg, int32_t width,
+                                         float *out, int32_t out_ld, const int32_t *out_idx, void *stream) {
+    G4C_REQUIRE(n_seg >= 0 && width > 0 && x_ld >= width && out_ld >= width, G4C_EINVAL,
+                "g4c_weighted_segment_mean: bad sizes n_seg=%d width=%d", n_seg, width);
+    G4C_REQUIRE(x && x_idx && w && off && out, G4C_EINVAL, "g4c_weighted_segment_mean: null pointer");
+    if (n_seg == 0) return G4C_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const long long total = (long long)n_seg * 64;
+    weighted_segment_mean_kernel<64><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
+        x, x_ld, x_idx, w, off, n_seg, width, out, out_ld, out_idx);
+    return g4c::check_launch("g4c_weighted_segment_mean");
+}

@@ -1,0 +1,5 @@
+"""`gfd.nn`: blocks, MuS-GNN and REMuS-GNN models, the GNN base with the rollout loop."""
+from . import blocks
+from .mus_gnn import *
+from .remus_gnn import NsRotEquiTreeScaleGNN
+from .model import GNN, collate

@@ -1,0 +1,386 @@
+"""`gfd.nn.blocks` on MI355X: same classes, constructor arguments, `forward` signatures, submodule
+names and `state_dict` keys as the reference's graphs4cfd/nn/blocks.py, with every forward routed
+to the hand-written HIP kernels of libg4c.so (fused gather+MLP+LayerNorm+activation on fp32 MFMA,
+CSR segmented reductions, static-plan pooling).  There is no torch / CPU fallback: tensors must live
+on a HIP device and the library must be built.
+
+Inference only (the training loop and backward kernels are out of scope):
+outputs carry no autograd graph.
+
+Extensions over the reference signatures are keyword-only and optional (`activation=` on the MP
+blocks fuses the `F.selu` the model applies right after the block, nn/mus_gnn.py:182).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Callable, List, Optional, Sequence, Tuple, Union
+
+import torch
+from torch import nn
+
+from .. import _lib, ops, plan
+from ..graph import Graph
+from ..ops import Source
+
+Tensor = torch.Tensor
+
+
+def _finish(x: Tensor, activation, code: Optional[int]) -> Tensor:
+    """Apply an activation that could not be fused into the kernel epilogue."""
+    return x if (activation is None or code is not None) else activation(x)
+
+
+# ------------------------------------------------------------------------------------- MLP
+class MLP(nn.Module):
+    r"""Multi-layer perceptron with SELU activations (reference: nn/blocks.py:117-144).
+
+    Args:
+        input_size (int): The size of the input.
+        layers_width (Tuple[int]): The width of each layer, excluding the input layer.
+        layer_norm (bool, optional): LayerNorm after the last layer. Defaults to False.
+
+    Parameters live in `self.MLP` (`linear_<i>`, `selu_<i>`, `layer_norm`) so checkpoints of the
+    reference load unchanged.
+    """
+
+    def __init__(self, input_size: int, layers_width: Tuple[int], layer_norm: bool = False):
+        super().__init__()
+        sizes = [int(input_size)] + [int(w) for w in layers_width]
+        n = len(layers_width)
+        if n < 2:
+            raise ValueError("layers_width needs at least two entries (nn/blocks.py:135-140)")
+        mods = OrderedDict()
+        for i in range(1, n + 1):
+            mods[f"linear_{i}"] = nn.Linear(sizes[i - 1], sizes[i])
+            if i < n:
+                mods[f"selu_{i}"] = nn.SELU()
+        if layer_norm:
+            mods["layer_norm"] = nn.LayerNorm(sizes[-1])
+        self.MLP = nn.Sequential(mods)
+        self.input_size, self.output_size = sizes[0], sizes[-1]
+        self._packed = {}
+
+    # -- kernel-side weight cache ---------------------------------------------------------
+    def _linears(self) -> List[nn.Linear]:
+        return [m for m in self.MLP if isinstance(m, nn.Linear)]
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed(self, seg_widths: Sequence[int], seg_negate: Sequence[bool]) -> ops.PackedMLP:
+        key = (tuple(seg_widths), tuple(bool(x) for x in seg_negate))
+        sig = self._signature()
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != sig:
+            if sum(seg_widths) != self.input_size:
+                raise ValueError(f"MLP expects {self.input_size} input columns, got blocks {list(seg_widths)}")
+            lin = self._linears()
+            ln = getattr(self.MLP, "layer_norm", None)
+            pk = ops.PackedMLP([l.weight for l in lin], [l.bias for l in lin],
+                               None if ln is None else (ln.weight, ln.bias, ln.eps), key[0], key[1])
+            self._packed[key] = (sig, pk)
+            hit = self._packed[key]
+        return hit[1]
+
+    def run(self, sources: Sequence[Source], n_rows: int, activation=None, out: Optional[Tensor] = None,
+            out_idx32: Optional[Tensor] = None, resid: Optional[Tensor] = None, resid_col0: int = 0) -> Tensor:
+        """cat(sources) -> MLP -> activation (+ resid), one fused launch."""
+        code = _lib.act_code(activation)
+        if code is None and resid is not None:
+            raise NotImplementedError("a residual after a non-fusable activation")
+        pk = self.packed([s.width for s in sources], [s.negate for s in sources])
+        y = ops.mlp_forward(pk, sources, n_rows, _lib.ACT_NONE if code is None else code, out, out_idx32, resid, resid_col0)
+        return _finish(y, activation, code)
+
+    def run_coded(self, sources: Sequence[Source], n_rows: int, act_code: int = _lib.ACT_NONE, **kw) -> Tensor:
+        pk = self.packed([s.width for s in sources], [s.negate for s in sources])
+        return ops.mlp_forward(pk, sources, n_rows, act_code, **kw)
+
+    def forward(self, x: Tensor) -> Tensor:
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.size(-1))
+        y = self.run([Source(x2)], int(x2.size(0)))
+        return y.reshape(*lead, y.size(-1))
+
+
+# ------------------------------------------------------------------------------------- helpers
+def scatter(src: Tensor, index: Tensor, dim: int = 0, dim_size: Optional[int] = None, reduce: str = "sum") -> Tensor:
+    """Drop-in for `torch_geometric.utils.scatter(src, index, dim=0, dim_size, reduce)` as the
+    reference uses it (nn/blocks.py:46-47,183,231,330,378): a CSR segmented reduction on a cached plan."""
+    if dim != 0:
+        raise NotImplementedError("scatter along dim != 0")
+    if reduce not in ("sum", "add", "mean"):
+        raise ValueError(f"unsupported reduce {reduce!r}")
+    csr = plan.segments_of_sorted(index, dim_size)
+    squeeze = src.dim() == 1
+    out = ops.segment_reduce(src.reshape(src.size(0), -1), csr, reduce == "mean")
+    return out.reshape(-1) if squeeze else out.reshape((csr.n_seg,) + tuple(src.shape[1:]))
+
+
+def restriction(graph: Graph, coarse_mask: Tensor, edge_attr: Tensor, edge_index: Tensor, num_nodes: int,
+                device: torch.device) -> None:
+    r"""Restricts a graph to a subset of nodes (gMuS-GNN models; reference: nn/blocks.py:9-32).
+    Pure index bookkeeping, static per mesh. The graph is modified in-place."""
+    lut = torch.full((num_nodes,), -1, dtype=torch.long, device=device)
+    lut[coarse_mask] = torch.arange(graph.field.size(0), dtype=torch.long, device=device)
+    graph.edge_index = lut[edge_index]
+    graph.edge_attr = edge_attr
+
+
+def knn_interpolate(x: Tensor, y_idx: Tensor, x_idx: Tensor, weights: Tensor,
+                    *, out: Optional[Tensor] = None, out_idx32: Optional[Tensor] = None) -> Tensor:
+    r"""Inverse-distance interpolation with precomputed indices and weights (reference: nn/blocks.py:34-48).
+    `y_idx` must be sorted (the layout `get_knn_interpolate_weights` produces)."""
+    csr = plan.segments_of_sorted(y_idx)
+    return ops.weighted_segment_mean(x, plan.index32(x_idx), weights, csr, out, out_idx32)
+
+
+def pool_edge(idxHR_to_idxLR: Tensor, edge_index: Tensor, edge_attr: Tensor, aggr: str = "mean") -> Tuple[Tensor, Tensor]:
+    r"""Pools the edges of a graph through the idxHR_to_idxLR mapping (reference: nn/blocks.py:51-68).
+    The topology (remap, self-loop removal, coalescing order) comes from the static plan; only the
+    feature reduction runs per call."""
+    if aggr not in ("mean", "sum", "add"):
+        raise ValueError(f"unsupported aggr {aggr!r}")
+    pp = plan.pool_edge_plan(idxHR_to_idxLR, edge_index)
+    return pp.edge_index, ops.segment_reduce(edge_attr, pp.csr, aggr == "mean")
+
+
+def lstsq(A: Tensor, B: Tensor) -> Tensor:
+    """Solves the least squares problem AX=B for X (reference: nn/blocks.py:71-85)."""
+    return torch.linalg.pinv(A) @ B
+
+
+def _num_nodes_of(edge_index: Tensor) -> int:
+    return plan.segments_of_sorted(edge_index[1]).n_seg
+
+
+def edgeScalarToNodeVector(edge_attr: Tensor, edge_index: Tensor, edgeUnitVector: Optional[Tensor] = None,
+                           edgeUnitVectorInverse: Optional[Tensor] = None, coarse_mask: Optional[Tensor] = None) -> Tensor:
+    r"""For each node j the least-squares vector from its k incoming edge scalars (reference:
+    nn/blocks.py:88-114). Edges must be grouped by receiver with constant in-degree k. Returns [|V|, 2 Fe]."""
+    assert (edgeUnitVector is None) != (edgeUnitVectorInverse is None), \
+        "Either edgeUnitVector or edgeUnitVectorInverse must be provided."
+    if edgeUnitVectorInverse is None:
+        n = int(coarse_mask.sum()) if coarse_mask is not None else _num_nodes_of(edge_index)
+        edgeUnitVectorInverse = torch.linalg.pinv(edgeUnitVector.reshape(n, -1, 2))
+    n, k = int(edgeUnitVectorInverse.size(0)), int(edgeUnitVectorInverse.size(2))
+    if edge_attr.size(0) != n * k:
+        raise ValueError(f"{edge_attr.size(0)} edges cannot be viewed as {n} nodes x {k} incoming edges")
+    return ops.edge_scalar_to_node_vector(edge_attr, edgeUnitVectorInverse, n, k)
+
+
+# ------------------------------------------------------------------------------------- MP
+def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, aggr: str, act_code: int,
+             e_pre_act: int = _lib.ACT_NONE, v_src: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """Shared body of GNBlock / EdgeMP / DownEdgeMP (nn/blocks.py:175-186,322-333,360-381):
+        e' = msg_mlp([e | s[row] | v[col]]);  agg = reduce(e' -> col);  v' = act(upd_mlp([agg | v])).
+    Returns (v', e') where e' is stored WITHOUT the activation: the aggregation consumes the raw
+    messages, and the consumer of e' applies the activation while loading (`e_pre_act` here is that
+    pending activation of the incoming `e`).  `v_src` (DownEdgeMP) gathers sender rows from another tensor."""
+    if aggr not in ("mean", "sum", "add"):
+        raise ValueError(f"unsupported aggr {aggr!r}")
+    ep, csr = plan.edge_csr(index, int(v.size(0)))
+    senders = v if v_src is None else v_src
+    e_new = msg_mlp.run_coded([Source(e, pre_act=e_pre_act), Source(senders, ep.row), Source(v, ep.col)], ep.n_edges)
+    agg = ops.segment_reduce(e_new, csr, aggr == "mean")
+    v_new = upd_mlp.run_coded([Source(agg), Source(v)], int(v.size(0)), act_code)
+    return v_new, e_new
+
+
+def _public_mp(msg_mlp: MLP, upd_mlp: MLP, v, e, index, aggr, activation, v_src=None):
+    code = _lib.act_code(activation)
+    v_new, e_new = _mp_step(msg_mlp, upd_mlp, v, e, index, aggr, _lib.ACT_NONE if code is None else code, v_src=v_src)
+    if activation is not None:
+        if code is None:
+            v_new, e_new = activation(v_new), activation(e_new)
+        else:
+            ops.activation_(e_new, code)
+    return v_new, e_new
+
+
+class GNBlock(nn.Module):
+    r"""Graph-network block (Battaglia et al. 2018; reference: nn/blocks.py:147-186).
+
+    Args:
+        edge_mlp_args (Tuple): Arguments for the MLP updating the edge features.
+        node_mlp_args (Tuple): Arguments for the MLP updating the node features.
+        aggr (str, optional): 'mean' or 'sum'. Defaults to 'mean'.
+    """
+
+    def __init__(self, edge_mlp_args: Tuple, node_mlp_args: Tuple, aggr: str = 'mean'):
+        super().__init__()
+        self.edge_mlp = MLP(*edge_mlp_args)
+        self.node_mlp = MLP(*node_mlp_args)
+        self.aggr = aggr
+
+    def reset_parameters(self):
+        for m in (self.node_mlp, self.edge_mlp):
+            if m is not None and hasattr(m, 'reset_parameters'):
+                m.reset_parameters()
+
+    def step(self, v: Tensor, e: Tensor, edge_index: Tensor, act_code: int, e_pre_act: int = _lib.ACT_NONE):
+        """Internal form used by the model programs: returns (act(v'), raw e')."""
+        return _mp_step(self.edge_mlp, self.node_mlp, v, e, edge_index, self.aggr, act_code, e_pre_act)
+
+    def forward(self, v: Tensor, e: Tensor, edge_index: Tensor, *, activation=None) -> Tuple[Tensor, Tensor]:
+        return _public_mp(self.edge_mlp, self.node_mlp, v, e, edge_index, self.aggr, activation)
+
+
+# Alias for GNBlock
+MP = GNBlock
+
+
+class DownMP(nn.Module):
+    r"""DownMP from Lino et al. (2022) (reference: nn/blocks.py:193-237).
+
+    Args:
+        down_mlp_args (Tuple): Arguments for the MLP of the downsampling edge-model.
+        hr_graph_idx (int): The index of the high-resolution graph.
+    """
+
+    def __init__(self, down_mlp_args: Tuple, hr_graph_idx: int):
+        super().__init__()
+        self.down_mlp = MLP(*down_mlp_args)
+        self.hr_graph_idx = hr_graph_idx
+        self.lr_graph_idx = hr_graph_idx + 1
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for item in [self.down_mlp]:
+            if hasattr(item, 'reset_parameters'):
+                item.reset_parameters()
+
+    def pool(self, graph: Graph, field: Tensor, edge_index: Tensor, edge_attr: Tensor, activation=None,
+             e_pre_act: int = _lib.ACT_NONE):
+        """Functional core: returns (field_l, edge_index_l, edge_attr_l) without touching the Graph.
+        `e_pre_act`: activation still pending on `edge_attr` (applied while pooling)."""
+        h, l = self.hr_graph_idx, self.lr_graph_idx
+        rel = getattr(graph, f'e_{h}{l}')
+        csr = plan.cluster_plan(getattr(graph, f'cluster_{l}'), getattr(graph, f'mask_{l}'))
+        m = self.down_mlp.run([Source(rel), Source(field)], int(field.size(0)))
+        code = _lib.act_code(activation)
+        pooled = ops.segment_reduce(m, csr, True, _lib.ACT_NONE if code is None else code)
+        pooled = _finish(pooled, activation, code)
+        pp = plan.pool_edge_plan(getattr(graph, f'idx{h}_to_idx{l}'), edge_index)
+        ea_l = ops.segment_reduce(edge_attr, pp.csr, True, src_act=e_pre_act)
+        return pooled, pp.edge_index, ea_l
+
+    def forward(self, graph: Graph, activation: Optional[Callable] = None) -> Graph:
+        field, ei, ea = self.pool(graph, graph.field, graph.edge_index, graph.edge_attr, activation)
+        graph.pos = getattr(graph, f'pos_{self.lr_graph_idx}')
+        graph.field, graph.edge_index, graph.edge_attr = field, ei, ea
+        return graph
+
+
+class UpMP(nn.Module):
+    r"""UpMP from Lino et al. (2022) (reference: nn/blocks.py:240-290).
+
+    Args:
+        up_mlp_args (Tuple): Arguments for the MLP of the upsampling edge-model.
+        lr_graph_idx (int): The index of the low-resolution graph.
+    """
+
+    def __init__(self, up_mlp_args: Tuple, lr_graph_idx: int):
+        super().__init__()
+        self.up_mlp = MLP(*up_mlp_args)
+        self.lr_graph_idx = lr_graph_idx
+        self.hr_graph_idx = lr_graph_idx - 1
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for item in [self.up_mlp]:
+            if hasattr(item, 'reset_parameters'):
+                item.reset_parameters()
+
+    def unpool(self, graph: Graph, field_lr: Tensor, field_hr_old: Tensor, activation=None) -> Tensor:
+        h, l = self.hr_graph_idx, self.lr_graph_idx
+        parent = plan.index32(getattr(graph, f'idx{h}_to_idx{l}'))
+        rel = getattr(graph, f'e_{h}{l}')
+        # [-e_hl | field_l[parent] | field_hr_old]; the sign flip is folded into the packed weights
+        return self.up_mlp.run([Source(rel, negate=True), Source(field_lr, parent), Source(field_hr_old)],
+                               int(field_hr_old.size(0)), activation=activation)
+
+    def forward(self, graph: Graph, field_hr_old: Tensor, pos_hr: Tensor, activation: Optional[Callable] = None) -> Graph:
+        graph.field = self.unpool(graph, graph.field, field_hr_old, activation)
+        graph.pos = pos_hr
+        return graph
+
+
+# ------------------------------------------------------------------------------------- REMuS
+class EdgeMP(nn.Module):
+    r"""EdgeMP from Lino et al. (2022) (reference: nn/blocks.py:293-333): a GNBlock with
+    (edges, angles) in the roles of (nodes, edges)."""
+
+    def __init__(self, angle_mlp_args: Tuple, edge_mlp_args: Tuple, aggr: str = "mean"):
+        super().__init__()
+        self.angle_mlp = MLP(*angle_mlp_args)
+        self.edge_mlp = MLP(*edge_mlp_args)
+        self.aggr = aggr
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for item in [self.edge_mlp, self.angle_mlp]:
+            if hasattr(item, 'reset_parameters'):
+                item.reset_parameters()
+
+    def step(self, e: Tensor, a: Tensor, angle_index: Tensor, act_code: int, a_pre_act: int = _lib.ACT_NONE):
+        """Internal form: returns (act(e'), raw a')."""
+        return _mp_step(self.angle_mlp, self.edge_mlp, e, a, angle_index, self.aggr, act_code, a_pre_act)
+
+    def forward(self, e: Tensor, a: Tensor, angle_index: Tensor, *, activation=None) -> Tuple[Tensor, Tensor]:
+        return _public_mp(self.angle_mlp, self.edge_mlp, e, a, angle_index, self.aggr, activation)
+
+
+class DownEdgeMP(nn.Module):
+    r"""DownEdgeMP from Lino et al. (2022) (reference: nn/blocks.py:336-381)."""
+
+    def __init__(self, angle_mlp_args: Tuple, edge_mlp_args: Tuple):
+        super().__init__()
+        self.angle_mlp = MLP(*angle_mlp_args)
+        self.edge_mlp = MLP(*edge_mlp_args)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for item in [self.edge_mlp, self.angle_mlp]:
+            if hasattr(item, 'reset_parameters'):
+                item.reset_parameters()
+
+    def forward(self, e1: Tensor, e2: Tensor, a12: Tensor, angle_index12: Tensor, *, activation=None) -> Tensor:
+        code = _lib.act_code(activation)
+        e2_new, _ = _mp_step(self.angle_mlp, self.edge_mlp, e2, a12, angle_index12, "mean",
+                             _lib.ACT_NONE if code is None else code, v_src=e1)
+        return _finish(e2_new, activation, code)
+
+
+class UpEdgeMP(nn.Module):
+    r"""UpEdgeMP from Lino et al. (2022) (reference: nn/blocks.py:384-456)."""
+
+    def __init__(self, up_mlp_args: Tuple):
+        super().__init__()
+        self.up_mlp = MLP(*up_mlp_args)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for item in [self.up_mlp]:
+            if hasattr(item, 'reset_parameters'):
+                item.reset_parameters()
+
+    def forward(self, pos: Tensor, y_idx_21: Tensor, x_idx_21: Tensor, weights_21: Tensor, edge_attr2: Tensor,
+                edge_index2: Tensor, edgeUnitVectorInverse2: Tensor, coarse_mask2: Tensor, edge_attr1: Tensor,
+                edge_index1: Tensor, edgeUnitVector1: Tensor, coarse_mask1=None, *, activation=None) -> Tensor:
+        n_total, nfeat = int(pos.size(0)), int(edge_attr2.size(1))
+        # 1- edge scalars of level 2 -> node vectors [|V_2|, 2F]
+        v2 = edgeScalarToNodeVector(edge_attr2, edge_index2, edgeUnitVectorInverse=edgeUnitVectorInverse2,
+                                    coarse_mask=coarse_mask2)
+        # 2- interpolate to the nodes of level 1, written at their level-1 numbering
+        if coarse_mask1 is None:
+            v1 = torch.empty(n_total, 2 * nfeat, dtype=torch.float32, device=pos.device)
+            knn_interpolate(v2, y_idx_21, x_idx_21, weights_21, out=v1)
+        else:
+            v1 = torch.zeros(n_total, 2 * nfeat, dtype=torch.float32, device=pos.device)
+            knn_interpolate(v2, y_idx_21, x_idx_21, weights_21, out=v1, out_idx32=plan.mask_index32(coarse_mask1))
+        # 3- project node vectors on the level-1 edges [|E_1|, F]
+        ep = plan.edge_plan(edge_index1)
+        e1 = ops.project_to_edges(v1, ep.col, edgeUnitVector1, ep.n_edges, nfeat)
+        # 4- skip connection + per-edge MLP
+        return self.up_mlp.run([Source(e1), Source(edge_attr1)], ep.n_edges, activation=activation)

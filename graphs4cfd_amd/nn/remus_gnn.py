@@ -1,0 +1,110 @@
+"""REMuS-GNN (rotation-equivariant multi-scale GNN), three-scale model.
+
+Same class name, constructor, arch keys, submodule names and forward contract as the reference's
+graphs4cfd/nn/remus_gnn.py (NsRotEquiTreeScaleGNN, :11-199).  The V-cycle over (edges, angles) is
+interpreted from a table and runs on the fused HIP blocks (EdgeMP = the GNBlock kernels with edges
+in the role of nodes and angles in the role of edges).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import _lib, ops, plan
+from ..graph import Graph
+from ..ops import Source
+from .blocks import MLP, EdgeMP, DownEdgeMP, UpEdgeMP, edgeScalarToNodeVector
+from .model import GNN
+
+SELU, NONE = _lib.ACT_SELU, _lib.ACT_NONE
+
+
+class NsRotEquiTreeScaleGNN(GNN):
+    """The three-scale REMuS-GNN for incompressible flow inference from Lino et al. (2022)
+    (https://doi.org/10.1063/5.0097679); reference: nn/remus_gnn.py:11-199.
+
+    `arch` keys: angle_encoder{,12,2,23,3}, edge_encoder{,2,3}, mp111..mp114, down_mp12, mp211, mp212,
+    down_mp23, mp31..mp34, up_mp32, mp221, mp222, up_mp21, mp121..mp124, decoder.
+
+    Args:
+        model (str, optional): Name of the pretrained model to load ("RE3S-GNN-NsEllipse-v1").
+    """
+
+    _PRETRAINED = {"RE3S-GNN-NsEllipse-v1": "weights/NsREMuSGNN/NsRotEquiThreeScaleGNN.chk"}
+    _ENCODERS = ("angle_encoder", "angle_encoder12", "angle_encoder2", "angle_encoder23", "angle_encoder3",
+                 "edge_encoder", "edge_encoder2", "edge_encoder3")
+    # (op, module, level)
+    _PROGRAM = (("mp", "mp111", 1), ("mp", "mp112", 1), ("mp", "mp113", 1), ("mp", "mp114", 1),
+                ("down", "down_mp12", 1),
+                ("mp", "mp211", 2), ("mp", "mp212", 2),
+                ("down", "down_mp23", 2),
+                ("mp", "mp31", 3), ("mp", "mp32", 3), ("mp", "mp33", 3), ("mp", "mp34", 3),
+                ("up", "up_mp32", 3),
+                ("mp", "mp221", 2), ("mp", "mp222", 2),
+                ("up", "up_mp21", 2),
+                ("mp", "mp121", 1), ("mp", "mp122", 1), ("mp", "mp123", 1), ("mp", "mp124", 1))
+
+    def __init__(self, model: str = None, *args, **kwargs) -> None:
+        if model is not None:
+            super().__init__(arch=None, weights=None, checkpoint=self._pretrained(self._PRETRAINED, model), *args, **kwargs)
+        else:
+            super().__init__(*args, **kwargs)
+        self.num_fields = 2
+
+    def load_arch(self, arch: dict):
+        self.arch = arch
+        for name in self._ENCODERS:
+            setattr(self, name, MLP(*arch[name]))
+        for op, name, _ in self._PROGRAM:
+            if op == "mp":
+                setattr(self, name, EdgeMP(*arch[name]))
+            elif op == "down":
+                setattr(self, name, DownEdgeMP(*arch[name]))
+            else:
+                setattr(self, name, UpEdgeMP(arch[name]))
+        self.edge_decoder = MLP(*arch["decoder"])
+        self.to(self.device)
+
+    def forward(self, graph: Graph, t: Optional[int] = None) -> torch.Tensor:
+        g = graph
+        sfx = {1: "", 2: "2", 3: "3"}
+        nfeat = int(g.field.size(1)) // 2
+        e, a, aidx = {}, {}, {}
+        for lvl, s in sfx.items():
+            ep = plan.edge_plan(getattr(g, f"edge_index{s}"))
+            # project the node vectors along the edges, then [proj | glob[col] | omega[col]] -> encoder
+            proj = ops.project_to_edges(g.field, ep.col, getattr(g, f"edgeUnitVector{s}"), ep.n_edges, nfeat)
+            e[lvl] = getattr(self, f"edge_encoder{s}").run_coded(
+                [Source(proj), Source(g.glob, ep.col), Source(g.omega, ep.col)], ep.n_edges, SELU)
+            att = getattr(g, f"angle_attr{s}")
+            a[lvl] = getattr(self, f"angle_encoder{s}").run_coded([Source(att)], int(att.size(0)), SELU)
+            aidx[lvl] = getattr(g, f"angle_index{s}")
+        a12 = self.angle_encoder12.run_coded([Source(g.angle_attr12)], int(g.angle_attr12.size(0)), SELU)
+        a23 = self.angle_encoder23.run_coded([Source(g.angle_attr23)], int(g.angle_attr23.size(0)), SELU)
+        a_pending = {1: NONE, 2: NONE, 3: NONE}
+        for op, name, lvl in self._PROGRAM:
+            block = getattr(self, name)
+            if op == "mp":
+                e[lvl], a[lvl] = block.step(e[lvl], a[lvl], aidx[lvl], SELU, a_pre_act=a_pending[lvl])
+                a_pending[lvl] = SELU
+            elif op == "down":
+                a_x, idx_x = (a12, g.angle_index12) if lvl == 1 else (a23, g.angle_index23)
+                e[lvl + 1] = block(e[lvl], e[lvl + 1], a_x, idx_x, activation="selu")
+            else:
+                lo, hi = lvl, lvl - 1
+                e[hi] = block(g.pos, getattr(g, f"y_idx_{lo}{hi}"), getattr(g, f"x_idx_{lo}{hi}"),
+                              getattr(g, f"weights_{lo}{hi}"), e[lo], getattr(g, f"edge_index{sfx[lo]}"),
+                              getattr(g, f"edgeUnitVectorInverse{sfx[lo]}"), getattr(g, f"coarse_mask{sfx[lo]}"),
+                              e[hi], getattr(g, f"edge_index{sfx[hi]}"), getattr(g, f"edgeUnitVector{sfx[hi]}"),
+                              getattr(g, f"coarse_mask{sfx[hi]}") if hi > 1 else None, activation="selu")
+        s = self.edge_decoder.run_coded([Source(e[1])], int(e[1].size(0)), NONE)
+        out = edgeScalarToNodeVector(s, g.edge_index, edgeUnitVectorInverse=g.edgeUnitVectorInverse)
+        # time step: field[:, -2:] + output (nn/remus_gnn.py:199)
+        return _add_last_fields(g.field, out, self.num_fields)
+
+
+def _add_last_fields(field: torch.Tensor, out: torch.Tensor, nf: int) -> torch.Tensor:
+    res = torch.empty_like(out)
+    ops.add_cols(field, int(field.size(1)) - nf, out, res)
+    return res

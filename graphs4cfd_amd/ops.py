@@ -1,0 +1,218 @@
+"""Thin Python wrappers over the C-ABI of libg4c.so: argument checking, output allocation
+(torch is used for device memory and the current HIP stream only), one launch per call.
+Nothing here computes on the host or with torch ops."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .plan import CsrPlan
+
+Tensor = torch.Tensor
+
+
+def _f32_2d(t: Tensor, name: str) -> Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if t.dim() != 2:
+        raise ValueError(f"{name}: expected a 2-D tensor, got shape {tuple(t.shape)}")
+    if t.stride(1) != 1 and t.size(1) > 1:
+        t = t.contiguous()
+    if t.size(0) > 1 and t.stride(0) < t.size(1):
+        t = t.contiguous()
+    return t
+
+
+def _ld(t: Tensor) -> int:
+    return int(t.stride(0)) if t.size(0) > 1 else int(max(t.size(1), t.stride(0)))
+
+
+class Source:
+    """One column block of a virtually concatenated MLP input."""
+
+    __slots__ = ("tensor", "index", "col0", "width", "negate", "pre_act")
+
+    def __init__(self, tensor: Tensor, index: Optional[Tensor] = None, col0: int = 0, width: Optional[int] = None,
+                 negate: bool = False, pre_act: int = _lib.ACT_NONE):
+        self.tensor = _f32_2d(tensor, "source")
+        self.index = index          # int32 gather index or None
+        self.col0 = col0
+        self.width = int(self.tensor.size(1) - col0 if width is None else width)
+        self.negate = negate        # folded into the packed weights
+        self.pre_act = pre_act      # activation applied while loading (producer stored the raw tensor)
+
+
+def segment_reduce(src: Tensor, csr: CsrPlan, mean: bool, act: int = _lib.ACT_NONE, out: Optional[Tensor] = None,
+                   src_act: int = _lib.ACT_NONE) -> Tensor:
+    """out[s] = act(sum|mean of src_act(src[perm[p]]) over the plan's segments) (g4c_segment_reduce)."""
+    lib = _lib.load()
+    src = _f32_2d(src, "src")
+    dev = _lib.require_hip(src, csr.off, csr.perm)
+    width = int(src.size(1))
+    if out is None:
+        out = torch.empty((csr.n_seg, width), dtype=torch.float32, device=dev)
+    _lib.check(lib.g4c_segment_reduce(_lib.ptr(src), _ld(src), _lib.ptr(csr.perm), _lib.ptr(csr.off), csr.n_seg, width,
+                                      1 if mean else 0, src_act, act, _lib.ptr(out), _ld(out), _lib.stream_handle(dev)))
+    return out
+
+
+def activation_(x: Tensor, act: int) -> Tensor:
+    """In-place activation of a contiguous tensor (g4c_activation_inplace)."""
+    lib = _lib.load()
+    dev = _lib.require_hip(x)
+    if not x.is_contiguous():
+        raise ValueError("activation_: tensor must be contiguous")
+    _lib.check(lib.g4c_activation_inplace(_lib.ptr(x), x.numel(), act, _lib.stream_handle(dev)))
+    return x
+
+
+def weighted_segment_mean(x: Tensor, x_idx32: Tensor, w: Tensor, csr: CsrPlan, out: Optional[Tensor] = None,
+                          out_idx32: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    x = _f32_2d(x, "x")
+    w = w.reshape(-1).contiguous()
+    dev = _lib.require_hip(x, x_idx32, w, csr.off)
+    if csr.perm is not None:
+        raise NotImplementedError("knn_interpolate needs y_idx sorted (the BuildKnnInterpWeights layout)")
+    width = int(x.size(1))
+    if out is None:
+        out = torch.empty((csr.n_seg, width), dtype=torch.float32, device=dev)
+    _lib.check(lib.g4c_weighted_segment_mean(_lib.ptr(x), _ld(x), _lib.ptr(x_idx32), _lib.ptr(w), _lib.ptr(csr.off),
+                                             csr.n_seg, width, _lib.ptr(out), _ld(out), _lib.ptr(out_idx32),
+                                             _lib.stream_handle(dev)))
+    return out
+
+
+def project_to_edges(v: Tensor, node32: Optional[Tensor], unit: Tensor, n_edges: int, n_feat: int) -> Tensor:
+    lib = _lib.load()
+    v = _f32_2d(v, "v")
+    unit = _f32_2d(unit, "edgeUnitVector").contiguous()
+    dev = _lib.require_hip(v, node32, unit)
+    out = torch.empty((n_edges, n_feat), dtype=torch.float32, device=dev)
+    _lib.check(lib.g4c_project_to_edges(_lib.ptr(v), _ld(v), _lib.ptr(node32), _lib.ptr(unit), n_edges, n_feat,
+                                        _lib.ptr(out), _ld(out), _lib.stream_handle(dev)))
+    return out
+
+
+def edge_scalar_to_node_vector(e: Tensor, unit_inv: Tensor, n_nodes: int, k: int) -> Tensor:
+    lib = _lib.load()
+    e = _f32_2d(e, "edge_attr")
+    unit_inv = unit_inv.contiguous()
+    dev = _lib.require_hip(e, unit_inv)
+    n_feat = int(e.size(1))
+    out = torch.empty((n_nodes, 2 * n_feat), dtype=torch.float32, device=dev)
+    _lib.check(lib.g4c_edge_scalar_to_node_vector(_lib.ptr(e), _ld(e), _lib.ptr(unit_inv), k, n_nodes, n_feat,
+                                                  _lib.ptr(out), _ld(out), _lib.stream_handle(dev)))
+    return out
+
+
+def copy_cols(src: Tensor, dst: Tensor, dcol0: int, scol0: int = 0, width: Optional[int] = None,
+              idx32: Optional[Tensor] = None, n_rows: Optional[int] = None) -> None:
+    lib = _lib.load()
+    dev = _lib.require_hip(src, dst, idx32)
+    width = int(src.size(1) - scol0 if width is None else width)
+    n_rows = int(dst.size(0) if n_rows is None else n_rows)
+    _lib.check(lib.g4c_copy_cols(_lib.ptr(src), _ld(src), scol0, _lib.ptr(idx32), _lib.ptr(dst), _ld(dst), dcol0, width,
+                                 n_rows, _lib.stream_handle(dev)))
+
+
+def add_cols(a: Tensor, a_col0: int, b: Tensor, out: Tensor) -> Tensor:
+    """out = a[:, a_col0:a_col0+w] + b (g4c_add_cols)."""
+    lib = _lib.load()
+    dev = _lib.require_hip(a, b, out)
+    _lib.check(lib.g4c_add_cols(_lib.ptr(a), _ld(a), a_col0, _lib.ptr(b), _ld(b), _lib.ptr(out), _ld(out),
+                                int(b.size(1)), int(b.size(0)), _lib.stream_handle(dev)))
+    return out
+
+
+def rollout_advance(field: Tensor, pred: Tensor, outputs: Tensor, step: Tensor, nf: int) -> None:
+    lib = _lib.load()
+    dev = _lib.require_hip(field, pred, outputs, step)
+    assert field.is_contiguous() and pred.is_contiguous() and outputs.is_contiguous()
+    _lib.check(lib.g4c_rollout_advance(_lib.ptr(field), int(field.size(1)), _lib.ptr(pred), nf, _lib.ptr(outputs),
+                                       int(outputs.size(1)), _lib.ptr(step), int(field.size(0)), _lib.stream_handle(dev)))
+
+
+class PackedMLP:
+    """Device-side packed weights of one MLP for a given input block structure."""
+
+    def __init__(self, weights: Sequence[Tensor], biases: Sequence[Tensor], ln: Optional[Tuple[Tensor, Tensor, float]],
+                 seg_widths: Sequence[int], seg_negate: Sequence[bool]):
+        lib = _lib.load()
+        dev = _lib.require_hip(*weights, *biases)
+        n_layers = len(weights)
+        if not 2 <= n_layers <= _lib.MAX_LAYERS:
+            raise NotImplementedError(f"MLP with {n_layers} Linear layers (supported: 2..{_lib.MAX_LAYERS})")
+        if len(seg_widths) > _lib.MAX_SRC:
+            raise NotImplementedError(f"MLP input concatenated from {len(seg_widths)} blocks (max {_lib.MAX_SRC})")
+        self.desc = _lib.g4c_mlp_t()
+        self.desc.n_layers = n_layers
+        self._keep: List[Tensor] = []
+        stream = _lib.stream_handle(dev)
+        for l, (W, b) in enumerate(zip(weights, biases)):
+            n_out, k_in = int(W.size(0)), int(W.size(1))
+            if n_out > 128:
+                raise NotImplementedError(f"layer width {n_out} > 128 is outside the fused-MLP kernel envelope")
+            n_pad = 32 if n_out <= 32 else 64 if n_out <= 64 else 128
+            if l == 0:
+                segs, negs = list(seg_widths), [1 if x else 0 for x in seg_negate]
+            else:
+                prev = int(weights[l - 1].size(0))
+                if k_in != prev:
+                    raise ValueError(f"layer {l + 1} expects {k_in} inputs, previous layer gives {prev}")
+                segs, negs = [k_in], [0]
+            k_pad = sum((s + 3) // 4 * 4 for s in segs) if l == 0 else self.desc.n_pad[l - 1]
+            Wc = W.detach().to(torch.float32).contiguous()
+            packed = torch.zeros(k_pad * n_pad, dtype=torch.float32, device=dev)
+            if l == 0:
+                seg_arr = (C.c_int32 * len(segs))(*segs)
+                neg_arr = (C.c_int32 * len(segs))(*negs)
+                _lib.check(lib.g4c_mlp_pack_layer(_lib.ptr(Wc), n_out, k_in, seg_arr, neg_arr, len(segs), _lib.ptr(packed),
+                                                  k_pad, n_pad, stream))
+            else:
+                # hidden layers: one block of width k_in, zero rows up to the previous layer's padded width
+                seg_arr = (C.c_int32 * 1)(k_in)
+                neg_arr = (C.c_int32 * 1)(0)
+                kp_real = (k_in + 3) // 4 * 4
+                _lib.check(lib.g4c_mlp_pack_layer(_lib.ptr(Wc), n_out, k_in, seg_arr, neg_arr, 1, _lib.ptr(packed),
+                                                  kp_real, n_pad, stream))
+            bias = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+            bias[:n_out].copy_(b.detach())
+            self.desc.k_pad[l], self.desc.n_pad[l] = k_pad, n_pad
+            self.desc.w[l], self.desc.b[l] = packed.data_ptr(), bias.data_ptr()
+            self._keep += [packed, bias]
+        self.n_out = int(weights[-1].size(0))
+        self.desc.n_out = self.n_out
+        if ln is not None:
+            g, be, eps = ln
+            g, be = g.detach().to(torch.float32).contiguous(), be.detach().to(torch.float32).contiguous()
+            self.desc.ln_gamma, self.desc.ln_beta, self.desc.ln_eps = g.data_ptr(), be.data_ptr(), float(eps)
+            self._keep += [g, be]
+        else:
+            self.desc.ln_gamma, self.desc.ln_beta, self.desc.ln_eps = None, None, 0.0
+        self.seg_widths = tuple(seg_widths)
+        self.device = dev
+
+
+def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: int = _lib.ACT_NONE,
+                out: Optional[Tensor] = None, out_idx32: Optional[Tensor] = None,
+                resid: Optional[Tensor] = None, resid_col0: int = 0) -> Tensor:
+    lib = _lib.load()
+    dev = _lib.require_hip(*[s.tensor for s in sources], *[s.index for s in sources], out, out_idx32, resid)
+    if dev != packed.device:
+        raise RuntimeError(f"MLP weights on {packed.device}, inputs on {dev}")
+    if tuple(s.width for s in sources) != packed.seg_widths:
+        raise ValueError(f"input blocks {[s.width for s in sources]} do not match packed layout {packed.seg_widths}")
+    arr = (_lib.g4c_src_t * len(sources))()
+    for a, s in zip(arr, sources):
+        a.ptr, a.idx, a.width, a.ld, a.col0, a.pre_act = (s.tensor.data_ptr(), _lib.ptr(s.index), s.width, _ld(s.tensor),
+                                                          s.col0, s.pre_act)
+    if out is None:
+        out = torch.empty((n_rows, packed.n_out), dtype=torch.float32, device=dev)
+    _lib.check(lib.g4c_mlp_forward(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out), _ld(out),
+                                   _lib.ptr(out_idx32), act, _lib.ptr(resid), _ld(resid) if resid is not None else 0,
+                                   resid_col0, _lib.stream_handle(dev)))
+    return out

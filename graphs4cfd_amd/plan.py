@@ -1,0 +1,217 @@
+"""Static mesh plan: everything about the (fixed) topology that the reference recomputes in every
+forward with device->host syncs is computed here once and cached.
+
+  * int32 copies of the int64 index tensors of the `Graph` layout,
+  * CSR-by-destination permutation + segment offsets for every aggregation
+    (replaces the index handling inside `torch_geometric.utils.scatter`, nn/blocks.py:183,231,330,378),
+  * the topology part of `pool_edge` (nn/blocks.py:63-67): coarse edge_index, fine->coarse edge
+    map as a segmented permutation.
+
+Plans are keyed on tensor identity (data_ptr, shape, version counter, device) so the block API
+keeps the reference's signatures (`GNBlock.forward(v, e, edge_index)` gets only the tensor).
+Building a plan copies the index tensor to the host once (the C-ABI plan builders are host code)
+and uploads int32 results; a rollout step itself never syncs.
+"""
+from __future__ import annotations
+
+import collections
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass
+class CsrPlan:
+    perm: Optional[torch.Tensor]   # int32 [n] on device; None when the input is already grouped in order
+    off: torch.Tensor              # int32 [n_seg+1] on device
+    n: int
+    n_seg: int
+    max_deg: int
+
+
+@dataclass
+class EdgePlan:
+    """Plan of one `edge_index` / `angle_index` ([2, E] int64, row = sender, col = receiver)."""
+    row: torch.Tensor              # int32 [E]
+    col: torch.Tensor              # int32 [E]
+    n_edges: int
+    csr: dict                      # n_targets -> CsrPlan grouped by col
+
+
+@dataclass
+class PoolEdgePlan:
+    edge_index: torch.Tensor       # int64 [2, E_l], ordered like torch_geometric coalesce output
+    csr: CsrPlan                   # fine edges grouped by coarse edge
+    n_coarse: int
+
+
+def _host_i64(t: torch.Tensor) -> np.ndarray:
+    return np.ascontiguousarray(t.detach().to("cpu", torch.int64).numpy())
+
+
+def build_csr(keys: torch.Tensor, n_seg: int, device: torch.device, drop_last_segment: bool = False) -> CsrPlan:
+    """Group positions by key (stable). `drop_last_segment`: keys == n_seg-1 are a trash bin."""
+    lib = _lib.load()
+    k = _host_i64(keys)
+    n = int(k.shape[0])
+    perm = np.empty(n, dtype=np.int32)
+    off = np.empty(n_seg + 1, dtype=np.int32)
+    _lib.check(lib.g4c_plan_csr(k.ctypes.data, n, n_seg, perm.ctypes.data, off.ctypes.data))
+    if drop_last_segment:
+        n_seg -= 1
+        off = off[: n_seg + 1]
+        perm = perm[: int(off[-1])]
+    n_kept = int(perm.shape[0])
+    identity = n_kept == n and bool(np.array_equal(perm, np.arange(n, dtype=np.int32)))
+    deg = np.diff(off)
+    return CsrPlan(
+        perm=None if identity else torch.from_numpy(perm.copy()).to(device),
+        off=torch.from_numpy(off.copy()).to(device),
+        n=n_kept, n_seg=n_seg, max_deg=int(deg.max()) if deg.size else 0)
+
+
+class _Cache:
+    def __init__(self, capacity: int = 256):
+        self.capacity = capacity
+        self.data = collections.OrderedDict()
+
+    @staticmethod
+    def key(*tensors: torch.Tensor):
+        return tuple((t.data_ptr(), tuple(t.shape), t._version, str(t.device), t.dtype) for t in tensors)
+
+    def get(self, key):
+        hit = self.data.get(key)
+        if hit is not None:
+            self.data.move_to_end(key)
+            return hit[1]
+        return None
+
+    def put(self, key, tensors, value):
+        # keep the key tensors alive so their data_ptr cannot be recycled under the cached plan
+        self.data[key] = (tensors, value)
+        if len(self.data) > self.capacity:
+            self.data.popitem(last=False)
+        return value
+
+
+_edge_plans = _Cache()
+_pool_plans = _Cache()
+_index_plans = _Cache()
+_cluster_plans = _Cache()
+
+
+def clear_caches() -> None:
+    for c in (_edge_plans, _pool_plans, _index_plans, _cluster_plans):
+        c.data.clear()
+
+
+def edge_plan(edge_index: torch.Tensor) -> EdgePlan:
+    key = _Cache.key(edge_index)
+    plan = _edge_plans.get(key)
+    if plan is None:
+        if edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
+        dev = _lib.require_hip(edge_index)
+        plan = EdgePlan(row=edge_index[0].to(torch.int32).contiguous(), col=edge_index[1].to(torch.int32).contiguous(),
+                        n_edges=int(edge_index.size(1)), csr={})
+        _edge_plans.put(key, (edge_index,), plan)
+    return plan
+
+
+def edge_csr(edge_index: torch.Tensor, n_targets: int) -> Tuple[EdgePlan, CsrPlan]:
+    plan = edge_plan(edge_index)
+    csr = plan.csr.get(n_targets)
+    if csr is None:
+        csr = build_csr(edge_index[1], n_targets, edge_index.device)
+        plan.csr[n_targets] = csr
+    return plan, csr
+
+
+def index32(index: torch.Tensor) -> torch.Tensor:
+    """Cached int32 copy of an int64 gather index (idx{h}_to_idx{l}, x_idx, col, ...)."""
+    if index.dtype == torch.int32:
+        return index
+    key = _Cache.key(index)
+    out = _index_plans.get(key)
+    if out is None:
+        _lib.require_hip(index)
+        out = _index_plans.put(key, (index,), index.to(torch.int32).contiguous())
+    return out
+
+
+def mask_index32(mask: torch.Tensor) -> torch.Tensor:
+    """Cached int32 positions of the True entries of a boolean node mask (coarse_mask{l})."""
+    key = _Cache.key(mask) + ("nonzero",)
+    out = _index_plans.get(key)
+    if out is None:
+        _lib.require_hip(mask)
+        out = _index_plans.put(key, (mask,), mask.nonzero().reshape(-1).to(torch.int32).contiguous())
+    return out
+
+
+def segments_of_sorted(index: torch.Tensor, n_seg: Optional[int] = None) -> CsrPlan:
+    """CSR plan for an index vector (knn_interpolate's y_idx; any `scatter` index)."""
+    key = _Cache.key(index) + (n_seg,)
+    plan = _index_plans.get(key)
+    if plan is None:
+        if n_seg is None:
+            n_seg = int(index.max()) + 1 if index.numel() else 0
+        plan = _index_plans.put(key, (index,), build_csr(index, n_seg, index.device))
+    return plan
+
+
+def cluster_plan(cluster: torch.Tensor, mask: torch.Tensor) -> CsrPlan:
+    """Plan for `scatter(x, cluster, reduce='mean')[mask]` (DownMP, nn/blocks.py:231): output row j
+    averages the rows i with cluster[i] == mask[j]; cluster ids absent from `mask` are dropped."""
+    key = _Cache.key(cluster, mask)
+    plan = _cluster_plans.get(key)
+    if plan is None:
+        dev = _lib.require_hip(cluster, mask)
+        c, m = _host_i64(cluster), _host_i64(mask)
+        if m.dtype == np.bool_ or mask.dtype == torch.bool:
+            raise NotImplementedError("boolean mask_l is not part of the GridClustering layout (int64 ids expected)")
+        n_out = int(m.shape[0])
+        if np.unique(m).shape[0] != n_out:
+            raise NotImplementedError("mask_l with repeated cluster ids is not supported")
+        sorter = np.argsort(m, kind="stable")
+        ms = m[sorter]
+        pos = np.searchsorted(ms, c)
+        pos_c = np.minimum(pos, max(n_out - 1, 0))
+        valid = (ms[pos_c] == c) if n_out else np.zeros_like(c, dtype=bool)
+        keys = np.where(valid, sorter[pos_c] if n_out else 0, n_out).astype(np.int64)
+        plan = build_csr(torch.from_numpy(keys), n_out + 1, dev, drop_last_segment=True)
+        _cluster_plans.put(key, (cluster, mask), plan)
+    return plan
+
+
+def pool_edge_plan(idx_hr_to_lr: torch.Tensor, edge_index: torch.Tensor) -> PoolEdgePlan:
+    key = _Cache.key(idx_hr_to_lr, edge_index)
+    plan = _pool_plans.get(key)
+    if plan is None:
+        lib = _lib.load()
+        dev = _lib.require_hip(idx_hr_to_lr, edge_index)
+        idx, ei = _host_i64(idx_hr_to_lr), _host_i64(edge_index)
+        n_hr, n_edges = int(idx.shape[0]), int(ei.shape[1])
+        coarse = np.empty((2, max(n_edges, 1)), dtype=np.int64)
+        perm = np.empty(max(n_edges, 1), dtype=np.int32)
+        off = np.empty(n_edges + 1, dtype=np.int32)
+        kept = C.c_int64(0)
+        n_coarse = lib.g4c_plan_pool_edge(idx.ctypes.data, n_hr, ei.ctypes.data, n_edges, coarse.ctypes.data,
+                                          perm.ctypes.data, off.ctypes.data, C.byref(kept))
+        if n_coarse < 0:
+            _lib.check(int(n_coarse))
+        n_coarse, n_kept = int(n_coarse), int(kept.value)
+        # the builder writes the two rows back to back at stride n_coarse
+        flat = coarse.reshape(-1)[: 2 * n_coarse].reshape(2, n_coarse) if n_coarse else np.empty((2, 0), dtype=np.int64)
+        off = off[: n_coarse + 1].copy()
+        deg = np.diff(off)
+        csr = CsrPlan(perm=torch.from_numpy(perm[:n_kept].copy()).to(dev), off=torch.from_numpy(off).to(dev),
+                      n=n_kept, n_seg=n_coarse, max_deg=int(deg.max()) if deg.size else 0)
+        plan = PoolEdgePlan(edge_index=torch.from_numpy(flat.copy()).to(dev), csr=csr, n_coarse=n_coarse)
+        _pool_plans.put(key, (idx_hr_to_lr, edge_index), plan)
+    return plan

@@ -1,0 +1,260 @@
+"""Synthetic meshes in the reference's `Graph` attribute layout, and the published arch dicts.
+
+The benchmark and the parity tests need inputs shaped exactly like what the reference's
+pre-processing transforms emit (SURVEY.md §8(b) "Graph data layout"), at sizes (100k nodes) where
+the reference's own Python-loop transforms are infeasible and on a box without PyG / torch_cluster.
+These builders are vectorised CPU restatements of
+  * `connect_knn` + `ScaleEdgeAttr`      (transforms/connect.py:9-92, transforms/scale.py:29),
+  * `grid_clustering` / `GridClustering` (transforms/mus.py:9-65),
+  * `guillard_coarsening`                (transforms/mugs.py:8-29),
+  * `extend_graph`, `BuildRemusGraph`, `angleIndexDownMP` (transforms/remus.py:9-175),
+  * `get_knn_interpolate_weights` / `BuildKnnInterpWeights` (transforms/interpolate.py:110-155),
+checked against outputs of the reference transforms in tests/test_synthetic.py.  They are one-off
+pre-processing (out of the hot path's HIP scope).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from scipy.spatial import cKDTree
+
+from .graph import Graph
+
+
+# ------------------------------------------------------------------------------ connectivity
+def knn_neighbours(points: np.ndarray, queries: np.ndarray, k: int) -> np.ndarray:
+    """Indices [len(queries), k] of the k nearest `points` of every query, by ascending distance."""
+    _, nbr = cKDTree(points).query(queries, k=k)
+    return np.asarray(nbr).reshape(len(queries), k)
+
+
+def connect_knn(pos: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Non-periodic `connect_knn` (transforms/connect.py:58-60): edges neighbour -> centre, grouped by
+    centre, k per centre, nearest first; edge_attr = pos[col] - pos[row]."""
+    p = pos.detach().cpu().double().numpy()
+    n = p.shape[0]
+    nbr = knn_neighbours(p, p, k + 1)
+    centre = np.repeat(np.arange(n), k + 1)
+    flat = nbr.reshape(-1)
+    keep = flat != centre
+    row = torch.from_numpy(flat[keep].astype(np.int64))
+    col = torch.from_numpy(centre[keep].astype(np.int64))
+    edge_index = torch.stack([row, col], 0)
+    return edge_index, pos[col] - pos[row]
+
+
+def grid_clustering(pos_1: torch.Tensor, cell_size_2: float):
+    """`grid_clustering` (transforms/mus.py:9-38): voxel-grid clusters -> (pos_2, cluster_2, mask_2,
+    idx1_to_idx2, e_12).  Voxel id = sum_d floor((p_d - min_d)/size) * stride_d with
+    stride = exclusive cumprod of floor((max-min)/size)+1 (torch_cluster.grid_cluster)."""
+    n, dim = pos_1.shape
+    size = torch.full((dim,), float(cell_size_2), dtype=pos_1.dtype)
+    start, end = pos_1.min(0)[0], pos_1.max(0)[0]
+    nvox = (end - start).true_divide(size).to(torch.long) + 1
+    stride = torch.cat([torch.ones(1, dtype=torch.long), nvox.cumprod(0)[:-1]])
+    cluster_2 = ((pos_1 - start).true_divide(size).to(torch.long) * stride).sum(1)
+    mask_2, idx1_to_idx2 = torch.unique(cluster_2, sorted=True, return_inverse=True)
+    n2 = mask_2.numel()
+    cnt = torch.bincount(idx1_to_idx2, minlength=n2).clamp(min=1).to(pos_1.dtype)
+    pos_2 = torch.zeros(n2, dim, dtype=pos_1.dtype).index_add_(0, idx1_to_idx2, pos_1) / cnt[:, None]
+    e_12 = (pos_2[idx1_to_idx2] - pos_1) / cell_size_2
+    return pos_2, cluster_2, mask_2, idx1_to_idx2, e_12
+
+
+def add_grid_levels(graph: Graph, cells_size: Sequence[float]) -> Graph:
+    """`GridClustering.__call__` (transforms/mus.py:56-65)."""
+    pos = graph.pos
+    for lvl, cell in enumerate(cells_size, start=2):
+        p, c, m, idx, e = grid_clustering(pos, cell)
+        setattr(graph, f"pos_{lvl}", p)
+        setattr(graph, f"cluster_{lvl}", c)
+        setattr(graph, f"mask_{lvl}", m)
+        setattr(graph, f"idx{lvl - 1}_to_idx{lvl}", idx)
+        setattr(graph, f"e_{lvl - 1}{lvl}", e)
+        pos = p
+    return graph
+
+
+def default_cells(n: int, dim: int, levels: int) -> List[float]:
+    """Cell sizes 2h * 2^(l-2), h = n^(-1/dim): ~2^dim nodes per level-2 cell, doubling per level like the
+    examples' 0.15/0.30/0.60."""
+    h = float(n) ** (-1.0 / dim)
+    return [2.0 * h * (2 ** i) for i in range(levels - 1)]
+
+
+def mus_graph(n: int, levels: int = 1, k: int = 6, dim: int = 2, nf: int = 3, n_in: int = 1, seed: int = 0,
+              r: Optional[float] = None, cells: Optional[Sequence[float]] = None, loc: bool = False) -> Graph:
+    """Synthetic MuS-GNN input: uniform random points in [0,1]^dim, kNN edges scaled by 1/(2r),
+    grid-clustered coarse levels, `field ~ N(0,1)`, `glob ~ U(0,1)`, `omega = U(0,1) > 0.9`."""
+    gen = torch.Generator().manual_seed(seed)
+    pos = torch.rand(n, dim, generator=gen)
+    g = Graph(pos=pos)
+    g.edge_index, ea = connect_knn(pos, k)
+    if r is None:
+        r = 2.0 * float(n) ** (-1.0 / dim)   # keeps |edge_attr| = O(1) at every mesh size
+    g.edge_attr = ea / (2 * r)
+    if levels > 1:
+        add_grid_levels(g, cells if cells is not None else default_cells(n, dim, levels))
+    g.field = torch.randn(n, nf * n_in, generator=gen)
+    if loc:
+        g.loc = torch.randn(n, 2, generator=gen)
+    g.glob = torch.rand(n, 1, generator=gen)
+    g.omega = (torch.rand(n, 1, generator=gen) > 0.9).float()
+    return g
+
+
+# ------------------------------------------------------------------------------ REMuS graphs
+def guillard_coarsening(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """Node-nested greedy coarsening (transforms/mugs.py:8-29): visit nodes in order; a node still
+    marked coarse removes all its k senders.  Sequential by definition."""
+    row = edge_index[0].numpy()
+    k = int((edge_index[1] == 0).sum())
+    senders = row.reshape(-1, k)
+    coarse = np.ones(num_nodes, dtype=bool)
+    for i in range(senders.shape[0]):
+        if coarse[i]:
+            coarse[senders[i]] = False
+    return torch.from_numpy(coarse)
+
+
+def extend_graph(edge_index: torch.Tensor, edge_attr: torch.Tensor, k: int):
+    """`extend_graph` (transforms/remus.py:9-45), vectorised: unit vectors, angle_index [2, k|E|]
+    (row = the k edges entering the sender of each edge, col = the edge), angle_attr [k|E|, 4]."""
+    row, col = edge_index[0], edge_index[1]
+    n_edges = edge_index.size(1)
+    size = edge_attr.norm(2, dim=1, keepdim=True)
+    unit = edge_attr / size
+    # edges are grouped by receiver, k per receiver, receivers in increasing order: the edges entering
+    # node r are the block starting at k * (rank of r among the receivers)
+    receivers = col[::k].contiguous()
+    rank = torch.searchsorted(receivers, row)
+    a_row = (rank[:, None] * k + torch.arange(k)[None, :]).reshape(-1)
+    a_col = torch.arange(n_edges).repeat_interleave(k)
+    cos = (unit[a_row] * unit[a_col]).sum(1)
+    sin = unit[a_row, 0] * unit[a_col, 1] - unit[a_row, 1] * unit[a_col, 0]
+    attr = torch.cat([size[a_row], size[a_col], cos[:, None], sin[:, None]], dim=1)
+    return unit, torch.stack([a_row, a_col], 0), attr
+
+
+def angle_index_down(edge_index1, edge_attr1, edge_index2, edge_attr2, coarse_index2, k):
+    """`BuildRemusGraph.angleIndexDownMP` (transforms/remus.py:151-176), vectorised."""
+    recv1 = edge_index1[1][::k].contiguous()
+    rank1 = torch.searchsorted(recv1, coarse_index2)
+    in_edges = rank1[:, None] * k + torch.arange(k)[None, :]          # [n2, k] level-1 edges entering each coarse node
+    # level-2 edges leaving each coarse node, in edge order
+    snd2 = edge_index2[0]
+    order = torch.argsort(snd2, stable=True)
+    rank_snd = torch.searchsorted(coarse_index2, snd2[order])
+    num_out = torch.bincount(rank_snd, minlength=coarse_index2.numel())
+    out_edges = order                                                  # grouped by coarse sender, ascending edge id
+    row = torch.repeat_interleave(in_edges, num_out, dim=0).reshape(-1)
+    col = torch.repeat_interleave(out_edges, k)
+    s1 = edge_attr1.norm(2, dim=1, keepdim=True)
+    s2 = edge_attr2.norm(2, dim=1, keepdim=True)
+    u1, u2 = edge_attr1 / s1, edge_attr2 / s2
+    cos = (u1[row] * u2[col]).sum(1)
+    sin = u1[row, 0] * u2[col, 1] - u1[row, 1] * u2[col, 0]
+    return torch.stack([row, col], 0), torch.cat([s1[row], s2[col], cos[:, None], sin[:, None]], dim=1)
+
+
+def knn_interp_weights(pos_x: torch.Tensor, pos_y: torch.Tensor, k: int):
+    """`get_knn_interpolate_weights` (transforms/interpolate.py:110-131): for every node of pos_y its k
+    nearest nodes of pos_x; weights = 1 / max(squared distance, 1e-16)."""
+    nbr = knn_neighbours(pos_x.double().numpy(), pos_y.double().numpy(), k)
+    y_idx = torch.arange(pos_y.size(0)).repeat_interleave(k)
+    x_idx = torch.from_numpy(nbr.reshape(-1).astype(np.int64))
+    diff = pos_x[x_idx] - pos_y[y_idx]
+    w = 1.0 / torch.clamp((diff * diff).sum(-1, keepdim=True), min=1e-16)
+    return y_idx, x_idx, w
+
+
+def remus_graph(n: int, k: int = 5, seed: int = 0, scale: Optional[Sequence[float]] = None,
+                pos: Optional[torch.Tensor] = None) -> Graph:
+    """Synthetic 3-level REMuS-GNN input: `BuildRemusGraph(num_levels=3, k, scale_edge_length)` +
+    `BuildKnnInterpWeights(k)` (transforms/remus.py:84-148, interpolate.py:134-155)."""
+    gen = torch.Generator().manual_seed(seed)
+    if pos is None:
+        pos = torch.rand(n, 2, generator=gen)
+    n = pos.size(0)
+    if scale is None:
+        h = 2.0 * float(n) ** -0.5
+        scale = (h, 2 * h, 4 * h)
+    g = Graph(pos=pos)
+    g.edge_index, g.edge_attr = connect_knn(pos, k)
+    g.edge_attr = g.edge_attr / (2 * scale[0])
+    g.coarse_mask2 = guillard_coarsening(g.edge_index, n)
+    ci2 = g.coarse_mask2.nonzero().reshape(-1)
+    ei2, ea2 = connect_knn(pos[ci2], k)
+    ea2 = ea2 / (2 * scale[1])
+    m3 = torch.zeros(n, dtype=torch.bool)
+    m3[g.coarse_mask2] = guillard_coarsening(ei2, ci2.numel())
+    g.coarse_mask3 = m3
+    ci3 = m3.nonzero().reshape(-1)
+    ei3, ea3 = connect_knn(pos[ci3], k)
+    ea3 = ea3 / (2 * scale[2])
+    g.edge_index2, g.edge_attr2 = ci2[ei2], ea2
+    g.edge_index3, g.edge_attr3 = ci3[ei3], ea3
+    for s, cnt in (("", n), ("2", ci2.numel()), ("3", ci3.numel())):
+        u, ai, aa = extend_graph(getattr(g, f"edge_index{s}"), getattr(g, f"edge_attr{s}"), k)
+        setattr(g, f"edgeUnitVector{s}", u)
+        setattr(g, f"angle_index{s}", ai)
+        setattr(g, f"angle_attr{s}", aa)
+        setattr(g, f"edgeUnitVectorInverse{s}", torch.linalg.pinv(u.reshape(cnt, -1, 2)))
+    g.angle_index12, g.angle_attr12 = angle_index_down(g.edge_index, g.edge_attr, g.edge_index2, g.edge_attr2, ci2, k)
+    g.angle_index23, g.angle_attr23 = angle_index_down(g.edge_index2, g.edge_attr2, g.edge_index3, g.edge_attr3, ci3, k)
+    g.y_idx_21, g.x_idx_21, g.weights_21 = knn_interp_weights(pos[ci2], pos, k)
+    g.y_idx_32, g.x_idx_32, g.weights_32 = knn_interp_weights(pos[ci3], pos[ci2], k)
+    g.field = torch.randn(n, 2, generator=gen)
+    g.glob = torch.rand(n, 1, generator=gen)
+    g.omega = (torch.rand(n, 1, generator=gen) > 0.9).float()
+    return g
+
+
+# ------------------------------------------------------------------------------ arch dicts
+MUS_LAYERS: Dict[str, str] = {
+    "NsOneScaleGNN": "mp11 mp12 mp13 mp14 mp15 mp16 mp17 mp18",
+    "NsTwoScaleGNN": "mp111 mp112 mp113 mp114 down_mp12 mp21 mp22 mp23 mp24 up_mp21 mp121 mp122 mp123 mp124",
+    "NsThreeScaleGNN": "mp111 mp112 mp113 mp114 down_mp12 mp211 mp212 down_mp23 mp31 mp32 mp33 mp34 up_mp32 mp221 mp222 "
+                       "up_mp21 mp121 mp122 mp123 mp124",
+    "NsFourScaleGNN": "mp111 mp112 mp113 mp114 down_mp12 mp211 mp212 down_mp23 mp311 mp312 down_mp34 mp41 mp42 mp43 mp44 "
+                      "up_mp43 mp321 mp322 up_mp32 mp221 mp222 up_mp21 mp121 mp122 mp123 mp124",
+    "AdvOneScaleGNN": "mp111 mp112 mp121 mp122",
+    "AdvTwoScaleGNN": "mp111 mp112 down_mp12 mp21 mp22 mp23 mp24 up_mp21 mp121 mp122",
+    "AdvThreeScaleGNN": "mp111 mp112 down_mp12 mp211 mp212 down_mp23 mp31 mp32 mp33 mp34 up_mp32 mp221 mp222 up_mp21 "
+                        "mp121 mp122",
+    "AdvFourScaleGNN": "mp111 mp112 down_mp12 mp211 mp212 down_mp23 mp311 mp312 down_mp34 mp41 mp42 mp43 mp44 up_mp43 "
+                       "mp321 mp322 up_mp32 mp221 mp222 up_mp21 mp121 mp122",
+}
+
+
+def mus_arch(model: str, hidden: int = 128, nf: int = 3, node_in: int = 5, dim: int = 2) -> dict:
+    """The arch dict published in the docstring of each reference class (e.g. nn/mus_gnn.py:105-129)
+    with latent width `hidden` (128 in every published model)."""
+    H = hidden
+    mp = ((H + 2 * H, (H, H, H), True), (H + H, (H, H, H), True))
+    arch = {"edge_encoder": (dim, (H, H, H), False), "node_encoder": (node_in, (H, H, H), False)}
+    for name in MUS_LAYERS[model].split():
+        arch[name] = (dim + H, (H, H, H), True) if name.startswith("down") else \
+            (dim + H + H, (H, H, H), True) if name.startswith("up") else mp
+    arch["decoder"] = (H, (H, H, nf), False)
+    return arch
+
+
+def remus_arch(hidden: int = 128) -> dict:
+    """Arch of NsRotEquiTreeScaleGNN (nn/remus_gnn.py:16-58)."""
+    H = hidden
+    mp = ((H + 2 * H, (H, H), True), (H + H, (H, H), True))
+    arch = {}
+    for n in ("angle_encoder", "angle_encoder12", "angle_encoder2", "angle_encoder23", "angle_encoder3"):
+        arch[n] = (4, (H, H), True)
+    for n in ("edge_encoder", "edge_encoder2", "edge_encoder3"):
+        arch[n] = (3, (H, H), True)
+    for n in ("mp111 mp112 mp113 mp114 down_mp12 mp211 mp212 down_mp23 mp31 mp32 mp33 mp34 mp221 mp222 "
+              "mp121 mp122 mp123 mp124").split():
+        arch[n] = mp
+    arch["up_mp32"] = (H + H, (H, H, H), True)
+    arch["up_mp21"] = (H + H, (H, H, H), True)
+    arch["decoder"] = (H, (H, 1), False)
+    return arch

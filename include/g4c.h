@@ -1,0 +1,157 @@
+/*
+ * g4c.h — C-ABI of libg4c.so: the MI355X (gfx950) implementation of graphs4cfd's
+ * message-passing hot path.
+ *
+ * The reference (mario-linov/graphs4cfd) has no FFI / operator registry: its hot path is
+ * Python calling torch + torch_geometric ops.  Each entry point below
+ * therefore names the reference *op sequence* (file:line under graphs4cfd/) that it
+ * replaces.  All pointers are raw device pointers unless marked "host"; `stream` is a
+ * hipStream_t passed as void*; indices are int32 (the reference's int64 index tensors are
+ * narrowed once, when the static mesh plan is built).  Every function returns 0 on
+ * success or a negative G4C_E* code; g4c_last_error() returns a thread-local message.
+ * No entry point synchronises the stream or allocates device memory, so a whole rollout
+ * step can be captured in a hipGraph.
+ *
+ * Reference-side binding: see INTEGRATION.md (ctypes stub for graphs4cfd/nn/blocks.py).
+ */
+#ifndef G4C_H
+#define G4C_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define G4C_OK 0
+#define G4C_EINVAL (-1)   /* bad argument (the Python binding raises ValueError) */
+#define G4C_ELAUNCH (-2)  /* HIP launch / runtime failure (RuntimeError) */
+#define G4C_EUNSUPPORTED (-3) /* shape outside the kernels' envelope (NotImplementedError) */
+
+#define G4C_ACT_NONE 0
+#define G4C_ACT_SELU 1
+#define G4C_ACT_TANH 2
+
+#define G4C_MAX_SRC 4
+#define G4C_MAX_LAYERS 4
+
+int g4c_version(void);
+const char *g4c_last_error(void);
+
+/* ---------------------------------------------------------------- static mesh plan (host)
+ * The reference recomputes topology every step with host syncs: `scatter(dim_size=None)`,
+ * `idx.max().item()`, `remove_self_loops`, `coalesce` (nn/blocks.py:45,63-67,109,231).  The
+ * plan builders do that work once per mesh.  Host pointers in, host pointers out. */
+
+/* Stable counting sort of `n` keys in [0, n_seg): perm[p] = original position of the p-th
+ * entry in key order, off[s]..off[s+1] = its segment.  Replaces the index handling inside
+ * torch_geometric.utils.scatter as called at nn/blocks.py:183,231,330,378. */
+int g4c_plan_csr(const int64_t *keys /*host*/, int64_t n, int64_t n_seg,
+                 int32_t *perm /*host, n*/, int32_t *off /*host, n_seg+1*/);
+
+/* Topology part of pool_edge (nn/blocks.py:51-68): remap endpoints through idx_hr_to_lr,
+ * drop intra-cluster edges, merge duplicates; coarse edges ordered by (row, col) exactly as
+ * torch_geometric.utils.coalesce orders them.  Outputs: coarse edge_index (2 x n_coarse,
+ * row-major), `perm` = surviving fine edges grouped by coarse edge (stable), `off` =
+ * n_coarse+1 segment offsets into perm.  Returns n_coarse (>= 0) or a negative error. */
+int64_t g4c_plan_pool_edge(const int64_t *idx_hr_to_lr /*host, n_hr*/, int64_t n_hr,
+                           const int64_t *edge_index /*host, 2 x n_edges*/, int64_t n_edges,
+                           int64_t *coarse_edge_index /*host, 2 x n_edges capacity*/,
+                           int32_t *perm /*host, n_edges capacity*/,
+                           int32_t *off /*host, n_edges+1 capacity*/,
+                           int64_t *n_kept /*host, 1*/);
+
+/* ---------------------------------------------------------------- aggregation (HBM-bound)
+ * out[s, :] = act( reduce_{p in [off[s], off[s+1])} src_act( src[perm ? perm[p] : p, :] ) )
+ * mean = sum / max(count, 1) (empty segments give 0).  Summation runs in p order, so with a
+ * stable plan the result equals a sequential scatter_add_.  Replaces
+ * torch_geometric.utils.scatter(reduce='sum'|'mean') at nn/blocks.py:183,231,330,378 and the
+ * feature part of coalesce(reduce='mean') at nn/blocks.py:67. */
+int g4c_segment_reduce(const float *src, int32_t src_ld, const int32_t *perm, const int32_t *off,
+                       int32_t n_seg, int32_t width, int32_t mean, int32_t src_act, int32_t act,
+                       float *out, int32_t out_ld, void *stream);
+
+/* knn_interpolate (nn/blocks.py:34-48) with fixed, y-sorted segments:
+ * out[o(s), :] = sum_p w[p] * x[x_idx[p], :] / sum_p w[p],  o(s) = out_idx ? out_idx[s] : s. */
+int g4c_weighted_segment_mean(const float *x, int32_t x_ld, const int32_t *x_idx, const float *w,
+                              const int32_t *off, int32_t n_seg, int32_t width,
+                              float *out, int32_t out_ld, const int32_t *out_idx, void *stream);
+
+/* ---------------------------------------------------------------- fused MLP (MFMA-bound)
+ * One kernel for: gather + concatenate up to 4 sources -> Linear -> (SELU -> Linear)* ->
+ * [LayerNorm] -> [SELU|tanh] -> [+ residual] -> store (optionally row-scattered).
+ * Replaces `MLP.forward` (nn/blocks.py:117-144) together with the torch.cat / index ops that
+ * feed it and the F.selu / torch.tanh / residual add that follow it at every call site
+ * (nn/blocks.py:181,185,229,285,328,332,373,380,456; nn/mus_gnn.py:178-218). */
+typedef struct {
+    const float *ptr;   /* [rows, ld] row-major */
+    const int32_t *idx; /* NULL: row r of the tile reads row r; else reads row idx[r] */
+    int32_t width;      /* columns taken from this source */
+    int32_t ld;         /* row stride in floats */
+    int32_t col0;       /* first column taken */
+    int32_t pre_act;    /* G4C_ACT_*: applied to the values as they are loaded (lets a producer store the
+                           un-activated tensor its aggregation needs, nn/blocks.py:181-183 vs nn/mus_gnn.py:182) */
+} g4c_src_t;
+
+typedef struct {
+    int32_t n_layers;                /* number of Linear layers, 2..G4C_MAX_LAYERS */
+    int32_t k_pad[G4C_MAX_LAYERS];   /* padded input width of each layer (see g4c_mlp_pack_layer) */
+    int32_t n_pad[G4C_MAX_LAYERS];   /* padded output width: 32, 64 or 128 */
+    const float *w[G4C_MAX_LAYERS];  /* packed weights, k_pad*n_pad floats each */
+    const float *b[G4C_MAX_LAYERS];  /* bias padded with zeros to n_pad */
+    const float *ln_gamma;           /* NULL: no LayerNorm */
+    const float *ln_beta;
+    float ln_eps;
+    int32_t n_out;                   /* true output width of the last layer */
+} g4c_mlp_t;
+
+/* Packs one nn.Linear weight W[n_out, k_in] (row-major, device) for the kernel.  The input
+ * dimension is the concatenation of `n_seg` column blocks of widths seg_width[] (each padded
+ * to a multiple of 4); seg_negate[s] != 0 folds a sign flip of that block into the weights
+ * (UpMP's `-e_hl`, nn/blocks.py:283).  Layout: [k_pad/2][n_pad][2].  k_pad = sum of padded
+ * block widths, n_pad = n_out rounded up to 32/64/128.  `packed` must hold k_pad*n_pad floats. */
+int g4c_mlp_pack_layer(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width /*host*/,
+                       const int32_t *seg_negate /*host*/, int32_t n_seg, float *packed,
+                       int32_t k_pad, int32_t n_pad, void *stream);
+
+int g4c_mlp_forward(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
+                    int64_t n_rows, float *out, int32_t out_ld, const int32_t *out_idx,
+                    int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0,
+                    void *stream);
+
+/* ---------------------------------------------------------------- REMuS helpers (HBM-bound)
+ * out[e, f] = v[node[e], 2f]*U[e,0] + v[node[e], 2f+1]*U[e,1]
+ * (nn/remus_gnn.py:124-126, nn/blocks.py:454). node == NULL reads row e. */
+int g4c_project_to_edges(const float *v, int32_t v_ld, const int32_t *node, const float *unit,
+                         int64_t n_edges, int32_t n_feat, float *out, int32_t out_ld, void *stream);
+
+/* edgeScalarToNodeVector with edgeUnitVectorInverse (nn/blocks.py:88-114):
+ * out[n, 2f+c] = sum_j unit_inv[n, c, j] * e[n*k + j, f]. */
+int g4c_edge_scalar_to_node_vector(const float *e, int32_t e_ld, const float *unit_inv, int32_t k,
+                                   int64_t n_nodes, int32_t n_feat, float *out, int32_t out_ld,
+                                   void *stream);
+
+/* ---------------------------------------------------------------- rollout (nn/model.py:303-327)
+ * One step's bookkeeping without host involvement: t = *step;
+ * outputs[:, nf*t : nf*(t+1)] = pred;  field = roll(field, -nf, dim=1); field[:, -nf:] = pred;
+ * then *step = t + 1 (by a trailing single-thread kernel on the same stream). */
+int g4c_rollout_advance(float *field, int32_t field_cols, const float *pred, int32_t nf,
+                        float *outputs, int32_t out_ld, int32_t *step, int64_t n_nodes, void *stream);
+
+/* out[r, c] = a[r, a_col0 + c] + b[r, c]: the residual time step `field[:, -nf:] + output`
+ * (nn/remus_gnn.py:199; the MuS-GNN decoder fuses it into g4c_mlp_forward's epilogue instead). */
+int g4c_add_cols(const float *a, int32_t a_ld, int32_t a_col0, const float *b, int32_t b_ld,
+                 float *out, int32_t out_ld, int32_t width, int64_t n_rows, void *stream);
+
+/* dst[r, dcol0 : dcol0+width] = src[r, scol0 : scol0+width]  (torch.cat of the narrow node inputs,
+ * nn/mus_gnn.py:71; also used to assemble halo send buffers when idx != NULL: reads src[idx[r]]). */
+/* x[i] = act(x[i]) in place, n contiguous floats (F.selu / torch.tanh on a block output). */
+int g4c_activation_inplace(float *x, int64_t n, int32_t act, void *stream);
+
+int g4c_copy_cols(const float *src, int32_t src_ld, int32_t scol0, const int32_t *idx,
+                  float *dst, int32_t dst_ld, int32_t dcol0, int32_t width, int64_t n_rows, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G4C_H */

@@ -1,0 +1,309 @@
+"""Parity of the HIP path (through the C-ABI of libg4c.so) with the oracle and with the golden
+vectors produced by the reference's own source.  Every test needs a real MI355X.
+
+Tolerances (fp32): per block max|d| <= 1e-4 on O(1) LayerNorm-scale outputs;
+full forward <= 5e-4; rollouts stated per length (error compounds autoregressively)."""
+import pytest
+import torch
+
+import graphs4cfd_amd as gfd
+from graphs4cfd_amd import _lib, ops, plan, synthetic as S
+from graphs4cfd_amd.nn import blocks as B
+from oracle import g4c_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+BLOCK = dict(rtol=1e-4, atol=1e-4)
+FWD = dict(rtol=5e-4, atol=5e-4)
+
+
+def cu(x):
+    if torch.is_tensor(x):
+        return x.to(DEV)
+    if isinstance(x, dict):
+        return {k: cu(v) for k, v in x.items()}
+    return x
+
+
+def load_weights(module, weights):
+    module.load_state_dict(weights)
+    return module.to(DEV)
+
+
+# ------------------------------------------------------------------ segment reduce (the scatter)
+@pytest.mark.parametrize("width", [128, 64, 32, 16, 6, 1])
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_segment_reduce_random_index(width, reduce):
+    torch.manual_seed(width)
+    n_seg, m = 500, 4000
+    idx = torch.randint(0, n_seg - 20, (m,))      # last 20 segments empty
+    idx[:300] = 7                                  # hub
+    src = torch.randn(m, width)
+    ref = O.scatter(src, idx, n_seg, reduce)
+    csr = plan.build_csr(idx, n_seg, DEV)
+    out = ops.segment_reduce(src.to(DEV), csr, reduce == "mean")
+    # plan order == index order within a segment -> same summation order as a sequential scatter_add_
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+    assert torch.all(out[-20:] == 0)
+
+
+def test_segment_reduce_sorted_bit_exact_and_activations():
+    torch.manual_seed(0)
+    k, n = 6, 3000
+    idx = torch.arange(n).repeat_interleave(k)
+    src = torch.randn(n * k, 128)
+    csr = plan.build_csr(idx, n, DEV)
+    assert csr.perm is None
+    out = ops.segment_reduce(src.to(DEV), csr, False)
+    ref = torch.zeros(n, 128).index_add_(0, idx, src)
+    assert torch.equal(out.cpu(), ref)
+    out = ops.segment_reduce(src.to(DEV), csr, True, act=_lib.ACT_TANH, src_act=_lib.ACT_SELU)
+    ref = torch.tanh(O.scatter(torch.nn.functional.selu(src), idx, n, "mean"))
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_scatter_dropin(golden):
+    c = golden("blocks.pt")["scatter"]
+    src, idx = c["src"].to(DEV), c["index"].to(DEV)
+    torch.testing.assert_close(B.scatter(src, idx, 0, 7, "sum").cpu(), c["sum_7"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(B.scatter(src, idx, 0, 7, "mean").cpu(), c["mean_7"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(B.scatter(src, idx, 0, None, "mean").cpu(), c["mean_none"], rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ blocks vs golden
+@pytest.mark.parametrize("i", range(8))
+def test_mlp(golden, i):
+    c = golden("blocks.pt")[f"mlp_{i}"]
+    mlp = load_weights(B.MLP(*c["args"]), c["weights"])
+    y = mlp(c["x"].to(DEV))
+    torch.testing.assert_close(y.cpu(), c["y"], **BLOCK)
+
+
+def test_mlp_row_tails_and_leading_dims(golden):
+    c = golden("blocks.pt")["mlp_1"]
+    mlp = load_weights(B.MLP(*c["args"]), c["weights"])
+    w = {f"m.{k}": v for k, v in c["weights"].items()}
+    for m in (1, 63, 64, 65, 200):
+        x = torch.randn(m, 384)
+        torch.testing.assert_close(mlp(x.to(DEV)).cpu(), O.mlp(x, w, "m"), **BLOCK)
+    x = torch.randn(3, 5, 384)
+    assert mlp(x.to(DEV)).shape == (3, 5, 128)
+
+
+@pytest.mark.parametrize("tag", ["h128_mean", "h32_sum", "h32_mean", "irregular"])
+def test_gnblock(golden, tag):
+    c = golden("blocks.pt")[f"gnblock_{tag}"]
+    blk = load_weights(B.GNBlock(*c["args"], aggr=c["aggr"]), c["weights"])
+    v, e = blk(c["v"].to(DEV), c["e"].to(DEV), c["edge_index"].to(DEV))
+    torch.testing.assert_close(v.cpu(), c["v_out"], **BLOCK)
+    torch.testing.assert_close(e.cpu(), c["e_out"], **BLOCK)
+    # fused-activation extension == activation applied afterwards
+    v2, e2 = blk(c["v"].to(DEV), c["e"].to(DEV), c["edge_index"].to(DEV), activation="selu")
+    torch.testing.assert_close(v2.cpu(), torch.nn.functional.selu(c["v_out"]), **BLOCK)
+    torch.testing.assert_close(e2.cpu(), torch.nn.functional.selu(c["e_out"]), **BLOCK)
+
+
+@pytest.mark.parametrize("tag", ["mean", "sum", "empty"])
+def test_pool_edge(golden, tag):
+    c = golden("blocks.pt")[f"pool_edge_{tag}"]
+    ei, ea = B.pool_edge(c["idx"].to(DEV), c["edge_index"].to(DEV), c["edge_attr"].to(DEV),
+                         aggr="sum" if tag == "sum" else "mean")
+    assert torch.equal(ei.cpu(), c["edge_index_out"])
+    torch.testing.assert_close(ea.cpu(), c["edge_attr_out"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("H", [32, 128])
+def test_down_up(golden, H):
+    c = golden("blocks.pt")[f"downup_h{H}"]
+    g = gfd.Graph(**cu(c["graph"]))
+    down = load_weights(B.DownMP(*c["down_args"]), c["down_weights"])
+    up = load_weights(B.UpMP(*c["up_args"]), c["up_weights"])
+    field1, pos1 = c["field1"].to(DEV), g.pos
+    g.field, g.edge_attr = field1, c["edge_attr1"].to(DEV)
+    g = down(g, activation=torch.tanh)
+    torch.testing.assert_close(g.field.cpu(), c["down_field"], **BLOCK)
+    assert torch.equal(g.edge_index.cpu(), c["down_edge_index"])
+    torch.testing.assert_close(g.edge_attr.cpu(), c["down_edge_attr"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(g.pos.cpu(), c["down_pos"])
+    g = up(g, field1, pos1, activation=torch.tanh)
+    torch.testing.assert_close(g.field.cpu(), c["up_field"], **BLOCK)
+    assert g.pos is pos1
+
+
+def test_remus_blocks(golden):
+    b = golden("blocks.pt")
+    g = cu(b["remus_graph"])
+    c = b["edgemp"]
+    emp = load_weights(B.EdgeMP(*c["args"]), c["weights"])
+    e, a = emp(c["e"].to(DEV), c["a"].to(DEV), c["angle_index"].to(DEV))
+    torch.testing.assert_close(e.cpu(), c["e_out"], **BLOCK)
+    torch.testing.assert_close(a.cpu(), c["a_out"], **BLOCK)
+    c = b["downedgemp"]
+    dmp = load_weights(B.DownEdgeMP(*c["args"]), c["weights"])
+    e2 = dmp(c["e1"].to(DEV), c["e2"].to(DEV), c["a12"].to(DEV), c["angle_index12"].to(DEV))
+    torch.testing.assert_close(e2.cpu(), c["e2_out"], **BLOCK)
+    c = b["upedgemp_21"]
+    ump = load_weights(B.UpEdgeMP(*c["args"]), c["weights"])
+    e1 = ump(g["pos"], g["y_idx_21"], g["x_idx_21"], g["weights_21"], c["edge_attr2"].to(DEV), g["edge_index2"],
+             g["edgeUnitVectorInverse2"], g["coarse_mask2"], c["edge_attr1"].to(DEV), g["edge_index"], g["edgeUnitVector"])
+    torch.testing.assert_close(e1.cpu(), c["e1_out"], **BLOCK)
+    c2 = b["upedgemp_32"]
+    e2 = ump(g["pos"], g["y_idx_32"], g["x_idx_32"], g["weights_32"], c2["edge_attr3"].to(DEV), g["edge_index3"],
+             g["edgeUnitVectorInverse3"], g["coarse_mask3"], c2["edge_attr2"].to(DEV), g["edge_index2"],
+             g["edgeUnitVector2"], g["coarse_mask2"])
+    torch.testing.assert_close(e2.cpu(), c2["e2_out"], **BLOCK)
+
+
+def test_remus_helpers(golden):
+    b = golden("blocks.pt")
+    g = cu(b["remus_graph"])
+    c = b["es2nv"]
+    out = B.edgeScalarToNodeVector(c["s1"].to(DEV), g["edge_index"], edgeUnitVectorInverse=g["edgeUnitVectorInverse"])
+    torch.testing.assert_close(out.cpu(), c["v1"], rtol=1e-5, atol=1e-5)
+    out = B.edgeScalarToNodeVector(c["sH"].to(DEV), g["edge_index2"], edgeUnitVectorInverse=g["edgeUnitVectorInverse2"],
+                                   coarse_mask=g["coarse_mask2"])
+    torch.testing.assert_close(out.cpu(), c["vH"], rtol=1e-5, atol=1e-5)
+    out = B.edgeScalarToNodeVector(c["s1"].to(DEV), g["edge_index"], edgeUnitVector=g["edgeUnitVector"])
+    torch.testing.assert_close(out.cpu(), c["v1_lstsq"], rtol=1e-3, atol=1e-4)
+    with pytest.raises(AssertionError):
+        B.edgeScalarToNodeVector(c["s1"].to(DEV), g["edge_index"])
+    c = b["knn_interpolate"]
+    y = B.knn_interpolate(c["x"].to(DEV), g["y_idx_21"], g["x_idx_21"], g["weights_21"])
+    torch.testing.assert_close(y.cpu(), c["y"], rtol=1e-5, atol=1e-5)
+    c = b["restriction"]
+    rg = gfd.Graph(field=torch.zeros(int(g["coarse_mask2"].sum()), 4, device=DEV))
+    B.restriction(rg, g["coarse_mask2"], torch.zeros(1, device=DEV), g["edge_index2"], g["pos"].size(0), DEV)
+    assert torch.equal(rg.edge_index.cpu(), c["edge_index_out"])
+
+
+# ------------------------------------------------------------------ models vs golden
+@pytest.mark.parametrize("cls", sorted(S.MUS_LAYERS))
+def test_mus_models(golden, cls):
+    c = golden("models_mus.pt")[cls]
+    model = getattr(gfd.nn, cls)(arch=c["arch"], device=DEV)
+    model.load_state_dict(c["weights"])
+    assert model.num_params == c["num_params"]
+    g = gfd.Graph(**cu(c["graph"]))
+    before = {k: v for k, v in g.to_dict().items()}
+    with torch.no_grad():
+        y = model.forward(g)
+    torch.testing.assert_close(y.cpu(), c["forward"], **FWD)
+    assert all(g.to_dict()[k] is v for k, v in before.items()), "forward must leave the Graph untouched"
+    y3 = model.solve(g, 3)
+    torch.testing.assert_close(y3.cpu(), c["solve3"], rtol=1e-3, atol=1e-3)
+    assert g.field is before["field"]
+
+
+def test_remus_model(golden):
+    c = golden("model_remus.pt")
+    model = gfd.nn.NsRotEquiTreeScaleGNN(arch=c["arch"], device=DEV)
+    model.load_state_dict(c["weights"])
+    assert model.num_params == c["num_params"] and model.num_fields == 2
+    g = gfd.Graph(**cu(c["graph"]))
+    with torch.no_grad():
+        y = model.forward(g)
+    torch.testing.assert_close(y.cpu(), c["forward"], **FWD)
+    torch.testing.assert_close(model.solve(g, 3).cpu(), c["solve3"], rtol=1e-3, atol=1e-3)
+
+
+def test_rollouts_eager_and_hipgraph(golden):
+    r = golden("rollout.pt")
+    c = r["two_scale"]
+    model = gfd.nn.NsTwoScaleGNN(arch=c["arch"], device=DEV)
+    model.load_state_dict(c["weights"])
+    g = gfd.Graph(**cu(c["graph"]))
+    torch.testing.assert_close(model.solve(g, 1).cpu(), c["solve1"], **FWD)
+    eager5 = model.solve(g, 5, capture=False)
+    torch.testing.assert_close(eager5.cpu(), c["solve5"], rtol=1e-3, atol=1e-3)
+    graph5 = model.solve(g, 5, capture=True)
+    assert torch.equal(eager5, graph5), "hipGraph replay must reproduce the eager rollout bit for bit"
+    s50 = model.solve(g, 50).cpu()
+    torch.testing.assert_close(s50[:, :30], c["solve50"][:, :30], rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(s50, c["solve50"], rtol=2e-2, atol=2e-2)
+    # history window n_in = 2 (shift_and_replace)
+    c = r["one_scale_nin2"]
+    model = gfd.nn.NsOneScaleGNN(arch=c["arch"], device=DEV)
+    model.load_state_dict(c["weights"])
+    g = gfd.Graph(**cu(c["graph"]))
+    torch.testing.assert_close(model.solve(g, 4, capture=False).cpu(), c["solve4"], rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(model.solve(g, 4, capture=True).cpu(), c["solve4"], rtol=1e-3, atol=1e-3)
+    x, y = torch.randn(10, 6, device=DEV), torch.randn(10, 3, device=DEV)
+    torch.testing.assert_close(model.shift_and_replace(x, y), torch.cat([x[:, 3:], y], 1))
+    with pytest.raises(AssertionError):
+        model.solve(g, 0)
+
+
+def test_reference_checkpoint_loads_and_runs(golden):
+    import os
+    c = golden("checkpoint_io.pt")
+    path = os.path.join(os.path.dirname(__file__), "golden", "reference_saved.chk")
+    model = gfd.nn.NsOneScaleGNN(checkpoint=path, device=DEV)
+    assert list(model.state_dict().keys()) == c["keys"]
+    g = gfd.Graph(**cu(c["graph"]))
+    with torch.no_grad():
+        torch.testing.assert_close(model.forward(g).cpu(), c["forward"], **FWD)
+
+
+# ------------------------------------------------------------------ production width vs oracle
+def test_three_scale_h128_vs_oracle():
+    g = S.mus_graph(6000, levels=3, seed=3)
+    arch = S.mus_arch("NsThreeScaleGNN", 128)
+    torch.manual_seed(5)
+    model = gfd.nn.NsThreeScaleGNN(arch=arch, device=DEV)
+    w = {k: v.cpu() for k, v in model.state_dict().items()}
+    ref = O.mus_forward("NsThreeScaleGNN", g.to_dict(), w, 3)
+    with torch.no_grad():
+        y = model.forward(g.clone().to(DEV))
+    torch.testing.assert_close(y.cpu(), ref, **FWD)
+
+
+def test_remus_h128_vs_oracle():
+    g = S.remus_graph(1500, k=5, seed=4)
+    torch.manual_seed(6)
+    model = gfd.nn.NsRotEquiTreeScaleGNN(arch=S.remus_arch(128), device=DEV)
+    w = {k: v.cpu() for k, v in model.state_dict().items()}
+    ref = O.remus_forward(g.to_dict(), w)
+    with torch.no_grad():
+        y = model.forward(g.clone().to(DEV))
+    torch.testing.assert_close(y.cpu(), ref, **FWD)
+
+
+# ------------------------------------------------------------------ full-size properties (100k nodes)
+def test_full_size_properties():
+    n, k, H = 100_000, 6, 128
+    g = S.mus_graph(n, levels=1, seed=9).to(DEV)
+    ep, csr = plan.edge_csr(g.edge_index, n)
+    assert csr.perm is None and csr.max_deg == k
+    # mean of per-edge constants equals the constant; sum is linear
+    a = torch.randn(n * k, H, device=DEV)
+    b = torch.randn(n * k, H, device=DEV)
+    sa, sb = ops.segment_reduce(a, csr, False), ops.segment_reduce(b, csr, False)
+    sab = ops.segment_reduce(a + 2 * b, csr, False)
+    torch.testing.assert_close(sab, sa + 2 * sb, rtol=1e-5, atol=1e-4)
+    ones = torch.full((n * k, H), 3.25, device=DEV)
+    assert torch.all(ops.segment_reduce(ones, csr, True) == 3.25)
+    # checksum: total of all segment sums == total of all messages (fp64 reference)
+    torch.testing.assert_close(sa.double().sum(), a.double().sum(), rtol=1e-9, atol=1e-3)
+    # one GNBlock at full size: permuting the edge order must not change node outputs
+    torch.manual_seed(1)
+    blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
+    v, e = torch.randn(n, H, device=DEV), torch.randn(n * k, H, device=DEV)
+    v1, e1 = blk(v, e, g.edge_index)
+    p = torch.randperm(n * k, device=DEV)
+    v2, e2 = blk(v, e[p], g.edge_index[:, p].contiguous())
+    torch.testing.assert_close(v2, v1, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(e2, e1[p], rtol=1e-5, atol=1e-5)
+    assert torch.isfinite(v1).all() and abs(float(v1.mean())) < 0.2
+
+
+# ------------------------------------------------------------------ error behaviour
+def test_errors():
+    mlp = B.MLP(8, (16, 16), True).to(DEV)
+    with pytest.raises(RuntimeError, match="HIP"):
+        mlp(torch.randn(4, 8))
+    with pytest.raises(ValueError):
+        mlp(torch.randn(4, 9, device=DEV))
+    with pytest.raises(NotImplementedError):
+        B.MLP(8, (256, 16)).to(DEV)(torch.randn(4, 8, device=DEV))
+    with pytest.raises(ValueError):
+        gfd.nn.NsOneScaleGNN(model="no-such-model")
