@@ -1,0 +1,175 @@
+"""bench.py — rollout timesteps/s of the MuS-GNN hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Workload (BASELINE.json metric "rollout timesteps/s ... on 100k-node 2D mesh"; SURVEY.md §8(d) C4 mesh):
+NsThreeScaleGNN with the published arch (H = 128, 4/2/4/2/4 MP layers), synthetic 100 000-node 2D
+mesh (uniform random points, kNN k = 6, grid-clustered levels 2 and 3), fp32, random-init weights.
+A step = one forward of the whole V-cycle + the rollout bookkeeping kernel, replayed from a hipGraph.
+With N > 1 the same mesh is node-partitioned over the ranks (strong scaling, one halo exchange per MP
+layer over RCCL).
+
+One JSON line on stdout (rank 0).  Extra objects:
+  roofline     — dominant kernel (g4c fused MLP, fp32 MFMA): algorithmic FLOP / measured duration,
+                 from HIP-event pairs around every launch of an eager pass of the same step.
+  roofline_scatter — the CSR segment-reduce ("scatter-sum") against the HBM roofline, same method.
+  cpu_baseline — the oracle (pure-torch restatement of the reference CPU path) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+PEAK_HBM_GBS = 8000.0           # HBM3E spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--nodes", type=int, default=100_000)
+    ap.add_argument("--model", default="NsThreeScaleGNN")
+    ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=30.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(model_name, graph, weights, nf, budget_s):
+    """Oracle rollout steps on the host cores: bounded sample (>= 1 step, <= budget)."""
+    from oracle import g4c_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = graph.to_dict()
+    t0 = time.perf_counter()
+    steps = 0
+    with torch.no_grad():
+        while True:
+            pred = O.mus_forward(model_name, g, weights, nf)
+            g = dict(g)
+            g["field"] = O.shift_and_replace(g["field"], pred, nf)
+            steps += 1
+            el = time.perf_counter() - t0
+            if steps >= 3 or el + el / steps > budget_s:
+                break
+    return {"value": steps / el, "unit": "rollout timesteps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} rollout step(s) of the same {graph.num_nodes}-node mesh and weights, "
+                      f"oracle (op-for-op torch restatement of the reference CPU path, per-step pool_edge rebuild), "
+                      f"{torch.get_num_threads()} torch threads, {el:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    import graphs4cfd_amd as gfd
+    from graphs4cfd_amd import ops, synthetic as S
+    from graphs4cfd_amd.nn.model import Rollout
+
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    levels = {"NsOneScaleGNN": 1, "NsTwoScaleGNN": 2, "NsThreeScaleGNN": 3, "NsFourScaleGNN": 4}[args.model]
+    graph_cpu = S.mus_graph(args.nodes, levels=levels, seed=0)
+    arch = S.mus_arch(args.model, args.hidden)
+    torch.manual_seed(0)
+    model = getattr(gfd.nn, args.model)(arch=arch, device=dev)
+    model.eval()
+    nf = model.num_fields
+    total_steps = args.warmup + args.steps
+
+    if world > 1:
+        from graphs4cfd_amd import partition
+        runner = partition.DistributedRollout(model, graph_cpu, total_steps + 2, rank, world, dev)
+    else:
+        runner = Rollout(model, graph_cpu.clone().to(dev), total_steps + 2, capture=True)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    # untimed: the eager first step (plans, packing), the capture step, then W warm-up replays
+    runner.run(2)
+    runner.run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    runner.run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    finite = bool(torch.isfinite(runner.outputs).all().item())
+
+    result = {
+        "metric": "rollout timesteps/s (100k-node 2D mesh)", "value": args.steps / elapsed, "unit": "rollout timesteps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model} (published arch, H={args.hidden}) rollout on a {args.nodes}-node synthetic 2D mesh, "
+                               f"kNN k=6, {levels} grid-clustered scale(s), hipGraph-replayed step",
+                   "nodes": args.nodes, "edges": int(graph_cpu.edge_index.size(1)), "mp_layers_per_step": sum(
+                       1 for n in S.MUS_LAYERS[args.model].split() if n.startswith("mp")),
+                   "partition": "none" if world == 1 else f"{world}-way node partition, halo exchange per MP layer (RCCL)"},
+        "outputs_finite": finite,
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        # eager instrumented pass of the same step: HIP-event pair around every launch, on the launch stream
+        eager = Rollout(model, graph_cpu.clone().to(dev), 8, capture=False)
+        eager.run(2)
+        torch.cuda.synchronize(dev)
+        with ops.KernelTimer() as kt:
+            eager.run(3)
+        torch.cuda.synchronize(dev)
+        summ = kt.summary()
+        m, s = summ["mlp_fused"], summ["segment_reduce"]
+        result["roofline"] = {"bound": "mfma", "kernel": "mlp_fused_kernel (g4c_mlp_forward)",
+                              "achieved": m["flops"] / m["seconds"] / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": m["flops"] / m["seconds"] / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                              "launches_per_step": m["launches"] // 3, "avg_launch_us": 1e6 * m["seconds"] / m["launches"],
+                              "flop_per_step": m["flops"] / 3, "ms_per_step_in_kernel": 1e3 * m["seconds"] / 3}
+        result["roofline_scatter"] = {"bound": "hbm", "kernel": "segment_reduce_kernel (g4c_segment_reduce)",
+                                      "achieved": s["bytes"] / s["seconds"] / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": s["bytes"] / s["seconds"] / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                                      "launches_per_step": s["launches"] // 3,
+                                      "avg_launch_us": 1e6 * s["seconds"] / s["launches"]}
+        # the level-1 aggregation alone (the 358.8 MB case of BASELINE.md §4)
+        big = [(b, a.elapsed_time(e) * 1e-3) for k, f, b, a, e in kt.records if k == "segment_reduce"]
+        bmax = max(b for b, _ in big)
+        sel = [(b, t) for b, t in big if b == bmax]
+        result["roofline_scatter"]["level1"] = {"bytes": bmax, "avg_launch_us": 1e6 * sum(t for _, t in sel) / len(sel),
+                                                "achieved": bmax * len(sel) / sum(t for _, t in sel) / 1e9,
+                                                "frac": bmax * len(sel) / sum(t for _, t in sel) / 1e9 / PEAK_HBM_GBS}
+        eager.close()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        weights = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        result["cpu_baseline"] = cpu_baseline(args.model, graph_cpu, weights, nf, args.cpu_budget_s)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -103,9 +103,9 @@ extern "C" int g4c_segment_reduce(const float *src, int32_t src_ld, const int32_
                                   float *out, int32_t out_ld, void *stream) {
     G4C_REQUIRE(n_seg >= 0 && width > 0 && src_ld >= width && out_ld >= width, G4C_EINVAL,
                 "g4c_segment_reduce: bad sizes n_seg=%d width=%d src_ld=%d out_ld=%d", n_seg, width, src_ld, out_ld);
-    G4C_REQUIRE(off != nullptr && out != nullptr && (src != nullptr || n_seg == 0), G4C_EINVAL,
-                "g4c_segment_reduce: null pointer");
     if (n_seg == 0) return G4C_OK;
+    G4C_REQUIRE(off != nullptr && out != nullptr, G4C_EINVAL, "g4c_segment_reduce: null pointer");
+    G4C_REQUIRE(src != nullptr || perm == nullptr, G4C_EINVAL, "g4c_segment_reduce: null src with a permutation");
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (width % 4 == 0) && (src_ld % 4 == 0) && (out_ld % 4 == 0) &&
                      ((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0);

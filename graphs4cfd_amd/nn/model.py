@@ -112,35 +112,11 @@ class GNN(nn.Module):
             else:
                 graph.batch = torch.zeros(graph.num_nodes, dtype=torch.long, device=self.device)
             graph.to(self.device)
-            _lib.require_hip(graph.field)
-            field = graph.field
-            nf = self.num_fields
-            n = graph.num_nodes
-            outputs = torch.zeros((n, nf * n_out), dtype=torch.float32, device=self.device)
-            work = field.to(torch.float32).clone(memory_format=torch.contiguous_format)
-            step = torch.zeros(1, dtype=torch.int32, device=self.device)
             if capture is None:
                 capture = n_out >= 4 and os.environ.get("G4C_HIPGRAPH", "1") != "0"
-            graph.field = work
-            try:
-                # step 1 eagerly: builds every static plan and packs the weights (host work, one-off)
-                pred = self.forward(graph, 0)
-                ops.rollout_advance(work, pred, outputs, step, nf)
-                if capture and n_out > 1:
-                    torch.cuda.synchronize(self.device)
-                    hg = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(hg):
-                        pred = self.forward(graph, 1)
-                        ops.rollout_advance(work, pred, outputs, step, nf)
-                    for _ in range(2, n_out):
-                        hg.replay()
-                else:
-                    for t in range(1, n_out):
-                        pred = self.forward(graph, t)
-                        ops.rollout_advance(work, pred, outputs, step, nf)
-            finally:
-                graph.field = field
-            return outputs
+            with Rollout(self, graph, n_out, capture=capture) as ro:
+                ro.run(n_out)
+                return ro.outputs
 
     def shift_and_replace(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         """Shift the fields in x by num_fields and replace the last num_fields with y (nn/model.py:323-327).
@@ -170,3 +146,69 @@ class GNN(nn.Module):
     def num_params(self):
         """Returns the number of trainable parameters."""
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+
+class Rollout:
+    """Device-resident autoregressive rollout state for one (model, Graph) pair (GNN.solve,
+    nn/model.py:303-321).
+
+    `step()` = one forward + one `g4c_rollout_advance` (writes outputs[:, nf*t:nf*(t+1)], shifts the
+    history window, bumps the device-side step counter).  The first step runs eagerly and builds all
+    static plans / packed weights; with `capture=True` the second step is captured into a hipGraph and
+    every later step is a replay: no host synchronisation, no per-kernel launch cost.
+    The caller's `graph.field` is swapped for a private working copy and restored on close()."""
+
+    def __init__(self, model: "GNN", graph: Graph, max_steps: int, capture: bool = True):
+        _lib.require_hip(graph.field)
+        self.model, self.graph, self.capture = model, graph, capture
+        self.nf = int(model.num_fields)
+        self.max_steps = int(max_steps)
+        dev = graph.field.device
+        self._orig_field = graph.field
+        self.field = graph.field.to(torch.float32).clone(memory_format=torch.contiguous_format)
+        self.outputs = torch.zeros((graph.num_nodes, self.nf * self.max_steps), dtype=torch.float32, device=dev)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.steps_done = 0
+        self._hipgraph = None
+        graph.field = self.field
+
+    def _one(self):
+        pred = self.model.forward(self.graph, self.steps_done)
+        ops.rollout_advance(self.field, pred, self.outputs, self.step_counter, self.nf)
+
+    def step(self) -> None:
+        if self.steps_done >= self.max_steps:
+            raise RuntimeError(f"rollout buffer holds {self.max_steps} steps")
+        with torch.no_grad():
+            if self.steps_done == 0 or not self.capture:
+                self._one()
+            elif self._hipgraph is None:
+                torch.cuda.synchronize(self.field.device)
+                self._hipgraph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._hipgraph):   # records only; nothing executes during capture
+                    self._one()
+                self._hipgraph.replay()
+            else:
+                self._hipgraph.replay()
+        self.steps_done += 1
+
+    def run(self, n: int) -> None:
+        for _ in range(n):
+            self.step()
+
+    def rewind(self) -> None:
+        """Restart writing at step 0 (benchmarks: keeps the captured hipGraph and the current field)."""
+        self.step_counter.zero_()
+        self.steps_done = 1 if self.steps_done > 0 else 0
+        if self.steps_done:   # slot 0 is kept so that replays continue from slot 1
+            self.step_counter.fill_(1)
+
+    def close(self) -> None:
+        self.graph.field = self._orig_field
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

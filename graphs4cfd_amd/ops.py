@@ -14,6 +14,47 @@ from .plan import CsrPlan
 Tensor = torch.Tensor
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).
+    `with KernelTimer() as kt: ...` brackets every g4c_mlp_forward / g4c_segment_reduce launch with an
+    event pair and records its algorithmic work; `kt.summary()` after a device sync."""
+    active = None
+
+    def __init__(self):
+        self.records = []   # (kind, flops, bytes, start_event, end_event)
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+        return False
+
+    def launch(self, kind: str, flops: float, nbytes: float, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        self.records.append((kind, flops, nbytes, a, b))
+        return out
+
+    def summary(self):
+        out = {}
+        for kind, flops, nbytes, a, b in self.records:
+            d = out.setdefault(kind, {"launches": 0, "seconds": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["seconds"] += a.elapsed_time(b) * 1e-3
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+def _timed(kind: str, flops: float, nbytes: float, fn):
+    kt = KernelTimer.active
+    return fn() if kt is None else kt.launch(kind, flops, nbytes, fn)
+
+
 def _f32_2d(t: Tensor, name: str) -> Tensor:
     if t.dtype != torch.float32:
         raise TypeError(f"{name}: expected float32, got {t.dtype}")
@@ -54,8 +95,11 @@ def segment_reduce(src: Tensor, csr: CsrPlan, mean: bool, act: int = _lib.ACT_NO
     width = int(src.size(1))
     if out is None:
         out = torch.empty((csr.n_seg, width), dtype=torch.float32, device=dev)
-    _lib.check(lib.g4c_segment_reduce(_lib.ptr(src), _ld(src), _lib.ptr(csr.perm), _lib.ptr(csr.off), csr.n_seg, width,
-                                      1 if mean else 0, src_act, act, _lib.ptr(out), _ld(out), _lib.stream_handle(dev)))
+    # algorithmic bytes: messages read + rows written + offsets (+ permutation)
+    nbytes = 4.0 * (csr.n * width + csr.n_seg * width + csr.n_seg + 1 + (csr.n if csr.perm is not None else 0))
+    _timed("segment_reduce", 0.0, nbytes, lambda: _lib.check(lib.g4c_segment_reduce(
+        _lib.ptr(src), _ld(src), _lib.ptr(csr.perm), _lib.ptr(csr.off), csr.n_seg, width,
+        1 if mean else 0, src_act, act, _lib.ptr(out), _ld(out), _lib.stream_handle(dev))))
     return out
 
 
@@ -152,11 +196,19 @@ class PackedMLP:
         self.desc.n_layers = n_layers
         self._keep: List[Tensor] = []
         stream = _lib.stream_handle(dev)
+        KC, NP = 32, 128                       # kernel constants: K chunk, computed layer width
+        k_pad0 = sum((s + KC - 1) // KC * KC for s in seg_widths)
+        k_pads = [k_pad0] + [NP] * (n_layers - 1)
+        # one contiguous weight stream (layer after layer, 32-k chunk after chunk) + one chunk of slack:
+        # the kernel's register ring prefetches one chunk past the end
+        stream_buf = torch.zeros((sum(k_pads) + KC) * NP, dtype=torch.float32, device=dev)
+        bias_buf = torch.zeros(n_layers * NP, dtype=torch.float32, device=dev)
+        self._keep += [stream_buf, bias_buf]
+        off = 0
         for l, (W, b) in enumerate(zip(weights, biases)):
             n_out, k_in = int(W.size(0)), int(W.size(1))
-            if n_out > 128:
+            if n_out > NP:
                 raise NotImplementedError(f"layer width {n_out} > 128 is outside the fused-MLP kernel envelope")
-            n_pad = 32 if n_out <= 32 else 64 if n_out <= 64 else 128
             if l == 0:
                 segs, negs = list(seg_widths), [1 if x else 0 for x in seg_negate]
             else:
@@ -164,28 +216,19 @@ class PackedMLP:
                 if k_in != prev:
                     raise ValueError(f"layer {l + 1} expects {k_in} inputs, previous layer gives {prev}")
                 segs, negs = [k_in], [0]
-            k_pad = sum((s + 3) // 4 * 4 for s in segs) if l == 0 else self.desc.n_pad[l - 1]
             Wc = W.detach().to(torch.float32).contiguous()
-            packed = torch.zeros(k_pad * n_pad, dtype=torch.float32, device=dev)
-            if l == 0:
-                seg_arr = (C.c_int32 * len(segs))(*segs)
-                neg_arr = (C.c_int32 * len(segs))(*negs)
-                _lib.check(lib.g4c_mlp_pack_layer(_lib.ptr(Wc), n_out, k_in, seg_arr, neg_arr, len(segs), _lib.ptr(packed),
-                                                  k_pad, n_pad, stream))
-            else:
-                # hidden layers: one block of width k_in, zero rows up to the previous layer's padded width
-                seg_arr = (C.c_int32 * 1)(k_in)
-                neg_arr = (C.c_int32 * 1)(0)
-                kp_real = (k_in + 3) // 4 * 4
-                _lib.check(lib.g4c_mlp_pack_layer(_lib.ptr(Wc), n_out, k_in, seg_arr, neg_arr, 1, _lib.ptr(packed),
-                                                  kp_real, n_pad, stream))
-            bias = torch.zeros(n_pad, dtype=torch.float32, device=dev)
-            bias[:n_out].copy_(b.detach())
-            self.desc.k_pad[l], self.desc.n_pad[l] = k_pad, n_pad
-            self.desc.w[l], self.desc.b[l] = packed.data_ptr(), bias.data_ptr()
-            self._keep += [packed, bias]
+            seg_arr = (C.c_int32 * len(segs))(*segs)
+            neg_arr = (C.c_int32 * len(segs))(*negs)
+            wptr = stream_buf.data_ptr() + 4 * off
+            _lib.check(lib.g4c_mlp_pack_layer(_lib.ptr(Wc), n_out, k_in, seg_arr, neg_arr, len(segs), wptr,
+                                              k_pads[l], NP, stream))
+            bias_buf[l * NP: l * NP + n_out].copy_(b.detach())
+            self.desc.k_pad[l], self.desc.n_pad[l] = k_pads[l], NP
+            self.desc.w[l], self.desc.b[l] = wptr, bias_buf.data_ptr() + 4 * l * NP
+            off += k_pads[l] * NP
         self.n_out = int(weights[-1].size(0))
         self.desc.n_out = self.n_out
+        self.flops_per_row = float(sum(2 * int(W.size(0)) * int(W.size(1)) for W in weights))   # nn.Linear MACs x 2
         if ln is not None:
             g, be, eps = ln
             g, be = g.detach().to(torch.float32).contiguous(), be.detach().to(torch.float32).contiguous()
@@ -212,7 +255,8 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                                                           s.col0, s.pre_act)
     if out is None:
         out = torch.empty((n_rows, packed.n_out), dtype=torch.float32, device=dev)
-    _lib.check(lib.g4c_mlp_forward(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out), _ld(out),
-                                   _lib.ptr(out_idx32), act, _lib.ptr(resid), _ld(resid) if resid is not None else 0,
-                                   resid_col0, _lib.stream_handle(dev)))
+    _timed("mlp_fused", packed.flops_per_row * n_rows, 4.0 * n_rows * (sum(packed.seg_widths) + packed.n_out),
+           lambda: _lib.check(lib.g4c_mlp_forward(
+               C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out), _ld(out), _lib.ptr(out_idx32), act,
+               _lib.ptr(resid), _ld(resid) if resid is not None else 0, resid_col0, _lib.stream_handle(dev))))
     return out
