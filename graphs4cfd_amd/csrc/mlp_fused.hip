@@ -60,6 +60,7 @@ struct Params {
     const float *resid;
     int resid_ld, resid_col0;
     int n_tiles;
+    int ablate;   // debug only (env G4C_ABLATE): 1 no ring refill, 2 no input staging, 4 no epilogues/final pass
 };
 
 template <int RT> struct Acc { f32x16 t[RT][4]; };
@@ -112,7 +113,7 @@ __device__ __forceinline__ void ring_fill(Ring &g, const float *wchunk, int lane
 // MFMAs, then refill the ring slot just consumed with the same step of the NEXT chunk.  The
 // sched_barrier pins that order (without it hipcc sinks all 16 refill loads to the chunk boundary,
 // which exposes a full L2 round trip per chunk).
-template <int RT>
+template <int RT, bool REFILL = true>
 __device__ __forceinline__ void mma_chunk(const float *pa, int a_tile_stride, Ring &g, const float *wnext, int lane,
                                           Acc<RT> &acc) {
     AOp<RT> a = load_a<RT>(pa, a_tile_stride);
@@ -120,7 +121,7 @@ __device__ __forceinline__ void mma_chunk(const float *pa, int a_tile_stride, Ri
     {                                                                         \
         const AOp<RT> an = load_a<RT>(pa + (((U) + 1) & 7) * 4, a_tile_stride); \
         mma_step<RT>(a, g.SLOT, acc);                                         \
-        g.SLOT = load_b(wnext, (U), lane);                                    \
+        if (REFILL) g.SLOT = load_b(wnext, (U), lane);                        \
         __builtin_amdgcn_sched_barrier(0);                                    \
         a = an;                                                               \
     }
@@ -129,43 +130,65 @@ __device__ __forceinline__ void mma_chunk(const float *pa, int a_tile_stride, Ri
 #undef G4C_STEP
 }
 
-// ---- gathered input chunk: lane (r = lane>>3 [+8q], c4 = lane&7) loads 4 consecutive columns
+// ---- gathered input chunk: lane (r = lane>>3 [+8q], c4 = lane&7) loads 4 consecutive columns.
+// VEC: every source is 16-byte addressable (width, ld, col0 multiples of 4, aligned base) -> one
+// unconditional 16-byte load per row; the generic path does 4 clamped scalar loads.
+template <bool VEC>
 __device__ __forceinline__ f32x4 ldx1(const Src &s, int srow, int c) {
     const float *base = s.ptr + (long long)srow * s.ld + s.col0;
     f32x4 t;
-    if (s.vec) {
-        // columns beyond the source width (padding up to 32) are zero-filled; the load itself is
-        // unconditional from a clamped column
+    if (VEC) {
+        // columns beyond the source width (padding up to 32) are zero-filled by select; the load
+        // itself is unconditional from a clamped column (no path-dependent load count: hipcc can
+        // then wait for these loads with an exact vmcnt instead of draining the weight ring)
+        // (the zero fill itself happens in finish_x, after the MFMAs: touching the loaded value here
+        // would make the wave wait for the gather before it starts computing)
         t = *reinterpret_cast<const f32x4 *>(base + (c < s.width ? c : 0));
-        if (c >= s.width) { t[0] = 0.f; t[1] = 0.f; t[2] = 0.f; t[3] = 0.f; }
     } else {
         const int w1 = s.width - 1;
         t[0] = base[c + 0 < w1 ? c + 0 : w1];
         t[1] = base[c + 1 < w1 ? c + 1 : w1];
         t[2] = base[c + 2 < w1 ? c + 2 : w1];
         t[3] = base[c + 3 < w1 ? c + 3 : w1];
-        t[0] = (c + 0 < s.width) ? t[0] : 0.f;
-        t[1] = (c + 1 < s.width) ? t[1] : 0.f;
-        t[2] = (c + 2 < s.width) ? t[2] : 0.f;
-        t[3] = (c + 3 < s.width) ? t[3] : 0.f;
-    }
-    if (s.pre_act) {   // act(0) == 0 for SELU and tanh, so the zero fill survives
-        t[0] = g4c::apply_act(t[0], s.pre_act); t[1] = g4c::apply_act(t[1], s.pre_act);
-        t[2] = g4c::apply_act(t[2], s.pre_act); t[3] = g4c::apply_act(t[3], s.pre_act);
     }
     return t;
 }
 
 template <int RT> struct XRegs { f32x16 v[RT]; };   // RT*4 float4 per lane
 
-template <int RT>
+template <int RT, bool VEC>
 __device__ __forceinline__ void load_x(const Src &s, const int *sRow, int k0, int lane, XRegs<RT> &x) {
     const int c = k0 + (lane & 7) * 4;
 #pragma unroll
     for (int q = 0; q < RT * 4; ++q) {
-        const f32x4 t = ldx1(s, sRow[(lane >> 3) + 8 * q], c);
+        const f32x4 t = ldx1<VEC>(s, sRow[(lane >> 3) + 8 * q], c);
         x.v[q >> 2][(q & 3) * 4 + 0] = t[0]; x.v[q >> 2][(q & 3) * 4 + 1] = t[1];
         x.v[q >> 2][(q & 3) * 4 + 2] = t[2]; x.v[q >> 2][(q & 3) * 4 + 3] = t[3];
+    }
+}
+
+// On the way from registers to LDS (after the MFMAs that hid the gather's latency): zero the
+// columns beyond the source width (padding up to 32) and apply the source's pending activation
+// (its producer stored the raw tensor).
+template <int RT>
+__device__ __forceinline__ void pre_act_x(XRegs<RT> &x, int act, int width, int k0, int lane) {
+    const int c = k0 + (lane & 7) * 4;
+    if (c + 3 >= width) {   // only the last chunk of a source whose width is not a multiple of 32
+#pragma unroll
+        for (int q = 0; q < RT; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x.v[q][e] = (c + (e & 3) < width) ? x.v[q][e] : 0.f;
+    }
+    if (act == G4C_ACT_SELU) {
+#pragma unroll
+        for (int q = 0; q < RT; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x.v[q][e] = g4c::selu_f(x.v[q][e]);
+    } else if (act == G4C_ACT_TANH) {
+#pragma unroll
+        for (int q = 0; q < RT; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x.v[q][e] = g4c::tanh_f(x.v[q][e]);
     }
 }
 
@@ -182,20 +205,21 @@ __device__ __forceinline__ void store_x(float *sX, int lane, const XRegs<RT> &x)
 
 // bias (+ SELU unless last layer) of the accumulators -> hidden buffer.
 // C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-template <int RT>
-__device__ __forceinline__ void store_hidden(const Acc<RT> &acc, float *sH, const float *bias, int lane, bool last) {
+template <int RT, bool LAST>
+__device__ __forceinline__ void store_hidden(const Acc<RT> &acc, float *sH, const float *sBias, int lane) {
     const int i = lane & 31, h = lane >> 5;
+    float *base = sH + (4 * h) * HS + i;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float bv = bias[c * 32 + i];
+        const float bv = sBias[c * 32 + i];
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int row = r * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const int row = r * 32 + (q & 3) + 8 * (q >> 2);
                 float x = acc.t[r][c][q] + bv;
-                if (!last) x = g4c::selu_f(x);
-                sH[row * HS + c * 32 + i] = x;
+                if (!LAST) x = g4c::selu_f(x);
+                base[row * HS + c * 32] = x;
             }
         }
     }
@@ -211,14 +235,16 @@ __device__ __forceinline__ void zero_acc(Acc<RT> &acc) {
             for (int q = 0; q < 16; ++q) acc.t[r][c][q] = 0.f;
 }
 
-template <int RT>
+template <int RT, bool VEC>
 __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Params p) {
     constexpr int ROWS = RT * 32;
-    __shared__ __attribute__((aligned(16))) float lds[ROWS * HS + G4C_MAX_SRC * ROWS];
+    __shared__ __attribute__((aligned(16))) float lds[ROWS * HS + G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
     float *sH = lds;                         // hidden activations (layers >= 1) ...
     float *sX0 = lds;                        // ... aliasing the two input-chunk buffers of layer 0
     float *sX1 = lds + ROWS * XS;
     int *sRow = reinterpret_cast<int *>(lds + ROWS * HS);
+    float *sBias = lds + ROWS * HS + G4C_MAX_SRC * ROWS;   // [n_layers][128]
+    float *sGB = sBias + G4C_MAX_LAYERS * NP;              // gamma[128], beta[128]
 
     const int lane = threadIdx.x;
     const int i = lane & 31, h = lane >> 5;
@@ -238,6 +264,14 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
         if (gr >= p.M) gr = p.M - 1;
         for (int s = 0; s < p.n_src; ++s) sRow[s * ROWS + r] = p.src[s].idx ? p.src[s].idx[gr] : (int)gr;
     }
+    for (int e = lane; e < p.n_layers * NP; e += 64) sBias[e] = p.b[e];
+    if (p.gamma) {
+        for (int e = lane; e < NP; e += 64) {
+            const int ee = e < p.n_out ? e : 0;
+            sGB[e] = p.gamma[ee];
+            sGB[NP + e] = p.beta[ee];
+        }
+    }
     // (single wave: LDS operations complete in order, no barrier needed)
 
     Acc<RT> acc;
@@ -250,19 +284,27 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
     ring_fill(ring, w, lane);
     {
         int s = 0, k0 = 0;
-        load_x<RT>(p.src[0], sRow, 0, lane, xr);
+        load_x<RT, VEC>(p.src[0], sRow, 0, lane, xr);
+        pre_act_x<RT>(xr, p.src[0].pre_act, p.src[0].width, 0, lane);
         store_x<RT>(sX0, lane, xr);
         for (int c = 0; c < p.chunks0; ++c) {
-            // next chunk of layer 0: issue its gather now, park it in LDS after this chunk's MFMAs
+            // next chunk of layer 0: issue its gather now, park it in LDS after this chunk's MFMAs.
+            // Straight-line on purpose (the last iteration re-loads its own chunk into the idle
+            // buffer): hipcc then waits for the gather with an exact vmcnt(16) and leaves the 16
+            // younger weight-ring loads in flight.
             int ns = s, nk0 = k0 + KC;
             if (nk0 >= p.src[s].wpad) { ns = s + 1; nk0 = 0; }
-            const bool more = (c + 1) < p.chunks0;
-            if (more) load_x<RT>(p.src[ns], sRow + ns * ROWS, nk0, lane, xr);
+            if (c + 1 >= p.chunks0) { ns = s; nk0 = k0; }
+            if (!(p.ablate & 2)) load_x<RT, VEC>(p.src[ns], sRow + ns * ROWS, nk0, lane, xr);
             __builtin_amdgcn_sched_barrier(0);
             const float *sX = (c & 1) ? sX1 : sX0;
             w += CHUNK_FLOATS;
-            mma_chunk<RT>(sX + i * XS + 2 * h, 32 * XS, ring, w, lane, acc);
-            if (more) store_x<RT>((c & 1) ? sX0 : sX1, lane, xr);
+            if (p.ablate & 1) mma_chunk<RT, false>(sX + i * XS + 2 * h, 32 * XS, ring, w, lane, acc);
+            else mma_chunk<RT>(sX + i * XS + 2 * h, 32 * XS, ring, w, lane, acc);
+            if (!(p.ablate & 2)) {
+                pre_act_x<RT>(xr, p.src[ns].pre_act, p.src[ns].width, nk0, lane);
+                store_x<RT>((c & 1) ? sX0 : sX1, lane, xr);
+            }
             s = ns; k0 = nk0;
         }
     }
@@ -270,61 +312,81 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
     // ------------------------------------------------------------------ layers 1..L-1 (K = 128 from LDS)
     for (int l = 0;; ++l) {
         const bool last = (l == p.n_layers - 1);
-        store_hidden<RT>(acc, sH, p.b + l * NP, lane, last);
+        if (!(p.ablate & 4)) {
+            if (last) store_hidden<RT, true>(acc, sH, sBias + l * NP, lane);
+            else store_hidden<RT, false>(acc, sH, sBias + l * NP, lane);
+        }
         if (last) break;
         zero_acc<RT>(acc);
 #pragma unroll 1
         for (int k0 = 0; k0 < NP; k0 += KC) {
             w += CHUNK_FLOATS;
-            mma_chunk<RT>(sH + i * HS + k0 + 2 * h, 32 * HS, ring, w, lane, acc);
+            if (p.ablate & 1) mma_chunk<RT, false>(sH + i * HS + k0 + 2 * h, 32 * HS, ring, w, lane, acc);
+            else mma_chunk<RT>(sH + i * HS + k0 + 2 * h, 32 * HS, ring, w, lane, acc);
         }
     }
 
     // ------------------------------------------------------------------ LayerNorm / activation (in LDS)
     // lane (row = i [+32 per pass], half h) owns columns [64h, 64h+64) of its row
     const int n_out = p.n_out;
+    if (p.ablate & 4) {
+        if (acc.t[0][0][0] == 12345.f) p.out[0] = acc.t[0][1][1] + acc.t[RT - 1][2][2] + acc.t[RT - 1][3][3];   // keep acc live
+        return;
+    }
     if (p.gamma || p.act) {
+        // RT = 2: lane = row, all 128 columns in registers (no cross-lane traffic at all);
+        // RT = 1: lane (row = i, half h) owns 64 columns, one exchange with its partner lane.
+        constexpr int NC = (RT == 2) ? 128 : 64;
+        const int cb = (RT == 2) ? 0 : 64 * h;
+        float *rowp = sH + ((RT == 2) ? lane : i) * HS + cb;
         const float inv_n = 1.0f / (float)n_out;
-#pragma unroll 1
-        for (int r = 0; r < RT; ++r) {
-            float *rowp = sH + (r * 32 + i) * HS + 64 * h;
-            float x[64];
+        float x[NC];
 #pragma unroll
-            for (int c = 0; c < 64; c += 4) {
-                const f32x4 t = *reinterpret_cast<const f32x4 *>(rowp + c);
-                x[c] = t[0]; x[c + 1] = t[1]; x[c + 2] = t[2]; x[c + 3] = t[3];
+        for (int c = 0; c < NC; c += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(rowp + c);
+            x[c] = t[0]; x[c + 1] = t[1]; x[c + 2] = t[2]; x[c + 3] = t[3];
+        }
+        if (p.gamma) {
+            float sum = 0.f;
+            if (n_out == NP) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) sum += x[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) sum += (cb + c < n_out) ? x[c] : 0.f;
             }
-            if (p.gamma) {
-                float s = 0.f;
+            if (RT == 1) sum += __shfl_xor(sum, 32);
+            const float mean = sum * inv_n;
+            float var = 0.f;
+            if (n_out == NP) {
 #pragma unroll
-                for (int c = 0; c < 64; ++c) s += (64 * h + c < n_out) ? x[c] : 0.f;
-                s += __shfl_xor(s, 32);
-                const float mean = s * inv_n;
-                float v = 0.f;
+                for (int c = 0; c < NC; ++c) { const float d = x[c] - mean; var = fmaf(d, d, var); }
+            } else {
 #pragma unroll
-                for (int c = 0; c < 64; ++c) {
-                    const float d = x[c] - mean;
-                    v += (64 * h + c < n_out) ? d * d : 0.f;
-                }
-                v += __shfl_xor(v, 32);
-                const float rstd = rsqrtf(v * inv_n + p.eps);
-                const float *gp = p.gamma + 64 * h, *bp = p.beta + 64 * h;
-#pragma unroll
-                for (int c = 0; c < 64; ++c) {
-                    const int cc = (64 * h + c < n_out) ? c : 0;
-                    x[c] = (x[c] - mean) * rstd * gp[cc] + bp[cc];
-                }
+                for (int c = 0; c < NC; ++c) { const float d = x[c] - mean; var += (cb + c < n_out) ? d * d : 0.f; }
             }
-            if (p.act) {
+            if (RT == 1) var += __shfl_xor(var, 32);
+            const float rstd = rsqrtf(var * inv_n + p.eps);
 #pragma unroll
-                for (int c = 0; c < 64; ++c) x[c] = g4c::apply_act(x[c], p.act);
-            }
+            for (int c = 0; c < NC; c += 4) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4 *>(sGB + cb + c);        // broadcast reads
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sGB + NP + cb + c);
 #pragma unroll
-            for (int c = 0; c < 64; c += 4) {
-                f32x4 t;
-                t[0] = x[c]; t[1] = x[c + 1]; t[2] = x[c + 2]; t[3] = x[c + 3];
-                *reinterpret_cast<f32x4 *>(rowp + c) = t;
+                for (int u = 0; u < 4; ++u) x[c + u] = fmaf((x[c + u] - mean) * rstd, g4[u], b4[u]);
             }
+        }
+        if (p.act == G4C_ACT_SELU) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) x[c] = g4c::selu_f(x[c]);
+        } else if (p.act == G4C_ACT_TANH) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) x[c] = g4c::tanh_f(x[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c += 4) {
+            f32x4 t;
+            t[0] = x[c]; t[1] = x[c + 1]; t[2] = x[c + 2]; t[3] = x[c + 3];
+            *reinterpret_cast<f32x4 *>(rowp + c) = t;
         }
     }
 
@@ -424,6 +486,7 @@ extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int3
     Params p;
     p.n_src = n_src;
     int kp = 0;
+    bool all_vec = true;
     for (int s = 0; s < n_src; ++s) {
         const g4c_src_t &g = srcs[s];
         G4C_REQUIRE(g.ptr && g.width > 0 && g.ld >= g.col0 + g.width && g.col0 >= 0, G4C_EINVAL,
@@ -433,6 +496,7 @@ extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int3
         d.ptr = g.ptr; d.idx = g.idx; d.width = g.width; d.wpad = (g.width + KC - 1) / KC * KC; d.ld = g.ld; d.col0 = g.col0;
         d.pre_act = g.pre_act;
         d.vec = (g.width % 4 == 0) && (g.ld % 4 == 0) && (g.col0 % 4 == 0) && ((uintptr_t)g.ptr % 16 == 0);
+        all_vec = all_vec && d.vec;
         kp += d.wpad;
     }
     for (int s = n_src; s < G4C_MAX_SRC; ++s) p.src[s] = p.src[0];
@@ -459,15 +523,19 @@ extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int3
     p.out = out; p.out_ld = out_ld; p.out_idx = out_idx; p.act = act;
     p.resid = resid; p.resid_ld = resid_ld; p.resid_col0 = resid_col0;
     hipStream_t st = (hipStream_t)stream;
+    static const int ablate = getenv("G4C_ABLATE") ? atoi(getenv("G4C_ABLATE")) : 0;
+    p.ablate = ablate;
     // 64-row tiles when they still fill the chip (4 waves/CU x 256 CUs), else 32-row tiles (8 waves/CU)
     static const int force_rt = getenv("G4C_MLP_RT") ? atoi(getenv("G4C_MLP_RT")) : 0;
     const bool big = force_rt ? (force_rt == 2) : (n_rows >= 64LL * 1024);
     if (big) {
         p.n_tiles = (int)((n_rows + 63) / 64);
-        mlp_fused_kernel<2><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
+        if (all_vec) mlp_fused_kernel<2, true><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
+        else mlp_fused_kernel<2, false><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
     } else {
         p.n_tiles = (int)((n_rows + 31) / 32);
-        mlp_fused_kernel<1><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
+        if (all_vec) mlp_fused_kernel<1, true><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
+        else mlp_fused_kernel<1, false><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
     }
     return g4c::check_launch("g4c_mlp_forward");
 }
