@@ -24,6 +24,14 @@
 #include "g4c_common.h"
 #include <cstdlib>
 
+// Timing-only ablations, compile-time so that the production kernel has no extra control flow
+// (a runtime switch between two mma_chunk instantiations makes hipcc reconcile the weight-ring
+// registers at the join, i.e. wait for the in-flight loads at every chunk):
+//   -DG4C_ABLATE=1 no ring refill, 2 no input staging, 4 no epilogues / final pass (bits can be OR-ed)
+#ifndef G4C_ABLATE
+#define G4C_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int KC = 32;        // K chunk = one revolution of the weight ring (8 steps of 4 k)
@@ -60,7 +68,6 @@ struct Params {
     const float *resid;
     int resid_ld, resid_col0;
     int n_tiles;
-    int ablate;   // debug only (env G4C_ABLATE): 1 no ring refill, 2 no input staging, 4 no epilogues/final pass
 };
 
 template <int RT> struct Acc { f32x16 t[RT][4]; };
@@ -172,23 +179,17 @@ __device__ __forceinline__ void load_x(const Src &s, const int *sRow, int k0, in
 // (its producer stored the raw tensor).
 template <int RT>
 __device__ __forceinline__ void pre_act_x(XRegs<RT> &x, int act, int width, int k0, int lane) {
+    // zero fill by select (always); the pending activation (SELU only) under ONE wave-uniform branch
     const int c = k0 + (lane & 7) * 4;
-    if (c + 3 >= width) {   // only the last chunk of a source whose width is not a multiple of 32
 #pragma unroll
-        for (int q = 0; q < RT; ++q)
+    for (int q = 0; q < RT; ++q)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) x.v[q][e] = (c + (e & 3) < width) ? x.v[q][e] : 0.f;
-    }
-    if (act == G4C_ACT_SELU) {
+        for (int e = 0; e < 16; ++e) x.v[q][e] = (c + (e & 3) < width) ? x.v[q][e] : 0.f;
+    if (act) {
 #pragma unroll
         for (int q = 0; q < RT; ++q)
 #pragma unroll
             for (int e = 0; e < 16; ++e) x.v[q][e] = g4c::selu_f(x.v[q][e]);
-    } else if (act == G4C_ACT_TANH) {
-#pragma unroll
-        for (int q = 0; q < RT; ++q)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) x.v[q][e] = g4c::tanh_f(x.v[q][e]);
     }
 }
 
@@ -295,13 +296,12 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
             int ns = s, nk0 = k0 + KC;
             if (nk0 >= p.src[s].wpad) { ns = s + 1; nk0 = 0; }
             if (c + 1 >= p.chunks0) { ns = s; nk0 = k0; }
-            if (!(p.ablate & 2)) load_x<RT, VEC>(p.src[ns], sRow + ns * ROWS, nk0, lane, xr);
+            if (!(G4C_ABLATE & 2)) load_x<RT, VEC>(p.src[ns], sRow + ns * ROWS, nk0, lane, xr);
             __builtin_amdgcn_sched_barrier(0);
             const float *sX = (c & 1) ? sX1 : sX0;
             w += CHUNK_FLOATS;
-            if (p.ablate & 1) mma_chunk<RT, false>(sX + i * XS + 2 * h, 32 * XS, ring, w, lane, acc);
-            else mma_chunk<RT>(sX + i * XS + 2 * h, 32 * XS, ring, w, lane, acc);
-            if (!(p.ablate & 2)) {
+            mma_chunk<RT, !(G4C_ABLATE & 1)>(sX + i * XS + 2 * h, 32 * XS, ring, w, lane, acc);
+            if (!(G4C_ABLATE & 2)) {
                 pre_act_x<RT>(xr, p.src[ns].pre_act, p.src[ns].width, nk0, lane);
                 store_x<RT>((c & 1) ? sX0 : sX1, lane, xr);
             }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
     // ------------------------------------------------------------------ layers 1..L-1 (K = 128 from LDS)
     for (int l = 0;; ++l) {
         const bool last = (l == p.n_layers - 1);
-        if (!(p.ablate & 4)) {
+        if (!(G4C_ABLATE & 4)) {
             if (last) store_hidden<RT, true>(acc, sH, sBias + l * NP, lane);
             else store_hidden<RT, false>(acc, sH, sBias + l * NP, lane);
         }
@@ -321,15 +321,14 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
 #pragma unroll 1
         for (int k0 = 0; k0 < NP; k0 += KC) {
             w += CHUNK_FLOATS;
-            if (p.ablate & 1) mma_chunk<RT, false>(sH + i * HS + k0 + 2 * h, 32 * HS, ring, w, lane, acc);
-            else mma_chunk<RT>(sH + i * HS + k0 + 2 * h, 32 * HS, ring, w, lane, acc);
+            mma_chunk<RT, !(G4C_ABLATE & 1)>(sH + i * HS + k0 + 2 * h, 32 * HS, ring, w, lane, acc);
         }
     }
 
     // ------------------------------------------------------------------ LayerNorm / activation (in LDS)
     // lane (row = i [+32 per pass], half h) owns columns [64h, 64h+64) of its row
     const int n_out = p.n_out;
-    if (p.ablate & 4) {
+    if (G4C_ABLATE & 4) {
         if (acc.t[0][0][0] == 12345.f) p.out[0] = acc.t[0][1][1] + acc.t[RT - 1][2][2] + acc.t[RT - 1][3][3];   // keep acc live
         return;
     }
@@ -491,7 +490,8 @@ extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int3
         const g4c_src_t &g = srcs[s];
         G4C_REQUIRE(g.ptr && g.width > 0 && g.ld >= g.col0 + g.width && g.col0 >= 0, G4C_EINVAL,
                     "g4c_mlp_forward: bad source %d (width=%d ld=%d col0=%d)", s, g.width, g.ld, g.col0);
-        G4C_REQUIRE(g.pre_act >= 0 && g.pre_act <= 2, G4C_EINVAL, "g4c_mlp_forward: source %d bad pre_act %d", s, g.pre_act);
+        G4C_REQUIRE(g.pre_act == G4C_ACT_NONE || g.pre_act == G4C_ACT_SELU, G4C_EUNSUPPORTED,
+                    "g4c_mlp_forward: source %d pre_act %d (only NONE / SELU can be applied on load)", s, g.pre_act);
         Src &d = p.src[s];
         d.ptr = g.ptr; d.idx = g.idx; d.width = g.width; d.wpad = (g.width + KC - 1) / KC * KC; d.ld = g.ld; d.col0 = g.col0;
         d.pre_act = g.pre_act;
@@ -523,8 +523,6 @@ extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int3
     p.out = out; p.out_ld = out_ld; p.out_idx = out_idx; p.act = act;
     p.resid = resid; p.resid_ld = resid_ld; p.resid_col0 = resid_col0;
     hipStream_t st = (hipStream_t)stream;
-    static const int ablate = getenv("G4C_ABLATE") ? atoi(getenv("G4C_ABLATE")) : 0;
-    p.ablate = ablate;
     // 64-row tiles when they still fill the chip (4 waves/CU x 256 CUs), else 32-row tiles (8 waves/CU)
     static const int force_rt = getenv("G4C_MLP_RT") ? atoi(getenv("G4C_MLP_RT")) : 0;
     const bool big = force_rt ? (force_rt == 2) : (n_rows >= 64LL * 1024);
