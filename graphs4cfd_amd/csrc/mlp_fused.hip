@@ -32,6 +32,17 @@
 #define G4C_ABLATE 0
 #endif
 
+// -DG4C_TIMING: per-phase s_memtime stamps of the first 4096 tiles into g4c_dbg_stamps (debug builds only)
+#ifdef G4C_TIMING
+__device__ unsigned long long g4c_dbg_stamps[4096 * 16];
+#define G4C_STAMP(k) do { if (tile < 4096 && lane == 0) g4c_dbg_stamps[tile * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int g4c_debug_read_stamps(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4c_dbg_stamps), sizeof(unsigned long long) * n);
+}
+#else
+#define G4C_STAMP(k) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int KC = 32;        // K chunk = one revolution of the weight ring (8 steps of 4 k)
@@ -68,15 +79,18 @@ struct Params {
     const float *resid;
     int resid_ld, resid_col0;
     int n_tiles;
+    long long row_base;       // first row of this launch (a call may be split into a 64-row and a 32-row launch)
 };
 
 template <int RT> struct Acc { f32x16 t[RT][4]; };
 
-// B operands of one 4-k step for this lane: 4 column tiles x (k, k+1)  -> 8 floats = two 16-byte loads
-__device__ __forceinline__ f32x8 load_b(const float *wchunk, int step, int lane) {
-    const float *p = wchunk + ((step * 2 + (lane >> 5)) * 32 + (lane & 31)) * 8;
-    const f32x4 lo = *reinterpret_cast<const f32x4 *>(p);
-    const f32x4 hi = *reinterpret_cast<const f32x4 *>(p + 4);
+// B operands of one 4-k step for this lane: 4 column tiles x (k, k+1) -> 8 floats = two 16-byte loads.
+// `wstep` is wave-uniform (SGPR base), `lane_off` the lane's 32-bit offset in floats: lets hipcc use the
+// scalar-base addressing form instead of per-step 64-bit VALU address arithmetic.
+__device__ __forceinline__ f32x8 load_b(const float *wstep, unsigned lane_off) {
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(wstep + lane_off);
+    const f32x4 lo = p[0];
+    const f32x4 hi = p[1];
     f32x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -108,27 +122,29 @@ __device__ __forceinline__ void mma_step(const AOp<RT> &a, const f32x8 &b, Acc<R
 
 struct Ring { f32x8 s0, s1, s2, s3, s4, s5, s6, s7; };
 
-__device__ __forceinline__ void ring_fill(Ring &g, const float *wchunk, int lane) {
-    g.s0 = load_b(wchunk, 0, lane); g.s1 = load_b(wchunk, 1, lane);
-    g.s2 = load_b(wchunk, 2, lane); g.s3 = load_b(wchunk, 3, lane);
-    g.s4 = load_b(wchunk, 4, lane); g.s5 = load_b(wchunk, 5, lane);
-    g.s6 = load_b(wchunk, 6, lane); g.s7 = load_b(wchunk, 7, lane);
+__device__ __forceinline__ void ring_fill(Ring &g, const float *wchunk, unsigned lo) {
+    g.s0 = load_b(wchunk + 0 * 512, lo); g.s1 = load_b(wchunk + 1 * 512, lo);
+    g.s2 = load_b(wchunk + 2 * 512, lo); g.s3 = load_b(wchunk + 3 * 512, lo);
+    g.s4 = load_b(wchunk + 4 * 512, lo); g.s5 = load_b(wchunk + 5 * 512, lo);
+    g.s6 = load_b(wchunk + 6 * 512, lo); g.s7 = load_b(wchunk + 7 * 512, lo);
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// one 32-k chunk: 8 steps.  Per step: read the NEXT step's A operands from LDS, run this step's
-// MFMAs, then refill the ring slot just consumed with the same step of the NEXT chunk.  The
-// sched_barrier pins that order (without it hipcc sinks all 16 refill loads to the chunk boundary,
-// which exposes a full L2 round trip per chunk).
+// one 32-k chunk: 8 steps.  Per step: (1) issue the NEXT step's A reads from LDS, (2) this step's
+// MFMAs, (3) refill the ring slot just consumed with the same step of the NEXT chunk.  The
+// sched_barriers pin that order: without them hipcc sinks all 16 refill loads to the chunk boundary
+// (a full L2 round trip exposed per chunk) and issues the A reads after the MFMAs (LDS latency
+// exposed per step).
 template <int RT, bool REFILL = true>
-__device__ __forceinline__ void mma_chunk(const float *pa, int a_tile_stride, Ring &g, const float *wnext, int lane,
+__device__ __forceinline__ void mma_chunk(const float *pa, int a_tile_stride, Ring &g, const float *wnext, unsigned lo,
                                           Acc<RT> &acc) {
     AOp<RT> a = load_a<RT>(pa, a_tile_stride);
 #define G4C_STEP(U, SLOT)                                                     \
     {                                                                         \
         const AOp<RT> an = load_a<RT>(pa + (((U) + 1) & 7) * 4, a_tile_stride); \
+        __builtin_amdgcn_sched_barrier(0);                                    \
         mma_step<RT>(a, g.SLOT, acc);                                         \
-        if (REFILL) g.SLOT = load_b(wnext, (U), lane);                        \
+        if (REFILL) g.SLOT = load_b(wnext + (U) * 512, lo);                   \
         __builtin_amdgcn_sched_barrier(0);                                    \
         a = an;                                                               \
     }
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
         const int q = nt >> 3, r = nt & 7, x = b & 7, j = b >> 3;
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
-    const long long row0 = (long long)tile * ROWS;
+    const long long row0 = p.row_base + (long long)tile * ROWS;
 
     for (int r = lane; r < ROWS; r += 64) {
         long long gr = row0 + r;
@@ -279,15 +295,18 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
     Ring ring;
     XRegs<RT> xr;
     const float *w = p.w;
+    G4C_STAMP(0);
 
     // ------------------------------------------------------------------ layer 0 (gathered input)
     zero_acc<RT>(acc);
-    ring_fill(ring, w, lane);
+    const unsigned lo = (unsigned)(((lane >> 5) * 32 + (lane & 31)) * 8);   // lane's offset inside a step's 512 floats
+    ring_fill(ring, w, lo);
     {
         int s = 0, k0 = 0;
         load_x<RT, VEC>(p.src[0], sRow, 0, lane, xr);
         pre_act_x<RT>(xr, p.src[0].pre_act, p.src[0].width, 0, lane);
         store_x<RT>(sX0, lane, xr);
+        G4C_STAMP(1);
         for (int c = 0; c < p.chunks0; ++c) {
             // next chunk of layer 0: issue its gather now, park it in LDS after this chunk's MFMAs.
             // Straight-line on purpose (the last iteration re-loads its own chunk into the idle
@@ -300,7 +319,7 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
             __builtin_amdgcn_sched_barrier(0);
             const float *sX = (c & 1) ? sX1 : sX0;
             w += CHUNK_FLOATS;
-            mma_chunk<RT, !(G4C_ABLATE & 1)>(sX + i * XS + 2 * h, 32 * XS, ring, w, lane, acc);
+            mma_chunk<RT, !(G4C_ABLATE & 1)>(sX + i * XS + 2 * h, 32 * XS, ring, w, lo, acc);
             if (!(G4C_ABLATE & 2)) {
                 pre_act_x<RT>(xr, p.src[ns].pre_act, p.src[ns].width, nk0, lane);
                 store_x<RT>((c & 1) ? sX0 : sX1, lane, xr);
@@ -312,16 +331,18 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
     // ------------------------------------------------------------------ layers 1..L-1 (K = 128 from LDS)
     for (int l = 0;; ++l) {
         const bool last = (l == p.n_layers - 1);
+        G4C_STAMP(2 + 2 * l);
         if (!(G4C_ABLATE & 4)) {
             if (last) store_hidden<RT, true>(acc, sH, sBias + l * NP, lane);
             else store_hidden<RT, false>(acc, sH, sBias + l * NP, lane);
         }
+        G4C_STAMP(3 + 2 * l);
         if (last) break;
         zero_acc<RT>(acc);
 #pragma unroll 1
         for (int k0 = 0; k0 < NP; k0 += KC) {
             w += CHUNK_FLOATS;
-            mma_chunk<RT, !(G4C_ABLATE & 1)>(sH + i * HS + k0 + 2 * h, 32 * HS, ring, w, lane, acc);
+            mma_chunk<RT, !(G4C_ABLATE & 1)>(sH + i * HS + k0 + 2 * h, 32 * HS, ring, w, lo, acc);
         }
     }
 
@@ -389,6 +410,7 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
         }
     }
 
+    G4C_STAMP(12);
     // ------------------------------------------------------------------ store (+ residual)
     const bool fast = (n_out == NP) && ((p.out_ld & 3) == 0) && (((uintptr_t)p.out & 15) == 0) && (p.resid == nullptr);
     if (fast) {
@@ -414,6 +436,7 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
             }
         }
     }
+    G4C_STAMP(13);
 }
 
 // W[n_out, k_in] (nn.Linear layout) -> this layer's chunks of the packed stream:
@@ -523,15 +546,24 @@ extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int3
     p.out = out; p.out_ld = out_ld; p.out_idx = out_idx; p.act = act;
     p.resid = resid; p.resid_ld = resid_ld; p.resid_col0 = resid_col0;
     hipStream_t st = (hipStream_t)stream;
-    // 64-row tiles when they still fill the chip (4 waves/CU x 256 CUs), else 32-row tiles (8 waves/CU)
+    // Tile scheduling.  A 64-row tile (one wave, 512 registers) keeps a SIMD busy for one "round"; the
+    // chip holds 1024 of them.  Whole rounds go to the 64-row kernel; the remainder (< 64 Ki rows) goes to
+    // 32-row tiles, which finish in about half a round when there are at most 1024 of them, instead of
+    // leaving most of the chip idle for a full last round.
     static const int force_rt = getenv("G4C_MLP_RT") ? atoi(getenv("G4C_MLP_RT")) : 0;
-    const bool big = force_rt ? (force_rt == 2) : (n_rows >= 64LL * 1024);
-    if (big) {
-        p.n_tiles = (int)((n_rows + 63) / 64);
+    const long long round_rows = 64LL * 1024;
+    long long bulk = (n_rows / round_rows) * round_rows;
+    if (force_rt == 2) bulk = n_rows;
+    if (force_rt == 1) bulk = 0;
+    if (bulk > 0) {
+        p.row_base = 0;
+        p.n_tiles = (int)((bulk + 63) / 64);
         if (all_vec) mlp_fused_kernel<2, true><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
         else mlp_fused_kernel<2, false><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
-    } else {
-        p.n_tiles = (int)((n_rows + 31) / 32);
+    }
+    if (n_rows > bulk) {
+        p.row_base = bulk;
+        p.n_tiles = (int)((n_rows - bulk + 31) / 32);
         if (all_vec) mlp_fused_kernel<1, true><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
         else mlp_fused_kernel<1, false><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
     }
