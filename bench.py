@@ -49,7 +49,10 @@ def parse():
 def cpu_baseline(model_name, graph, weights, nf, budget_s):
     """Oracle rollout steps on the host cores: bounded sample (>= 1 step, <= budget)."""
     from oracle import g4c_oracle as O
-    cores = os.cpu_count() or 1
+    # torch CPU ops stop scaling long before the host's core count on this path (measured on the GPU box,
+    # 2 x EPYC 9575F = 256 hw threads: 8/16/32/64/128/256 threads -> 1.29/1.10/1.26/2.13/6.11/103 s per
+    # 20k-node step, profiles/r01_cpu_thread_sweep.log), so the baseline uses the fastest setting
+    cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     g = graph.to_dict()
     t0 = time.perf_counter()

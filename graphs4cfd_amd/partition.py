@@ -1,0 +1,365 @@
+"""Node-partitioned multi-GPU execution of the MuS-GNN hot path (new functionality: the reference is
+single-device).
+
+One process per GPU.  The fixed mesh is cut into `world` spatially compact parts:
+
+  * ownership is decided on the COARSEST level (strips along x over the coarsest nodes, balanced by
+    the number of level-1 nodes underneath) and inherited downwards through `idx{l-1}_to_idx{l}`, so
+    every cluster of every level is wholly owned by one rank: DownMP node pooling, `pool_edge`
+    (a coarse edge I->J only collects fine edges whose target lies in J) and UpMP are rank-local;
+  * an edge is owned by the rank of its TARGET node, so aggregation (`scatter` onto `col`) and the
+    CSR-by-destination layout need no edge communication and edge latents never move;
+  * the only exchange is the halo of SOURCE-node latents: before every MP layer each rank sends the
+    rows of its owned nodes that appear as edge sources on other ranks.  Halo rows live behind the
+    owned rows of the same tensor ([n_own + n_halo, H]), grouped by owner rank, so the receive side of
+    one `all_to_all_single` (RCCL over xGMI; gloo in the CPU tests) lands in place.
+
+`MusPartitionedForward` interprets the same per-class program as `nn/mus_gnn.py` on the local
+sub-mesh; the arithmetic is delegated to an `impl` object: `HipImpl` (the HIP kernels, product path) or,
+in tests only, an oracle-backed implementation that exercises the partition / halo logic on CPU + gloo.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib, ops, plan
+from .graph import Graph
+from .ops import Source
+
+SELU, TANH, NONE = _lib.ACT_SELU, _lib.ACT_TANH, _lib.ACT_NONE
+
+
+# ------------------------------------------------------------------------------------- host-side partitioner
+@dataclass
+class LevelPart:
+    """One level of one rank's sub-mesh (all index arrays are numpy int64 on the host)."""
+    owned: np.ndarray              # global ids of owned nodes, ascending
+    halo: np.ndarray               # global ids of halo nodes, grouped by owner rank, ascending inside a group
+    halo_owner: np.ndarray         # owner rank of every halo node
+    edge_ids: np.ndarray           # global ids (positions in the level's edge list) of owned edges, ascending
+    edge_index: np.ndarray         # [2, E_own] in LOCAL node ids (owned first, then halo)
+    send_idx: List[np.ndarray] = field(default_factory=list)   # per peer: local owned ids to send, in the peer's halo order
+    recv_counts: List[int] = field(default_factory=list)       # per peer: number of halo rows received
+
+    @property
+    def n_own(self) -> int:
+        return int(self.owned.shape[0])
+
+    @property
+    def n_halo(self) -> int:
+        return int(self.halo.shape[0])
+
+
+def coarse_topology(graph: Graph, levels: int):
+    """Global edge lists of every level: level 1 from the Graph, level l from the topology part of
+    `pool_edge` (nn/blocks.py:51-68) applied to level l-1."""
+    lib = _lib.load()
+    import ctypes as C
+    edges = [np.ascontiguousarray(graph.edge_index.cpu().numpy().astype(np.int64))]
+    for l in range(2, levels + 1):
+        idx = np.ascontiguousarray(getattr(graph, f"idx{l - 1}_to_idx{l}").cpu().numpy().astype(np.int64))
+        ei = edges[-1]
+        n_edges = int(ei.shape[1])
+        coarse = np.empty((2, max(n_edges, 1)), dtype=np.int64)
+        perm = np.empty(max(n_edges, 1), dtype=np.int32)
+        off = np.empty(n_edges + 1, dtype=np.int32)
+        kept = C.c_int64(0)
+        nc = lib.g4c_plan_pool_edge(idx.ctypes.data, int(idx.shape[0]), ei.ctypes.data, n_edges, coarse.ctypes.data,
+                                    perm.ctypes.data, off.ctypes.data, C.byref(kept))
+        if nc < 0:
+            _lib.check(int(nc))
+        edges.append(coarse.reshape(-1)[: 2 * nc].reshape(2, nc).copy())
+    return edges
+
+
+def assign_owners(graph: Graph, levels: int, world: int) -> List[np.ndarray]:
+    """Owner rank of every node of every level.  Strips along x over the coarsest level, balanced by the
+    number of level-1 nodes below each coarsest node; finer levels inherit their parent's owner."""
+    n1 = int(graph.pos.size(0))
+    weight = np.ones(n1, dtype=np.int64)
+    maps = []
+    for l in range(2, levels + 1):
+        idx = getattr(graph, f"idx{l - 1}_to_idx{l}").cpu().numpy().astype(np.int64)
+        maps.append(idx)
+        weight = np.bincount(idx, weights=weight, minlength=int(idx.max()) + 1).astype(np.int64)
+    pos_top = (graph.pos if levels == 1 else getattr(graph, f"pos_{levels}")).cpu().numpy()
+    order = np.argsort(pos_top[:, 0], kind="stable")
+    cum = np.cumsum(weight[order])
+    total = int(cum[-1])
+    owner_top = np.empty(order.shape[0], dtype=np.int64)
+    owner_top[order] = np.minimum((cum - 1) * world // total, world - 1)
+    owners = [None] * levels
+    owners[levels - 1] = owner_top
+    for l in range(levels - 1, 0, -1):
+        owners[l - 1] = owners[l][maps[l - 1]]
+    return owners
+
+
+def build_partition(graph: Graph, levels: int, world: int) -> List[List[LevelPart]]:
+    """parts[rank][level-1] for every rank (the whole table is cheap and lets tests check consistency)."""
+    edges = coarse_topology(graph, levels)
+    owners = assign_owners(graph, levels, world)
+    parts: List[List[LevelPart]] = [[] for _ in range(world)]
+    for l in range(levels):
+        ei, own = edges[l], owners[l]
+        n = int(own.shape[0])
+        tgt_owner = own[ei[1]]
+        for r in range(world):
+            owned = np.nonzero(own == r)[0]
+            e_ids = np.nonzero(tgt_owner == r)[0]
+            src = ei[0, e_ids]
+            halo = np.unique(src[own[src] != r])
+            h_owner = own[halo]
+            order = np.lexsort((halo, h_owner))          # group by owner rank, ascending id inside
+            halo, h_owner = halo[order], h_owner[order]
+            g2l = np.full(n, -1, dtype=np.int64)
+            g2l[owned] = np.arange(owned.shape[0])
+            g2l[halo] = owned.shape[0] + np.arange(halo.shape[0])
+            local_ei = np.stack([g2l[ei[0, e_ids]], g2l[ei[1, e_ids]]], 0)
+            assert (local_ei >= 0).all()
+            parts[r].append(LevelPart(owned=owned, halo=halo, halo_owner=h_owner, edge_ids=e_ids, edge_index=local_ei))
+        # send lists: what q receives from r, in q's halo order
+        for r in range(world):
+            pr = parts[r][l]
+            g2l_own = {}
+            lut = np.full(n, -1, dtype=np.int64)
+            lut[pr.owned] = np.arange(pr.n_own)
+            pr.send_idx = []
+            for q in range(world):
+                pq = parts[q][l]
+                need = pq.halo[pq.halo_owner == r]
+                pr.send_idx.append(lut[need])
+                assert (pr.send_idx[-1] >= 0).all()
+            pr.recv_counts = [int((pr.halo_owner == q).sum()) for q in range(world)]
+    return parts
+
+
+# ------------------------------------------------------------------------------------- local sub-mesh on a device
+class LocalMesh:
+    """Rank-local tensors of the partitioned Graph, in local numbering, on `device`."""
+
+    def __init__(self, graph: Graph, levels: int, parts: List[LevelPart], device: torch.device, rank: int, world: int):
+        self.levels, self.device, self.rank, self.world = levels, device, rank, world
+        self.parts = parts
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)   # noqa: E731
+        p1 = parts[0]
+        own1 = torch.from_numpy(p1.owned)
+        self.n_own = [p.n_own for p in parts]
+        self.n_halo = [p.n_halo for p in parts]
+        self.owned_global = [t(p.owned) for p in parts]
+        # node inputs of owned level-1 nodes (the reference's concat order: field, loc, glob, omega)
+        self.inputs = {k: getattr(graph, k)[own1].contiguous().to(device) for k in ("field", "loc", "glob", "omega")
+                       if hasattr(graph, k)}
+        # per level: owned edges in local ids (+ the input edge_attr at level 1)
+        self.edge_index = [t(p.edge_index) for p in parts]
+        self.edge_attr = graph.edge_attr[torch.from_numpy(p1.edge_ids)].contiguous().to(device)
+        # inter-level maps for owned fine nodes -> local coarse id, relative positions, pooling of edges
+        self.parent, self.rel, self.parent_full = [], [], []
+        for l in range(1, levels):
+            fine, coarse = parts[l - 1], parts[l]
+            idx = getattr(graph, f"idx{l}_to_idx{l + 1}").cpu().numpy().astype(np.int64)
+            n_c = int(idx.max()) + 1
+            g2l_c = np.full(n_c, -1, dtype=np.int64)
+            g2l_c[coarse.owned] = np.arange(coarse.n_own)
+            g2l_c[coarse.halo] = coarse.n_own + np.arange(coarse.n_halo)
+            par_own = g2l_c[idx[fine.owned]]
+            assert (par_own >= 0).all() and (par_own < coarse.n_own).all(), "cluster not wholly owned"
+            par_halo = g2l_c[idx[fine.halo]]
+            # a fine halo whose parent is neither owned nor a coarse halo only feeds intra-cluster edges elsewhere;
+            # point it at its own (unused) slot so the coarse-edge plan drops nothing it should keep
+            self.parent.append(t(par_own))
+            self.parent_full.append((par_own, par_halo))
+            self.rel.append(getattr(graph, f"e_{l}{l + 1}")[torch.from_numpy(fine.owned)].contiguous().to(device))
+        self.send_idx32 = [[t(ix.astype(np.int32)) for ix in p.send_idx] for p in parts]
+        self.send_counts = [[int(ix.shape[0]) for ix in p.send_idx] for p in parts]
+        self.recv_counts = [list(p.recv_counts) for p in parts]
+        self._pool_plans: Dict[int, object] = {}
+
+    def pool_edge_csr(self, l: int):
+        """Plan that averages owned fine edges of level l into the owned coarse edges of level l+1 (rows in
+        the local coarse edge order).  Built on the host from the global coarse edge ids (static)."""
+        if l not in self._pool_plans:
+            fine, coarse = self.parts[l - 1], self.parts[l]
+            par_own, par_halo = self.parent_full[l - 1]
+            par = np.concatenate([par_own, par_halo])
+            fe = fine.edge_index
+            cr, cc = par[fe[0]], par[fe[1]]
+            keep = np.nonzero((cr != cc) & (cr >= 0))[0]
+            # local coarse edges, keyed like the local coarse edge list
+            ce = coarse.edge_index
+            n_loc = coarse.n_own + coarse.n_halo
+            key_c = ce[0] * n_loc + ce[1]
+            order_c = np.argsort(key_c, kind="stable")
+            key_f = cr[keep] * n_loc + cc[keep]
+            pos = np.searchsorted(key_c[order_c], key_f)
+            assert (key_c[order_c][np.minimum(pos, len(order_c) - 1)] == key_f).all(), "coarse edge missing on this rank"
+            seg = order_c[pos]                                   # local coarse edge id of every kept fine edge
+            csr = plan.build_csr(torch.from_numpy(seg), int(ce.shape[1]), self.device)
+            perm = csr.perm.cpu().numpy() if csr.perm is not None else np.arange(len(seg))
+            csr.perm = torch.from_numpy(keep[perm].astype(np.int32)).to(self.device)   # positions in the fine edge list
+            self._pool_plans[l] = csr
+        return self._pool_plans[l]
+
+
+# ------------------------------------------------------------------------------------- halo exchange
+class HaloExchanger:
+    """v[n_own:] <- owned rows of the peers, one collective per call (`all_to_all_single` with split sizes:
+    RCCL grouped send/recv over xGMI on GPUs, gloo in the CPU tests).  world == 1: no-op."""
+
+    def __init__(self, mesh: LocalMesh, group=None):
+        self.mesh, self.group = mesh, group
+        self._send_buf: Dict[tuple, torch.Tensor] = {}
+
+    def exchange(self, v: torch.Tensor, level: int) -> None:
+        m = self.mesh
+        if m.world == 1 or (sum(m.send_counts[level - 1]) == 0 and sum(m.recv_counts[level - 1]) == 0):
+            return
+        import torch.distributed as dist
+        width = int(v.size(1))
+        n_send = sum(m.send_counts[level - 1])
+        key = (level, width)
+        buf = self._send_buf.get(key)
+        if buf is None:
+            buf = self._send_buf[key] = torch.empty((max(n_send, 1), width), dtype=v.dtype, device=v.device)
+        off = 0
+        for q, idx in enumerate(m.send_idx32[level - 1]):
+            k = m.send_counts[level - 1][q]
+            if k:
+                if v.is_cuda:
+                    ops.copy_cols(v, buf[off:off + k], 0, scol0=0, width=width, idx32=idx, n_rows=k)
+                else:   # CPU tests (gloo): host logic only
+                    buf[off:off + k] = v[idx.long()]
+                off += k
+        recv = v[m.n_own[level - 1]:]
+        dist.all_to_all_single(recv, buf[:n_send], output_split_sizes=m.recv_counts[level - 1],
+                               input_split_sizes=m.send_counts[level - 1], group=self.group)
+
+
+# ------------------------------------------------------------------------------------- compute back-ends
+class HipImpl:
+    """Arithmetic of the partitioned forward on the HIP kernels (the product path)."""
+
+    def __init__(self, model):
+        self.m = model
+
+    def new(self, rows: int, width: int, device) -> torch.Tensor:
+        return torch.empty((rows, width), dtype=torch.float32, device=device)
+
+    def encode(self, mesh: LocalMesh, v_out: torch.Tensor):
+        m = self.m
+        e = m.edge_encoder.run_coded([Source(mesh.edge_attr)], int(mesh.edge_attr.size(0)), SELU)
+        srcs = [Source(mesh.inputs[k]) for k in ("field", "loc", "glob", "omega") if k in mesh.inputs]
+        m.node_encoder.run_coded(srcs, mesh.n_own[0], SELU, out=v_out)
+        return e
+
+    def mp(self, name: str, v: torch.Tensor, e: torch.Tensor, e_pending: int, edge_index: torch.Tensor, n_own: int,
+           v_out: torch.Tensor):
+        blk = getattr(self.m, name)
+        ep, csr = plan.edge_csr(edge_index, n_own)
+        e_new = blk.edge_mlp.run_coded([Source(e, pre_act=e_pending), Source(v, ep.row), Source(v, ep.col)], ep.n_edges)
+        agg = ops.segment_reduce(e_new, csr, blk.aggr == "mean")
+        blk.node_mlp.run_coded([Source(agg), Source(v[:n_own])], n_own, SELU, out=v_out)
+        return e_new
+
+    def down(self, name: str, v_own: torch.Tensor, rel: torch.Tensor, parent: torch.Tensor, n_coarse: int, e: torch.Tensor,
+             e_pending: int, pool_csr, v_out: torch.Tensor):
+        blk = getattr(self.m, name)
+        msg = blk.down_mlp.run_coded([Source(rel), Source(v_own)], int(v_own.size(0)))
+        csr = plan.segments_of_sorted(parent, n_coarse)
+        ops.segment_reduce(msg, csr, True, TANH, out=v_out)
+        return ops.segment_reduce(e, pool_csr, True, src_act=e_pending)
+
+    def up(self, name: str, v_coarse: torch.Tensor, v_old_own: torch.Tensor, rel: torch.Tensor, parent: torch.Tensor,
+           v_out: torch.Tensor):
+        blk = getattr(self.m, name)
+        blk.up_mlp.run_coded([Source(rel, negate=True), Source(v_coarse, plan.index32(parent)), Source(v_old_own)],
+                             int(v_old_own.size(0)), TANH, out=v_out)
+
+    def decode(self, v_own: torch.Tensor, field: torch.Tensor, nf: int) -> torch.Tensor:
+        return self.m.node_decoder.run_coded([Source(v_own)], int(v_own.size(0)), NONE, resid=field,
+                                             resid_col0=int(field.size(1)) - nf)
+
+
+class MusPartitionedForward:
+    """The MuS-GNN V-cycle of `nn/mus_gnn.py` on one rank's sub-mesh, with a halo exchange of the node latents
+    before every MP layer."""
+
+    def __init__(self, program: Sequence[str], mesh: LocalMesh, impl, exchanger: HaloExchanger, width: int, nf: int):
+        self.program, self.mesh, self.impl, self.xch, self.width, self.nf = tuple(program), mesh, impl, exchanger, width, nf
+
+    def _buf(self, level: int) -> torch.Tensor:
+        m = self.mesh
+        return self.impl.new(m.n_own[level - 1] + m.n_halo[level - 1], self.width, m.device)
+
+    def forward(self) -> torch.Tensor:
+        m, impl = self.mesh, self.impl
+        level = 1
+        v = self._buf(1)
+        e = impl.encode(m, v[: m.n_own[0]])
+        e_pending = NONE
+        stash = []
+        for name in self.program:
+            n_own = m.n_own[level - 1]
+            if name.startswith("down_mp"):
+                stash.append((v, e, e_pending))
+                v_c = self._buf(level + 1)
+                e = impl.down(name, v[:n_own], m.rel[level - 1], m.parent[level - 1], m.n_own[level], e, e_pending,
+                              m.pool_edge_csr(level), v_c[: m.n_own[level]])
+                v, e_pending = v_c, NONE
+                level += 1
+            elif name.startswith("up_mp"):
+                v_old, e, e_pending = stash.pop()
+                level -= 1
+                v_f = self._buf(level)
+                impl.up(name, v, v_old[: m.n_own[level - 1]], m.rel[level - 1], m.parent[level - 1], v_f[: m.n_own[level - 1]])
+                v = v_f
+            else:
+                self.xch.exchange(v, level)
+                v_new = self._buf(level)
+                e = impl.mp(name, v, e, e_pending, m.edge_index[level - 1], n_own, v_new[:n_own])
+                v, e_pending = v_new, SELU
+        return impl.decode(v[: m.n_own[0]], m.inputs["field"], self.nf)
+
+
+class DistributedRollout:
+    """`Rollout` over a node-partitioned mesh: every rank advances its owned nodes; `outputs` holds the owned
+    rows ([n_own, nf*steps]); `gather_outputs()` assembles the global tensor on every rank (validation / I/O)."""
+
+    def __init__(self, model, graph_cpu: Graph, max_steps: int, rank: int, world: int, device: torch.device, group=None):
+        from .synthetic import MUS_LAYERS
+        self.model, self.rank, self.world, self.device = model, rank, world, device
+        program = model._PROGRAM
+        levels = 1 + sum(1 for n in program if n.startswith("down_mp"))
+        parts = build_partition(graph_cpu, levels, world)
+        self.n_global = int(graph_cpu.pos.size(0))
+        self.mesh = LocalMesh(graph_cpu, levels, parts[rank], device, rank, world)
+        self.nf = int(model.num_fields)
+        width = int(model.node_encoder.output_size)
+        self.fwd = MusPartitionedForward(program, self.mesh, HipImpl(model), HaloExchanger(self.mesh, group), width, self.nf)
+        self.max_steps = max_steps
+        self.field = self.mesh.inputs["field"] = self.mesh.inputs["field"].clone()
+        self.outputs = torch.zeros((self.mesh.n_own[0], self.nf * max_steps), dtype=torch.float32, device=device)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=device)
+        self.steps_done = 0
+
+    def step(self) -> None:
+        with torch.no_grad():
+            pred = self.fwd.forward()
+            ops.rollout_advance(self.field, pred, self.outputs, self.step_counter, self.nf)
+        self.steps_done += 1
+
+    def run(self, n: int) -> None:
+        for _ in range(n):
+            self.step()
+
+    def gather_outputs(self) -> torch.Tensor:
+        import torch.distributed as dist
+        full = torch.zeros((self.n_global, self.outputs.size(1)), dtype=torch.float32, device=self.device)
+        full[self.mesh.owned_global[0]] = self.outputs
+        if self.world > 1:
+            dist.all_reduce(full)
+        return full

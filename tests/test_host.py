@@ -1,0 +1,127 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every symbol the header declares,
+the static-plan builders (host C++) agree with the oracle's topology, the gfd-compatible module surface
+(state_dict keys, checkpoint format, Graph container, error behaviour)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import graphs4cfd_amd as gfd
+from graphs4cfd_amd import _lib, plan, synthetic as S
+from oracle import g4c_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "g4c.h")).read()
+    declared = set(re.findall(r"\b(g4c_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libg4c.so does not export {name}"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), (declared ^ set(_lib.EXPORTED_SYMBOLS))
+    assert lib.g4c_version() >= 1
+
+
+def test_plan_csr_matches_stable_argsort():
+    rng = np.random.default_rng(0)
+    keys = torch.from_numpy(rng.integers(0, 37, size=500))
+    p = plan.build_csr(keys, 40, torch.device("cpu"))
+    order = torch.sort(keys, stable=True)[1].to(torch.int32)
+    assert torch.equal(p.perm, order)
+    assert torch.equal(p.off.long(), torch.cat([torch.zeros(1, dtype=torch.long), torch.bincount(keys, minlength=40).cumsum(0)]))
+    assert p.max_deg == int(torch.bincount(keys).max())
+    # already grouped in order -> no permutation at all
+    sorted_keys = torch.arange(50).repeat_interleave(6)
+    assert plan.build_csr(sorted_keys, 50, torch.device("cpu")).perm is None
+    with pytest.raises(ValueError):
+        plan.build_csr(torch.tensor([0, 7]), 5, torch.device("cpu"))
+
+
+def test_pool_edge_plan_topology_matches_oracle(golden):
+    import ctypes as C
+    lib = _lib.load()
+    for tag in ("mean", "empty"):
+        c = golden("blocks.pt")[f"pool_edge_{tag}"]
+        idx = np.ascontiguousarray(c["idx"].numpy())
+        ei = np.ascontiguousarray(c["edge_index"].numpy())
+        n_edges = ei.shape[1]
+        coarse = np.empty((2, n_edges), dtype=np.int64)
+        perm = np.empty(n_edges, dtype=np.int32)
+        off = np.empty(n_edges + 1, dtype=np.int32)
+        kept = C.c_int64(0)
+        nc = lib.g4c_plan_pool_edge(idx.ctypes.data, idx.shape[0], ei.ctypes.data, n_edges, coarse.ctypes.data,
+                                    perm.ctypes.data, off.ctypes.data, C.byref(kept))
+        got = torch.from_numpy(coarse.reshape(-1)[: 2 * nc].reshape(2, nc).copy())
+        assert torch.equal(got, c["edge_index_out"])
+        # the segmented permutation reproduces the reference's mean of duplicate edges
+        ea = c["edge_attr"]
+        if nc:
+            seg = torch.repeat_interleave(torch.arange(nc), torch.from_numpy(np.diff(off[: nc + 1])).long())
+            pooled = O.scatter(ea[torch.from_numpy(perm[: kept.value].copy()).long()], seg, nc, "mean")
+            torch.testing.assert_close(pooled, c["edge_attr_out"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("cls", sorted(S.MUS_LAYERS))
+def test_state_dict_keys_and_shapes_match_reference(golden, cls):
+    c = golden("models_mus.pt")[cls]
+    model = getattr(gfd.nn, cls)(arch=c["arch"])
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(c["weights"].keys())
+    assert all(sd[k].shape == v.shape for k, v in c["weights"].items())
+    model.load_state_dict(c["weights"])
+    assert model.num_params == c["num_params"] and model.num_fields == c["arch"]["decoder"][1][-1]
+
+
+def test_remus_state_dict_and_seeded_init_match_reference(golden):
+    c = golden("model_remus.pt")
+    torch.manual_seed(400)           # the seed make_golden.py used: same construction order -> same init
+    model = gfd.nn.NsRotEquiTreeScaleGNN(arch=c["arch"])
+    assert list(model.state_dict().keys()) == list(c["weights"].keys())
+    for k, v in c["weights"].items():
+        assert torch.equal(model.state_dict()[k], v), k
+
+
+def test_checkpoint_round_trip_in_reference_format(golden, tmp_path):
+    path = os.path.join(os.path.dirname(__file__), "golden", "reference_saved.chk")
+    model = gfd.nn.NsOneScaleGNN(checkpoint=path)      # a file written by the reference's save_checkpoint
+    assert list(model.state_dict().keys()) == golden("checkpoint_io.pt")["keys"]
+    out = str(tmp_path / "mine.chk")
+    model.save_checkpoint(out, n_out=2, epoch=5)
+    chk = torch.load(out, weights_only=False)
+    assert set(chk) >= {"arch", "weights", "n_out", "epoch"} and chk["arch"] == model.arch
+    again = gfd.nn.NsOneScaleGNN(checkpoint=out)
+    assert all(torch.equal(a, b) for a, b in zip(again.state_dict().values(), model.state_dict().values()))
+    w = str(tmp_path / "weights.pt")
+    torch.save(model.state_dict(), w)
+    third = gfd.nn.NsOneScaleGNN(arch=model.arch, weights=w)
+    assert all(torch.equal(a, b) for a, b in zip(third.state_dict().values(), model.state_dict().values()))
+
+
+def test_graph_container_and_collate():
+    g = gfd.Graph(pos=torch.zeros(5, 2), field=torch.ones(5, 3), edge_index=torch.tensor([[0, 1], [1, 2]]))
+    assert g.num_nodes == 5 and g.num_edges == 2 and hasattr(g, "field") and not hasattr(g, "loc")
+    g.idx1_to_idx2 = torch.arange(5)
+    assert getattr(g, "idx1_to_idx2").numel() == 5 and "idx1_to_idx2" in g.keys()
+    assert g.to("cpu") is g
+    b = gfd.nn.collate([g.clone(), g.clone()])
+    assert b.num_nodes == 10 and b.edge_index.tolist() == [[0, 1, 5, 6], [1, 2, 6, 7]]
+    assert b.batch.tolist() == [0] * 5 + [1] * 5
+
+
+def test_product_path_has_no_cpu_fallback_and_validates():
+    mlp = gfd.nn.blocks.MLP(8, (16, 16), True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mlp(torch.randn(4, 8))
+    model = gfd.nn.NsOneScaleGNN(arch=S.mus_arch("NsOneScaleGNN", 32))
+    with pytest.raises(AssertionError):
+        model.solve(S.mus_graph(50), 0)
+    with pytest.raises(ValueError, match="not recognized"):
+        gfd.nn.NsTwoScaleGNN(model="nope")
+    with pytest.raises(ValueError):
+        gfd.nn.blocks.MLP(4, (8,))
+    src = open(os.path.join(ROOT, "graphs4cfd_amd", "ops.py")).read() + open(os.path.join(ROOT, "graphs4cfd_amd", "nn", "blocks.py")).read()
+    assert "oracle" not in src, "the product path must not import the oracle"

@@ -1,0 +1,119 @@
+"""Node partition + halo exchange (graphs4cfd_amd/partition.py) on CPU: structural invariants of the
+partition, and the partitioned V-cycle run on 2 gloo ranks with the ORACLE as the arithmetic back-end,
+compared with the single-process oracle forward (the HIP back-end is covered by the -m gpu tests)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from graphs4cfd_amd import partition as P, synthetic as S
+from oracle import g4c_oracle as O
+
+
+def test_partition_invariants():
+    g = S.mus_graph(3000, levels=3, seed=2)
+    for world in (2, 4):
+        parts = P.build_partition(g, 3, world)
+        edges = P.coarse_topology(g, 3)
+        owners = P.assign_owners(g, 3, world)
+        sizes = [int(g.pos.size(0)), int(g.pos_2.size(0)), int(g.pos_3.size(0))]
+        for l in range(3):
+            own_all = np.concatenate([parts[r][l].owned for r in range(world)])
+            assert np.array_equal(np.sort(own_all), np.arange(sizes[l])), "every node owned exactly once"
+            e_all = np.concatenate([parts[r][l].edge_ids for r in range(world)])
+            assert np.array_equal(np.sort(e_all), np.arange(edges[l].shape[1])), "every edge owned exactly once"
+            for r in range(world):
+                p = parts[r][l]
+                loc2glob = np.concatenate([p.owned, p.halo])
+                assert np.array_equal(loc2glob[p.edge_index[0]], edges[l][0, p.edge_ids])
+                assert np.array_equal(loc2glob[p.edge_index[1]], edges[l][1, p.edge_ids])
+                assert (p.edge_index[1] < p.n_own).all(), "edges are owned by the rank of their target"
+                assert (owners[l][p.halo] != r).all() and np.array_equal(owners[l][p.halo], p.halo_owner)
+                for q in range(world):   # what r sends to q is exactly q's halo owned by r, in q's order
+                    need = parts[q][l].halo[parts[q][l].halo_owner == r]
+                    assert np.array_equal(p.owned[p.send_idx[q]], need)
+                    assert parts[q][l].recv_counts[r] == len(need)
+        # clusters are wholly owned: a fine node and its parent have the same owner
+        assert np.array_equal(owners[0], owners[1][g.idx1_to_idx2.numpy()])
+        assert np.array_equal(owners[1], owners[2][g.idx2_to_idx3.numpy()])
+        # balance: strips within 25 % of the mean
+        counts = np.bincount(owners[0], minlength=world)
+        assert counts.max() < 1.25 * counts.mean()
+
+
+class OracleImpl:
+    """Test-only arithmetic back-end for MusPartitionedForward (CPU, oracle ops)."""
+
+    def __init__(self, w):
+        self.w = w
+
+    def new(self, rows, width, device):
+        return torch.zeros(rows, width)
+
+    def encode(self, mesh, v_out):
+        x = torch.cat([mesh.inputs[k] for k in ("field", "loc", "glob", "omega") if k in mesh.inputs], 1)
+        v_out.copy_(F.selu(O.mlp(x, self.w, "node_encoder")))
+        return F.selu(O.mlp(mesh.edge_attr, self.w, "edge_encoder"))
+
+    @staticmethod
+    def _act(e, pending):
+        return F.selu(e) if pending else e
+
+    def mp(self, name, v, e, e_pending, edge_index, n_own, v_out):
+        row, col = edge_index
+        e_new = O.mlp(torch.cat((self._act(e, e_pending), v[row], v[col]), 1), self.w, f"{name}.edge_mlp")
+        agg = O.scatter(e_new, col, n_own, "mean")
+        v_out.copy_(F.selu(O.mlp(torch.cat((agg, v[:n_own]), 1), self.w, f"{name}.node_mlp")))
+        return e_new
+
+    def down(self, name, v_own, rel, parent, n_coarse, e, e_pending, pool_csr, v_out):
+        msg = O.mlp(torch.cat((rel, v_own), 1), self.w, f"{name}.down_mlp")
+        v_out.copy_(torch.tanh(O.scatter(msg, parent, n_coarse, "mean")))
+        seg = torch.repeat_interleave(torch.arange(pool_csr.n_seg), (pool_csr.off[1:] - pool_csr.off[:-1]).long())
+        return O.scatter(self._act(e, e_pending)[pool_csr.perm.long()], seg, pool_csr.n_seg, "mean")
+
+    def up(self, name, v_coarse, v_old_own, rel, parent, v_out):
+        v_out.copy_(torch.tanh(O.mlp(torch.cat((-rel, v_coarse[parent], v_old_own), 1), self.w, f"{name}.up_mlp")))
+
+    def decode(self, v_own, field, nf):
+        return field[:, -nf:] + O.mlp(v_own, self.w, "node_decoder")
+
+
+def _worker(rank, world, port, model_name, levels, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        g = S.mus_graph(1500, levels=levels, seed=5)
+        arch = S.mus_arch(model_name, 32)
+        torch.manual_seed(11)
+        import graphs4cfd_amd as gfd
+        model = getattr(gfd.nn, model_name)(arch=arch)     # CPU: parameters only, never run
+        w = {k: v.detach() for k, v in model.state_dict().items()}
+        parts = P.build_partition(g, levels, world)
+        mesh = P.LocalMesh(g, levels, parts[rank], torch.device("cpu"), rank, world)
+        fwd = P.MusPartitionedForward(model._PROGRAM, mesh, OracleImpl(w), P.HaloExchanger(mesh), 32, 3)
+        with torch.no_grad():
+            pred = fwd.forward()
+        full = torch.zeros(g.pos.size(0), 3)
+        full[mesh.owned_global[0]] = pred
+        dist.all_reduce(full)
+        if rank == 0:
+            with torch.no_grad():
+                ref = O.mus_forward(model_name, g.to_dict(), w, 3)
+            torch.save({"full": full, "ref": ref, "halo": [mesh.n_halo, mesh.n_own]}, os.path.join(out_dir, "result.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model_name,levels", [("NsThreeScaleGNN", 3), ("NsOneScaleGNN", 1)])
+def test_partitioned_forward_matches_global_on_two_gloo_ranks(tmp_path, model_name, levels):
+    import torch.multiprocessing as mp
+    port = 29600 + (os.getpid() % 300) + levels
+    mp.spawn(_worker, args=(2, port, model_name, levels, str(tmp_path)), nprocs=2, join=True)
+    r = torch.load(os.path.join(str(tmp_path), "result.pt"))
+    assert all(h > 0 for h in r["halo"][0]), "the test mesh must actually have halos on every level"
+    torch.testing.assert_close(r["full"], r["ref"], rtol=1e-4, atol=1e-4)
