@@ -494,9 +494,42 @@ extern "C" int g4c_mlp_pack_layer(const float *W, int32_t n_out, int32_t k_in, c
     return g4c::check_launch("g4c_mlp_pack_layer");
 }
 
+extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                                    int64_t row_begin, int64_t row_count, int32_t tile_rows,
+                                    float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
+                                    const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
+
+extern "C" int64_t g4c_mlp_bulk_rows(int64_t n_rows) {
+    // Tile scheduling.  A 64-row tile (one wave, 512 registers) keeps a SIMD busy for one "round"; the
+    // chip holds 1024 of them.  Whole rounds go to the 64-row kernel; the remainder (< 64 Ki rows) goes to
+    // 32-row tiles, which finish in about half a round when there are at most 1024 of them, instead of
+    // leaving most of the chip idle for a full last round.
+    static const int force_rt = getenv("G4C_MLP_RT") ? atoi(getenv("G4C_MLP_RT")) : 0;
+    const long long round_rows = 64LL * 1024;
+    if (force_rt == 2) return n_rows;
+    if (force_rt == 1) return 0;
+    return (n_rows / round_rows) * round_rows;
+}
+
 extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                                const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream) {
+    const int64_t bulk = g4c_mlp_bulk_rows(n_rows);
+    int rc = G4C_OK;
+    if (bulk > 0)
+        rc = g4c_mlp_forward_rows(mlp, srcs, n_src, n_rows, 0, bulk, 64, out, out_ld, out_idx, act, resid, resid_ld, resid_col0, stream);
+    if (rc == G4C_OK && n_rows > bulk)
+        rc = g4c_mlp_forward_rows(mlp, srcs, n_src, n_rows, bulk, n_rows - bulk, 32, out, out_ld, out_idx, act, resid, resid_ld, resid_col0, stream);
+    return rc;
+}
+
+extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                                    int64_t row_begin, int64_t row_count, int32_t tile_rows,
+                                    float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
+                                    const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream) {
+    G4C_REQUIRE(tile_rows == 64 || tile_rows == 32, G4C_EINVAL, "g4c_mlp_forward_rows: tile_rows must be 64 or 32");
+    G4C_REQUIRE(row_begin >= 0 && row_count >= 0 && row_begin + row_count <= n_rows && row_begin % 32 == 0, G4C_EINVAL,
+                "g4c_mlp_forward_rows: bad row range [%lld, +%lld) of %lld", (long long)row_begin, (long long)row_count, (long long)n_rows);
     G4C_REQUIRE(mlp && srcs, G4C_EINVAL, "g4c_mlp_forward: null pointer");
     G4C_REQUIRE(n_src >= 1 && n_src <= G4C_MAX_SRC, G4C_EUNSUPPORTED, "g4c_mlp_forward: %d sources (max %d)", n_src, G4C_MAX_SRC);
     G4C_REQUIRE(mlp->n_layers >= 2 && mlp->n_layers <= G4C_MAX_LAYERS, G4C_EUNSUPPORTED,
@@ -546,24 +579,15 @@ extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int3
     p.out = out; p.out_ld = out_ld; p.out_idx = out_idx; p.act = act;
     p.resid = resid; p.resid_ld = resid_ld; p.resid_col0 = resid_col0;
     hipStream_t st = (hipStream_t)stream;
-    // Tile scheduling.  A 64-row tile (one wave, 512 registers) keeps a SIMD busy for one "round"; the
-    // chip holds 1024 of them.  Whole rounds go to the 64-row kernel; the remainder (< 64 Ki rows) goes to
-    // 32-row tiles, which finish in about half a round when there are at most 1024 of them, instead of
-    // leaving most of the chip idle for a full last round.
-    static const int force_rt = getenv("G4C_MLP_RT") ? atoi(getenv("G4C_MLP_RT")) : 0;
-    const long long round_rows = 64LL * 1024;
-    long long bulk = (n_rows / round_rows) * round_rows;
-    if (force_rt == 2) bulk = n_rows;
-    if (force_rt == 1) bulk = 0;
-    if (bulk > 0) {
-        p.row_base = 0;
-        p.n_tiles = (int)((bulk + 63) / 64);
+    if (row_count == 0) return G4C_OK;
+    p.row_base = row_begin;
+    p.M = row_begin + row_count;          // rows past the range are neither gathered nor stored
+    if (tile_rows == 64) {
+        p.n_tiles = (int)((row_count + 63) / 64);
         if (all_vec) mlp_fused_kernel<2, true><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
         else mlp_fused_kernel<2, false><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
-    }
-    if (n_rows > bulk) {
-        p.row_base = bulk;
-        p.n_tiles = (int)((n_rows - bulk + 31) / 32);
+    } else {
+        p.n_tiles = (int)((row_count + 31) / 32);
         if (all_vec) mlp_fused_kernel<1, true><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
         else mlp_fused_kernel<1, false><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
     }

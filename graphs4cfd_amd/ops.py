@@ -255,8 +255,16 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                                                           s.col0, s.pre_act)
     if out is None:
         out = torch.empty((n_rows, packed.n_out), dtype=torch.float32, device=dev)
-    _timed("mlp_fused", packed.flops_per_row * n_rows, 4.0 * n_rows * (sum(packed.seg_widths) + packed.n_out),
-           lambda: _lib.check(lib.g4c_mlp_forward(
-               C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out), _ld(out), _lib.ptr(out_idx32), act,
-               _lib.ptr(resid), _ld(resid) if resid is not None else 0, resid_col0, _lib.stream_handle(dev))))
+    args = (_lib.ptr(out), _ld(out), _lib.ptr(out_idx32), act, _lib.ptr(resid), _ld(resid) if resid is not None else 0,
+            resid_col0, _lib.stream_handle(dev))
+    if KernelTimer.active is None:
+        _lib.check(lib.g4c_mlp_forward(C.byref(packed.desc), arr, len(sources), n_rows, *args))
+    else:
+        # same two launches as g4c_mlp_forward, bracketed separately (kernel names as rocprofv3 reports them)
+        bulk = int(lib.g4c_mlp_bulk_rows(n_rows))
+        bpr = 4.0 * (sum(packed.seg_widths) + packed.n_out)
+        for kind, begin, count, tile in (("mlp_fused_kernel<2>", 0, bulk, 64), ("mlp_fused_kernel<1>", bulk, n_rows - bulk, 32)):
+            if count > 0:
+                _timed(kind, packed.flops_per_row * count, bpr * count, lambda: _lib.check(lib.g4c_mlp_forward_rows(
+                    C.byref(packed.desc), arr, len(sources), n_rows, begin, count, tile, *args)))
     return out

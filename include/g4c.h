@@ -119,6 +119,16 @@ int g4c_mlp_forward(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*
                     int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0,
                     void *stream);
 
+/* The two launches g4c_mlp_forward is made of, exposed so that a profiler can bracket them separately:
+ * rows [0, g4c_mlp_bulk_rows(n)) run as 64-row tiles (whole "rounds" of 1024 tiles), the remainder as 32-row
+ * tiles.  g4c_mlp_forward_rows processes rows [row_begin, row_begin + row_count) with tile_rows in {64, 32};
+ * row_begin must be a multiple of 32. */
+int64_t g4c_mlp_bulk_rows(int64_t n_rows);
+int g4c_mlp_forward_rows(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
+                         int64_t n_rows, int64_t row_begin, int64_t row_count, int32_t tile_rows,
+                         float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
+                         const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
+
 /* ---------------------------------------------------------------- REMuS helpers (HBM-bound)
  * out[e, f] = v[node[e], 2f]*U[e,0] + v[node[e], 2f+1]*U[e,1]
  * (nn/remus_gnn.py:124-126, nn/blocks.py:454). node == NULL reads row e. */
