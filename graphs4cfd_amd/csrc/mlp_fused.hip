@@ -179,6 +179,37 @@ __device__ __forceinline__ f32x4 ldx1(const Src &s, int srow, int c) {
 
 template <int RT> struct XRegs { f32x16 v[RT]; };   // RT*4 float4 per lane
 
+// Row base pointers of the source being gathered, one per piece (rows (lane>>3) + 8q): computed once per
+// source, so a chunk's gather is one 64-bit add + one load per piece (no kernarg reloads, no LDS reads,
+// no 64-bit multiplies at every chunk).
+template <int RT> struct RowPtrs { const float *p[RT * 4]; };
+
+template <int RT>
+__device__ __forceinline__ void row_ptrs(RowPtrs<RT> &rp, const float *ptr, int ld, int col0, const int *sRow, int lane) {
+#pragma unroll
+    for (int q = 0; q < RT * 4; ++q) rp.p[q] = ptr + (long long)sRow[(lane >> 3) + 8 * q] * ld + col0;
+}
+
+template <int RT, bool VEC>
+__device__ __forceinline__ void load_x_rp(const RowPtrs<RT> &rp, int width, int k0, int lane, XRegs<RT> &x) {
+    const int c = k0 + (lane & 7) * 4;
+#pragma unroll
+    for (int q = 0; q < RT * 4; ++q) {
+        f32x4 t;
+        if (VEC) {
+            t = *reinterpret_cast<const f32x4 *>(rp.p[q] + (c < width ? c : 0));
+        } else {
+            const int w1 = width - 1;
+            t[0] = rp.p[q][c + 0 < w1 ? c + 0 : w1];
+            t[1] = rp.p[q][c + 1 < w1 ? c + 1 : w1];
+            t[2] = rp.p[q][c + 2 < w1 ? c + 2 : w1];
+            t[3] = rp.p[q][c + 3 < w1 ? c + 3 : w1];
+        }
+        x.v[q >> 2][(q & 3) * 4 + 0] = t[0]; x.v[q >> 2][(q & 3) * 4 + 1] = t[1];
+        x.v[q >> 2][(q & 3) * 4 + 2] = t[2]; x.v[q >> 2][(q & 3) * 4 + 3] = t[3];
+    }
+}
+
 template <int RT, bool VEC>
 __device__ __forceinline__ void load_x(const Src &s, const int *sRow, int k0, int lane, XRegs<RT> &x) {
     const int c = k0 + (lane & 7) * 4;
@@ -302,29 +333,42 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
     const unsigned lo = (unsigned)(((lane >> 5) * 32 + (lane & 31)) * 8);   // lane's offset inside a step's 512 floats
     ring_fill(ring, w, lo);
     {
+        // descriptor of the source currently being gathered, kept in scalars / registers
         int s = 0, k0 = 0;
-        load_x<RT, VEC>(p.src[0], sRow, 0, lane, xr);
-        pre_act_x<RT>(xr, p.src[0].pre_act, p.src[0].width, 0, lane);
+        int cur_width = p.src[0].width, cur_wpad = p.src[0].wpad, cur_act = p.src[0].pre_act;
+        RowPtrs<RT> rp;
+        row_ptrs<RT>(rp, p.src[0].ptr, p.src[0].ld, p.src[0].col0, sRow, lane);
+        load_x_rp<RT, VEC>(rp, cur_width, 0, lane, xr);
+        pre_act_x<RT>(xr, cur_act, cur_width, 0, lane);
         store_x<RT>(sX0, lane, xr);
         G4C_STAMP(1);
         for (int c = 0; c < p.chunks0; ++c) {
             // next chunk of layer 0: issue its gather now, park it in LDS after this chunk's MFMAs.
             // Straight-line on purpose (the last iteration re-loads its own chunk into the idle
             // buffer): hipcc then waits for the gather with an exact vmcnt(16) and leaves the 16
-            // younger weight-ring loads in flight.
-            int ns = s, nk0 = k0 + KC;
-            if (nk0 >= p.src[s].wpad) { ns = s + 1; nk0 = 0; }
-            if (c + 1 >= p.chunks0) { ns = s; nk0 = k0; }
-            if (!(G4C_ABLATE & 2)) load_x<RT, VEC>(p.src[ns], sRow + ns * ROWS, nk0, lane, xr);
+            // younger weight-ring loads in flight.  Only a source switch (2-3 per tile) touches the
+            // kernel arguments and the row-index table.
+            int nk0 = k0 + KC;
+            if (nk0 >= cur_wpad) {
+                if (s + 1 < p.n_src) {
+                    ++s;
+                    nk0 = 0;
+                    cur_width = p.src[s].width; cur_wpad = p.src[s].wpad; cur_act = p.src[s].pre_act;
+                    row_ptrs<RT>(rp, p.src[s].ptr, p.src[s].ld, p.src[s].col0, sRow + s * ROWS, lane);
+                } else {
+                    nk0 = k0;
+                }
+            }
+            if (!(G4C_ABLATE & 2)) load_x_rp<RT, VEC>(rp, cur_width, nk0, lane, xr);
             __builtin_amdgcn_sched_barrier(0);
             const float *sX = (c & 1) ? sX1 : sX0;
             w += CHUNK_FLOATS;
             mma_chunk<RT, !(G4C_ABLATE & 1)>(sX + i * XS + 2 * h, 32 * XS, ring, w, lo, acc);
             if (!(G4C_ABLATE & 2)) {
-                pre_act_x<RT>(xr, p.src[ns].pre_act, p.src[ns].width, nk0, lane);
+                pre_act_x<RT>(xr, cur_act, cur_width, nk0, lane);
                 store_x<RT>((c & 1) ? sX0 : sX1, lane, xr);
             }
-            s = ns; k0 = nk0;
+            k0 = nk0;
         }
     }
 
@@ -414,14 +458,19 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
     // ------------------------------------------------------------------ store (+ residual)
     const bool fast = (n_out == NP) && ((p.out_ld & 3) == 0) && (((uintptr_t)p.out & 15) == 0) && (p.resid == nullptr);
     if (fast) {
-        // two whole rows (2 x 512 B) per instruction
-#pragma unroll 4
-        for (int r = h; r < ROWS; r += 2) {
-            const long long grow = row0 + r;
-            if (grow < p.M) {
-                const long long orow = p.out_idx ? p.out_idx[grow] : grow;
-                const f32x4 t = *reinterpret_cast<const f32x4 *>(sH + r * HS + 4 * i);
-                *reinterpret_cast<f32x4 *>(p.out + orow * p.out_ld + 4 * i) = t;
+        // two whole rows (2 x 512 B) per instruction; LDS reads issued 8 at a time ahead of the stores
+#pragma unroll 1
+        for (int r0 = 0; r0 < ROWS; r0 += 16) {
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4 *>(sH + (r0 + 2 * u + h) * HS + 4 * i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long grow = row0 + r0 + 2 * u + h;
+                if (grow < p.M) {
+                    const long long orow = p.out_idx ? p.out_idx[grow] : grow;
+                    *reinterpret_cast<f32x4 *>(p.out + orow * p.out_ld + 4 * i) = t[u];
+                }
             }
         }
     } else {
