@@ -488,6 +488,283 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
     G4C_STAMP(13);
 }
 
+// ======================================================================================================
+// Column-split variant for SMALL launches (coarse levels, remainders, per-rank sub-meshes): NW waves share
+// one 32-row tile, each computing NCT = 4/NW of the four 32-column tiles.  A launch with few tiles is
+// latency-bound on one wave's ~80k MFMA cycles; splitting the columns gives NW x more waves with 1/NW of
+// the MFMA work each, so the tile finishes ~NW x sooner and the launch fills more SIMDs.
+// The waves of a tile share the gathered input chunk and the hidden activations through LDS:
+// one barrier per layer-0 chunk, two per layer.  Weights still stream L2 -> registers (each wave only its
+// own column tiles), accumulators stay in registers.
+template <int NCT> struct BVec;
+template <> struct BVec<2> { typedef f32x4 type; };
+template <> struct BVec<1> { typedef float2 type; };
+
+template <int NCT>
+__device__ __forceinline__ typename BVec<NCT>::type load_bn(const float *wstep, unsigned lane_off) {
+    return *reinterpret_cast<const typename BVec<NCT>::type *>(wstep + lane_off);
+}
+
+template <int NCT> struct AccN { f32x16 t[NCT]; };
+template <int NCT> struct RingN { typename BVec<NCT>::type s0, s1, s2, s3, s4, s5, s6, s7; };
+
+__device__ __forceinline__ float bget(const f32x4 &b, int k) { return b[k]; }
+__device__ __forceinline__ float bget(const float2 &b, int k) { return k ? b.y : b.x; }
+
+template <int NCT>
+__device__ __forceinline__ void mma_chunk_n(const float *pa, RingN<NCT> &g, const float *wnext, unsigned lo, AccN<NCT> &acc) {
+    float2 a = *reinterpret_cast<const float2 *>(pa);
+#define G4C_STEP(U, SLOT)                                                                  \
+    {                                                                                      \
+        const float2 an = *reinterpret_cast<const float2 *>(pa + (((U) + 1) & 7) * 4);     \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        _Pragma("unroll") for (int c = 0; c < NCT; ++c) {                                  \
+            acc.t[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bget(g.SLOT, 2 * c), acc.t[c], 0, 0, 0);     \
+        }                                                                                  \
+        _Pragma("unroll") for (int c = 0; c < NCT; ++c) {                                  \
+            acc.t[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bget(g.SLOT, 2 * c + 1), acc.t[c], 0, 0, 0); \
+        }                                                                                  \
+        g.SLOT = load_bn<NCT>(wnext + (U) * 512, lo);                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        a = an;                                                                            \
+    }
+    G4C_STEP(0, s0) G4C_STEP(1, s1) G4C_STEP(2, s2) G4C_STEP(3, s3)
+    G4C_STEP(4, s4) G4C_STEP(5, s5) G4C_STEP(6, s6) G4C_STEP(7, s7)
+#undef G4C_STEP
+}
+
+template <int NW, bool VEC>
+__global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
+    constexpr int ROWS = 32, NCT = 4 / NW, NPIECE = 4 / NW;   // pieces (8 rows x 32 cols) of a chunk gathered per wave
+    __shared__ __attribute__((aligned(16))) float lds[ROWS * HS + G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
+    float *sH = lds;
+    float *sX0 = lds;
+    float *sX1 = lds + ROWS * XS;
+    int *sRow = reinterpret_cast<int *>(lds + ROWS * HS);
+    float *sBias = lds + ROWS * HS + G4C_MAX_SRC * ROWS;
+    float *sGB = sBias + G4C_MAX_LAYERS * NP;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int ct0 = wave * NCT;
+
+    int tile;
+    {
+        const int b = blockIdx.x, nt = p.n_tiles;
+        const int q = nt >> 3, r = nt & 7, x = b & 7, j = b >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const long long row0 = p.row_base + (long long)tile * ROWS;
+
+    for (int r = tid; r < ROWS; r += 64 * NW) {
+        long long gr = row0 + r;
+        if (gr >= p.M) gr = p.M - 1;
+        for (int s = 0; s < p.n_src; ++s) sRow[s * ROWS + r] = p.src[s].idx ? p.src[s].idx[gr] : (int)gr;
+    }
+    for (int e = tid; e < p.n_layers * NP; e += 64 * NW) sBias[e] = p.b[e];
+    if (p.gamma) {
+        for (int e = tid; e < NP; e += 64 * NW) {
+            const int ee = e < p.n_out ? e : 0;
+            sGB[e] = p.gamma[ee];
+            sGB[NP + e] = p.beta[ee];
+        }
+    }
+    __syncthreads();
+
+    AccN<NCT> acc;
+    RingN<NCT> ring;
+    const float *w = p.w;
+    const unsigned lo = (unsigned)((h * 32 + i) * 8 + ct0 * 2);
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc.t[c][q] = 0.f;
+    ring.s0 = load_bn<NCT>(w + 0 * 512, lo); ring.s1 = load_bn<NCT>(w + 1 * 512, lo);
+    ring.s2 = load_bn<NCT>(w + 2 * 512, lo); ring.s3 = load_bn<NCT>(w + 3 * 512, lo);
+    ring.s4 = load_bn<NCT>(w + 4 * 512, lo); ring.s5 = load_bn<NCT>(w + 5 * 512, lo);
+    ring.s6 = load_bn<NCT>(w + 6 * 512, lo); ring.s7 = load_bn<NCT>(w + 7 * 512, lo);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---------------------------------------------------------------- layer 0: shared gather, one barrier per chunk
+    {
+        const int c4 = (lane & 7) * 4;
+        f32x4 xp[NPIECE];
+        const float *rp[NPIECE];
+        int s = 0, k0 = 0;
+        int cur_width = p.src[0].width, cur_wpad = p.src[0].wpad, cur_act = p.src[0].pre_act;
+        auto set_rows = [&](int sidx) {
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q)
+                rp[q] = p.src[sidx].ptr + (long long)sRow[sidx * ROWS + (lane >> 3) + 8 * (wave + NW * q)] * p.src[sidx].ld + p.src[sidx].col0;
+        };
+        auto gather = [&](int kk) {
+            const int c = kk + c4;
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q) {
+                if (VEC) {
+                    xp[q] = *reinterpret_cast<const f32x4 *>(rp[q] + (c < cur_width ? c : 0));
+                } else {
+                    const int w1 = cur_width - 1;
+                    xp[q][0] = rp[q][c + 0 < w1 ? c + 0 : w1]; xp[q][1] = rp[q][c + 1 < w1 ? c + 1 : w1];
+                    xp[q][2] = rp[q][c + 2 < w1 ? c + 2 : w1]; xp[q][3] = rp[q][c + 3 < w1 ? c + 3 : w1];
+                }
+            }
+        };
+        auto park = [&](float *dst, int kk) {
+            const int c = kk + c4;
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q) {
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (c + e < cur_width) ? xp[q][e] : 0.f;
+                if (cur_act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = g4c::selu_f(t[e]);
+                }
+                float *d = dst + ((lane >> 3) + 8 * (wave + NW * q)) * XS + c4;
+                *reinterpret_cast<float2 *>(d) = make_float2(t[0], t[1]);
+                *reinterpret_cast<float2 *>(d + 2) = make_float2(t[2], t[3]);
+            }
+        };
+        set_rows(0);
+        gather(0);
+        park(sX0, 0);
+        __syncthreads();
+        for (int c = 0; c < p.chunks0; ++c) {
+            int nk0 = k0 + KC;
+            if (nk0 >= cur_wpad) {
+                if (s + 1 < p.n_src) {
+                    ++s; nk0 = 0;
+                    cur_width = p.src[s].width; cur_wpad = p.src[s].wpad; cur_act = p.src[s].pre_act;
+                    set_rows(s);
+                } else {
+                    nk0 = k0;
+                }
+            }
+            gather(nk0);
+            __builtin_amdgcn_sched_barrier(0);
+            w += CHUNK_FLOATS;
+            mma_chunk_n<NCT>(((c & 1) ? sX1 : sX0) + i * XS + 2 * h, ring, w, lo, acc);
+            park((c & 1) ? sX0 : sX1, nk0);
+            k0 = nk0;
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------- layers 1..L-1
+    for (int l = 0;; ++l) {
+        const bool last = (l == p.n_layers - 1);
+        {   // this wave's column tiles of the layer output -> shared hidden buffer
+            float *base = sH + (4 * h) * HS + i;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float bv = sBias[l * NP + (ct0 + c) * 32 + i];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int row = (q & 3) + 8 * (q >> 2);
+                    float x = acc.t[c][q] + bv;
+                    if (!last) x = g4c::selu_f(x);
+                    base[row * HS + (ct0 + c) * 32] = x;
+                }
+            }
+        }
+        __syncthreads();
+        if (last) break;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc.t[c][q] = 0.f;
+#pragma unroll 1
+        for (int k0 = 0; k0 < NP; k0 += KC) {
+            w += CHUNK_FLOATS;
+            mma_chunk_n<NCT>(sH + i * HS + k0 + 2 * h, ring, w, lo, acc);
+        }
+        __syncthreads();   // everybody is done reading sH before the next layer's output overwrites it
+    }
+
+    // ---------------------------------------------------------------- LayerNorm / activation: rows split over the waves
+    // wave w owns rows [w*RPW, (w+1)*RPW); lane = part * RPW + row_local, each part = NC consecutive columns
+    constexpr int RPW = ROWS / NW, PARTS = 64 / RPW, NC = NP / PARTS;
+    const int n_out = p.n_out;
+    const int rloc = lane % RPW, part = lane / RPW;
+    const int myrow = wave * RPW + rloc;
+    const int cb = part * NC;
+    if (p.gamma || p.act) {
+        float *rowp = sH + myrow * HS + cb;
+        const float inv_n = 1.0f / (float)n_out;
+        float x[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(rowp + c);
+            x[c] = t[0]; x[c + 1] = t[1]; x[c + 2] = t[2]; x[c + 3] = t[3];
+        }
+        if (p.gamma) {
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sum += (cb + c < n_out) ? x[c] : 0.f;
+#pragma unroll
+            for (int o = RPW; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum * inv_n;
+            float var = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { const float d = x[c] - mean; var += (cb + c < n_out) ? d * d : 0.f; }
+#pragma unroll
+            for (int o = RPW; o < 64; o <<= 1) var += __shfl_xor(var, o);
+            const float rstd = rsqrtf(var * inv_n + p.eps);
+#pragma unroll
+            for (int c = 0; c < NC; c += 4) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4 *>(sGB + cb + c);
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sGB + NP + cb + c);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[c + u] = fmaf((x[c + u] - mean) * rstd, g4[u], b4[u]);
+            }
+        }
+        if (p.act == G4C_ACT_SELU) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) x[c] = g4c::selu_f(x[c]);
+        } else if (p.act == G4C_ACT_TANH) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) x[c] = g4c::tanh_f(x[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c += 4) {
+            f32x4 t;
+            t[0] = x[c]; t[1] = x[c + 1]; t[2] = x[c + 2]; t[3] = x[c + 3];
+            *reinterpret_cast<f32x4 *>(rowp + c) = t;
+        }
+    }
+    // (each wave reads back only the rows it normalised itself: no barrier needed)
+
+    // ---------------------------------------------------------------- store this wave's rows
+    const bool fast = (n_out == NP) && ((p.out_ld & 3) == 0) && (((uintptr_t)p.out & 15) == 0) && (p.resid == nullptr);
+    if (fast) {
+#pragma unroll
+        for (int r = h; r < RPW; r += 2) {
+            const int row = wave * RPW + r;
+            const long long grow = row0 + row;
+            if (grow < p.M) {
+                const long long orow = p.out_idx ? p.out_idx[grow] : grow;
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(sH + row * HS + 4 * i);
+                *reinterpret_cast<f32x4 *>(p.out + orow * p.out_ld + 4 * i) = t;
+            }
+        }
+    } else {
+        for (int e = lane; e < RPW * n_out; e += 64) {
+            const int r = e / n_out, c = e - r * n_out;
+            const int row = wave * RPW + r;
+            const long long grow = row0 + row;
+            if (grow < p.M) {
+                const long long orow = p.out_idx ? p.out_idx[grow] : grow;
+                float y = sH[row * HS + c];
+                if (p.resid) y += p.resid[grow * p.resid_ld + p.resid_col0 + c];
+                p.out[orow * p.out_ld + c] = y;
+            }
+        }
+    }
+}
+
 // W[n_out, k_in] (nn.Linear layout) -> this layer's chunks of the packed stream:
 // packed[((kp*32 + j)*4 + ct)*2 + e] = W^T[k = 2kp+e][n = ct*32 + j], zero padded to k_pad x 128,
 // with an optional per-block sign flip.  seg tables live in the kernel argument.
@@ -560,6 +837,20 @@ extern "C" int64_t g4c_mlp_bulk_rows(int64_t n_rows) {
     return (n_rows / round_rows) * round_rows;
 }
 
+extern "C" int32_t g4c_mlp_small_tile_mode(int64_t rows) {
+    // remainder / small launches: 32-row tiles on 1, 2 or 4 waves.  The chip holds 2048 single-wave
+    // 32-row tiles (two per SIMD); with fewer tiles than that, splitting the columns over more waves
+    // shortens the critical path of the launch.
+    static const int force = getenv("G4C_MLP_SPLIT") ? atoi(getenv("G4C_MLP_SPLIT")) : 0;
+    if (force == 1) return 32;
+    if (force == 2) return 322;
+    if (force == 4) return 324;
+    const long long tiles = (rows + 31) / 32;
+    if (tiles <= 1024) return 324;
+    if (tiles <= 2048) return 322;
+    return 32;
+}
+
 extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                                const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream) {
@@ -568,7 +859,8 @@ extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int3
     if (bulk > 0)
         rc = g4c_mlp_forward_rows(mlp, srcs, n_src, n_rows, 0, bulk, 64, out, out_ld, out_idx, act, resid, resid_ld, resid_col0, stream);
     if (rc == G4C_OK && n_rows > bulk)
-        rc = g4c_mlp_forward_rows(mlp, srcs, n_src, n_rows, bulk, n_rows - bulk, 32, out, out_ld, out_idx, act, resid, resid_ld, resid_col0, stream);
+        rc = g4c_mlp_forward_rows(mlp, srcs, n_src, n_rows, bulk, n_rows - bulk, g4c_mlp_small_tile_mode(n_rows - bulk), out, out_ld,
+                                  out_idx, act, resid, resid_ld, resid_col0, stream);
     return rc;
 }
 
@@ -576,7 +868,8 @@ extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs,
                                     int64_t row_begin, int64_t row_count, int32_t tile_rows,
                                     float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                                     const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream) {
-    G4C_REQUIRE(tile_rows == 64 || tile_rows == 32, G4C_EINVAL, "g4c_mlp_forward_rows: tile_rows must be 64 or 32");
+    G4C_REQUIRE(tile_rows == 64 || tile_rows == 32 || tile_rows == 322 || tile_rows == 324, G4C_EINVAL,
+                "g4c_mlp_forward_rows: tile_rows must be 64, 32, 322 (32 rows / 2 waves) or 324 (32 rows / 4 waves)");
     G4C_REQUIRE(row_begin >= 0 && row_count >= 0 && row_begin + row_count <= n_rows && row_begin % 32 == 0, G4C_EINVAL,
                 "g4c_mlp_forward_rows: bad row range [%lld, +%lld) of %lld", (long long)row_begin, (long long)row_count, (long long)n_rows);
     G4C_REQUIRE(mlp && srcs, G4C_EINVAL, "g4c_mlp_forward: null pointer");
@@ -635,10 +928,18 @@ extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs,
         p.n_tiles = (int)((row_count + 63) / 64);
         if (all_vec) mlp_fused_kernel<2, true><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
         else mlp_fused_kernel<2, false><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
-    } else {
+    } else if (tile_rows == 32) {
         p.n_tiles = (int)((row_count + 31) / 32);
         if (all_vec) mlp_fused_kernel<1, true><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
         else mlp_fused_kernel<1, false><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
+    } else if (tile_rows == 322) {
+        p.n_tiles = (int)((row_count + 31) / 32);
+        if (all_vec) mlp_split_kernel<2, true><<<dim3(p.n_tiles), dim3(128), 0, st>>>(p);
+        else mlp_split_kernel<2, false><<<dim3(p.n_tiles), dim3(128), 0, st>>>(p);
+    } else {
+        p.n_tiles = (int)((row_count + 31) / 32);
+        if (all_vec) mlp_split_kernel<4, true><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
+        else mlp_split_kernel<4, false><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
     }
     return g4c::check_launch("g4c_mlp_forward");
 }

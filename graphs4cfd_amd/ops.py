@@ -263,7 +263,9 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
         # same two launches as g4c_mlp_forward, bracketed separately (kernel names as rocprofv3 reports them)
         bulk = int(lib.g4c_mlp_bulk_rows(n_rows))
         bpr = 4.0 * (sum(packed.seg_widths) + packed.n_out)
-        for kind, begin, count, tile in (("mlp_fused_kernel<2>", 0, bulk, 64), ("mlp_fused_kernel<1>", bulk, n_rows - bulk, 32)):
+        small = int(lib.g4c_mlp_small_tile_mode(n_rows - bulk)) if n_rows > bulk else 32
+        small_name = {32: "mlp_fused_kernel<1>", 322: "mlp_split_kernel<2>", 324: "mlp_split_kernel<4>"}[small]
+        for kind, begin, count, tile in (("mlp_fused_kernel<2>", 0, bulk, 64), (small_name, bulk, n_rows - bulk, small)):
             if count > 0:
                 _timed(kind, packed.flops_per_row * count, bpr * count, lambda: _lib.check(lib.g4c_mlp_forward_rows(
                     C.byref(packed.desc), arr, len(sources), n_rows, begin, count, tile, *args)))
