@@ -72,6 +72,23 @@ def cpu_baseline(model_name, graph, weights, nf, budget_s):
                       f"{torch.get_num_threads()} torch threads, {el:.1f} s"}
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the committed PMC collection (scripts/collect_pmc_traffic.sh: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same bench, gfx950 FETCH_SIZE correction).
+    rocprofv3 cannot run inside the timed process, so the latest committed collection is quoted with its source."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    k = json.load(open(files[-1]))["kernels"]
+
+    def avg(prefix):
+        sel = [v for name, v in k.items() if name.startswith(prefix)]
+        n = sum(v["dispatches"] for v in sel)
+        return sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in sel) / n if n else None
+    return {"mlp": avg("mlp_fused_kernel<2"), "scatter": avg("segment_reduce_kernel")}, os.path.relpath(files[-1], ROOT)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -152,6 +169,10 @@ def main():
                     "flop_per_launch": m["flops"] / m["launches"], "achieved": m["flops"] / m["seconds"] / 1e12,
                     "frac": m["flops"] / m["seconds"] / 1e12 / PEAK_FP32_MFMA_TFLOPS, "ms_per_step": 1e3 * m["seconds"] / 3}
 
+        traffic, traffic_src = pmc_traffic()
+        default_workload = (args.nodes == 100_000 and args.model == "NsThreeScaleGNN" and args.hidden == 128)
+        if not default_workload:
+            traffic = None
         mlp_kinds = [k for k in summ if k.startswith("mlp_")]
         big = mfma_entry("mlp_fused_kernel<2>")
         tot_f = sum(summ[k]["flops"] for k in mlp_kinds)
@@ -159,7 +180,8 @@ def main():
         # dominant kernel: the 64-row-tile instantiation (rocprofv3 name mlp_fused_kernel<2, true|false>)
         result["roofline"] = {"bound": "mfma", "kernel": "mlp_fused_kernel<2, *> (g4c_mlp_forward, 64-row tiles)",
                               "achieved": big["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": big["frac"],
-                              "traffic": None, "launches_per_step": big["launches_per_step"],
+                              "traffic": traffic["mlp"] if traffic else None, "traffic_source": traffic_src if traffic else None,
+                              "launches_per_step": big["launches_per_step"],
                               "avg_launch_us": big["avg_launch_us"], "flop_per_launch": big["flop_per_launch"],
                               "ms_per_step_in_kernel": big["ms_per_step"],
                               "all_mlp_kernels": {"achieved": tot_f / tot_t / 1e12, "frac": tot_f / tot_t / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -167,7 +189,9 @@ def main():
                               "small_launch_kernels": {k: mfma_entry(k) for k in mlp_kinds if k != "mlp_fused_kernel<2>"}}
         result["roofline_scatter"] = {"bound": "hbm", "kernel": "segment_reduce_kernel (g4c_segment_reduce)",
                                       "achieved": s["bytes"] / s["seconds"] / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                      "frac": s["bytes"] / s["seconds"] / 1e9 / PEAK_HBM_GBS, "traffic": None,
+                                      "frac": s["bytes"] / s["seconds"] / 1e9 / PEAK_HBM_GBS,
+                                      "traffic": traffic["scatter"] if traffic else None,
+                                      "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
                                       "launches_per_step": s["launches"] // 3,
                                       "avg_launch_us": 1e6 * s["seconds"] / s["launches"]}
         # the level-1 aggregation alone (the 358.8 MB case of BASELINE.md §4)
