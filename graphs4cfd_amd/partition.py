@@ -329,8 +329,10 @@ class DistributedRollout:
     """`Rollout` over a node-partitioned mesh: every rank advances its owned nodes; `outputs` holds the owned
     rows ([n_own, nf*steps]); `gather_outputs()` assembles the global tensor on every rank (validation / I/O)."""
 
-    def __init__(self, model, graph_cpu: Graph, max_steps: int, rank: int, world: int, device: torch.device, group=None):
-        from .synthetic import MUS_LAYERS
+    def __init__(self, model, graph_cpu: Graph, max_steps: int, rank: int, world: int, device: torch.device, group=None,
+                 capture: bool = True):
+        import os
+        capture = capture and os.environ.get("G4C_DIST_HIPGRAPH", "1") != "0"
         self.model, self.rank, self.world, self.device = model, rank, world, device
         program = model._PROGRAM
         levels = 1 + sum(1 for n in program if n.startswith("down_mp"))
@@ -345,11 +347,38 @@ class DistributedRollout:
         self.outputs = torch.zeros((self.mesh.n_own[0], self.nf * max_steps), dtype=torch.float32, device=device)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=device)
         self.steps_done = 0
+        self.capture = capture and device.type == "cuda"
+        self._hipgraph = None
+
+    def _one(self) -> None:
+        pred = self.fwd.forward()
+        ops.rollout_advance(self.field, pred, self.outputs, self.step_counter, self.nf)
 
     def step(self) -> None:
+        """Step 1 eager (plans, packing), step 2 captured into a hipGraph together with its RCCL halo
+        exchanges (every rank captures the same sequence), later steps replayed."""
+        if self.steps_done >= self.max_steps:
+            raise RuntimeError(f"rollout buffer holds {self.max_steps} steps")
         with torch.no_grad():
-            pred = self.fwd.forward()
-            ops.rollout_advance(self.field, pred, self.outputs, self.step_counter, self.nf)
+            if self.steps_done == 0 or not self.capture:
+                self._one()
+            elif self._hipgraph is None:
+                torch.cuda.synchronize(self.device)
+                try:
+                    hg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(hg):
+                        self._one()
+                    self._hipgraph = hg
+                    self._hipgraph.replay()
+                except Exception as exc:   # keep the rollout alive on stacks where the collective cannot be captured
+                    import sys
+                    print(f"[graphs4cfd_amd] rank {self.rank}: hipGraph capture of the partitioned step failed "
+                          f"({type(exc).__name__}: {exc}); continuing with eager launches", file=sys.stderr)
+                    self.capture, self._hipgraph = False, None
+                    torch.cuda.synchronize(self.device)
+                    self._one()
+            else:
+                self._hipgraph.replay()
         self.steps_done += 1
 
     def run(self, n: int) -> None:
