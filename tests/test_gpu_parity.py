@@ -375,3 +375,18 @@ def test_distributed_rollout_single_rank_equals_rollout():
     dr = P.DistributedRollout(model, g, 3, 0, 1, DEV)
     dr.run(3)
     torch.testing.assert_close(dr.gather_outputs(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_distributed_rollout_two_processes_one_gpu():
+    """Two ranks (two processes) drive the partitioned HIP path end to end on this box's single GPU, with the
+    gloo transport for the halo exchange (the RCCL transport needs one GPU per rank; the driver's scaling run
+    uses it).  Compared inside the script with the single-process rollout."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "scripts", "dist_check.py"), "--backend", "gloo", "--same-gpu",
+           "--nodes", "12000", "--steps", "3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "max|partitioned - single|" in out.stdout
