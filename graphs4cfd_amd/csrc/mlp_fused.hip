@@ -61,9 +61,17 @@ struct Src {
     int width, wpad, ld, col0, vec, pre_act;
 };
 
+struct AddSrc {          // pre-multiplied first-layer term, gathered per row and added to the layer-0 output
+    const float *ptr;
+    const int *idx;
+    int width, ld;
+};
+
 struct Params {
     Src src[G4C_MAX_SRC];
     int n_src;
+    AddSrc add[G4C_MAX_SRC];
+    int n_add;
     int n_layers;
     int chunks0;              // number of 32-k chunks of layer 0 (sum of source widths padded to 32)
     const float *w;           // all layers packed back to back, chunk after chunk (+ one chunk of slack)
@@ -273,6 +281,81 @@ __device__ __forceinline__ void store_hidden(const Acc<RT> &acc, float *sH, cons
     }
 }
 
+// acc (C/D layout) += P[idx[row], col] for this wave's rows: the first-layer terms of the node-side inputs
+// that were multiplied once per NODE instead of once per edge (linearity of the first Linear layer).
+// For a fixed register q and column tile c the 32 lanes of a half-wave read 128 contiguous bytes.
+// one batch = 8 accumulator registers x 4 column tiles = 32 independent 4-byte loads per lane
+struct AddBatch { float t[8][4]; };
+
+template <int RT>
+__device__ __forceinline__ void add_batch_load(AddBatch &b, const AddSrc &a, const int *rows, int r, int q0, int i, int h) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int q = q0 + u;
+        const int row = r * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        const float *pr = a.ptr + (long long)rows[row] * a.ld;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = c * 32 + i;
+            b.t[u][c] = pr[col < a.width ? col : 0];
+        }
+    }
+}
+
+template <int RT, int R, int Q0>
+__device__ __forceinline__ void add_batch_apply(Acc<RT> &acc, const AddBatch &b, int width, int i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc.t[R][c][Q0 + u] += (c * 32 + i < width) ? b.t[u][c] : 0.f;
+}
+
+// All additive sources together, software-pipelined: while batch k (8 registers x 4 column tiles of every
+// source) is added, the loads of batch k+1 are in flight; runs before the weight ring is filled, so the
+// temporaries live in registers that are idle at that point.
+template <int RT>
+__device__ __forceinline__ void add_gathered_all(Acc<RT> &acc, const AddSrc *a, int n_add, const int *rows, int rows_stride, int lane) {
+    const int i = lane & 31, h = lane >> 5;
+    if (n_add == 2) {
+        AddBatch b0[2], b1[2];
+#define G4C_LD(B, R, Q0) add_batch_load<RT>(B[0], a[0], rows, R, Q0, i, h); add_batch_load<RT>(B[1], a[1], rows + rows_stride, R, Q0, i, h); \
+                         __builtin_amdgcn_sched_barrier(0);
+#define G4C_AP(B, R, Q0) add_batch_apply<RT, R, Q0>(acc, B[0], a[0].width, i); add_batch_apply<RT, R, Q0>(acc, B[1], a[1].width, i);
+        G4C_LD(b0, 0, 0)
+        G4C_LD(b1, 0, 8)
+        G4C_AP(b0, 0, 0)
+        if (RT == 2) { G4C_LD(b0, RT - 1, 0) }
+        G4C_AP(b1, 0, 8)
+        if (RT == 2) {
+            G4C_LD(b1, RT - 1, 8)
+            G4C_AP(b0, RT - 1, 0)
+            G4C_AP(b1, RT - 1, 8)
+        }
+#undef G4C_LD
+#undef G4C_AP
+    } else {
+        for (int s = 0; s < n_add; ++s) {
+            AddBatch b0, b1;
+            add_batch_load<RT>(b0, a[s], rows + s * rows_stride, 0, 0, i, h);
+            __builtin_amdgcn_sched_barrier(0);
+            add_batch_load<RT>(b1, a[s], rows + s * rows_stride, 0, 8, i, h);
+            __builtin_amdgcn_sched_barrier(0);
+            add_batch_apply<RT, 0, 0>(acc, b0, a[s].width, i);
+            if (RT == 2) {
+                add_batch_load<RT>(b0, a[s], rows + s * rows_stride, RT - 1, 0, i, h);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            add_batch_apply<RT, 0, 8>(acc, b1, a[s].width, i);
+            if (RT == 2) {
+                add_batch_load<RT>(b1, a[s], rows + s * rows_stride, RT - 1, 8, i, h);
+                __builtin_amdgcn_sched_barrier(0);
+                add_batch_apply<RT, RT - 1, 0>(acc, b0, a[s].width, i);
+                add_batch_apply<RT, RT - 1, 8>(acc, b1, a[s].width, i);
+            }
+        }
+    }
+}
+
 template <int RT>
 __device__ __forceinline__ void zero_acc(Acc<RT> &acc) {
 #pragma unroll
@@ -286,13 +369,14 @@ __device__ __forceinline__ void zero_acc(Acc<RT> &acc) {
 template <int RT, bool VEC>
 __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Params p) {
     constexpr int ROWS = RT * 32;
-    __shared__ __attribute__((aligned(16))) float lds[ROWS * HS + G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
+    __shared__ __attribute__((aligned(16))) float lds[ROWS * HS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
     float *sH = lds;                         // hidden activations (layers >= 1) ...
     float *sX0 = lds;                        // ... aliasing the two input-chunk buffers of layer 0
     float *sX1 = lds + ROWS * XS;
-    int *sRow = reinterpret_cast<int *>(lds + ROWS * HS);
-    float *sBias = lds + ROWS * HS + G4C_MAX_SRC * ROWS;   // [n_layers][128]
-    float *sGB = sBias + G4C_MAX_LAYERS * NP;              // gamma[128], beta[128]
+    int *sRow = reinterpret_cast<int *>(lds + ROWS * HS);                 // gather rows of the K sources ...
+    int *sRowAdd = sRow + G4C_MAX_SRC * ROWS;                              // ... and of the additive sources
+    float *sBias = lds + ROWS * HS + 2 * G4C_MAX_SRC * ROWS;   // [n_layers][128]
+    float *sGB = sBias + G4C_MAX_LAYERS * NP;                  // gamma[128], beta[128]
 
     const int lane = threadIdx.x;
     const int i = lane & 31, h = lane >> 5;
@@ -311,6 +395,7 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
         long long gr = row0 + r;
         if (gr >= p.M) gr = p.M - 1;
         for (int s = 0; s < p.n_src; ++s) sRow[s * ROWS + r] = p.src[s].idx ? p.src[s].idx[gr] : (int)gr;
+        for (int s = 0; s < p.n_add; ++s) sRowAdd[s * ROWS + r] = p.add[s].idx ? p.add[s].idx[gr] : (int)gr;
     }
     for (int e = lane; e < p.n_layers * NP; e += 64) sBias[e] = p.b[e];
     if (p.gamma) {
@@ -330,6 +415,7 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
 
     // ------------------------------------------------------------------ layer 0 (gathered input)
     zero_acc<RT>(acc);
+    if (p.n_add) add_gathered_all<RT>(acc, p.add, p.n_add, sRowAdd, ROWS, lane);
     const unsigned lo = (unsigned)(((lane >> 5) * 32 + (lane & 31)) * 8);   // lane's offset inside a step's 512 floats
     ring_fill(ring, w, lo);
     {
@@ -536,12 +622,13 @@ __device__ __forceinline__ void mma_chunk_n(const float *pa, RingN<NCT> &g, cons
 template <int NW, bool VEC>
 __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
     constexpr int ROWS = 32, NCT = 4 / NW, NPIECE = 4 / NW;   // pieces (8 rows x 32 cols) of a chunk gathered per wave
-    __shared__ __attribute__((aligned(16))) float lds[ROWS * HS + G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
+    __shared__ __attribute__((aligned(16))) float lds[ROWS * HS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
     float *sH = lds;
     float *sX0 = lds;
     float *sX1 = lds + ROWS * XS;
     int *sRow = reinterpret_cast<int *>(lds + ROWS * HS);
-    float *sBias = lds + ROWS * HS + G4C_MAX_SRC * ROWS;
+    int *sRowAdd = sRow + G4C_MAX_SRC * ROWS;
+    float *sBias = lds + ROWS * HS + 2 * G4C_MAX_SRC * ROWS;
     float *sGB = sBias + G4C_MAX_LAYERS * NP;
 
     const int tid = threadIdx.x;
@@ -562,6 +649,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
         long long gr = row0 + r;
         if (gr >= p.M) gr = p.M - 1;
         for (int s = 0; s < p.n_src; ++s) sRow[s * ROWS + r] = p.src[s].idx ? p.src[s].idx[gr] : (int)gr;
+        for (int s = 0; s < p.n_add; ++s) sRowAdd[s * ROWS + r] = p.add[s].idx ? p.add[s].idx[gr] : (int)gr;
     }
     for (int e = tid; e < p.n_layers * NP; e += 64 * NW) sBias[e] = p.b[e];
     if (p.gamma) {
@@ -581,6 +669,19 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc.t[c][q] = 0.f;
+    for (int a = 0; a < p.n_add; ++a) {   // pre-multiplied node-side terms of the first layer
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+            const float *pr = p.add[a].ptr + (long long)sRowAdd[a * ROWS + row] * p.add[a].ld;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const int col = (ct0 + c) * 32 + i;
+                const float v = pr[col < p.add[a].width ? col : 0];
+                acc.t[c][q] += (col < p.add[a].width) ? v : 0.f;
+            }
+        }
+    }
     ring.s0 = load_bn<NCT>(w + 0 * 512, lo); ring.s1 = load_bn<NCT>(w + 1 * 512, lo);
     ring.s2 = load_bn<NCT>(w + 2 * 512, lo); ring.s3 = load_bn<NCT>(w + 3 * 512, lo);
     ring.s4 = load_bn<NCT>(w + 4 * 512, lo); ring.s5 = load_bn<NCT>(w + 5 * 512, lo);
@@ -874,30 +975,40 @@ extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs,
                 "g4c_mlp_forward_rows: bad row range [%lld, +%lld) of %lld", (long long)row_begin, (long long)row_count, (long long)n_rows);
     G4C_REQUIRE(mlp && srcs, G4C_EINVAL, "g4c_mlp_forward: null pointer");
     G4C_REQUIRE(n_src >= 1 && n_src <= G4C_MAX_SRC, G4C_EUNSUPPORTED, "g4c_mlp_forward: %d sources (max %d)", n_src, G4C_MAX_SRC);
-    G4C_REQUIRE(mlp->n_layers >= 2 && mlp->n_layers <= G4C_MAX_LAYERS, G4C_EUNSUPPORTED,
-                "g4c_mlp_forward: %d layers (supported 2..%d)", mlp->n_layers, G4C_MAX_LAYERS);
+    G4C_REQUIRE(mlp->n_layers >= 1 && mlp->n_layers <= G4C_MAX_LAYERS, G4C_EUNSUPPORTED,
+                "g4c_mlp_forward: %d layers (supported 1..%d)", mlp->n_layers, G4C_MAX_LAYERS);
     G4C_REQUIRE(n_rows >= 0 && n_rows < (1LL << 31), G4C_EINVAL, "g4c_mlp_forward: n_rows %lld out of range", (long long)n_rows);
     G4C_REQUIRE(act >= 0 && act <= 2, G4C_EINVAL, "g4c_mlp_forward: bad activation %d", act);
     if (n_rows == 0) return G4C_OK;
     G4C_REQUIRE(out, G4C_EINVAL, "g4c_mlp_forward: null output");
     Params p;
-    p.n_src = n_src;
     int kp = 0;
     bool all_vec = true;
+    int nk = 0;
+    p.n_add = 0;
     for (int s = 0; s < n_src; ++s) {
         const g4c_src_t &g = srcs[s];
         G4C_REQUIRE(g.ptr && g.width > 0 && g.ld >= g.col0 + g.width && g.col0 >= 0, G4C_EINVAL,
                     "g4c_mlp_forward: bad source %d (width=%d ld=%d col0=%d)", s, g.width, g.ld, g.col0);
+        if (g.additive) {
+            G4C_REQUIRE(g.pre_act == G4C_ACT_NONE && g.width <= NP, G4C_EINVAL, "g4c_mlp_forward: bad additive source %d", s);
+            AddSrc &a = p.add[p.n_add++];
+            a.ptr = g.ptr + g.col0; a.idx = g.idx; a.width = g.width; a.ld = g.ld;
+            continue;
+        }
         G4C_REQUIRE(g.pre_act == G4C_ACT_NONE || g.pre_act == G4C_ACT_SELU, G4C_EUNSUPPORTED,
                     "g4c_mlp_forward: source %d pre_act %d (only NONE / SELU can be applied on load)", s, g.pre_act);
-        Src &d = p.src[s];
+        Src &d = p.src[nk++];
         d.ptr = g.ptr; d.idx = g.idx; d.width = g.width; d.wpad = (g.width + KC - 1) / KC * KC; d.ld = g.ld; d.col0 = g.col0;
         d.pre_act = g.pre_act;
         d.vec = (g.width % 4 == 0) && (g.ld % 4 == 0) && (g.col0 % 4 == 0) && ((uintptr_t)g.ptr % 16 == 0);
         all_vec = all_vec && d.vec;
         kp += d.wpad;
     }
-    for (int s = n_src; s < G4C_MAX_SRC; ++s) p.src[s] = p.src[0];
+    G4C_REQUIRE(nk >= 1, G4C_EINVAL, "g4c_mlp_forward: no input block goes through the weights");
+    p.n_src = nk;
+    for (int s = nk; s < G4C_MAX_SRC; ++s) p.src[s] = p.src[0];
+    for (int s = p.n_add; s < G4C_MAX_SRC; ++s) p.add[s] = AddSrc{nullptr, nullptr, 0, 0};
     G4C_REQUIRE(kp == mlp->k_pad[0], G4C_EINVAL, "g4c_mlp_forward: sources give %d padded columns, layer 1 packed for %d", kp, mlp->k_pad[0]);
     p.n_layers = mlp->n_layers;
     p.chunks0 = kp / KC;

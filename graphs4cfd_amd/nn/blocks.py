@@ -96,6 +96,44 @@ class MLP(nn.Module):
         pk = self.packed([s.width for s in sources], [s.negate for s in sources])
         return ops.mlp_forward(pk, sources, n_rows, act_code, **kw)
 
+    # -- first-layer hoisting ------------------------------------------------------------------
+    def _packed_cols(self, tag: str, a: int, b: int, seg_widths, seg_negate, first_only: bool) -> ops.PackedMLP:
+        """Packed variant using only columns [a, b) of the first Linear layer (`first_only`: that layer alone, no bias)."""
+        key = (tag, a, b, tuple(seg_widths), tuple(bool(x) for x in seg_negate))
+        sig = self._signature()
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != sig:
+            lin = self._linears()
+            w1 = lin[0].weight.detach()[:, a:b].contiguous()
+            if first_only:
+                pk = ops.PackedMLP([w1], [None], None, key[3], key[4])
+            else:
+                ln = getattr(self.MLP, "layer_norm", None)
+                pk = ops.PackedMLP([w1] + [l.weight for l in lin[1:]], [l.bias for l in lin],
+                                   None if ln is None else (ln.weight, ln.bias, ln.eps), key[3], key[4])
+            self._packed[key] = (sig, pk)
+            hit = self._packed[key]
+        return hit[1]
+
+    def run_hoisted(self, k_sources: Sequence[Source], gathered: Sequence[Tuple[Tensor, Tensor]], n_rows: int,
+                    act_code: int = _lib.ACT_NONE, **kw) -> Tensor:
+        """MLP(cat(k_sources..., t0[idx0], t1[idx1], ...)) with the first layer's products of the gathered node-side
+        inputs hoisted: W1 [x | t[idx]] = W1x x + (W1t t)[idx] (exact up to fp32 re-association), so `W1t t` costs
+        rows(t) instead of n_rows.  `gathered` = [(tensor [n_t, w_t], int32 index [n_rows])] in concat order."""
+        kw_widths = [s.width for s in k_sources]
+        off = sum(kw_widths)
+        adds = []
+        for t, idx in gathered:
+            w_t = int(t.size(1))
+            pk1 = self._packed_cols("hoist1", off, off + w_t, [w_t], [False], True)
+            part = ops.mlp_forward(pk1, [Source(t)], int(t.size(0)))
+            adds.append(Source(part, index=idx, additive=True))
+            off += w_t
+        if off != self.input_size:
+            raise ValueError(f"MLP expects {self.input_size} input columns, got {off}")
+        pk = self._packed_cols("hoist", 0, sum(kw_widths), kw_widths, [s.negate for s in k_sources], False)
+        return ops.mlp_forward(pk, list(k_sources) + adds, n_rows, act_code, **kw)
+
     def forward(self, x: Tensor) -> Tensor:
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.size(-1))
@@ -181,7 +219,7 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
         raise ValueError(f"unsupported aggr {aggr!r}")
     ep, csr = plan.edge_csr(index, int(v.size(0)))
     senders = v if v_src is None else v_src
-    e_new = msg_mlp.run_coded([Source(e, pre_act=e_pre_act), Source(senders, ep.row), Source(v, ep.col)], ep.n_edges)
+    e_new = msg_mlp.run_hoisted([Source(e, pre_act=e_pre_act)], [(senders, ep.row), (v, ep.col)], ep.n_edges)
     agg = ops.segment_reduce(e_new, csr, aggr == "mean")
     v_new = upd_mlp.run_coded([Source(agg), Source(v)], int(v.size(0)), act_code)
     return v_new, e_new

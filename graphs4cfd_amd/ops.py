@@ -74,16 +74,17 @@ def _ld(t: Tensor) -> int:
 class Source:
     """One column block of a virtually concatenated MLP input."""
 
-    __slots__ = ("tensor", "index", "col0", "width", "negate", "pre_act")
+    __slots__ = ("tensor", "index", "col0", "width", "negate", "pre_act", "additive")
 
     def __init__(self, tensor: Tensor, index: Optional[Tensor] = None, col0: int = 0, width: Optional[int] = None,
-                 negate: bool = False, pre_act: int = _lib.ACT_NONE):
+                 negate: bool = False, pre_act: int = _lib.ACT_NONE, additive: bool = False):
         self.tensor = _f32_2d(tensor, "source")
         self.index = index          # int32 gather index or None
         self.col0 = col0
         self.width = int(self.tensor.size(1) - col0 if width is None else width)
         self.negate = negate        # folded into the packed weights
         self.pre_act = pre_act      # activation applied while loading (producer stored the raw tensor)
+        self.additive = additive    # already multiplied by its block of the first layer: gathered and added, not multiplied
 
 
 def segment_reduce(src: Tensor, csr: CsrPlan, mean: bool, act: int = _lib.ACT_NONE, out: Optional[Tensor] = None,
@@ -186,10 +187,10 @@ class PackedMLP:
     def __init__(self, weights: Sequence[Tensor], biases: Sequence[Tensor], ln: Optional[Tuple[Tensor, Tensor, float]],
                  seg_widths: Sequence[int], seg_negate: Sequence[bool]):
         lib = _lib.load()
-        dev = _lib.require_hip(*weights, *biases)
+        dev = _lib.require_hip(*weights, *[b for b in biases if b is not None])
         n_layers = len(weights)
-        if not 2 <= n_layers <= _lib.MAX_LAYERS:
-            raise NotImplementedError(f"MLP with {n_layers} Linear layers (supported: 2..{_lib.MAX_LAYERS})")
+        if not 1 <= n_layers <= _lib.MAX_LAYERS:
+            raise NotImplementedError(f"MLP with {n_layers} Linear layers (supported: 1..{_lib.MAX_LAYERS})")
         if len(seg_widths) > _lib.MAX_SRC:
             raise NotImplementedError(f"MLP input concatenated from {len(seg_widths)} blocks (max {_lib.MAX_SRC})")
         self.desc = _lib.g4c_mlp_t()
@@ -222,7 +223,8 @@ class PackedMLP:
             wptr = stream_buf.data_ptr() + 4 * off
             _lib.check(lib.g4c_mlp_pack_layer(_lib.ptr(Wc), n_out, k_in, seg_arr, neg_arr, len(segs), wptr,
                                               k_pads[l], NP, stream))
-            bias_buf[l * NP: l * NP + n_out].copy_(b.detach())
+            if b is not None:
+                bias_buf[l * NP: l * NP + n_out].copy_(b.detach())
             self.desc.k_pad[l], self.desc.n_pad[l] = k_pads[l], NP
             self.desc.w[l], self.desc.b[l] = wptr, bias_buf.data_ptr() + 4 * l * NP
             off += k_pads[l] * NP
@@ -247,12 +249,13 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
     dev = _lib.require_hip(*[s.tensor for s in sources], *[s.index for s in sources], out, out_idx32, resid)
     if dev != packed.device:
         raise RuntimeError(f"MLP weights on {packed.device}, inputs on {dev}")
-    if tuple(s.width for s in sources) != packed.seg_widths:
-        raise ValueError(f"input blocks {[s.width for s in sources]} do not match packed layout {packed.seg_widths}")
+    if tuple(s.width for s in sources if not s.additive) != packed.seg_widths:
+        raise ValueError(f"input blocks {[s.width for s in sources if not s.additive]} do not match packed layout {packed.seg_widths}")
     arr = (_lib.g4c_src_t * len(sources))()
     for a, s in zip(arr, sources):
         a.ptr, a.idx, a.width, a.ld, a.col0, a.pre_act = (s.tensor.data_ptr(), _lib.ptr(s.index), s.width, _ld(s.tensor),
                                                           s.col0, s.pre_act)
+        a.additive = 1 if s.additive else 0
     if out is None:
         out = torch.empty((n_rows, packed.n_out), dtype=torch.float32, device=dev)
     args = (_lib.ptr(out), _ld(out), _lib.ptr(out_idx32), act, _lib.ptr(resid), _ld(resid) if resid is not None else 0,

@@ -260,7 +260,7 @@ class HipImpl:
            v_out: torch.Tensor):
         blk = getattr(self.m, name)
         ep, csr = plan.edge_csr(edge_index, n_own)
-        e_new = blk.edge_mlp.run_coded([Source(e, pre_act=e_pending), Source(v, ep.row), Source(v, ep.col)], ep.n_edges)
+        e_new = blk.edge_mlp.run_hoisted([Source(e, pre_act=e_pending)], [(v, ep.row), (v, ep.col)], ep.n_edges)
         agg = ops.segment_reduce(e_new, csr, blk.aggr == "mean")
         blk.node_mlp.run_coded([Source(agg), Source(v[:n_own])], n_own, SELU, out=v_out)
         return e_new

@@ -91,10 +91,16 @@ typedef struct {
     int32_t col0;       /* first column taken */
     int32_t pre_act;    /* G4C_ACT_*: applied to the values as they are loaded (lets a producer store the
                            un-activated tensor its aggregation needs, nn/blocks.py:181-183 vs nn/mus_gnn.py:182) */
+    int32_t additive;   /* 0: a column block of the concatenated input (multiplied by the first layer's weights);
+                           1: a term ALREADY multiplied by its block of the first layer's weights, at the row count of
+                           the tensor it was gathered from; row idx[r] is added to row r of the first layer's output.
+                           Linearity: W1 [e | v[row] | v[col]] = W1e e + (W1r v)[row] + (W1c v)[col], so the node-side
+                           products cost N rows instead of E (nn/blocks.py:181, :328, :373). */
+    int32_t reserved;
 } g4c_src_t;
 
 typedef struct {
-    int32_t n_layers;                /* number of Linear layers, 2..G4C_MAX_LAYERS */
+    int32_t n_layers;                /* number of Linear layers, 1..G4C_MAX_LAYERS */
     int32_t k_pad[G4C_MAX_LAYERS];   /* padded input width of each layer (see g4c_mlp_pack_layer) */
     int32_t n_pad[G4C_MAX_LAYERS];   /* padded output width: 32, 64 or 128 */
     const float *w[G4C_MAX_LAYERS];  /* packed weights, k_pad*n_pad floats each */

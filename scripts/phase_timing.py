@@ -14,7 +14,7 @@ ep, csr = plan.edge_csr(g.edge_index, n)
 out = torch.empty(E, H, device=dev)
 srcs = [ops.Source(e), ops.Source(v, ep.row), ops.Source(v, ep.col)]
 for _ in range(3):
-    blk.edge_mlp.run_coded(srcs, E, 0, out=out)
+    blk.edge_mlp.run_hoisted([ops.Source(e)], [(v, ep.row), (v, ep.col)], E, 0, out=out)
 torch.cuda.synchronize()
 lib = _lib.load()
 buf = np.zeros(4096 * 16, dtype=np.uint64)
