@@ -125,11 +125,18 @@ def main():
     from graphs4cfd_amd import ops, synthetic as S
     from graphs4cfd_amd.nn.model import Rollout
 
+    # G4C_BENCH_SAME_GPU=1 (functional check on a single-GPU box only): every rank uses cuda:0 and the gloo transport
+    same_gpu = os.environ.get("G4C_BENCH_SAME_GPU", "0") == "1"
+    if same_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     levels = {"NsOneScaleGNN": 1, "NsTwoScaleGNN": 2, "NsThreeScaleGNN": 3, "NsFourScaleGNN": 4}[args.model]
     graph_cpu = S.mus_graph(args.nodes, levels=levels, seed=0)
@@ -142,7 +149,7 @@ def main():
 
     if world > 1:
         from graphs4cfd_amd import partition
-        runner = partition.DistributedRollout(model, graph_cpu, total_steps + 2, rank, world, dev)
+        runner = partition.DistributedRollout(model, graph_cpu, total_steps + 2, rank, world, dev, capture=not same_gpu)
     else:
         runner = Rollout(model, graph_cpu.clone().to(dev), total_steps + 2, capture=True)
 
