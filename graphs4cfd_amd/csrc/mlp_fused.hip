@@ -669,7 +669,10 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc.t[c][q] = 0.f;
-    for (int a = 0; a < p.n_add; ++a) {   // pre-multiplied node-side terms of the first layer
+    // pre-multiplied node-side terms of the first layer: one source at a time, its 16*NCT loads issued together
+    // (16 temporaries keep the kernel at 7 waves per SIMD; batching both sources at once costs occupancy and is slower)
+    for (int a = 0; a < p.n_add; ++a) {
+        float t[16][NCT];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
@@ -677,10 +680,15 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
                 const int col = (ct0 + c) * 32 + i;
-                const float v = pr[col < p.add[a].width ? col : 0];
-                acc.t[c][q] += (col < p.add[a].width) ? v : 0.f;
+                t[q][c] = pr[col < p.add[a].width ? col : 0];
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc.t[c][q] += ((ct0 + c) * 32 + i < p.add[a].width) ? t[q][c] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
     }
     ring.s0 = load_bn<NCT>(w + 0 * 512, lo); ring.s1 = load_bn<NCT>(w + 1 * 512, lo);
     ring.s2 = load_bn<NCT>(w + 2 * 512, lo); ring.s3 = load_bn<NCT>(w + 3 * 512, lo);
@@ -932,10 +940,9 @@ extern "C" int64_t g4c_mlp_bulk_rows(int64_t n_rows) {
     // 32-row tiles, which finish in about half a round when there are at most 1024 of them, instead of
     // leaving most of the chip idle for a full last round.
     static const int force_rt = getenv("G4C_MLP_RT") ? atoi(getenv("G4C_MLP_RT")) : 0;
-    const long long round_rows = 64LL * 1024;
     if (force_rt == 2) return n_rows;
-    if (force_rt == 1) return 0;
-    return (n_rows / round_rows) * round_rows;
+    (void)n_rows;
+    return 0;   // default: everything on the column-split kernel (see g4c_mlp_small_tile_mode)
 }
 
 extern "C" int32_t g4c_mlp_small_tile_mode(int64_t rows) {
@@ -946,15 +953,18 @@ extern "C" int32_t g4c_mlp_small_tile_mode(int64_t rows) {
     if (force == 1) return 32;
     if (force == 2) return 322;
     if (force == 4) return 324;
-    const long long tiles = (rows + 31) / 32;
-    if (tiles <= 1024) return 324;
-    if (tiles <= 2048) return 322;
-    return 32;
+    // measured (scripts/sweep_tile_modes.py, hoisted edge MLP, 8k .. 1M rows): the 4-wave column split is the fastest
+    // or within 2 % of the fastest mode at every size (four waves per SIMD hide each other's non-MFMA phases)
+    (void)rows;
+    return 324;
 }
 
 extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                                const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream) {
+    static const int force_mode = getenv("G4C_MLP_FORCE_MODE") ? atoi(getenv("G4C_MLP_FORCE_MODE")) : 0;   // tuning only
+    if (force_mode)
+        return g4c_mlp_forward_rows(mlp, srcs, n_src, n_rows, 0, n_rows, force_mode, out, out_ld, out_idx, act, resid, resid_ld, resid_col0, stream);
     const int64_t bulk = g4c_mlp_bulk_rows(n_rows);
     int rc = G4C_OK;
     if (bulk > 0)
