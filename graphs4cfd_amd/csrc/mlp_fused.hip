@@ -597,6 +597,9 @@ template <int NCT> struct RingN { typename BVec<NCT>::type s0, s1, s2, s3, s4, s
 __device__ __forceinline__ float bget(const f32x4 &b, int k) { return b[k]; }
 __device__ __forceinline__ float bget(const float2 &b, int k) { return k ? b.y : b.x; }
 
+#ifndef G4C_SPLIT_PRIO
+#define G4C_SPLIT_PRIO 0
+#endif
 template <int NCT>
 __device__ __forceinline__ void mma_chunk_n(const float *pa, RingN<NCT> &g, const float *wnext, unsigned lo, AccN<NCT> &acc) {
     float2 a = *reinterpret_cast<const float2 *>(pa);
@@ -604,12 +607,14 @@ __device__ __forceinline__ void mma_chunk_n(const float *pa, RingN<NCT> &g, cons
     {                                                                                      \
         const float2 an = *reinterpret_cast<const float2 *>(pa + (((U) + 1) & 7) * 4);     \
         __builtin_amdgcn_sched_barrier(0);                                                 \
+        if (G4C_SPLIT_PRIO) __builtin_amdgcn_s_setprio(1);                                 \
         _Pragma("unroll") for (int c = 0; c < NCT; ++c) {                                  \
             acc.t[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bget(g.SLOT, 2 * c), acc.t[c], 0, 0, 0);     \
         }                                                                                  \
         _Pragma("unroll") for (int c = 0; c < NCT; ++c) {                                  \
             acc.t[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bget(g.SLOT, 2 * c + 1), acc.t[c], 0, 0, 0); \
         }                                                                                  \
+        if (G4C_SPLIT_PRIO) __builtin_amdgcn_s_setprio(0);                                 \
         g.SLOT = load_bn<NCT>(wnext + (U) * 512, lo);                                      \
         __builtin_amdgcn_sched_barrier(0);                                                 \
         a = an;                                                                            \
@@ -619,10 +624,16 @@ __device__ __forceinline__ void mma_chunk_n(const float *pa, RingN<NCT> &g, cons
 #undef G4C_STEP
 }
 
+#ifndef G4C_SPLIT_SLIM
+#define G4C_SPLIT_SLIM 0
+#endif
 template <int NW, bool VEC>
 __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
     constexpr int ROWS = 32, NCT = 4 / NW, NPIECE = 4 / NW;   // pieces (8 rows x 32 cols) of a chunk gathered per wave
-    __shared__ __attribute__((aligned(16))) float lds[ROWS * HS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
+    // LDS budget: 8 workgroups of NW = 4 waves per CU (= the 32-wave limit) need <= 20 KiB each, so the LayerNorm
+    // parameters are read from global memory (L1/L2 hits) instead of being staged
+    constexpr int GB_ROWS = G4C_SPLIT_SLIM ? 0 : 2;
+    __shared__ __attribute__((aligned(16))) float lds[ROWS * HS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + GB_ROWS) * NP];
     float *sH = lds;
     float *sX0 = lds;
     float *sX1 = lds + ROWS * XS;
@@ -652,7 +663,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
         for (int s = 0; s < p.n_add; ++s) sRowAdd[s * ROWS + r] = p.add[s].idx ? p.add[s].idx[gr] : (int)gr;
     }
     for (int e = tid; e < p.n_layers * NP; e += 64 * NW) sBias[e] = p.b[e];
-    if (p.gamma) {
+    if (p.gamma && !G4C_SPLIT_SLIM) {
         for (int e = tid; e < NP; e += 64 * NW) {
             const int ee = e < p.n_out ? e : 0;
             sGB[e] = p.gamma[ee];
@@ -671,7 +682,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
         for (int q = 0; q < 16; ++q) acc.t[c][q] = 0.f;
     // pre-multiplied node-side terms of the first layer: one source at a time, its 16*NCT loads issued together
     // (16 temporaries keep the kernel at 7 waves per SIMD; batching both sources at once costs occupancy and is slower)
-    for (int a = 0; a < p.n_add; ++a) {
+    for (int a = 0; a < ((G4C_ABLATE & 8) ? 0 : p.n_add); ++a) {
         float t[16][NCT];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -752,13 +763,13 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
                     nk0 = k0;
                 }
             }
-            gather(nk0);
+            if (!(G4C_ABLATE & 2)) gather(nk0);
             __builtin_amdgcn_sched_barrier(0);
             w += CHUNK_FLOATS;
             mma_chunk_n<NCT>(((c & 1) ? sX1 : sX0) + i * XS + 2 * h, ring, w, lo, acc);
-            park((c & 1) ? sX0 : sX1, nk0);
+            if (!(G4C_ABLATE & 2)) park((c & 1) ? sX0 : sX1, nk0);
             k0 = nk0;
-            __syncthreads();
+            if (!(G4C_ABLATE & 16)) __syncthreads();
         }
     }
 
@@ -774,7 +785,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
                 for (int q = 0; q < 16; ++q) {
                     const int row = (q & 3) + 8 * (q >> 2);
                     float x = acc.t[c][q] + bv;
-                    if (!last) x = g4c::selu_f(x);
+                    if (!last && !(G4C_ABLATE & 4)) x = g4c::selu_f(x);
                     base[row * HS + (ct0 + c) * 32] = x;
                 }
             }
@@ -800,7 +811,7 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
     const int rloc = lane % RPW, part = lane / RPW;
     const int myrow = wave * RPW + rloc;
     const int cb = part * NC;
-    if (p.gamma || p.act) {
+    if ((p.gamma || p.act) && !(G4C_ABLATE & 4)) {
         float *rowp = sH + myrow * HS + cb;
         const float inv_n = 1.0f / (float)n_out;
         float x[NC];
@@ -824,8 +835,17 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
             const float rstd = rsqrtf(var * inv_n + p.eps);
 #pragma unroll
             for (int c = 0; c < NC; c += 4) {
-                const f32x4 g4 = *reinterpret_cast<const f32x4 *>(sGB + cb + c);
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sGB + NP + cb + c);
+                f32x4 g4, b4;
+                if (G4C_SPLIT_SLIM) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int cc = (cb + c + u < n_out) ? cb + c + u : 0;
+                        g4[u] = p.gamma[cc]; b4[u] = p.beta[cc];
+                    }
+                } else {
+                    g4 = *reinterpret_cast<const f32x4 *>(sGB + cb + c);
+                    b4 = *reinterpret_cast<const f32x4 *>(sGB + NP + cb + c);
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) x[c + u] = fmaf((x[c + u] - mean) * rstd, g4[u], b4[u]);
             }

@@ -1,0 +1,8 @@
+#!/bin/bash
+# build_variant.sh <out.so> [extra hipcc -D flags...]: libg4c variant with extra defines for mlp_fused.hip (A/B tuning)
+set -e
+OUT=$1; shift
+cd "$(dirname "$0")/../graphs4cfd_amd/csrc"
+mkdir -p build
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 "$@" -c mlp_fused.hip -o build/mlp_fused_variant.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" build/error.o build/plan.o build/segment_reduce.o build/mlp_fused_variant.o build/remus_ops.o

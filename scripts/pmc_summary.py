@@ -10,7 +10,7 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"][:60]][r["Counter_Name"]] += float(r["Counter_Value"])
     for k, v in agg.items():
-        if "g4c" in k or "mlp_fused" in k or "segment_reduce" in k:
+        if "g4c" in k or "mlp_" in k or "segment_reduce" in k:
             print(k, f"dispatches={cnt[k]} total_us={dur[k]:.1f}")
             for c, x in sorted(v.items()):
                 print(f"    {c:32s} {x:16.0f}  per-dispatch {x / max(cnt[k], 1):14.0f}")
