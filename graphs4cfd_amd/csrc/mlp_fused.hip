@@ -92,16 +92,20 @@ struct Params {
 
 template <int RT> struct Acc { f32x16 t[RT][4]; };
 
-// B operands of one 4-k step for this lane: 4 column tiles x (k, k+1) -> 8 floats = two 16-byte loads.
+// B operands of one 4-k step for this lane: 4 column tiles x (k, k+1).  Inside a step's 512 floats the stream is
+// column-tile major ([ct][lane][e]), so every wave-level load is one contiguous 512-byte run whichever
+// subset of the column tiles the wave owns (the column-split kernel reads 1 or 2 of them).
 // `wstep` is wave-uniform (SGPR base), `lane_off` the lane's 32-bit offset in floats: lets hipcc use the
 // scalar-base addressing form instead of per-step 64-bit VALU address arithmetic.
 __device__ __forceinline__ f32x8 load_b(const float *wstep, unsigned lane_off) {
-    const f32x4 *p = reinterpret_cast<const f32x4 *>(wstep + lane_off);
-    const f32x4 lo = p[0];
-    const f32x4 hi = p[1];
+    const float *p = wstep + lane_off;
+    const float2 c0 = *reinterpret_cast<const float2 *>(p);
+    const float2 c1 = *reinterpret_cast<const float2 *>(p + 128);
+    const float2 c2 = *reinterpret_cast<const float2 *>(p + 256);
+    const float2 c3 = *reinterpret_cast<const float2 *>(p + 384);
     f32x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    r[0] = c0.x; r[1] = c0.y; r[2] = c1.x; r[3] = c1.y;
+    r[4] = c2.x; r[5] = c2.y; r[6] = c3.x; r[7] = c3.y;
     return r;
 }
 
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
     // ------------------------------------------------------------------ layer 0 (gathered input)
     zero_acc<RT>(acc);
     if (p.n_add) add_gathered_all<RT>(acc, p.add, p.n_add, sRowAdd, ROWS, lane);
-    const unsigned lo = (unsigned)(((lane >> 5) * 32 + (lane & 31)) * 8);   // lane's offset inside a step's 512 floats
+    const unsigned lo = (unsigned)(lane * 2);   // lane's offset inside one column tile's 128 floats of a step
     ring_fill(ring, w, lo);
     {
         // descriptor of the source currently being gathered, kept in scalars / registers
@@ -586,9 +590,13 @@ template <int NCT> struct BVec;
 template <> struct BVec<2> { typedef f32x4 type; };
 template <> struct BVec<1> { typedef float2 type; };
 
-template <int NCT>
-__device__ __forceinline__ typename BVec<NCT>::type load_bn(const float *wstep, unsigned lane_off) {
-    return *reinterpret_cast<const typename BVec<NCT>::type *>(wstep + lane_off);
+__device__ __forceinline__ void load_bn(float2 &b, const float *wstep, unsigned lane_off) {
+    b = *reinterpret_cast<const float2 *>(wstep + lane_off);
+}
+__device__ __forceinline__ void load_bn(f32x4 &b, const float *wstep, unsigned lane_off) {
+    const float2 c0 = *reinterpret_cast<const float2 *>(wstep + lane_off);
+    const float2 c1 = *reinterpret_cast<const float2 *>(wstep + lane_off + 128);
+    b[0] = c0.x; b[1] = c0.y; b[2] = c1.x; b[3] = c1.y;
 }
 
 template <int NCT> struct AccN { f32x16 t[NCT]; };
@@ -605,7 +613,7 @@ __device__ __forceinline__ void mma_chunk_n(const float *pa, RingN<NCT> &g, cons
     float2 a = *reinterpret_cast<const float2 *>(pa);
 #define G4C_STEP(U, SLOT)                                                                  \
     {                                                                                      \
-        const float2 an = *reinterpret_cast<const float2 *>(pa + (((U) + 1) & 7) * 4);     \
+        const float2 an = (G4C_ABLATE & 64) ? a : *reinterpret_cast<const float2 *>(pa + (((U) + 1) & 7) * 4); \
         __builtin_amdgcn_sched_barrier(0);                                                 \
         if (G4C_SPLIT_PRIO) __builtin_amdgcn_s_setprio(1);                                 \
         _Pragma("unroll") for (int c = 0; c < NCT; ++c) {                                  \
@@ -615,13 +623,42 @@ __device__ __forceinline__ void mma_chunk_n(const float *pa, RingN<NCT> &g, cons
             acc.t[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bget(g.SLOT, 2 * c + 1), acc.t[c], 0, 0, 0); \
         }                                                                                  \
         if (G4C_SPLIT_PRIO) __builtin_amdgcn_s_setprio(0);                                 \
-        g.SLOT = load_bn<NCT>(wnext + (U) * 512, lo);                                      \
+        if (!(G4C_ABLATE & 32) && !((G4C_ABLATE & 256) && ((U) & 1))) load_bn(g.SLOT, wnext + (U) * 512, lo); \
         __builtin_amdgcn_sched_barrier(0);                                                 \
         a = an;                                                                            \
     }
     G4C_STEP(0, s0) G4C_STEP(1, s1) G4C_STEP(2, s2) G4C_STEP(3, s3)
     G4C_STEP(4, s4) G4C_STEP(5, s5) G4C_STEP(6, s6) G4C_STEP(7, s7)
 #undef G4C_STEP
+}
+
+#ifndef G4C_SPLIT_B4
+#define G4C_SPLIT_B4 0
+#endif
+// ring of four 16-byte slots, each holding this lane's B operands of TWO consecutive steps (NCT == 1)
+struct Ring4 { f32x4 p0, p1, p2, p3; };
+__device__ __forceinline__ void ring4_fill(Ring4 &g, const float *w, unsigned lo4) {
+    g.p0 = *reinterpret_cast<const f32x4 *>(w + 0 * 1024 + lo4); g.p1 = *reinterpret_cast<const f32x4 *>(w + 1 * 1024 + lo4);
+    g.p2 = *reinterpret_cast<const f32x4 *>(w + 2 * 1024 + lo4); g.p3 = *reinterpret_cast<const f32x4 *>(w + 3 * 1024 + lo4);
+}
+__device__ __forceinline__ void mma_chunk_4(const float *pa, Ring4 &g, const float *wnext, unsigned lo4, AccN<1> &acc) {
+    float2 a = *reinterpret_cast<const float2 *>(pa);
+#define G4C_PAIR(V, SLOT)                                                                             \
+    {                                                                                                  \
+        const float2 a1 = *reinterpret_cast<const float2 *>(pa + (2 * (V) + 1) * 4);                   \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, g.SLOT[0], acc.t[0], 0, 0, 0);            \
+        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, g.SLOT[1], acc.t[0], 0, 0, 0);            \
+        const float2 a2 = *reinterpret_cast<const float2 *>(pa + ((2 * (V) + 2) & 7) * 4);             \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, g.SLOT[2], acc.t[0], 0, 0, 0);           \
+        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, g.SLOT[3], acc.t[0], 0, 0, 0);           \
+        g.SLOT = *reinterpret_cast<const f32x4 *>(wnext + (V) * 1024 + lo4);                           \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        a = a2;                                                                                        \
+    }
+    G4C_PAIR(0, p0) G4C_PAIR(1, p1) G4C_PAIR(2, p2) G4C_PAIR(3, p3)
+#undef G4C_PAIR
 }
 
 #ifndef G4C_SPLIT_SLIM
@@ -673,9 +710,12 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
     __syncthreads();
 
     AccN<NCT> acc;
+    constexpr bool B4 = G4C_SPLIT_B4 && NCT == 1;
     RingN<NCT> ring;
+    Ring4 ring4;
+    const unsigned lo4 = (unsigned)(ct0 * 256 + lane * 4);
     const float *w = p.w;
-    const unsigned lo = (unsigned)((h * 32 + i) * 8 + ct0 * 2);
+    const unsigned lo = (unsigned)(ct0 * 128 + lane * 2);
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -701,10 +741,14 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
             for (int c = 0; c < NCT; ++c) acc.t[c][q] += ((ct0 + c) * 32 + i < p.add[a].width) ? t[q][c] : 0.f;
         __builtin_amdgcn_sched_barrier(0);
     }
-    ring.s0 = load_bn<NCT>(w + 0 * 512, lo); ring.s1 = load_bn<NCT>(w + 1 * 512, lo);
-    ring.s2 = load_bn<NCT>(w + 2 * 512, lo); ring.s3 = load_bn<NCT>(w + 3 * 512, lo);
-    ring.s4 = load_bn<NCT>(w + 4 * 512, lo); ring.s5 = load_bn<NCT>(w + 5 * 512, lo);
-    ring.s6 = load_bn<NCT>(w + 6 * 512, lo); ring.s7 = load_bn<NCT>(w + 7 * 512, lo);
+    if constexpr (B4) {
+        ring4_fill(ring4, w, lo4);
+    } else {
+        load_bn(ring.s0, w + 0 * 512, lo); load_bn(ring.s1, w + 1 * 512, lo);
+        load_bn(ring.s2, w + 2 * 512, lo); load_bn(ring.s3, w + 3 * 512, lo);
+        load_bn(ring.s4, w + 4 * 512, lo); load_bn(ring.s5, w + 5 * 512, lo);
+        load_bn(ring.s6, w + 6 * 512, lo); load_bn(ring.s7, w + 7 * 512, lo);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---------------------------------------------------------------- layer 0: shared gather, one barrier per chunk
@@ -766,7 +810,8 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
             if (!(G4C_ABLATE & 2)) gather(nk0);
             __builtin_amdgcn_sched_barrier(0);
             w += CHUNK_FLOATS;
-            mma_chunk_n<NCT>(((c & 1) ? sX1 : sX0) + i * XS + 2 * h, ring, w, lo, acc);
+            if constexpr (B4) mma_chunk_4(((c & 1) ? sX1 : sX0) + i * XS + 2 * h, ring4, w, lo4, acc);
+            else mma_chunk_n<NCT>(((c & 1) ? sX1 : sX0) + i * XS + 2 * h, ring, w, lo, acc);
             if (!(G4C_ABLATE & 2)) park((c & 1) ? sX0 : sX1, nk0);
             k0 = nk0;
             if (!(G4C_ABLATE & 16)) __syncthreads();
@@ -782,11 +827,16 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
             for (int c = 0; c < NCT; ++c) {
                 const float bv = sBias[l * NP + (ct0 + c) * 32 + i];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int row = (q & 3) + 8 * (q >> 2);
-                    float x = acc.t[c][q] + bv;
-                    if (!last && !(G4C_ABLATE & 4)) x = g4c::selu_f(x);
-                    base[row * HS + (ct0 + c) * 32] = x;
+                for (int q0 = 0; q0 < 16; q0 += 4) {   // 4 at a time: more temporaries cost a wave of occupancy
+                    float x[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[q] = acc.t[c][q0 + q] + bv;
+                    if (!last && !(G4C_ABLATE & 4)) {   // uniform branch per group, not per element
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) x[q] = g4c::selu_f(x[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) base[(q + 2 * q0) * HS + (ct0 + c) * 32] = x[q];
                 }
             }
         }
@@ -799,7 +849,8 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
 #pragma unroll 1
         for (int k0 = 0; k0 < NP; k0 += KC) {
             w += CHUNK_FLOATS;
-            mma_chunk_n<NCT>(sH + i * HS + k0 + 2 * h, ring, w, lo, acc);
+            if constexpr (B4) mma_chunk_4(sH + i * HS + k0 + 2 * h, ring4, w, lo4, acc);
+            else mma_chunk_n<NCT>(sH + i * HS + k0 + 2 * h, ring, w, lo, acc);
         }
         __syncthreads();   // everybody is done reading sH before the next layer's output overwrites it
     }
@@ -895,7 +946,8 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
 }
 
 // W[n_out, k_in] (nn.Linear layout) -> this layer's chunks of the packed stream:
-// packed[((kp*32 + j)*4 + ct)*2 + e] = W^T[k = 2kp+e][n = ct*32 + j], zero padded to k_pad x 128,
+// chunk c = k/32 (4096 floats), step U = (k%32)/4 (512 floats), then [ct = n/32][h = (k%4)/2][j = n%32][e = k%2]:
+// packed[c*4096 + U*512 + ct*128 + (h*32 + j)*2 + e] = W^T[k][n], zero padded to k_pad x 128,
 // with an optional per-block sign flip.  seg tables live in the kernel argument.
 struct PackSegs {
     int n_seg;
@@ -919,7 +971,7 @@ __global__ void pack_layer_kernel(const float *__restrict__ W, int n_out, int k_
     float v = 0.f;
     if (k >= 0 && n < n_out) v = W[(long long)n * k_in + k];
     if (neg) v = -v;
-    packed[(((long long)(kp >> 1) * 32 + (n & 31)) * 4 + (n >> 5)) * 2 + (kp & 1)] = v;
+    packed[(long long)(kp >> 5) * CHUNK_FLOATS + ((kp & 31) >> 2) * 512 + (n >> 5) * 128 + (((kp >> 1) & 1) * 32 + (n & 31)) * 2 + (kp & 1)] = v;
 }
 
 }  // namespace

@@ -30,21 +30,27 @@ row = torch.randint(0, n, (rows,), device=dev, dtype=torch.int32)
 col = (torch.arange(rows, device=dev) // 6).clamp(max=n - 1).to(torch.int32)
 pr, pc = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev)
 out_e, out_v = torch.empty(rows, H, device=dev), torch.empty(n, H, device=dev)
-pk_e = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
-pk_v = blk.node_mlp.packed([H, H], [False, False])
+def pack_for(lib):   # weights are packed by the library that consumes them (the stream layout may differ)
+    _lib._lib = lib
+    blk.edge_mlp._packed.clear(); blk.node_mlp._packed.clear()
+    return blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False), blk.node_mlp.packed([H, H], [False, False])
+
+
+packs = [pack_for(lib) for lib in libs]
+cur = [0]
 src_e = [ops.Source(e), ops.Source(pr, index=row, additive=True), ops.Source(pc, index=col, additive=True)]
 src_v = [ops.Source(agg), ops.Source(v)]
-cases = {"edge(hoisted)": lambda: ops.mlp_forward(pk_e, src_e, rows, 0, out=out_e),
-         "node": lambda: ops.mlp_forward(pk_v, src_v, n, 1, out=out_v)}
+cases = {"edge(hoisted)": lambda: ops.mlp_forward(packs[cur[0]][0], src_e, rows, 0, out=out_e),
+         "node": lambda: ops.mlp_forward(packs[cur[0]][1], src_v, n, 1, out=out_v)}
 ref = {}
 for cname, fn in cases.items():
     times = [[] for _ in libs]
     for li, lib in enumerate(libs):
-        _lib._lib = lib; fn(); fn(); torch.cuda.synchronize()
+        _lib._lib = lib; cur[0] = li; fn(); fn(); torch.cuda.synchronize()
         ref.setdefault(cname, []).append((out_e if cname.startswith("edge") else out_v).clone())
     for r in range(a.rounds):
         for li, lib in enumerate(libs):
-            _lib._lib = lib
+            _lib._lib = lib; cur[0] = li
             s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); [fn() for _ in range(a.inner)]; t.record(); torch.cuda.synchronize()
             times[li].append(s.elapsed_time(t) / a.inner * 1e3)
