@@ -39,8 +39,10 @@ __device__ unsigned long long g4c_dbg_stamps[4096 * 16];
 extern "C" int g4c_debug_read_stamps(unsigned long long *host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4c_dbg_stamps), sizeof(unsigned long long) * n);
 }
+#define G4C_STAMPW(k) do { if (tile < 4096 && tid == 0) g4c_dbg_stamps[tile * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define G4C_STAMP(k) do {} while (0)
+#define G4C_STAMPW(k) do {} while (0)
 #endif
 
 namespace {
@@ -92,17 +94,21 @@ struct Params {
 
 template <int RT> struct Acc { f32x16 t[RT][4]; };
 
-// B operands of one 4-k step for this lane: 4 column tiles x (k, k+1).  Inside a step's 512 floats the stream is
-// column-tile major ([ct][lane][e]), so every wave-level load is one contiguous 512-byte run whichever
-// subset of the column tiles the wave owns (the column-split kernel reads 1 or 2 of them).
+// offset of 4-k step U inside a chunk of the weight stream: steps are stored in pairs (see pack_layer_kernel)
+__host__ __device__ constexpr int step_off(int U) { return (U >> 1) * 1024 + (U & 1) * 2; }
+
+
+// B operands of one 4-k step for this lane: 4 column tiles x (k, k+1).  Inside a PAIR of steps (1024 floats) the
+// stream is [column tile][lane][step of the pair][e]: the 4-wave column-split kernel, which owns one column tile
+// per wave, fetches both steps of a pair with ONE contiguous 16-byte-per-lane load (1 KiB per wave).
 // `wstep` is wave-uniform (SGPR base), `lane_off` the lane's 32-bit offset in floats: lets hipcc use the
 // scalar-base addressing form instead of per-step 64-bit VALU address arithmetic.
 __device__ __forceinline__ f32x8 load_b(const float *wstep, unsigned lane_off) {
     const float *p = wstep + lane_off;
     const float2 c0 = *reinterpret_cast<const float2 *>(p);
-    const float2 c1 = *reinterpret_cast<const float2 *>(p + 128);
-    const float2 c2 = *reinterpret_cast<const float2 *>(p + 256);
-    const float2 c3 = *reinterpret_cast<const float2 *>(p + 384);
+    const float2 c1 = *reinterpret_cast<const float2 *>(p + 256);
+    const float2 c2 = *reinterpret_cast<const float2 *>(p + 512);
+    const float2 c3 = *reinterpret_cast<const float2 *>(p + 768);
     f32x8 r;
     r[0] = c0.x; r[1] = c0.y; r[2] = c1.x; r[3] = c1.y;
     r[4] = c2.x; r[5] = c2.y; r[6] = c3.x; r[7] = c3.y;
@@ -135,10 +141,10 @@ __device__ __forceinline__ void mma_step(const AOp<RT> &a, const f32x8 &b, Acc<R
 struct Ring { f32x8 s0, s1, s2, s3, s4, s5, s6, s7; };
 
 __device__ __forceinline__ void ring_fill(Ring &g, const float *wchunk, unsigned lo) {
-    g.s0 = load_b(wchunk + 0 * 512, lo); g.s1 = load_b(wchunk + 1 * 512, lo);
-    g.s2 = load_b(wchunk + 2 * 512, lo); g.s3 = load_b(wchunk + 3 * 512, lo);
-    g.s4 = load_b(wchunk + 4 * 512, lo); g.s5 = load_b(wchunk + 5 * 512, lo);
-    g.s6 = load_b(wchunk + 6 * 512, lo); g.s7 = load_b(wchunk + 7 * 512, lo);
+    g.s0 = load_b(wchunk + step_off(0), lo); g.s1 = load_b(wchunk + step_off(1), lo);
+    g.s2 = load_b(wchunk + step_off(2), lo); g.s3 = load_b(wchunk + step_off(3), lo);
+    g.s4 = load_b(wchunk + step_off(4), lo); g.s5 = load_b(wchunk + step_off(5), lo);
+    g.s6 = load_b(wchunk + step_off(6), lo); g.s7 = load_b(wchunk + step_off(7), lo);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -156,7 +162,7 @@ __device__ __forceinline__ void mma_chunk(const float *pa, int a_tile_stride, Ri
         const AOp<RT> an = load_a<RT>(pa + (((U) + 1) & 7) * 4, a_tile_stride); \
         __builtin_amdgcn_sched_barrier(0);                                    \
         mma_step<RT>(a, g.SLOT, acc);                                         \
-        if (REFILL) g.SLOT = load_b(wnext + (U) * 512, lo);                   \
+        if (REFILL) g.SLOT = load_b(wnext + step_off(U), lo);                   \
         __builtin_amdgcn_sched_barrier(0);                                    \
         a = an;                                                               \
     }
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Pa
     // ------------------------------------------------------------------ layer 0 (gathered input)
     zero_acc<RT>(acc);
     if (p.n_add) add_gathered_all<RT>(acc, p.add, p.n_add, sRowAdd, ROWS, lane);
-    const unsigned lo = (unsigned)(lane * 2);   // lane's offset inside one column tile's 128 floats of a step
+    const unsigned lo = (unsigned)(lane * 4);   // lane's offset inside one column tile's 256 floats of a step pair
     ring_fill(ring, w, lo);
     {
         // descriptor of the source currently being gathered, kept in scalars / registers
@@ -595,7 +601,7 @@ __device__ __forceinline__ void load_bn(float2 &b, const float *wstep, unsigned 
 }
 __device__ __forceinline__ void load_bn(f32x4 &b, const float *wstep, unsigned lane_off) {
     const float2 c0 = *reinterpret_cast<const float2 *>(wstep + lane_off);
-    const float2 c1 = *reinterpret_cast<const float2 *>(wstep + lane_off + 128);
+    const float2 c1 = *reinterpret_cast<const float2 *>(wstep + lane_off + 256);
     b[0] = c0.x; b[1] = c0.y; b[2] = c1.x; b[3] = c1.y;
 }
 
@@ -623,7 +629,7 @@ __device__ __forceinline__ void mma_chunk_n(const float *pa, RingN<NCT> &g, cons
             acc.t[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bget(g.SLOT, 2 * c + 1), acc.t[c], 0, 0, 0); \
         }                                                                                  \
         if (G4C_SPLIT_PRIO) __builtin_amdgcn_s_setprio(0);                                 \
-        if (!(G4C_ABLATE & 32) && !((G4C_ABLATE & 256) && ((U) & 1))) load_bn(g.SLOT, wnext + (U) * 512, lo); \
+        if (!(G4C_ABLATE & 32) && !((G4C_ABLATE & 256) && ((U) & 1))) load_bn(g.SLOT, wnext + step_off(U), lo); \
         __builtin_amdgcn_sched_barrier(0);                                                 \
         a = an;                                                                            \
     }
@@ -632,229 +638,15 @@ __device__ __forceinline__ void mma_chunk_n(const float *pa, RingN<NCT> &g, cons
 #undef G4C_STEP
 }
 
-#ifndef G4C_SPLIT_B4
-#define G4C_SPLIT_B4 0
-#endif
-// ring of four 16-byte slots, each holding this lane's B operands of TWO consecutive steps (NCT == 1)
-struct Ring4 { f32x4 p0, p1, p2, p3; };
-__device__ __forceinline__ void ring4_fill(Ring4 &g, const float *w, unsigned lo4) {
-    g.p0 = *reinterpret_cast<const f32x4 *>(w + 0 * 1024 + lo4); g.p1 = *reinterpret_cast<const f32x4 *>(w + 1 * 1024 + lo4);
-    g.p2 = *reinterpret_cast<const f32x4 *>(w + 2 * 1024 + lo4); g.p3 = *reinterpret_cast<const f32x4 *>(w + 3 * 1024 + lo4);
-}
-__device__ __forceinline__ void mma_chunk_4(const float *pa, Ring4 &g, const float *wnext, unsigned lo4, AccN<1> &acc) {
-    float2 a = *reinterpret_cast<const float2 *>(pa);
-#define G4C_PAIR(V, SLOT)                                                                             \
-    {                                                                                                  \
-        const float2 a1 = *reinterpret_cast<const float2 *>(pa + (2 * (V) + 1) * 4);                   \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, g.SLOT[0], acc.t[0], 0, 0, 0);            \
-        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, g.SLOT[1], acc.t[0], 0, 0, 0);            \
-        const float2 a2 = *reinterpret_cast<const float2 *>(pa + ((2 * (V) + 2) & 7) * 4);             \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, g.SLOT[2], acc.t[0], 0, 0, 0);           \
-        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, g.SLOT[3], acc.t[0], 0, 0, 0);           \
-        g.SLOT = *reinterpret_cast<const f32x4 *>(wnext + (V) * 1024 + lo4);                           \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        a = a2;                                                                                        \
-    }
-    G4C_PAIR(0, p0) G4C_PAIR(1, p1) G4C_PAIR(2, p2) G4C_PAIR(3, p3)
-#undef G4C_PAIR
-}
-
 #ifndef G4C_SPLIT_SLIM
 #define G4C_SPLIT_SLIM 0
 #endif
-template <int NW, bool VEC>
-__global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
-    constexpr int ROWS = 32, NCT = 4 / NW, NPIECE = 4 / NW;   // pieces (8 rows x 32 cols) of a chunk gathered per wave
-    // LDS budget: 8 workgroups of NW = 4 waves per CU (= the 32-wave limit) need <= 20 KiB each, so the LayerNorm
-    // parameters are read from global memory (L1/L2 hits) instead of being staged
-    constexpr int GB_ROWS = G4C_SPLIT_SLIM ? 0 : 2;
-    __shared__ __attribute__((aligned(16))) float lds[ROWS * HS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + GB_ROWS) * NP];
-    float *sH = lds;
-    float *sX0 = lds;
-    float *sX1 = lds + ROWS * XS;
-    int *sRow = reinterpret_cast<int *>(lds + ROWS * HS);
-    int *sRowAdd = sRow + G4C_MAX_SRC * ROWS;
-    float *sBias = lds + ROWS * HS + 2 * G4C_MAX_SRC * ROWS;
-    float *sGB = sBias + G4C_MAX_LAYERS * NP;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// LayerNorm / activation / store of a finished 32-row tile held in sH; rows split over the NW waves of the workgroup.
+// Shared by the column-split kernels.  Needs: all waves' last-layer columns visible in sH (barrier done by the caller).
+template <int NW>
+__device__ __forceinline__ void split_finish(const Params &p, float *sH, const float *sGB, int wave, int lane, long long row0) {
+    constexpr int ROWS = 32;
     const int i = lane & 31, h = lane >> 5;
-    const int ct0 = wave * NCT;
-
-    int tile;
-    {
-        const int b = blockIdx.x, nt = p.n_tiles;
-        const int q = nt >> 3, r = nt & 7, x = b & 7, j = b >> 3;
-        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-    }
-    const long long row0 = p.row_base + (long long)tile * ROWS;
-
-    for (int r = tid; r < ROWS; r += 64 * NW) {
-        long long gr = row0 + r;
-        if (gr >= p.M) gr = p.M - 1;
-        for (int s = 0; s < p.n_src; ++s) sRow[s * ROWS + r] = p.src[s].idx ? p.src[s].idx[gr] : (int)gr;
-        for (int s = 0; s < p.n_add; ++s) sRowAdd[s * ROWS + r] = p.add[s].idx ? p.add[s].idx[gr] : (int)gr;
-    }
-    for (int e = tid; e < p.n_layers * NP; e += 64 * NW) sBias[e] = p.b[e];
-    if (p.gamma && !G4C_SPLIT_SLIM) {
-        for (int e = tid; e < NP; e += 64 * NW) {
-            const int ee = e < p.n_out ? e : 0;
-            sGB[e] = p.gamma[ee];
-            sGB[NP + e] = p.beta[ee];
-        }
-    }
-    __syncthreads();
-
-    AccN<NCT> acc;
-    constexpr bool B4 = G4C_SPLIT_B4 && NCT == 1;
-    RingN<NCT> ring;
-    Ring4 ring4;
-    const unsigned lo4 = (unsigned)(ct0 * 256 + lane * 4);
-    const float *w = p.w;
-    const unsigned lo = (unsigned)(ct0 * 128 + lane * 2);
-#pragma unroll
-    for (int c = 0; c < NCT; ++c)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc.t[c][q] = 0.f;
-    // pre-multiplied node-side terms of the first layer: one source at a time, its 16*NCT loads issued together
-    // (16 temporaries keep the kernel at 7 waves per SIMD; batching both sources at once costs occupancy and is slower)
-    for (int a = 0; a < ((G4C_ABLATE & 8) ? 0 : p.n_add); ++a) {
-        float t[16][NCT];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-            const float *pr = p.add[a].ptr + (long long)sRowAdd[a * ROWS + row] * p.add[a].ld;
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-                const int col = (ct0 + c) * 32 + i;
-                t[q][c] = pr[col < p.add[a].width ? col : 0];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) acc.t[c][q] += ((ct0 + c) * 32 + i < p.add[a].width) ? t[q][c] : 0.f;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (B4) {
-        ring4_fill(ring4, w, lo4);
-    } else {
-        load_bn(ring.s0, w + 0 * 512, lo); load_bn(ring.s1, w + 1 * 512, lo);
-        load_bn(ring.s2, w + 2 * 512, lo); load_bn(ring.s3, w + 3 * 512, lo);
-        load_bn(ring.s4, w + 4 * 512, lo); load_bn(ring.s5, w + 5 * 512, lo);
-        load_bn(ring.s6, w + 6 * 512, lo); load_bn(ring.s7, w + 7 * 512, lo);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---------------------------------------------------------------- layer 0: shared gather, one barrier per chunk
-    {
-        const int c4 = (lane & 7) * 4;
-        f32x4 xp[NPIECE];
-        const float *rp[NPIECE];
-        int s = 0, k0 = 0;
-        int cur_width = p.src[0].width, cur_wpad = p.src[0].wpad, cur_act = p.src[0].pre_act;
-        auto set_rows = [&](int sidx) {
-#pragma unroll
-            for (int q = 0; q < NPIECE; ++q)
-                rp[q] = p.src[sidx].ptr + (long long)sRow[sidx * ROWS + (lane >> 3) + 8 * (wave + NW * q)] * p.src[sidx].ld + p.src[sidx].col0;
-        };
-        auto gather = [&](int kk) {
-            const int c = kk + c4;
-#pragma unroll
-            for (int q = 0; q < NPIECE; ++q) {
-                if (VEC) {
-                    xp[q] = *reinterpret_cast<const f32x4 *>(rp[q] + (c < cur_width ? c : 0));
-                } else {
-                    const int w1 = cur_width - 1;
-                    xp[q][0] = rp[q][c + 0 < w1 ? c + 0 : w1]; xp[q][1] = rp[q][c + 1 < w1 ? c + 1 : w1];
-                    xp[q][2] = rp[q][c + 2 < w1 ? c + 2 : w1]; xp[q][3] = rp[q][c + 3 < w1 ? c + 3 : w1];
-                }
-            }
-        };
-        auto park = [&](float *dst, int kk) {
-            const int c = kk + c4;
-#pragma unroll
-            for (int q = 0; q < NPIECE; ++q) {
-                float t[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = (c + e < cur_width) ? xp[q][e] : 0.f;
-                if (cur_act) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = g4c::selu_f(t[e]);
-                }
-                float *d = dst + ((lane >> 3) + 8 * (wave + NW * q)) * XS + c4;
-                *reinterpret_cast<float2 *>(d) = make_float2(t[0], t[1]);
-                *reinterpret_cast<float2 *>(d + 2) = make_float2(t[2], t[3]);
-            }
-        };
-        set_rows(0);
-        gather(0);
-        park(sX0, 0);
-        __syncthreads();
-        for (int c = 0; c < p.chunks0; ++c) {
-            int nk0 = k0 + KC;
-            if (nk0 >= cur_wpad) {
-                if (s + 1 < p.n_src) {
-                    ++s; nk0 = 0;
-                    cur_width = p.src[s].width; cur_wpad = p.src[s].wpad; cur_act = p.src[s].pre_act;
-                    set_rows(s);
-                } else {
-                    nk0 = k0;
-                }
-            }
-            if (!(G4C_ABLATE & 2)) gather(nk0);
-            __builtin_amdgcn_sched_barrier(0);
-            w += CHUNK_FLOATS;
-            if constexpr (B4) mma_chunk_4(((c & 1) ? sX1 : sX0) + i * XS + 2 * h, ring4, w, lo4, acc);
-            else mma_chunk_n<NCT>(((c & 1) ? sX1 : sX0) + i * XS + 2 * h, ring, w, lo, acc);
-            if (!(G4C_ABLATE & 2)) park((c & 1) ? sX0 : sX1, nk0);
-            k0 = nk0;
-            if (!(G4C_ABLATE & 16)) __syncthreads();
-        }
-    }
-
-    // ---------------------------------------------------------------- layers 1..L-1
-    for (int l = 0;; ++l) {
-        const bool last = (l == p.n_layers - 1);
-        {   // this wave's column tiles of the layer output -> shared hidden buffer
-            float *base = sH + (4 * h) * HS + i;
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-                const float bv = sBias[l * NP + (ct0 + c) * 32 + i];
-#pragma unroll
-                for (int q0 = 0; q0 < 16; q0 += 4) {   // 4 at a time: more temporaries cost a wave of occupancy
-                    float x[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) x[q] = acc.t[c][q0 + q] + bv;
-                    if (!last && !(G4C_ABLATE & 4)) {   // uniform branch per group, not per element
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) x[q] = g4c::selu_f(x[q]);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) base[(q + 2 * q0) * HS + (ct0 + c) * 32] = x[q];
-                }
-            }
-        }
-        __syncthreads();
-        if (last) break;
-#pragma unroll
-        for (int c = 0; c < NCT; ++c)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc.t[c][q] = 0.f;
-#pragma unroll 1
-        for (int k0 = 0; k0 < NP; k0 += KC) {
-            w += CHUNK_FLOATS;
-            if constexpr (B4) mma_chunk_4(sH + i * HS + k0 + 2 * h, ring4, w, lo4, acc);
-            else mma_chunk_n<NCT>(sH + i * HS + k0 + 2 * h, ring, w, lo, acc);
-        }
-        __syncthreads();   // everybody is done reading sH before the next layer's output overwrites it
-    }
-
     // ---------------------------------------------------------------- LayerNorm / activation: rows split over the waves
     // wave w owns rows [w*RPW, (w+1)*RPW); lane = part * RPW + row_local, each part = NC consecutive columns
     constexpr int RPW = ROWS / NW, PARTS = 64 / RPW, NC = NP / PARTS;
@@ -945,9 +737,443 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
     }
 }
 
+#ifndef G4C_SPLIT_B4
+#define G4C_SPLIT_B4 1
+#endif
+// ring of four 16-byte slots, each holding this lane's B operands of TWO consecutive steps (NCT == 1)
+struct Ring4 { f32x4 p0, p1, p2, p3; };
+__device__ __forceinline__ void ring4_fill(Ring4 &g, const float *w, unsigned lo4) {
+    g.p0 = *reinterpret_cast<const f32x4 *>(w + 0 * 1024 + lo4); g.p1 = *reinterpret_cast<const f32x4 *>(w + 1 * 1024 + lo4);
+    g.p2 = *reinterpret_cast<const f32x4 *>(w + 2 * 1024 + lo4); g.p3 = *reinterpret_cast<const f32x4 *>(w + 3 * 1024 + lo4);
+}
+__device__ __forceinline__ void mma_chunk_4(const float *pa, Ring4 &g, const float *wnext, unsigned lo4, AccN<1> &acc) {
+    float2 a = *reinterpret_cast<const float2 *>(pa);
+#define G4C_PAIR(V, SLOT)                                                                             \
+    {                                                                                                  \
+        const float2 a1 = *reinterpret_cast<const float2 *>(pa + (2 * (V) + 1) * 4);                   \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, g.SLOT[0], acc.t[0], 0, 0, 0);            \
+        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, g.SLOT[1], acc.t[0], 0, 0, 0);            \
+        const float2 a2 = *reinterpret_cast<const float2 *>(pa + ((2 * (V) + 2) & 7) * 4);             \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, g.SLOT[2], acc.t[0], 0, 0, 0);           \
+        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, g.SLOT[3], acc.t[0], 0, 0, 0);           \
+        g.SLOT = *reinterpret_cast<const f32x4 *>(wnext + (V) * 1024 + lo4);                           \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        a = a2;                                                                                        \
+    }
+    G4C_PAIR(0, p0) G4C_PAIR(1, p1) G4C_PAIR(2, p2) G4C_PAIR(3, p3)
+#undef G4C_PAIR
+}
+
+#ifndef G4C_SPLIT_SLIM
+#define G4C_SPLIT_SLIM 0
+#endif
+template <int NW, bool VEC>
+__global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
+    constexpr int ROWS = 32, NCT = 4 / NW, NPIECE = 4 / NW;   // pieces (8 rows x 32 cols) of a chunk gathered per wave
+    // LDS budget: 8 workgroups of NW = 4 waves per CU (= the 32-wave limit) need <= 20 KiB each, so the LayerNorm
+    // parameters are read from global memory (L1/L2 hits) instead of being staged
+    constexpr int GB_ROWS = G4C_SPLIT_SLIM ? 0 : 2;
+    __shared__ __attribute__((aligned(16))) float lds[ROWS * HS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + GB_ROWS) * NP];
+    float *sH = lds;
+    float *sX0 = lds;
+    float *sX1 = lds + ROWS * XS;
+    int *sRow = reinterpret_cast<int *>(lds + ROWS * HS);
+    int *sRowAdd = sRow + G4C_MAX_SRC * ROWS;
+    float *sBias = lds + ROWS * HS + 2 * G4C_MAX_SRC * ROWS;
+    float *sGB = sBias + G4C_MAX_LAYERS * NP;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int ct0 = wave * NCT;
+
+    int tile;
+    {
+        const int b = blockIdx.x, nt = p.n_tiles;
+        const int q = nt >> 3, r = nt & 7, x = b & 7, j = b >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const long long row0 = p.row_base + (long long)tile * ROWS;
+    G4C_STAMPW(0);
+
+    // row indices of every input block: one (block, row) per thread, so all index loads are in flight together
+    for (int e = tid; e < 2 * G4C_MAX_SRC * ROWS; e += 64 * NW) {
+        const int slot = e / ROWS, r = e % ROWS;
+        long long gr = row0 + r;
+        if (gr >= p.M) gr = p.M - 1;
+        const int *ix = nullptr;
+        bool used;
+        if (slot < G4C_MAX_SRC) { used = slot < p.n_src; if (used) ix = p.src[slot].idx; }
+        else { used = slot - G4C_MAX_SRC < p.n_add; if (used) ix = p.add[slot - G4C_MAX_SRC].idx; }
+        if (used) sRow[e] = ix ? ix[gr] : (int)gr;      // sRowAdd == sRow + G4C_MAX_SRC * ROWS
+    }
+    for (int e = tid; e < p.n_layers * NP; e += 64 * NW) sBias[e] = p.b[e];
+    if (p.gamma && !G4C_SPLIT_SLIM) {
+        for (int e = tid; e < NP; e += 64 * NW) {
+            const int ee = e < p.n_out ? e : 0;
+            sGB[e] = p.gamma[ee];
+            sGB[NP + e] = p.beta[ee];
+        }
+    }
+    __syncthreads();
+    G4C_STAMPW(1);
+
+    AccN<NCT> acc;
+    constexpr bool B4 = G4C_SPLIT_B4 && NCT == 1;
+    RingN<NCT> ring;
+    Ring4 ring4;
+    const unsigned lo4 = (unsigned)(ct0 * 256 + lane * 4);
+    const float *w = p.w;
+    const unsigned lo = (unsigned)(ct0 * 256 + lane * 4);
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc.t[c][q] = 0.f;
+    // pre-multiplied node-side terms of the first layer: one source at a time, its 16*NCT loads issued together
+    // (16 temporaries keep the kernel at 7 waves per SIMD; batching both sources at once costs occupancy and is slower)
+    for (int a = 0; a < ((G4C_ABLATE & 8) ? 0 : p.n_add); ++a) {
+        float t[16][NCT];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+            const float *pr = p.add[a].ptr + (long long)sRowAdd[a * ROWS + row] * p.add[a].ld;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const int col = (ct0 + c) * 32 + i;
+                t[q][c] = pr[col < p.add[a].width ? col : 0];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc.t[c][q] += ((ct0 + c) * 32 + i < p.add[a].width) ? t[q][c] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    G4C_STAMPW(2);
+    if constexpr (B4) {
+        ring4_fill(ring4, w, lo4);
+    } else {
+        load_bn(ring.s0, w + step_off(0), lo); load_bn(ring.s1, w + step_off(1), lo);
+        load_bn(ring.s2, w + step_off(2), lo); load_bn(ring.s3, w + step_off(3), lo);
+        load_bn(ring.s4, w + step_off(4), lo); load_bn(ring.s5, w + step_off(5), lo);
+        load_bn(ring.s6, w + step_off(6), lo); load_bn(ring.s7, w + step_off(7), lo);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---------------------------------------------------------------- layer 0: shared gather, one barrier per chunk
+    {
+        const int c4 = (lane & 7) * 4;
+        f32x4 xp[NPIECE];
+        const float *rp[NPIECE];
+        int s = 0, k0 = 0;
+        int cur_width = p.src[0].width, cur_wpad = p.src[0].wpad, cur_act = p.src[0].pre_act;
+        auto set_rows = [&](int sidx) {
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q)
+                rp[q] = p.src[sidx].ptr + (long long)sRow[sidx * ROWS + (lane >> 3) + 8 * (wave + NW * q)] * p.src[sidx].ld + p.src[sidx].col0;
+        };
+        auto gather = [&](int kk) {
+            const int c = kk + c4;
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q) {
+                if (VEC) {
+                    xp[q] = *reinterpret_cast<const f32x4 *>(rp[q] + (c < cur_width ? c : 0));
+                } else {
+                    const int w1 = cur_width - 1;
+                    xp[q][0] = rp[q][c + 0 < w1 ? c + 0 : w1]; xp[q][1] = rp[q][c + 1 < w1 ? c + 1 : w1];
+                    xp[q][2] = rp[q][c + 2 < w1 ? c + 2 : w1]; xp[q][3] = rp[q][c + 3 < w1 ? c + 3 : w1];
+                }
+            }
+        };
+        auto park = [&](float *dst, int kk) {
+            const int c = kk + c4;
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q) {
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (c + e < cur_width) ? xp[q][e] : 0.f;
+                if (cur_act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = g4c::selu_f(t[e]);
+                }
+                float *d = dst + ((lane >> 3) + 8 * (wave + NW * q)) * XS + c4;
+                *reinterpret_cast<float2 *>(d) = make_float2(t[0], t[1]);
+                *reinterpret_cast<float2 *>(d + 2) = make_float2(t[2], t[3]);
+            }
+        };
+        set_rows(0);
+        gather(0);
+        park(sX0, 0);
+        __syncthreads();
+        G4C_STAMPW(3);
+        for (int c = 0; c < p.chunks0; ++c) {
+            int nk0 = k0 + KC;
+            if (nk0 >= cur_wpad) {
+                if (s + 1 < p.n_src) {
+                    ++s; nk0 = 0;
+                    cur_width = p.src[s].width; cur_wpad = p.src[s].wpad; cur_act = p.src[s].pre_act;
+                    set_rows(s);
+                } else {
+                    nk0 = k0;
+                }
+            }
+            if (!(G4C_ABLATE & 2)) gather(nk0);
+            __builtin_amdgcn_sched_barrier(0);
+            w += CHUNK_FLOATS;
+            if constexpr (B4) mma_chunk_4(((c & 1) ? sX1 : sX0) + i * XS + 2 * h, ring4, w, lo4, acc);
+            else mma_chunk_n<NCT>(((c & 1) ? sX1 : sX0) + i * XS + 2 * h, ring, w, lo, acc);
+            if (!(G4C_ABLATE & 2)) park((c & 1) ? sX0 : sX1, nk0);
+            k0 = nk0;
+            if (!(G4C_ABLATE & 16)) __syncthreads();
+        }
+    }
+
+    G4C_STAMPW(4);
+    // ---------------------------------------------------------------- layers 1..L-1
+    for (int l = 0;; ++l) {
+        const bool last = (l == p.n_layers - 1);
+        {   // this wave's column tiles of the layer output -> shared hidden buffer
+            float *base = sH + (4 * h) * HS + i;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float bv = sBias[l * NP + (ct0 + c) * 32 + i];
+#pragma unroll
+                for (int q0 = 0; q0 < 16; q0 += 4) {   // 4 at a time: more temporaries cost a wave of occupancy
+                    float x[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[q] = acc.t[c][q0 + q] + bv;
+                    if (!last && !(G4C_ABLATE & 4)) {   // uniform branch per group, not per element
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) x[q] = g4c::selu_f(x[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) base[(q + 2 * q0) * HS + (ct0 + c) * 32] = x[q];
+                }
+            }
+        }
+        __syncthreads();
+        G4C_STAMPW(5 + 2 * l);
+        if (last) break;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc.t[c][q] = 0.f;
+#pragma unroll 1
+        for (int k0 = 0; k0 < NP; k0 += KC) {
+            w += CHUNK_FLOATS;
+            if constexpr (B4) mma_chunk_4(sH + i * HS + k0 + 2 * h, ring4, w, lo4, acc);
+            else mma_chunk_n<NCT>(sH + i * HS + k0 + 2 * h, ring, w, lo, acc);
+        }
+        __syncthreads();   // everybody is done reading sH before the next layer's output overwrites it
+        G4C_STAMPW(6 + 2 * l);
+    }
+
+    G4C_STAMPW(12);
+    split_finish<NW>(p, sH, sGB, wave, lane, row0);
+    G4C_STAMPW(13);
+}
+
+// ======================================================================================================
+// Latency-oriented variant of the 4-wave column split for SMALL launches (at most a wave or two per SIMD: coarse
+// levels, per-rank sub-meshes).  There nothing hides a memory round trip, and the regular kernel pays one per
+// 32-column input chunk (gather -> barrier) and one per 8 weight steps (the 8-step ring is only ~0.5 us of MFMA
+// work when the wave has the SIMD to itself, less than an Infinity-Cache / HBM access).  This kernel
+//   * keeps FOUR chunks (one whole 128-k layer) of weights in flight per wave: 32 ring slots, refilled 4 chunks ahead;
+//   * gathers a whole 128-wide input block per barrier (4 x 16-byte loads per lane in flight), next block prefetched
+//     while the current one is multiplied.
+// Envelope: every weighted input block exactly 128 wide and 16-byte aligned; anything else runs mlp_split_kernel.
+struct RingD { float2 r[4][8]; };
+
+#define G4C_DSTEP(J, U)                                                                                  \
+    {                                                                                                    \
+        const float2 an = *reinterpret_cast<const float2 *>(pa + (J) * 32 + (((U) + 1) & 7) * 4 + ((U) == 7 && (J) < 3 ? 32 : 0)); \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, g.r[J][U].x, acc.t[0], 0, 0, 0);            \
+        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, g.r[J][U].y, acc.t[0], 0, 0, 0);            \
+        g.r[J][U] = *reinterpret_cast<const float2 *>(wn[J] + step_off(U) + lo);                           \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        a = an;                                                                                          \
+    }
+#define G4C_DCHUNK(J) G4C_DSTEP(J, 0) G4C_DSTEP(J, 1) G4C_DSTEP(J, 2) G4C_DSTEP(J, 3) G4C_DSTEP(J, 4) G4C_DSTEP(J, 5) G4C_DSTEP(J, 6) G4C_DSTEP(J, 7)
+
+// one 128-k block (4 chunks) from the LDS rows at `pa` (row stride HS); ring slot j is refilled from wn[j]
+__device__ __forceinline__ void mma_block_deep(const float *pa, RingD &g, const float *const (&wn)[4], unsigned lo, AccN<1> &acc) {
+    float2 a = *reinterpret_cast<const float2 *>(pa);
+    G4C_DCHUNK(0) G4C_DCHUNK(1) G4C_DCHUNK(2) G4C_DCHUNK(3)
+}
+#undef G4C_DCHUNK
+#undef G4C_DSTEP
+
+__global__ __launch_bounds__(256) void mlp_deep_kernel(const Params p) {
+    constexpr int ROWS = 32, NW = 4;
+    __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * HS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
+    float *sH = lds;                       // block buffer 0 doubles as the hidden buffer
+    float *sXb = lds + ROWS * HS;          // block buffer 1
+    int *sRow = reinterpret_cast<int *>(lds + 2 * ROWS * HS);
+    int *sRowAdd = sRow + G4C_MAX_SRC * ROWS;
+    float *sBias = lds + 2 * ROWS * HS + 2 * G4C_MAX_SRC * ROWS;
+    float *sGB = sBias + G4C_MAX_LAYERS * NP;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int ct0 = wave;
+
+    int tile;
+    {
+        const int b = blockIdx.x, nt = p.n_tiles;
+        const int q = nt >> 3, r = nt & 7, x = b & 7, j = b >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const long long row0 = p.row_base + (long long)tile * ROWS;
+    G4C_STAMPW(0);
+
+    // weights first: they depend on nothing, so their round trip overlaps the index loads below
+    const int total_chunks = p.chunks0 + (p.n_layers - 1) * (NP / KC);
+    const unsigned lo = (unsigned)(ct0 * 256 + lane * 4);
+    RingD ring;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float *wc = p.w + (size_t)(j < total_chunks ? j : total_chunks - 1) * CHUNK_FLOATS;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ring.r[j][u] = *reinterpret_cast<const float2 *>(wc + step_off(u) + lo);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // row indices of every input block: one (block, row) per thread, so all index loads are in flight together
+    for (int e = tid; e < 2 * G4C_MAX_SRC * ROWS; e += 64 * NW) {
+        const int slot = e / ROWS, r = e % ROWS;
+        long long gr = row0 + r;
+        if (gr >= p.M) gr = p.M - 1;
+        const int *ix = nullptr;
+        bool used;
+        if (slot < G4C_MAX_SRC) { used = slot < p.n_src; if (used) ix = p.src[slot].idx; }
+        else { used = slot - G4C_MAX_SRC < p.n_add; if (used) ix = p.add[slot - G4C_MAX_SRC].idx; }
+        if (used) sRow[e] = ix ? ix[gr] : (int)gr;      // sRowAdd == sRow + G4C_MAX_SRC * ROWS
+    }
+    for (int e = tid; e < p.n_layers * NP; e += 64 * NW) sBias[e] = p.b[e];
+    if (p.gamma) {
+        for (int e = tid; e < NP; e += 64 * NW) {
+            const int ee = e < p.n_out ? e : 0;
+            sGB[e] = p.gamma[ee];
+            sGB[NP + e] = p.beta[ee];
+        }
+    }
+    __syncthreads();
+    G4C_STAMPW(1);
+
+    // this wave's 8 rows of an input block: lane -> row (lane>>3) + 8*wave, 16 bytes at column 4*(lane&7) of each chunk
+    const int grow_l = (lane >> 3) + 8 * wave, c4 = (lane & 7) * 4;
+    f32x4 xp[4];
+    auto gather = [&](int sidx) {
+        const float *rp = p.src[sidx].ptr + (long long)sRow[sidx * ROWS + grow_l] * p.src[sidx].ld + p.src[sidx].col0 + c4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xp[q] = *reinterpret_cast<const f32x4 *>(rp + q * KC);
+    };
+    auto park = [&](float *dst, int act) {
+        float *d = dst + grow_l * HS + c4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 t = xp[q];
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = g4c::selu_f(t[e]);
+            }
+            *reinterpret_cast<f32x4 *>(d + q * KC) = t;
+        }
+    };
+    gather(0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    AccN<1> acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc.t[0][q] = 0.f;
+    // pre-multiplied node-side terms of the first layer (see mlp_split_kernel)
+    for (int a = 0; a < p.n_add; ++a) {
+        float t[16];
+        const int col = ct0 * 32 + i;
+        const bool ok = col < p.add[a].width;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+            t[q] = p.add[a].ptr[(long long)sRowAdd[a * ROWS + row] * p.add[a].ld + (ok ? col : 0)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc.t[0][q] += ok ? t[q] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    G4C_STAMPW(2);
+    park(sH, p.src[0].pre_act);
+    __syncthreads();
+    G4C_STAMPW(3);
+
+    int g = 0;                             // chunk index of ring slot 0's current contents
+    const float *wn[4];
+    auto set_refill = [&]() {              // slot j is refilled with chunk g + 4 + j (clamped: the tail is never used)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = g + 4 + j;
+            wn[j] = p.w + (size_t)(c < total_chunks ? c : total_chunks - 1) * CHUNK_FLOATS;
+        }
+    };
+    // ---------------------------------------------------------------- layer 0: one barrier per 128-wide input block
+    for (int s = 0; s < p.n_src; ++s) {
+        const bool more = s + 1 < p.n_src;
+        if (more) gather(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        set_refill();
+        mma_block_deep(((s & 1) ? sXb : sH) + i * HS + 2 * h, ring, wn, lo, acc);
+        g += 4;
+        if (more) park((s & 1) ? sH : sXb, p.src[s + 1].pre_act);
+        __syncthreads();
+    }
+
+    G4C_STAMPW(4);
+    // ---------------------------------------------------------------- layers 1..L-1
+    for (int l = 0;; ++l) {
+        const bool last = (l == p.n_layers - 1);
+        {
+            float *base = sH + (4 * h) * HS + i;
+            const float bv = sBias[l * NP + ct0 * 32 + i];
+#pragma unroll
+            for (int q0 = 0; q0 < 16; q0 += 4) {
+                float x[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = acc.t[0][q0 + q] + bv;
+                if (!last) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[q] = g4c::selu_f(x[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) base[(q + 2 * q0) * HS + ct0 * 32] = x[q];
+            }
+        }
+        __syncthreads();
+        G4C_STAMPW(5 + 2 * l);
+        if (last) break;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc.t[0][q] = 0.f;
+        set_refill();
+        mma_block_deep(sH + i * HS + 2 * h, ring, wn, lo, acc);
+        g += 4;
+        __syncthreads();
+        G4C_STAMPW(6 + 2 * l);
+    }
+    G4C_STAMPW(12);
+    split_finish<NW>(p, sH, sGB, wave, lane, row0);
+    G4C_STAMPW(13);
+}
+
 // W[n_out, k_in] (nn.Linear layout) -> this layer's chunks of the packed stream:
-// chunk c = k/32 (4096 floats), step U = (k%32)/4 (512 floats), then [ct = n/32][h = (k%4)/2][j = n%32][e = k%2]:
-// packed[c*4096 + U*512 + ct*128 + (h*32 + j)*2 + e] = W^T[k][n], zero padded to k_pad x 128,
+// chunk c = k/32 (4096 floats), step U = (k%32)/4, step pair V = U/2 (1024 floats), then
+// [ct = n/32][lane = ((k%4)/2)*32 + n%32][u = U%2][e = k%2]:
+// packed[c*4096 + V*1024 + ct*256 + lane*4 + u*2 + e] = W^T[k][n], zero padded to k_pad x 128,
 // with an optional per-block sign flip.  seg tables live in the kernel argument.
 struct PackSegs {
     int n_seg;
@@ -971,7 +1197,8 @@ __global__ void pack_layer_kernel(const float *__restrict__ W, int n_out, int k_
     float v = 0.f;
     if (k >= 0 && n < n_out) v = W[(long long)n * k_in + k];
     if (neg) v = -v;
-    packed[(long long)(kp >> 5) * CHUNK_FLOATS + ((kp & 31) >> 2) * 512 + (n >> 5) * 128 + (((kp >> 1) & 1) * 32 + (n & 31)) * 2 + (kp & 1)] = v;
+    const int U = (kp & 31) >> 2;
+    packed[(long long)(kp >> 5) * CHUNK_FLOATS + (U >> 1) * 1024 + (n >> 5) * 256 + (((kp >> 1) & 1) * 32 + (n & 31)) * 4 + (U & 1) * 2 + (kp & 1)] = v;
 }
 
 }  // namespace
@@ -1006,6 +1233,14 @@ extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs,
                                     float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                                     const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
 
+// Launches of at most this many rows (about two waves per SIMD) run mlp_deep_kernel when their input blocks allow it:
+// with so few waves nothing hides a memory round trip, so the kernel keeps a whole layer of weights and a whole
+// input block in flight.  G4C_MLP_DEEP_ROWS overrides (0 disables).
+static int64_t deep_rows() {
+    static const int64_t v = getenv("G4C_MLP_DEEP_ROWS") ? atoll(getenv("G4C_MLP_DEEP_ROWS")) : 16384;
+    return v;
+}
+
 extern "C" int64_t g4c_mlp_bulk_rows(int64_t n_rows) {
     // Tile scheduling.  A 64-row tile (one wave, 512 registers) keeps a SIMD busy for one "round"; the
     // chip holds 1024 of them.  Whole rounds go to the 64-row kernel; the remainder (< 64 Ki rows) goes to
@@ -1031,6 +1266,17 @@ extern "C" int32_t g4c_mlp_small_tile_mode(int64_t rows) {
     return 324;
 }
 
+extern "C" int32_t g4c_mlp_pick_mode(const g4c_src_t *srcs, int32_t n_src, int64_t rows) {
+    const int32_t mode = g4c_mlp_small_tile_mode(rows);
+    if (mode != 324 || rows > deep_rows() || !srcs) return mode;
+    for (int s = 0; s < n_src; ++s) {
+        const g4c_src_t &g = srcs[s];
+        if (g.additive) continue;
+        if (g.width != NP || g.ld % 4 || g.col0 % 4 || (uintptr_t)g.ptr % 16) return mode;
+    }
+    return 325;
+}
+
 extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                                const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream) {
@@ -1042,7 +1288,7 @@ extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int3
     if (bulk > 0)
         rc = g4c_mlp_forward_rows(mlp, srcs, n_src, n_rows, 0, bulk, 64, out, out_ld, out_idx, act, resid, resid_ld, resid_col0, stream);
     if (rc == G4C_OK && n_rows > bulk)
-        rc = g4c_mlp_forward_rows(mlp, srcs, n_src, n_rows, bulk, n_rows - bulk, g4c_mlp_small_tile_mode(n_rows - bulk), out, out_ld,
+        rc = g4c_mlp_forward_rows(mlp, srcs, n_src, n_rows, bulk, n_rows - bulk, g4c_mlp_pick_mode(srcs, n_src, n_rows - bulk), out, out_ld,
                                   out_idx, act, resid, resid_ld, resid_col0, stream);
     return rc;
 }
@@ -1051,8 +1297,8 @@ extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs,
                                     int64_t row_begin, int64_t row_count, int32_t tile_rows,
                                     float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                                     const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream) {
-    G4C_REQUIRE(tile_rows == 64 || tile_rows == 32 || tile_rows == 322 || tile_rows == 324, G4C_EINVAL,
-                "g4c_mlp_forward_rows: tile_rows must be 64, 32, 322 (32 rows / 2 waves) or 324 (32 rows / 4 waves)");
+    G4C_REQUIRE(tile_rows == 64 || tile_rows == 32 || tile_rows == 322 || tile_rows == 324 || tile_rows == 325, G4C_EINVAL,
+                "g4c_mlp_forward_rows: tile_rows must be 64, 32, 322 (32 rows / 2 waves), 324 (32 rows / 4 waves) or 325 (324, small-launch variant)");
     G4C_REQUIRE(row_begin >= 0 && row_count >= 0 && row_begin + row_count <= n_rows && row_begin % 32 == 0, G4C_EINVAL,
                 "g4c_mlp_forward_rows: bad row range [%lld, +%lld) of %lld", (long long)row_begin, (long long)row_count, (long long)n_rows);
     G4C_REQUIRE(mlp && srcs, G4C_EINVAL, "g4c_mlp_forward: null pointer");
@@ -1065,7 +1311,7 @@ extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs,
     G4C_REQUIRE(out, G4C_EINVAL, "g4c_mlp_forward: null output");
     Params p;
     int kp = 0;
-    bool all_vec = true;
+    bool all_vec = true, deep_ok = true;
     int nk = 0;
     p.n_add = 0;
     for (int s = 0; s < n_src; ++s) {
@@ -1085,6 +1331,7 @@ extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs,
         d.pre_act = g.pre_act;
         d.vec = (g.width % 4 == 0) && (g.ld % 4 == 0) && (g.col0 % 4 == 0) && ((uintptr_t)g.ptr % 16 == 0);
         all_vec = all_vec && d.vec;
+        deep_ok = deep_ok && d.vec && g.width == NP;
         kp += d.wpad;
     }
     G4C_REQUIRE(nk >= 1, G4C_EINVAL, "g4c_mlp_forward: no input block goes through the weights");
@@ -1129,6 +1376,10 @@ extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs,
         p.n_tiles = (int)((row_count + 31) / 32);
         if (all_vec) mlp_split_kernel<2, true><<<dim3(p.n_tiles), dim3(128), 0, st>>>(p);
         else mlp_split_kernel<2, false><<<dim3(p.n_tiles), dim3(128), 0, st>>>(p);
+    } else if (tile_rows == 325) {
+        G4C_REQUIRE(deep_ok, G4C_EUNSUPPORTED, "g4c_mlp_forward_rows: the small-launch variant needs 128-wide, 16-byte aligned input blocks");
+        p.n_tiles = (int)((row_count + 31) / 32);
+        mlp_deep_kernel<<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
     } else {
         p.n_tiles = (int)((row_count + 31) / 32);
         if (all_vec) mlp_split_kernel<4, true><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);

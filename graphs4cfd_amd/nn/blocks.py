@@ -22,6 +22,10 @@ from .. import _lib, ops, plan
 from ..graph import Graph
 from ..ops import Source
 
+import os
+# first-layer hoisting (MLP.run_hoisted) pays off only when the launch is throughput-bound
+HOIST_MIN_ROWS = int(os.environ.get("G4C_HOIST_MIN_ROWS", 24576))
+
 Tensor = torch.Tensor
 
 
@@ -119,7 +123,11 @@ class MLP(nn.Module):
                     act_code: int = _lib.ACT_NONE, **kw) -> Tensor:
         """MLP(cat(k_sources..., t0[idx0], t1[idx1], ...)) with the first layer's products of the gathered node-side
         inputs hoisted: W1 [x | t[idx]] = W1x x + (W1t t)[idx] (exact up to fp32 re-association), so `W1t t` costs
-        rows(t) instead of n_rows.  `gathered` = [(tensor [n_t, w_t], int32 index [n_rows])] in concat order."""
+        rows(t) instead of n_rows.  `gathered` = [(tensor [n_t, w_t], int32 index [n_rows])] in concat order.
+        Below HOIST_MIN_ROWS the launch is latency-bound and the extra product launches cost more than the MFMA
+        work they save (measured crossover ~25k rows, scripts/sweep_tile_modes.py): one plain fused launch then."""
+        if n_rows < HOIST_MIN_ROWS:
+            return self.run_coded(list(k_sources) + [Source(t, index=idx) for t, idx in gathered], n_rows, act_code, **kw)
         kw_widths = [s.width for s in k_sources]
         off = sum(kw_widths)
         adds = []

@@ -244,7 +244,9 @@ class PackedMLP:
 
 def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: int = _lib.ACT_NONE,
                 out: Optional[Tensor] = None, out_idx32: Optional[Tensor] = None,
-                resid: Optional[Tensor] = None, resid_col0: int = 0) -> Tensor:
+                resid: Optional[Tensor] = None, resid_col0: int = 0, tile_mode: Optional[int] = None) -> Tensor:
+    """One fused MLP launch (g4c_mlp_forward).  `tile_mode` (tests / tuning) runs every row through
+    g4c_mlp_forward_rows with that kernel variant instead of the library's own choice."""
     lib = _lib.load()
     dev = _lib.require_hip(*[s.tensor for s in sources], *[s.index for s in sources], out, out_idx32, resid)
     if dev != packed.device:
@@ -260,14 +262,16 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
         out = torch.empty((n_rows, packed.n_out), dtype=torch.float32, device=dev)
     args = (_lib.ptr(out), _ld(out), _lib.ptr(out_idx32), act, _lib.ptr(resid), _ld(resid) if resid is not None else 0,
             resid_col0, _lib.stream_handle(dev))
-    if KernelTimer.active is None:
+    if tile_mode is not None:
+        _lib.check(lib.g4c_mlp_forward_rows(C.byref(packed.desc), arr, len(sources), n_rows, 0, n_rows, tile_mode, *args))
+    elif KernelTimer.active is None:
         _lib.check(lib.g4c_mlp_forward(C.byref(packed.desc), arr, len(sources), n_rows, *args))
     else:
         # same two launches as g4c_mlp_forward, bracketed separately (kernel names as rocprofv3 reports them)
         bulk = int(lib.g4c_mlp_bulk_rows(n_rows))
         bpr = 4.0 * (sum(packed.seg_widths) + packed.n_out)
-        small = int(lib.g4c_mlp_small_tile_mode(n_rows - bulk)) if n_rows > bulk else 32
-        small_name = {32: "mlp_fused_kernel<1>", 322: "mlp_split_kernel<2>", 324: "mlp_split_kernel<4>"}[small]
+        small = int(lib.g4c_mlp_pick_mode(arr, len(sources), n_rows - bulk)) if n_rows > bulk else 32
+        small_name = {32: "mlp_fused_kernel<1>", 322: "mlp_split_kernel<2>", 324: "mlp_split_kernel<4>", 325: "mlp_deep_kernel"}[small]
         for kind, begin, count, tile in (("mlp_fused_kernel<2>", 0, bulk, 64), (small_name, bulk, n_rows - bulk, small)):
             if count > 0:
                 _timed(kind, packed.flops_per_row * count, bpr * count, lambda: _lib.check(lib.g4c_mlp_forward_rows(

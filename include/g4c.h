@@ -127,12 +127,16 @@ int g4c_mlp_forward(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*
 
 /* The two launches g4c_mlp_forward is made of, exposed so that a profiler can bracket them separately:
  * rows [0, g4c_mlp_bulk_rows(n)) run as 64-row tiles (whole "rounds" of 1024 tiles), the remainder as 32-row
- * tiles.  g4c_mlp_forward_rows processes rows [row_begin, row_begin + row_count) with tile_rows in {64, 32, 322, 324};
- * row_begin must be a multiple of 32. */
+ * tiles.  g4c_mlp_forward_rows processes rows [row_begin, row_begin + row_count) with tile_rows in
+ * {64, 32, 322, 324, 325}; row_begin must be a multiple of 32. */
 int64_t g4c_mlp_bulk_rows(int64_t n_rows);
 /* tile mode the policy picks for `rows` remainder rows: 32 (one wave per 32-row tile), 322 / 324 (the tile's
  * 128 output columns split over 2 / 4 waves: small launches are latency-bound on one wave's MFMA chain). */
 int32_t g4c_mlp_small_tile_mode(int64_t rows);
+/* the mode g4c_mlp_forward uses for `rows` remainder rows of these sources: g4c_mlp_small_tile_mode(rows), or 325 =
+ * the small-launch variant of 324 (a whole layer of weights and a whole 128-wide input block in flight per wave)
+ * when rows <= G4C_MLP_DEEP_ROWS (default 16384) and every weighted block is 128 wide and 16-byte aligned. */
+int32_t g4c_mlp_pick_mode(const g4c_src_t *srcs /*host*/, int32_t n_src, int64_t rows);
 int g4c_mlp_forward_rows(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
                          int64_t n_rows, int64_t row_begin, int64_t row_count, int32_t tile_rows,
                          float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,

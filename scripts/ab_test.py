@@ -15,7 +15,8 @@ a = ap.parse_args()
 def load(path):
     lib = C.CDLL(os.path.abspath(path))
     for name, (res, args) in _lib._SIGNATURES.items():
-        fn = getattr(lib, name); fn.restype, fn.argtypes = res, args
+        if hasattr(lib, name):       # older builds lack the newest entry points
+            fn = getattr(lib, name); fn.restype, fn.argtypes = res, args
     return lib
 
 

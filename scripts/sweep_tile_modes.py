@@ -1,35 +1,51 @@
-"""Tuning: hoisted edge-MLP / node-MLP time vs row count for each tile mode (env G4C_MLP_FORCE_MODE is read once per
-process, so this script re-executes itself per mode)."""
-import os, subprocess, sys
-if len(sys.argv) > 1 and sys.argv[1] == "child":
-    import torch
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from graphs4cfd_amd import ops
-    from graphs4cfd_amd.nn import blocks as B
-    dev = torch.device("cuda", 0); H = 128
-    torch.manual_seed(0)
-    blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(dev)
-    for rows in [int(x) for x in sys.argv[2].split(",")]:
-        n = max(rows // 6, 64)
-        v, e = torch.randn(n, H, device=dev), torch.randn(rows, H, device=dev)
-        row = torch.randint(0, n, (rows,), device=dev, dtype=torch.int32)
-        col = (torch.arange(rows, device=dev) // 6).clamp(max=n - 1).to(torch.int32)
-        pr, pc = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev)
-        out = torch.empty(rows, H, device=dev)
-        pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
-        srcs = [ops.Source(e), ops.Source(pr, index=row, additive=True), ops.Source(pc, index=col, additive=True)]
-        f = lambda: ops.mlp_forward(pk, srcs, rows, 0, out=out)
-        for _ in range(3): f()
-        torch.cuda.synchronize(); a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); [f() for _ in range(20)]; b.record(); torch.cuda.synchronize()
-        print(f"{rows} {a.elapsed_time(b) / 20 * 1e3:.1f}", flush=True)
-else:
-    rows = sys.argv[1] if len(sys.argv) > 1 else "8000,16000,32000,50000,65536,75000,100000,131072,160000,200000,300000"
-    res = {}
-    for mode in ("0", "64", "32", "322", "324"):
-        env = dict(os.environ, G4C_MLP_FORCE_MODE=mode)
-        out = subprocess.run([sys.executable, __file__, "child", rows], env=env, capture_output=True, text=True).stdout
-        res[mode] = {int(l.split()[0]): float(l.split()[1]) for l in out.strip().splitlines() if l[:1].isdigit()}
-    print("rows      policy     64-row     32-row   split<2>   split<4>   (us per hoisted edge-MLP launch)")
-    for r in [int(x) for x in rows.split(",")]:
-        print(f"{r:8d} " + " ".join(f"{res[m].get(r, float('nan')):10.1f}" for m in ("0", "64", "32", "322", "324")))
+"""Tuning: time of the hoisted edge MLP, the node MLP and the one-layer node-product launch vs row count for each
+kernel variant behind g4c_mlp_forward_rows (ops.mlp_forward(..., tile_mode=...)), interleaved in one process.
+Usage: python scripts/sweep_tile_modes.py [rows,rows,...] [--modes 324,325]"""
+import argparse, os, statistics, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphs4cfd_amd import ops
+from graphs4cfd_amd.nn import blocks as B
+
+ap = argparse.ArgumentParser()
+ap.add_argument("rows", nargs="?", default="192,768,3072,6144,12500,25000,50000,75000,150000,600000")
+ap.add_argument("--modes", default="64,32,322,324,325")
+a = ap.parse_args()
+modes = [int(m) for m in a.modes.split(",")]
+dev = torch.device("cuda", 0); H = 128
+torch.manual_seed(0)
+blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(dev)
+pk_e = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+pk_v = blk.node_mlp.packed([H, H], [False, False])
+pk_p = blk.edge_mlp._packed_cols("hoist1", H, 2 * H, [H], [False], True)
+pk_full = blk.edge_mlp.packed([H, H, H], [False, False, False])
+
+
+def timeit(f, reps):
+    for _ in range(2): f()
+    ts = []
+    for _ in range(5):
+        s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); [f() for _ in range(reps)]; t.record(); torch.cuda.synchronize()
+        ts.append(s.elapsed_time(t) / reps * 1e3)
+    return statistics.median(ts)
+
+
+print("case      rows " + " ".join(f"{m:>9d}" for m in modes) + "   (us per launch, median of 5 x reps)")
+for rows in [int(x) for x in a.rows.split(",")]:
+    n = max(rows // 6, 32)
+    v, e, agg = torch.randn(n, H, device=dev), torch.randn(rows, H, device=dev), torch.randn(n, H, device=dev)
+    row = torch.randint(0, n, (rows,), device=dev, dtype=torch.int32)
+    col = (torch.arange(rows, device=dev) // 6).clamp(max=n - 1).to(torch.int32)
+    pr, pc = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev)
+    out_e, out_v = torch.empty(rows, H, device=dev), torch.empty(rows, H, device=dev)
+    src_e = [ops.Source(e), ops.Source(pr, index=row, additive=True), ops.Source(pc, index=col, additive=True)]
+    vv, aa = torch.randn(rows, H, device=dev), torch.randn(rows, H, device=dev)
+    cases = {"edge": lambda m: ops.mlp_forward(pk_e, src_e, rows, 0, out=out_e, tile_mode=m),
+             "node": lambda m: ops.mlp_forward(pk_v, [ops.Source(aa), ops.Source(vv)], rows, 1, out=out_v, tile_mode=m),
+             "edge3src": lambda m: ops.mlp_forward(pk_full, [ops.Source(e), ops.Source(v, index=row), ops.Source(v, index=col)], rows, 0, out=out_e, tile_mode=m),
+             "prod(n)": lambda m: ops.mlp_forward(pk_p, [ops.Source(v)], n, 0, out=out_v, tile_mode=m),
+             "product": lambda m: ops.mlp_forward(pk_p, [ops.Source(vv)], rows, 0, out=out_v, tile_mode=m)}
+    reps = 20 if rows <= 100000 else 5
+    for name, f in cases.items():
+        print(f"{name:8s} {rows:7d} " + " ".join(f"{timeit(lambda: f(m), reps):9.1f}" for m in modes), flush=True)

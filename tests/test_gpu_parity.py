@@ -90,6 +90,37 @@ def test_mlp_row_tails_and_leading_dims(golden):
     assert mlp(x.to(DEV)).shape == (3, 5, 128)
 
 
+@pytest.mark.parametrize("rows", [1, 33, 1000, 20000])
+def test_mlp_kernel_variants_agree(rows):
+    """Every kernel variant behind g4c_mlp_forward_rows (64 / 32-row single-wave tiles, 2- and 4-wave column split,
+    the small-launch variant 325) computes the same MLP: hoisted edge form (gathered additive terms + SELU-on-load)
+    and the two-block node form, against the oracle MLP on the concatenated input."""
+    H, n = 128, max(rows // 6, 1)
+    torch.manual_seed(rows)
+    blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
+    e, v, agg = torch.randn(rows, H, device=DEV), torch.randn(n, H, device=DEV), torch.randn(n, H, device=DEV)
+    row = torch.randint(0, n, (rows,), device=DEV, dtype=torch.int32)
+    col = torch.randint(0, n, (rows,), device=DEV, dtype=torch.int32)
+    w = {f"m.{k}": t.cpu() for k, t in blk.edge_mlp.state_dict().items()}
+    x = torch.cat([torch.selu(e), v[row.long()], v[col.long()]], 1).cpu()
+    ref_e = O.mlp(x, w, "m")
+    # first-layer products of the node-side blocks, as _mp_step's hoisting computes them
+    W1 = blk.edge_mlp.state_dict()["MLP.linear_1.weight"]
+    pr, pc = v @ W1[:, H:2 * H].T, v @ W1[:, 2 * H:].T
+    pk_e = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+    src_e = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=row, additive=True), ops.Source(pc, index=col, additive=True)]
+    pk_v = blk.node_mlp.packed([H, H], [False, False])
+    idx = torch.randint(0, n, (n,), device=DEV, dtype=torch.int32)
+    src_v = [ops.Source(agg), ops.Source(v, index=idx)]
+    wn = {f"m.{k}": t.cpu() for k, t in blk.node_mlp.state_dict().items()}
+    ref_v = O.mlp(torch.cat([agg, v[idx.long()]], 1).cpu(), wn, "m")
+    for mode in (64, 32, 322, 324, 325):
+        y = ops.mlp_forward(pk_e, src_e, rows, tile_mode=mode)
+        torch.testing.assert_close(y.cpu(), ref_e, rtol=2e-4, atol=2e-4, msg=lambda m: f"edge mode {mode}: {m}")
+        y = ops.mlp_forward(pk_v, src_v, n, _lib.ACT_SELU, tile_mode=mode)
+        torch.testing.assert_close(y.cpu(), torch.selu(ref_v), rtol=2e-4, atol=2e-4, msg=lambda m: f"node mode {mode}: {m}")
+
+
 @pytest.mark.parametrize("tag", ["h128_mean", "h32_sum", "h32_mean", "irregular"])
 def test_gnblock(golden, tag):
     c = golden("blocks.pt")[f"gnblock_{tag}"]
