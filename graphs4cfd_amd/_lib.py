@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libg4c.so")
 OK, EINVAL, ELAUNCH, EUNSUPPORTED = 0, -1, -2, -3
 ACT_NONE, ACT_SELU, ACT_TANH = 0, 1, 2
 MAX_SRC, MAX_LAYERS = 4, 4
+MAX_HEADS = 2
 
 _ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "selu": ACT_SELU, "tanh": ACT_TANH}
 
@@ -64,6 +65,8 @@ _SIGNATURES = {
     "g4c_mlp_forward_rows": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                                        C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_void_p]),
+    "g4c_mlp_forward_heads": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
+                                        C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "g4c_project_to_edges": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                        C.c_void_p, C.c_int32, C.c_void_p]),
     "g4c_edge_scalar_to_node_vector": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32,

@@ -90,6 +90,12 @@ struct Params {
     int resid_ld, resid_col0;
     int n_tiles;
     long long row_base;       // first row of this launch (a call may be split into a 64-row and a 32-row launch)
+    // "heads": extra bias-free 128x128 products of the FINAL output tile (after LayerNorm / activation), their
+    // weights continuing the packed stream after the last layer.  Used to emit the next MP layer's pre-multiplied
+    // node-side terms (W1_row v', W1_col v') from the node-MLP launch that produces v' (column-split kernels only).
+    int n_heads;
+    float *head_out[G4C_MAX_HEADS];
+    int head_ld;
 };
 
 template <int RT> struct Acc { f32x16 t[RT][4]; };
@@ -643,9 +649,8 @@ __device__ __forceinline__ void mma_chunk_n(const float *pa, RingN<NCT> &g, cons
 #endif
 // LayerNorm / activation / store of a finished 32-row tile held in sH; rows split over the NW waves of the workgroup.
 // Shared by the column-split kernels.  Needs: all waves' last-layer columns visible in sH (barrier done by the caller).
-template <int NW>
+template <int NW, int ROWS = 32>
 __device__ __forceinline__ void split_finish(const Params &p, float *sH, const float *sGB, int wave, int lane, long long row0) {
-    constexpr int ROWS = 32;
     const int i = lane & 31, h = lane >> 5;
     // ---------------------------------------------------------------- LayerNorm / activation: rows split over the waves
     // wave w owns rows [w*RPW, (w+1)*RPW); lane = part * RPW + row_local, each part = NC consecutive columns
@@ -769,8 +774,11 @@ __device__ __forceinline__ void mma_chunk_4(const float *pa, Ring4 &g, const flo
 #ifndef G4C_SPLIT_SLIM
 #define G4C_SPLIT_SLIM 0
 #endif
+#ifndef G4C_SPLIT_MINW
+#define G4C_SPLIT_MINW 1
+#endif
 template <int NW, bool VEC>
-__global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
+__global__ __launch_bounds__(64 * NW, G4C_SPLIT_MINW) void mlp_split_kernel(const Params p) {
     constexpr int ROWS = 32, NCT = 4 / NW, NPIECE = 4 / NW;   // pieces (8 rows x 32 cols) of a chunk gathered per wave
     // LDS budget: 8 workgroups of NW = 4 waves per CU (= the 32-wave limit) need <= 20 KiB each, so the LayerNorm
     // parameters are read from global memory (L1/L2 hits) instead of being staged
@@ -975,6 +983,244 @@ __global__ __launch_bounds__(64 * NW) void mlp_split_kernel(const Params p) {
     G4C_STAMPW(12);
     split_finish<NW>(p, sH, sGB, wave, lane, row0);
     G4C_STAMPW(13);
+    if (p.n_heads) {
+        __syncthreads();                   // every wave's rows of the final tile are in sH
+        for (int hd = 0; hd < p.n_heads; ++hd) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc.t[c][q] = 0.f;
+#pragma unroll 1
+            for (int k0 = 0; k0 < NP; k0 += KC) {
+                w += CHUNK_FLOATS;
+                if constexpr (B4) mma_chunk_4(sH + i * HS + k0 + 2 * h, ring4, w, lo4, acc);
+                else mma_chunk_n<NCT>(sH + i * HS + k0 + 2 * h, ring, w, lo, acc);
+            }
+            float *ho = p.head_out[hd];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const long long grow = row0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                    if (grow < p.M) ho[grow * p.head_ld + (ct0 + c) * 32 + i] = acc.t[c][q];
+                }
+        }
+    }
+}
+
+// ======================================================================================================
+// 64-row form of the 4-wave column split for LARGE launches: each wave multiplies TWO 32-row tiles by its column
+// tile, so every weight element fetched from L2 feeds 4 MFMAs instead of 2 and the per-row count of barriers,
+// index loads and bias / LayerNorm staging halves.  The weight stream out of L2 (not HBM, not the MFMA pipe) is
+// what the 32-row kernel stalls on when every SIMD is full (scripts/ab_test.py ablations: halving it = -6 %).
+// 38 KiB of LDS per workgroup -> 4 workgroups (16 waves) per CU.
+__device__ __forceinline__ void mma_chunk_64(const float *pa0, const float *pa1, Ring4 &g, const float *wnext, unsigned lo4,
+                                             f32x16 &acc0, f32x16 &acc1) {
+    float2 a0 = *reinterpret_cast<const float2 *>(pa0), a1 = *reinterpret_cast<const float2 *>(pa1);
+#define G4C_HALF(AX, AY, B0, B1)                                                                       \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AX.x, B0, acc0, 0, 0, 0);                          \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AY.x, B0, acc1, 0, 0, 0);                          \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AX.y, B1, acc0, 0, 0, 0);                          \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AY.y, B1, acc1, 0, 0, 0);
+#define G4C_PAIR(V, SLOT)                                                                              \
+    {                                                                                                  \
+        const float2 b0 = *reinterpret_cast<const float2 *>(pa0 + (2 * (V) + 1) * 4);                  \
+        const float2 b1 = *reinterpret_cast<const float2 *>(pa1 + (2 * (V) + 1) * 4);                  \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        G4C_HALF(a0, a1, g.SLOT[0], g.SLOT[1])                                                         \
+        const float2 c0 = *reinterpret_cast<const float2 *>(pa0 + ((2 * (V) + 2) & 7) * 4);            \
+        const float2 c1 = *reinterpret_cast<const float2 *>(pa1 + ((2 * (V) + 2) & 7) * 4);            \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        G4C_HALF(b0, b1, g.SLOT[2], g.SLOT[3])                                                         \
+        g.SLOT = *reinterpret_cast<const f32x4 *>(wnext + (V) * 1024 + lo4);                           \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        a0 = c0; a1 = c1;                                                                              \
+    }
+    G4C_PAIR(0, p0) G4C_PAIR(1, p1) G4C_PAIR(2, p2) G4C_PAIR(3, p3)
+#undef G4C_PAIR
+#undef G4C_HALF
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 4) void mlp_split64_kernel(const Params p) {
+    constexpr int ROWS = 64, NW = 4, NPIECE = 2;
+    __shared__ __attribute__((aligned(16))) float lds[ROWS * HS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
+    float *sH = lds;
+    float *sX0 = lds;
+    float *sX1 = lds + ROWS * XS;
+    int *sRow = reinterpret_cast<int *>(lds + ROWS * HS);
+    int *sRowAdd = sRow + G4C_MAX_SRC * ROWS;
+    float *sBias = lds + ROWS * HS + 2 * G4C_MAX_SRC * ROWS;
+    float *sGB = sBias + G4C_MAX_LAYERS * NP;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int ct0 = wave;
+
+    int tile;
+    {
+        const int b = blockIdx.x, nt = p.n_tiles;
+        const int q = nt >> 3, r = nt & 7, x = b & 7, j = b >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const long long row0 = p.row_base + (long long)tile * ROWS;
+
+    for (int e = tid; e < 2 * G4C_MAX_SRC * ROWS; e += 64 * NW) {
+        const int slot = e / ROWS, r = e % ROWS;
+        long long gr = row0 + r;
+        if (gr >= p.M) gr = p.M - 1;
+        const int *ix = nullptr;
+        bool used;
+        if (slot < G4C_MAX_SRC) { used = slot < p.n_src; if (used) ix = p.src[slot].idx; }
+        else { used = slot - G4C_MAX_SRC < p.n_add; if (used) ix = p.add[slot - G4C_MAX_SRC].idx; }
+        if (used) sRow[e] = ix ? ix[gr] : (int)gr;
+    }
+    for (int e = tid; e < p.n_layers * NP; e += 64 * NW) sBias[e] = p.b[e];
+    if (p.gamma) {
+        for (int e = tid; e < NP; e += 64 * NW) {
+            const int ee = e < p.n_out ? e : 0;
+            sGB[e] = p.gamma[ee];
+            sGB[NP + e] = p.beta[ee];
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc0[q] = 0.f; acc1[q] = 0.f; }
+    // pre-multiplied node-side terms of the first layer: 16 loads in flight at a time (one row tile of one source)
+    {
+        const int col = ct0 * 32 + i;
+        for (int a = 0; a < p.n_add; ++a) {
+            const bool ok = col < p.add[a].width;
+            const float *base = p.add[a].ptr + (ok ? col : 0);
+            const int ld = p.add[a].ld;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                float t[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    t[q] = base[(long long)sRowAdd[a * ROWS + rt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h] * ld];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float v = ok ? t[q] : 0.f;
+                    if (rt == 0) acc0[q] += v; else acc1[q] += v;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    const float *w = p.w;
+    const unsigned lo4 = (unsigned)(ct0 * 256 + lane * 4);
+    Ring4 ring;
+    ring4_fill(ring, w, lo4);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---------------------------------------------------------------- layer 0: shared gather, one barrier per chunk
+    {
+        const int c4 = (lane & 7) * 4;
+        f32x4 xp[NPIECE];
+        const float *rp[NPIECE];
+        int s = 0, k0 = 0;
+        int cur_width = p.src[0].width, cur_wpad = p.src[0].wpad, cur_act = p.src[0].pre_act;
+        auto set_rows = [&](int sidx) {
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q)
+                rp[q] = p.src[sidx].ptr + (long long)sRow[sidx * ROWS + (lane >> 3) + 8 * (wave + NW * q)] * p.src[sidx].ld + p.src[sidx].col0;
+        };
+        auto gather = [&](int kk) {
+            const int c = kk + c4;
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q) {
+                if (VEC) {
+                    xp[q] = *reinterpret_cast<const f32x4 *>(rp[q] + (c < cur_width ? c : 0));
+                } else {
+                    const int w1 = cur_width - 1;
+                    xp[q][0] = rp[q][c + 0 < w1 ? c + 0 : w1]; xp[q][1] = rp[q][c + 1 < w1 ? c + 1 : w1];
+                    xp[q][2] = rp[q][c + 2 < w1 ? c + 2 : w1]; xp[q][3] = rp[q][c + 3 < w1 ? c + 3 : w1];
+                }
+            }
+        };
+        auto park = [&](float *dst, int kk) {
+            const int c = kk + c4;
+#pragma unroll
+            for (int q = 0; q < NPIECE; ++q) {
+                float t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (c + e < cur_width) ? xp[q][e] : 0.f;
+                if (cur_act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = g4c::selu_f(t[e]);
+                }
+                float *d = dst + ((lane >> 3) + 8 * (wave + NW * q)) * XS + c4;
+                *reinterpret_cast<float2 *>(d) = make_float2(t[0], t[1]);
+                *reinterpret_cast<float2 *>(d + 2) = make_float2(t[2], t[3]);
+            }
+        };
+        set_rows(0);
+        gather(0);
+        park(sX0, 0);
+        __syncthreads();
+        for (int c = 0; c < p.chunks0; ++c) {
+            int nk0 = k0 + KC;
+            if (nk0 >= cur_wpad) {
+                if (s + 1 < p.n_src) {
+                    ++s; nk0 = 0;
+                    cur_width = p.src[s].width; cur_wpad = p.src[s].wpad; cur_act = p.src[s].pre_act;
+                    set_rows(s);
+                } else {
+                    nk0 = k0;
+                }
+            }
+            gather(nk0);
+            __builtin_amdgcn_sched_barrier(0);
+            w += CHUNK_FLOATS;
+            const float *pa = ((c & 1) ? sX1 : sX0) + i * XS + 2 * h;
+            mma_chunk_64(pa, pa + 32 * XS, ring, w, lo4, acc0, acc1);
+            park((c & 1) ? sX0 : sX1, nk0);
+            k0 = nk0;
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------- layers 1..L-1
+    for (int l = 0;; ++l) {
+        const bool last = (l == p.n_layers - 1);
+        {
+            const float bv = sBias[l * NP + ct0 * 32 + i];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                float *base = sH + (rt * 32 + 4 * h) * HS + ct0 * 32 + i;
+#pragma unroll
+                for (int q0 = 0; q0 < 16; q0 += 4) {
+                    float x[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[q] = (rt == 0 ? acc0[q0 + q] : acc1[q0 + q]) + bv;
+                    if (!last) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) x[q] = g4c::selu_f(x[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) base[(q + 2 * q0) * HS] = x[q];
+                }
+            }
+        }
+        __syncthreads();
+        if (last) break;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { acc0[q] = 0.f; acc1[q] = 0.f; }
+#pragma unroll 1
+        for (int k0 = 0; k0 < NP; k0 += KC) {
+            w += CHUNK_FLOATS;
+            const float *pa = sH + i * HS + k0 + 2 * h;
+            mma_chunk_64(pa, pa + 32 * HS, ring, w, lo4, acc0, acc1);
+        }
+        __syncthreads();
+    }
+    split_finish<NW, ROWS>(p, sH, sGB, wave, lane, row0);
 }
 
 // ======================================================================================================
@@ -1034,7 +1280,7 @@ __global__ __launch_bounds__(256) void mlp_deep_kernel(const Params p) {
     G4C_STAMPW(0);
 
     // weights first: they depend on nothing, so their round trip overlaps the index loads below
-    const int total_chunks = p.chunks0 + (p.n_layers - 1) * (NP / KC);
+    const int total_chunks = p.chunks0 + (p.n_layers - 1 + p.n_heads) * (NP / KC);
     const unsigned lo = (unsigned)(ct0 * 256 + lane * 4);
     RingD ring;
 #pragma unroll
@@ -1168,6 +1414,22 @@ __global__ __launch_bounds__(256) void mlp_deep_kernel(const Params p) {
     G4C_STAMPW(12);
     split_finish<NW>(p, sH, sGB, wave, lane, row0);
     G4C_STAMPW(13);
+    if (p.n_heads) {
+        __syncthreads();
+        for (int hd = 0; hd < p.n_heads; ++hd) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc.t[0][q] = 0.f;
+            set_refill();
+            mma_block_deep(sH + i * HS + 2 * h, ring, wn, lo, acc);
+            g += 4;
+            float *ho = p.head_out[hd];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const long long grow = row0 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (grow < p.M) ho[grow * p.head_ld + ct0 * 32 + i] = acc.t[0][q];
+            }
+        }
+    }
 }
 
 // W[n_out, k_in] (nn.Linear layout) -> this layer's chunks of the packed stream:
@@ -1293,13 +1555,38 @@ extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int3
     return rc;
 }
 
+static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                      int64_t row_begin, int64_t row_count, int32_t tile_rows,
+                      float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
+                      const float *resid, int32_t resid_ld, int32_t resid_col0,
+                      const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream);
+
 extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                     int64_t row_begin, int64_t row_count, int32_t tile_rows,
                                     float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                                     const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream) {
-    G4C_REQUIRE(tile_rows == 64 || tile_rows == 32 || tile_rows == 322 || tile_rows == 324 || tile_rows == 325, G4C_EINVAL,
+    return mlp_launch(mlp, srcs, n_src, n_rows, row_begin, row_count, tile_rows, out, out_ld, out_idx, act, resid, resid_ld,
+                      resid_col0, nullptr, 0, nullptr, 0, stream);
+}
+
+extern "C" int g4c_mlp_forward_heads(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                                     float *out, int32_t out_ld, int32_t act,
+                                     const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream) {
+    G4C_REQUIRE(n_heads >= 1 && n_heads <= G4C_MAX_HEADS && head_w && head_out, G4C_EINVAL, "g4c_mlp_forward_heads: bad heads (n=%d)", n_heads);
+    const int32_t mode = g4c_mlp_pick_mode(srcs, n_src, n_rows);
+    G4C_REQUIRE(mode == 324 || mode == 325, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads: tile mode %d has no heads (only the 4-wave column split)", mode);
+    return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, mode, out, out_ld, nullptr, act, nullptr, 0, 0,
+                      head_w, n_heads, head_out, head_ld, stream);
+}
+
+static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                      int64_t row_begin, int64_t row_count, int32_t tile_rows,
+                      float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
+                      const float *resid, int32_t resid_ld, int32_t resid_col0,
+                      const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream) {
+    G4C_REQUIRE(tile_rows == 64 || tile_rows == 32 || tile_rows == 322 || tile_rows == 324 || tile_rows == 325 || tile_rows == 644, G4C_EINVAL,
                 "g4c_mlp_forward_rows: tile_rows must be 64, 32, 322 (32 rows / 2 waves), 324 (32 rows / 4 waves) or 325 (324, small-launch variant)");
-    G4C_REQUIRE(row_begin >= 0 && row_count >= 0 && row_begin + row_count <= n_rows && row_begin % 32 == 0, G4C_EINVAL,
+    G4C_REQUIRE(row_begin >= 0 && row_count >= 0 && row_begin + row_count <= n_rows && row_begin % 32 == 0 && (tile_rows != 644 || row_begin % 64 == 0), G4C_EINVAL,
                 "g4c_mlp_forward_rows: bad row range [%lld, +%lld) of %lld", (long long)row_begin, (long long)row_count, (long long)n_rows);
     G4C_REQUIRE(mlp && srcs, G4C_EINVAL, "g4c_mlp_forward: null pointer");
     G4C_REQUIRE(n_src >= 1 && n_src <= G4C_MAX_SRC, G4C_EUNSUPPORTED, "g4c_mlp_forward: %d sources (max %d)", n_src, G4C_MAX_SRC);
@@ -1360,6 +1647,17 @@ extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs,
     p.M = n_rows;
     p.out = out; p.out_ld = out_ld; p.out_idx = out_idx; p.act = act;
     p.resid = resid; p.resid_ld = resid_ld; p.resid_col0 = resid_col0;
+    p.n_heads = n_heads; p.head_ld = head_ld;
+    for (int hd = 0; hd < G4C_MAX_HEADS; ++hd) p.head_out[hd] = hd < n_heads ? head_out[hd] : nullptr;
+    if (n_heads) {
+        G4C_REQUIRE(tile_rows == 324 || tile_rows == 325, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads: tile mode %d has no heads", tile_rows);
+        G4C_REQUIRE(p.n_out == NP && !resid && !out_idx && head_ld >= NP, G4C_EINVAL,
+                    "g4c_mlp_forward_heads: heads need a 128-wide output without residual / output index (n_out=%d)", p.n_out);
+        const int last = mlp->n_layers - 1;
+        G4C_REQUIRE(head_w == (const float *)mlp->w[last] + (size_t)mlp->k_pad[last] * NP, G4C_EINVAL,
+                    "g4c_mlp_forward_heads: head weights must continue the packed stream");
+        for (int hd = 0; hd < n_heads; ++hd) G4C_REQUIRE(head_out[hd], G4C_EINVAL, "g4c_mlp_forward_heads: null head output %d", hd);
+    }
     hipStream_t st = (hipStream_t)stream;
     if (row_count == 0) return G4C_OK;
     p.row_base = row_begin;
@@ -1376,6 +1674,10 @@ extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs,
         p.n_tiles = (int)((row_count + 31) / 32);
         if (all_vec) mlp_split_kernel<2, true><<<dim3(p.n_tiles), dim3(128), 0, st>>>(p);
         else mlp_split_kernel<2, false><<<dim3(p.n_tiles), dim3(128), 0, st>>>(p);
+    } else if (tile_rows == 644) {
+        p.n_tiles = (int)((row_count + 63) / 64);
+        if (all_vec) mlp_split64_kernel<true><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
+        else mlp_split64_kernel<false><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
     } else if (tile_rows == 325) {
         G4C_REQUIRE(deep_ok, G4C_EUNSUPPORTED, "g4c_mlp_forward_rows: the small-launch variant needs 128-wide, 16-byte aligned input blocks");
         p.n_tiles = (int)((row_count + 31) / 32);

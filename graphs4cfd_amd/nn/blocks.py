@@ -100,6 +100,42 @@ class MLP(nn.Module):
         pk = self.packed([s.width for s in sources], [s.negate for s in sources])
         return ops.mlp_forward(pk, sources, n_rows, act_code, **kw)
 
+    def run_with_heads(self, sources: Sequence[Source], n_rows: int, act_code: int, consumer: "MLP", k_cols: int,
+                       widths: Sequence[int]) -> Optional[Tuple[Tensor, List[Tensor]]]:
+        """This MLP on `sources`, plus — from the same launch — the first-layer products `consumer` will need from
+        this MLP's output y: [W1c[:, a:b] y for consecutive column blocks [a, b) of `widths` after the first `k_cols`
+        columns of consumer's first layer] (see MLP.run_hoisted; g4c_mlp_forward_heads).
+        Returns None when the launch cannot carry heads (shape envelope / kernel variant): the caller then lets the
+        consumer compute its products itself."""
+        if self.output_size != 128 or any(int(w) != 128 for w in widths) or not 1 <= len(widths) <= _lib.MAX_HEADS:
+            return None
+        key = ("heads", id(consumer), k_cols, tuple(widths), tuple(s.width for s in sources), tuple(s.negate for s in sources))
+        sig = (self._signature(), consumer._signature())
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != sig:
+            lin = self._linears()
+            ln = getattr(self.MLP, "layer_norm", None)
+            w1 = consumer._linears()[0].weight.detach()
+            heads, off = [], k_cols
+            for w in widths:
+                heads.append(w1[:, off:off + w].contiguous())
+                off += w
+            if int(w1.size(0)) != 128:
+                return None
+            pk = ops.PackedMLP([l.weight for l in lin], [l.bias for l in lin],
+                               None if ln is None else (ln.weight, ln.bias, ln.eps), key[4], key[5], heads=heads)
+            self._packed[key] = (sig, pk)
+            hit = self._packed[key]
+        pk = hit[1]
+        arr_mode = ops.mlp_mode(sources, n_rows)
+        if arr_mode not in (324, 325):
+            return None
+        dev = sources[0].tensor.device
+        y = torch.empty((n_rows, 128), dtype=torch.float32, device=dev)
+        outs = [torch.empty((n_rows, 128), dtype=torch.float32, device=dev) for _ in widths]
+        ops.mlp_forward(pk, sources, n_rows, act_code, out=y, head_outs=outs)
+        return y, outs
+
     # -- first-layer hoisting ------------------------------------------------------------------
     def _packed_cols(self, tag: str, a: int, b: int, seg_widths, seg_negate, first_only: bool) -> ops.PackedMLP:
         """Packed variant using only columns [a, b) of the first Linear layer (`first_only`: that layer alone, no bias)."""
@@ -120,21 +156,25 @@ class MLP(nn.Module):
         return hit[1]
 
     def run_hoisted(self, k_sources: Sequence[Source], gathered: Sequence[Tuple[Tensor, Tensor]], n_rows: int,
-                    act_code: int = _lib.ACT_NONE, **kw) -> Tensor:
+                    act_code: int = _lib.ACT_NONE, products: Optional[Sequence[Tensor]] = None, **kw) -> Tensor:
         """MLP(cat(k_sources..., t0[idx0], t1[idx1], ...)) with the first layer's products of the gathered node-side
         inputs hoisted: W1 [x | t[idx]] = W1x x + (W1t t)[idx] (exact up to fp32 re-association), so `W1t t` costs
         rows(t) instead of n_rows.  `gathered` = [(tensor [n_t, w_t], int32 index [n_rows])] in concat order.
         Below HOIST_MIN_ROWS the launch is latency-bound and the extra product launches cost more than the MFMA
-        work they save (measured crossover ~25k rows, scripts/sweep_tile_modes.py): one plain fused launch then."""
-        if n_rows < HOIST_MIN_ROWS:
+        work they save (measured crossover ~25k rows, scripts/sweep_tile_modes.py): one plain fused launch then.
+        `products` (from the producer's launch, MLP.run_with_heads): the per-node terms, already multiplied."""
+        if n_rows < HOIST_MIN_ROWS and products is None:
             return self.run_coded(list(k_sources) + [Source(t, index=idx) for t, idx in gathered], n_rows, act_code, **kw)
         kw_widths = [s.width for s in k_sources]
         off = sum(kw_widths)
         adds = []
-        for t, idx in gathered:
+        for j, (t, idx) in enumerate(gathered):
             w_t = int(t.size(1))
-            pk1 = self._packed_cols("hoist1", off, off + w_t, [w_t], [False], True)
-            part = ops.mlp_forward(pk1, [Source(t)], int(t.size(0)))
+            if products is not None:
+                part = products[j]
+            else:
+                pk1 = self._packed_cols("hoist1", off, off + w_t, [w_t], [False], True)
+                part = ops.mlp_forward(pk1, [Source(t)], int(t.size(0)))
             adds.append(Source(part, index=idx, additive=True))
             off += w_t
         if off != self.input_size:
@@ -217,18 +257,32 @@ def edgeScalarToNodeVector(edge_attr: Tensor, edge_index: Tensor, edgeUnitVector
 
 # ------------------------------------------------------------------------------------- MP
 def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, aggr: str, act_code: int,
-             e_pre_act: int = _lib.ACT_NONE, v_src: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+             e_pre_act: int = _lib.ACT_NONE, v_src: Optional[Tensor] = None,
+             products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None):
     """Shared body of GNBlock / EdgeMP / DownEdgeMP (nn/blocks.py:175-186,322-333,360-381):
         e' = msg_mlp([e | s[row] | v[col]]);  agg = reduce(e' -> col);  v' = act(upd_mlp([agg | v])).
     Returns (v', e') where e' is stored WITHOUT the activation: the aggregation consumes the raw
     messages, and the consumer of e' applies the activation while loading (`e_pre_act` here is that
-    pending activation of the incoming `e`).  `v_src` (DownEdgeMP) gathers sender rows from another tensor."""
+    pending activation of the incoming `e`).  `v_src` (DownEdgeMP) gathers sender rows from another tensor.
+    `products` = (W1[:, H:2H] v, W1[:, 2H:3H] v) of msg_mlp's first layer when the launch that produced `v` already
+    multiplied them; `next_msg` = the message MLP of the MP layer that will consume v' on the SAME graph: the node
+    launch then emits its products as well and a third value (those products, or None) is returned."""
     if aggr not in ("mean", "sum", "add"):
         raise ValueError(f"unsupported aggr {aggr!r}")
     ep, csr = plan.edge_csr(index, int(v.size(0)))
     senders = v if v_src is None else v_src
-    e_new = msg_mlp.run_hoisted([Source(e, pre_act=e_pre_act)], [(senders, ep.row), (v, ep.col)], ep.n_edges)
+    e_new = msg_mlp.run_hoisted([Source(e, pre_act=e_pre_act)], [(senders, ep.row), (v, ep.col)], ep.n_edges,
+                                products=products)
     agg = ops.segment_reduce(e_new, csr, aggr == "mean")
+    if next_msg is not None:
+        nxt = None
+        if ep.n_edges >= HOIST_MIN_ROWS:     # the consumer will hoist: give it its node-side terms from this launch
+            w = int(v.size(1))
+            nxt = upd_mlp.run_with_heads([Source(agg), Source(v)], int(v.size(0)), act_code, next_msg,
+                                         next_msg.input_size - 2 * w, [w, w])
+        if nxt is None:
+            return upd_mlp.run_coded([Source(agg), Source(v)], int(v.size(0)), act_code), e_new, None
+        return nxt[0], e_new, nxt[1]
     v_new = upd_mlp.run_coded([Source(agg), Source(v)], int(v.size(0)), act_code)
     return v_new, e_new
 
@@ -264,9 +318,12 @@ class GNBlock(nn.Module):
             if m is not None and hasattr(m, 'reset_parameters'):
                 m.reset_parameters()
 
-    def step(self, v: Tensor, e: Tensor, edge_index: Tensor, act_code: int, e_pre_act: int = _lib.ACT_NONE):
-        """Internal form used by the model programs: returns (act(v'), raw e')."""
-        return _mp_step(self.edge_mlp, self.node_mlp, v, e, edge_index, self.aggr, act_code, e_pre_act)
+    def step(self, v: Tensor, e: Tensor, edge_index: Tensor, act_code: int, e_pre_act: int = _lib.ACT_NONE,
+             products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None):
+        """Internal form used by the model programs: returns (act(v'), raw e') — and, when `next_msg` (the edge MLP of
+        the next MP layer on the same graph) is given, a third value: that layer's `products` or None (see _mp_step)."""
+        return _mp_step(self.edge_mlp, self.node_mlp, v, e, edge_index, self.aggr, act_code, e_pre_act,
+                        products=products, next_msg=next_msg)
 
     def forward(self, v: Tensor, e: Tensor, edge_index: Tensor, *, activation=None) -> Tuple[Tensor, Tensor]:
         return _public_mp(self.edge_mlp, self.node_mlp, v, e, edge_index, self.aggr, activation)

@@ -9,7 +9,8 @@ drives the fused HIP blocks:
     separate narrow column blocks, nn/mus_gnn.py:71 never materialises; the residual time step
     `field[:, -nf:] + output`, :97, is the decoder's epilogue),
   * every MP layer: edge MLP (gather + 3 layers + LayerNorm), CSR mean, node MLP with the model's
-    `F.selu` fused; the SELU of the edge latents is deferred to their next reader,
+    `F.selu` fused; the SELU of the edge latents is deferred to their next reader; between consecutive MP layers
+    of one level the node launch also emits the next edge MLP's node-side first-layer terms (blocks.MLP.run_with_heads),
   * DownMP/UpMP on the static plan with `tanh` fused.
 
 The Graph is never mutated (the reference mutates and restores it, nn/mus_gnn.py:174,216).
@@ -62,17 +63,26 @@ class _MuSGNN(GNN):
         v = self.node_encoder.run_coded(inputs, n, SELU)
         e_pending = NONE          # activation not yet applied to `e` (deferred to its readers)
         stash = []
-        for name in self._PROGRAM:
+        products = None           # first-layer node-side terms of the next MP layer, when its producer already made them
+        prog = self._PROGRAM
+        for k, name in enumerate(prog):
             block = getattr(self, name)
             if name.startswith("down_mp"):
                 stash.append((v, edge_index, e, e_pending))
                 v, edge_index, e = block.pool(graph, v, edge_index, e, torch.tanh, e_pre_act=e_pending)
-                e_pending = NONE
+                e_pending, products = NONE, None
             elif name.startswith("up_mp"):
                 v_old, edge_index, e, e_pending = stash.pop()
                 v = block.unpool(graph, v, v_old, torch.tanh)
+                products = None
             else:
-                v, e = block.step(v, e, edge_index, SELU, e_pre_act=e_pending)
+                nxt = prog[k + 1] if k + 1 < len(prog) else ""
+                if nxt.startswith("mp"):      # next MP layer runs on the same graph: its node-side products ride along
+                    v, e, products = block.step(v, e, edge_index, SELU, e_pre_act=e_pending, products=products,
+                                                next_msg=getattr(self, nxt).edge_mlp)
+                else:
+                    v, e = block.step(v, e, edge_index, SELU, e_pre_act=e_pending, products=products)
+                    products = None
                 e_pending = SELU
         nf = self.num_fields
         return self.node_decoder.run_coded([Source(v)], n, NONE, resid=field0, resid_col0=int(field0.size(1)) - nf)

@@ -185,9 +185,11 @@ class PackedMLP:
     """Device-side packed weights of one MLP for a given input block structure."""
 
     def __init__(self, weights: Sequence[Tensor], biases: Sequence[Tensor], ln: Optional[Tuple[Tensor, Tensor, float]],
-                 seg_widths: Sequence[int], seg_negate: Sequence[bool]):
+                 seg_widths: Sequence[int], seg_negate: Sequence[bool], heads: Sequence[Tensor] = ()):
+        """`heads`: bias-free [128, 128] weights applied to the MLP's final output row (g4c_mlp_forward_heads); their
+        packed images continue the weight stream after the last layer."""
         lib = _lib.load()
-        dev = _lib.require_hip(*weights, *[b for b in biases if b is not None])
+        dev = _lib.require_hip(*weights, *[b for b in biases if b is not None], *heads)
         n_layers = len(weights)
         if not 1 <= n_layers <= _lib.MAX_LAYERS:
             raise NotImplementedError(f"MLP with {n_layers} Linear layers (supported: 1..{_lib.MAX_LAYERS})")
@@ -202,7 +204,11 @@ class PackedMLP:
         k_pads = [k_pad0] + [NP] * (n_layers - 1)
         # one contiguous weight stream (layer after layer, 32-k chunk after chunk) + one chunk of slack:
         # the kernel's register ring prefetches one chunk past the end
-        stream_buf = torch.zeros((sum(k_pads) + KC) * NP, dtype=torch.float32, device=dev)
+        if len(heads) > _lib.MAX_HEADS or any(tuple(h.shape) != (NP, NP) for h in heads):
+            raise NotImplementedError(f"heads must be at most {_lib.MAX_HEADS} weights of shape [128, 128]")
+        if heads and int(weights[-1].size(0)) != NP:
+            raise NotImplementedError("heads need a 128-wide MLP output")
+        stream_buf = torch.zeros((sum(k_pads) + NP * len(heads) + KC) * NP, dtype=torch.float32, device=dev)
         bias_buf = torch.zeros(n_layers * NP, dtype=torch.float32, device=dev)
         self._keep += [stream_buf, bias_buf]
         off = 0
@@ -228,9 +234,18 @@ class PackedMLP:
             self.desc.k_pad[l], self.desc.n_pad[l] = k_pads[l], NP
             self.desc.w[l], self.desc.b[l] = wptr, bias_buf.data_ptr() + 4 * l * NP
             off += k_pads[l] * NP
+        self.head_w = stream_buf.data_ptr() + 4 * off if heads else None
+        self.n_heads = len(heads)
+        one = (C.c_int32 * 1)(NP)
+        zero = (C.c_int32 * 1)(0)
+        for W in heads:
+            Wc = W.detach().to(torch.float32).contiguous()
+            _lib.check(lib.g4c_mlp_pack_layer(_lib.ptr(Wc), NP, NP, one, zero, 1, stream_buf.data_ptr() + 4 * off, NP, NP, stream))
+            off += NP * NP
         self.n_out = int(weights[-1].size(0))
         self.desc.n_out = self.n_out
-        self.flops_per_row = float(sum(2 * int(W.size(0)) * int(W.size(1)) for W in weights))   # nn.Linear MACs x 2
+        # nn.Linear MACs x 2 (+ the heads' products)
+        self.flops_per_row = float(sum(2 * int(W.size(0)) * int(W.size(1)) for W in list(weights) + list(heads)))
         if ln is not None:
             g, be, eps = ln
             g, be = g.detach().to(torch.float32).contiguous(), be.detach().to(torch.float32).contiguous()
@@ -242,27 +257,58 @@ class PackedMLP:
         self.device = dev
 
 
+def _src_array(sources: Sequence[Source]):
+    arr = (_lib.g4c_src_t * len(sources))()
+    for a, s in zip(arr, sources):
+        a.ptr, a.idx, a.width, a.ld, a.col0, a.pre_act = (s.tensor.data_ptr(), _lib.ptr(s.index), s.width, _ld(s.tensor),
+                                                          s.col0, s.pre_act)
+        a.additive = 1 if s.additive else 0
+    return arr
+
+
+def mlp_mode(sources: Sequence[Source], n_rows: int) -> int:
+    """Kernel variant g4c_mlp_forward would use for these input blocks (g4c_mlp_pick_mode; 0 when a bulk launch is split off)."""
+    lib = _lib.load()
+    if int(lib.g4c_mlp_bulk_rows(n_rows)) > 0:
+        return 0
+    return int(lib.g4c_mlp_pick_mode(_src_array(sources), len(sources), n_rows))
+
+
 def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: int = _lib.ACT_NONE,
                 out: Optional[Tensor] = None, out_idx32: Optional[Tensor] = None,
-                resid: Optional[Tensor] = None, resid_col0: int = 0, tile_mode: Optional[int] = None) -> Tensor:
+                resid: Optional[Tensor] = None, resid_col0: int = 0, tile_mode: Optional[int] = None,
+                head_outs: Optional[Sequence[Tensor]] = None) -> Tensor:
     """One fused MLP launch (g4c_mlp_forward).  `tile_mode` (tests / tuning) runs every row through
-    g4c_mlp_forward_rows with that kernel variant instead of the library's own choice."""
+    g4c_mlp_forward_rows with that kernel variant instead of the library's own choice.
+    `head_outs` ([n_rows, 128] tensors, one per head of `packed`): g4c_mlp_forward_heads."""
     lib = _lib.load()
     dev = _lib.require_hip(*[s.tensor for s in sources], *[s.index for s in sources], out, out_idx32, resid)
     if dev != packed.device:
         raise RuntimeError(f"MLP weights on {packed.device}, inputs on {dev}")
     if tuple(s.width for s in sources if not s.additive) != packed.seg_widths:
         raise ValueError(f"input blocks {[s.width for s in sources if not s.additive]} do not match packed layout {packed.seg_widths}")
-    arr = (_lib.g4c_src_t * len(sources))()
-    for a, s in zip(arr, sources):
-        a.ptr, a.idx, a.width, a.ld, a.col0, a.pre_act = (s.tensor.data_ptr(), _lib.ptr(s.index), s.width, _ld(s.tensor),
-                                                          s.col0, s.pre_act)
-        a.additive = 1 if s.additive else 0
+    arr = _src_array(sources)
     if out is None:
         out = torch.empty((n_rows, packed.n_out), dtype=torch.float32, device=dev)
     args = (_lib.ptr(out), _ld(out), _lib.ptr(out_idx32), act, _lib.ptr(resid), _ld(resid) if resid is not None else 0,
             resid_col0, _lib.stream_handle(dev))
-    if tile_mode is not None:
+    if head_outs is not None:
+        if len(head_outs) != packed.n_heads or packed.n_heads == 0:
+            raise ValueError(f"{len(head_outs)} head outputs for a packing with {packed.n_heads} heads")
+        if out_idx32 is not None or resid is not None or tile_mode is not None:
+            raise NotImplementedError("heads with an output index / residual / forced tile mode")
+        _lib.require_hip(*head_outs)
+        ho = (C.c_void_p * len(head_outs))(*[h.data_ptr() for h in head_outs])
+        call = lambda: _lib.check(lib.g4c_mlp_forward_heads(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out), _ld(out),
+                                                            act, packed.head_w, len(head_outs), ho, _ld(head_outs[0]),
+                                                            _lib.stream_handle(dev)))
+        if KernelTimer.active is None:
+            call()
+        else:
+            mode = int(lib.g4c_mlp_pick_mode(arr, len(sources), n_rows))
+            name = {324: "mlp_split_kernel<4>", 325: "mlp_deep_kernel"}.get(mode, "mlp_other")
+            _timed(name, packed.flops_per_row * n_rows, 4.0 * (sum(packed.seg_widths) + packed.n_out * (1 + packed.n_heads)) * n_rows, call)
+    elif tile_mode is not None:
         _lib.check(lib.g4c_mlp_forward_rows(C.byref(packed.desc), arr, len(sources), n_rows, 0, n_rows, tile_mode, *args))
     elif KernelTimer.active is None:
         _lib.check(lib.g4c_mlp_forward(C.byref(packed.desc), arr, len(sources), n_rows, *args))

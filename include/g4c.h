@@ -34,6 +34,7 @@ extern "C" {
 
 #define G4C_MAX_SRC 4
 #define G4C_MAX_LAYERS 4
+#define G4C_MAX_HEADS 2
 
 int g4c_version(void);
 const char *g4c_last_error(void);
@@ -141,6 +142,18 @@ int g4c_mlp_forward_rows(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*
                          int64_t n_rows, int64_t row_begin, int64_t row_count, int32_t tile_rows,
                          float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                          const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
+
+/* g4c_mlp_forward plus up to G4C_MAX_HEADS "heads": head_out[h][r, :] = W_h y[r, :], y = the MLP's final 128-wide output
+ * row (after LayerNorm / activation), W_h a bias-free 128x128 layer packed with g4c_mlp_pack_layer (k_pad = n_pad = 128)
+ * whose packed image continues the MLP's stream: head_w == w[last] + k_pad[last]*128, heads back to back, then the
+ * usual chunk of slack.  One launch of the node MLP (nn/blocks.py:185) thereby also emits the two node-side first-layer
+ * terms W1[:, H:2H] v', W1[:, 2H:3H] v' of the NEXT GNBlock's edge MLP (nn/blocks.py:181), which that edge MLP
+ * gathers as additive sources.  Only the 4-wave column-split kernels implement heads (g4c_mlp_pick_mode in {324, 325});
+ * G4C_EUNSUPPORTED otherwise, so the caller launches the products separately. */
+int g4c_mlp_forward_heads(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
+                          int64_t n_rows, float *out, int32_t out_ld, int32_t act,
+                          const float *head_w, int32_t n_heads, float *const *head_out /*host*/, int32_t head_ld,
+                          void *stream);
 
 /* ---------------------------------------------------------------- REMuS helpers (HBM-bound)
  * out[e, f] = v[node[e], 2f]*U[e,0] + v[node[e], 2f+1]*U[e,1]

@@ -9,7 +9,10 @@ from graphs4cfd_amd.nn import blocks as B
 
 ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--rows", type=int, default=600000)
 ap.add_argument("--rounds", type=int, default=15); ap.add_argument("--inner", type=int, default=3)
+ap.add_argument("--modes", default="", help="comma list of tile modes: each library is timed once per mode (default: the library's own policy)")
 a = ap.parse_args()
+_modes = [int(m) for m in a.modes.split(",")] if a.modes else [None]
+a.libs, modes = [l for l in a.libs for _ in _modes], [m for _ in a.libs for m in _modes]
 
 
 def load(path):
@@ -41,8 +44,8 @@ packs = [pack_for(lib) for lib in libs]
 cur = [0]
 src_e = [ops.Source(e), ops.Source(pr, index=row, additive=True), ops.Source(pc, index=col, additive=True)]
 src_v = [ops.Source(agg), ops.Source(v)]
-cases = {"edge(hoisted)": lambda: ops.mlp_forward(packs[cur[0]][0], src_e, rows, 0, out=out_e),
-         "node": lambda: ops.mlp_forward(packs[cur[0]][1], src_v, n, 1, out=out_v)}
+cases = {"edge(hoisted)": lambda: ops.mlp_forward(packs[cur[0]][0], src_e, rows, 0, out=out_e, tile_mode=modes[cur[0]]),
+         "node": lambda: ops.mlp_forward(packs[cur[0]][1], src_v, n, 1, out=out_v, tile_mode=modes[cur[0]])}
 ref = {}
 for cname, fn in cases.items():
     times = [[] for _ in libs]
@@ -57,4 +60,4 @@ for cname, fn in cases.items():
             times[li].append(s.elapsed_time(t) / a.inner * 1e3)
     for li, p in enumerate(a.libs):
         d = (ref[cname][li] - ref[cname][0]).abs().max().item()
-        print(f"{cname:14s} {os.path.basename(p):28s} median {statistics.median(times[li]):8.1f} us   min {min(times[li]):8.1f} us   max|out - out_A| {d:.1e}")
+        print(f"{cname:14s} {os.path.basename(p) + ('' if modes[li] is None else f' mode {modes[li]}'):28s} median {statistics.median(times[li]):8.1f} us   min {min(times[li]):8.1f} us   max|out - out_A| {d:.1e}")

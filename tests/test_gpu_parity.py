@@ -114,11 +114,52 @@ def test_mlp_kernel_variants_agree(rows):
     src_v = [ops.Source(agg), ops.Source(v, index=idx)]
     wn = {f"m.{k}": t.cpu() for k, t in blk.node_mlp.state_dict().items()}
     ref_v = O.mlp(torch.cat([agg, v[idx.long()]], 1).cpu(), wn, "m")
-    for mode in (64, 32, 322, 324, 325):
+    for mode in (64, 32, 322, 324, 325, 644):
         y = ops.mlp_forward(pk_e, src_e, rows, tile_mode=mode)
         torch.testing.assert_close(y.cpu(), ref_e, rtol=2e-4, atol=2e-4, msg=lambda m: f"edge mode {mode}: {m}")
         y = ops.mlp_forward(pk_v, src_v, n, _lib.ACT_SELU, tile_mode=mode)
         torch.testing.assert_close(y.cpu(), torch.selu(ref_v), rtol=2e-4, atol=2e-4, msg=lambda m: f"node mode {mode}: {m}")
+
+
+@pytest.mark.parametrize("rows", [33, 5000, 40000])
+def test_mlp_heads(rows):
+    """g4c_mlp_forward_heads: the node MLP launch also emits W1[:, H:2H] y and W1[:, 2H:] y of the next edge MLP
+    (both 4-wave split variants: 325 below 16384 rows, 324 above) == separate products of the stored output."""
+    H = 128
+    torch.manual_seed(rows)
+    blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
+    nxt = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
+    agg, v = torch.randn(rows, H, device=DEV), torch.randn(rows, H, device=DEV)
+    res = blk.node_mlp.run_with_heads([ops.Source(agg), ops.Source(v)], rows, _lib.ACT_SELU, nxt.edge_mlp, H, [H, H])
+    assert res is not None
+    y, (pr, pc) = res
+    wn = {f"m.{k}": t.cpu() for k, t in blk.node_mlp.state_dict().items()}
+    ref = torch.selu(O.mlp(torch.cat([agg, v], 1).cpu(), wn, "m"))
+    torch.testing.assert_close(y.cpu(), ref, rtol=2e-4, atol=2e-4)
+    W1 = nxt.edge_mlp.state_dict()["MLP.linear_1.weight"].cpu().double()
+    torch.testing.assert_close(pr.cpu(), (y.cpu().double() @ W1[:, H:2 * H].T).float(), rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(pc.cpu(), (y.cpu().double() @ W1[:, 2 * H:].T).float(), rtol=2e-4, atol=2e-4)
+    # a launch that cannot carry heads says so instead of computing something else
+    assert blk.node_mlp.run_with_heads([ops.Source(agg), ops.Source(v)], rows, _lib.ACT_SELU, nxt.edge_mlp, H, [H, H, H]) is None
+
+
+def test_mp_chain_with_and_without_heads(monkeypatch):
+    """Two chained GNBlocks: products riding on the producer's launch == the consumer computing them itself."""
+    H, n, k = 128, 3000, 6
+    g = S.mus_graph(n, levels=1, seed=2).to(DEV)
+    torch.manual_seed(3)
+    b1 = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
+    b2 = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
+    v, e = torch.randn(n, H, device=DEV), torch.randn(g.edge_index.size(1), H, device=DEV)
+    monkeypatch.setattr(B, "HOIST_MIN_ROWS", 0)
+    v1, e1, prod = b1.step(v, e, g.edge_index, _lib.ACT_SELU, next_msg=b2.edge_mlp)
+    assert prod is not None and len(prod) == 2
+    v2, e2 = b2.step(v1, e1, g.edge_index, _lib.ACT_SELU, e_pre_act=_lib.ACT_SELU, products=prod)
+    u1, f1 = b1.step(v, e, g.edge_index, _lib.ACT_SELU)
+    u2, f2 = b2.step(u1, f1, g.edge_index, _lib.ACT_SELU, e_pre_act=_lib.ACT_SELU)
+    torch.testing.assert_close(v1, u1, rtol=0, atol=0)
+    torch.testing.assert_close(v2, u2, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(e2, f2, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("tag", ["h128_mean", "h32_sum", "h32_mean", "irregular"])
