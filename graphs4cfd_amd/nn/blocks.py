@@ -395,13 +395,14 @@ class UpMP(nn.Module):
             if hasattr(item, 'reset_parameters'):
                 item.reset_parameters()
 
-    def unpool(self, graph: Graph, field_lr: Tensor, field_hr_old: Tensor, activation=None) -> Tensor:
+    def sources(self, graph: Graph, field_lr: Tensor, field_hr_old: Tensor) -> List[Source]:
+        """Input blocks of up_mlp: [-e_hl | field_l[parent] | field_hr_old]; the sign flip is folded into the packed weights."""
         h, l = self.hr_graph_idx, self.lr_graph_idx
         parent = plan.index32(getattr(graph, f'idx{h}_to_idx{l}'))
-        rel = getattr(graph, f'e_{h}{l}')
-        # [-e_hl | field_l[parent] | field_hr_old]; the sign flip is folded into the packed weights
-        return self.up_mlp.run([Source(rel, negate=True), Source(field_lr, parent), Source(field_hr_old)],
-                               int(field_hr_old.size(0)), activation=activation)
+        return [Source(getattr(graph, f'e_{h}{l}'), negate=True), Source(field_lr, parent), Source(field_hr_old)]
+
+    def unpool(self, graph: Graph, field_lr: Tensor, field_hr_old: Tensor, activation=None) -> Tensor:
+        return self.up_mlp.run(self.sources(graph, field_lr, field_hr_old), int(field_hr_old.size(0)), activation=activation)
 
     def forward(self, graph: Graph, field_hr_old: Tensor, pos_hr: Tensor, activation: Optional[Callable] = None) -> Graph:
         graph.field = self.unpool(graph, graph.field, field_hr_old, activation)

@@ -24,6 +24,7 @@ import torch
 from .. import _lib
 from ..graph import Graph
 from ..ops import Source
+from . import blocks as _blocks
 from .blocks import MLP, MP, DownMP, UpMP
 from .model import GNN
 
@@ -54,16 +55,29 @@ class _MuSGNN(GNN):
         self.node_decoder = MLP(*arch["decoder"])
         self.to(self.device)
 
+    def _launch_for(self, mlp: MLP, sources, n_rows: int, act_code: int, k: int, n_edges: int):
+        """One launch of `mlp` whose output is the node input of program entry k.  When that entry is an MP layer
+        that will hoist its first layer, the launch also emits its node-side products (MLP.run_with_heads).
+        Returns (output, products or None)."""
+        nxt = self._PROGRAM[k] if k < len(self._PROGRAM) else ""
+        if nxt.startswith("mp") and n_edges >= _blocks.HOIST_MIN_ROWS:
+            cons = getattr(self, nxt).edge_mlp
+            w = mlp.output_size
+            res = mlp.run_with_heads(sources, n_rows, act_code, cons, cons.input_size - 2 * w, [w, w])
+            if res is not None:
+                return res
+        return mlp.run_coded(sources, n_rows, act_code), None
+
     def forward(self, graph: Graph, t: Optional[int] = None) -> torch.Tensor:
         field0 = graph.field
         n = int(field0.size(0))
         inputs = [Source(getattr(graph, k)) for k in ('field', 'loc', 'glob', 'omega') if hasattr(graph, k)]
         edge_index = graph.edge_index
         e = self.edge_encoder.run_coded([Source(graph.edge_attr)], int(graph.edge_attr.size(0)), SELU)
-        v = self.node_encoder.run_coded(inputs, n, SELU)
+        # `products`: first-layer node-side terms of the next MP layer, when the launch producing its `v` made them
+        v, products = self._launch_for(self.node_encoder, inputs, n, SELU, 0, int(edge_index.size(1)))
         e_pending = NONE          # activation not yet applied to `e` (deferred to its readers)
         stash = []
-        products = None           # first-layer node-side terms of the next MP layer, when its producer already made them
         prog = self._PROGRAM
         for k, name in enumerate(prog):
             block = getattr(self, name)
@@ -73,8 +87,8 @@ class _MuSGNN(GNN):
                 e_pending, products = NONE, None
             elif name.startswith("up_mp"):
                 v_old, edge_index, e, e_pending = stash.pop()
-                v = block.unpool(graph, v, v_old, torch.tanh)
-                products = None
+                v, products = self._launch_for(block.up_mlp, block.sources(graph, v, v_old), int(v_old.size(0)), TANH,
+                                               k + 1, int(edge_index.size(1)))
             else:
                 nxt = prog[k + 1] if k + 1 < len(prog) else ""
                 if nxt.startswith("mp"):      # next MP layer runs on the same graph: its node-side products ride along
