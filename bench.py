@@ -183,6 +183,8 @@ def main():
                    "partition": "none" if world == 1 else f"{world}-way node partition, halo exchange per MP layer (RCCL)"},
         "outputs_finite": finite,
     }
+    # BASELINE.json's second figure: average over the step's MP layers of all levels (pool / unpool / encoders included)
+    result["ms_per_mp_layer"] = result["ms_per_step"] / result["config"]["mp_layers_per_step"]
 
     if rank == 0 and world == 1 and not args.no_roofline:
         # eager instrumented pass of the same step: HIP-event pair around every launch, on the launch stream
@@ -241,6 +243,17 @@ def main():
         result["roofline_scatter"]["level1"] = {"bytes": bmax, "avg_launch_us": 1e6 * sum(t for _, t in sel) / len(sel),
                                                 "achieved": bmax * len(sel) / sum(t for _, t in sel) / 1e9,
                                                 "frac": bmax * len(sel) / sum(t for _, t in sel) / 1e9 / PEAK_HBM_GBS}
+        # one level-1 MP layer = the launch before / at / after each level-1 aggregation (edge MLP, segment mean, node MLP)
+        recs = [(k, f, b, a.elapsed_time(e) * 1e-3) for k, f, b, a, e in kt.records]
+        l1 = [recs[i - 1][3] + recs[i][3] + recs[i + 1][3] for i in range(1, len(recs) - 1)
+              if recs[i][0] == "segment_reduce" and recs[i][2] == bmax and recs[i - 1][0].startswith("mlp_") and recs[i + 1][0].startswith("mlp_")]
+        if l1:
+            result["ms_per_mp_layer_level1"] = 1e3 * sum(l1) / len(l1)
+        fmax = max(f for k, f, b, t in recs if k.startswith("mlp_"))
+        top = [t for k, f, b, t in recs if k.startswith("mlp_") and f == fmax]
+        result["roofline"]["largest_launch"] = {"what": "level-1 edge MLP (first layer hoisted)", "flop": fmax, "launches_per_step": len(top) // 3,
+                                                "avg_launch_us": 1e6 * sum(top) / len(top), "achieved": fmax * len(top) / sum(top) / 1e12,
+                                                "frac": fmax * len(top) / sum(top) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
         eager.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -427,9 +427,11 @@ class EdgeMP(nn.Module):
             if hasattr(item, 'reset_parameters'):
                 item.reset_parameters()
 
-    def step(self, e: Tensor, a: Tensor, angle_index: Tensor, act_code: int, a_pre_act: int = _lib.ACT_NONE):
-        """Internal form: returns (act(e'), raw a')."""
-        return _mp_step(self.angle_mlp, self.edge_mlp, e, a, angle_index, self.aggr, act_code, a_pre_act)
+    def step(self, e: Tensor, a: Tensor, angle_index: Tensor, act_code: int, a_pre_act: int = _lib.ACT_NONE,
+             products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None):
+        """Internal form: returns (act(e'), raw a') (+ the next EdgeMP's `products` when `next_msg` is given, see GNBlock.step)."""
+        return _mp_step(self.angle_mlp, self.edge_mlp, e, a, angle_index, self.aggr, act_code, a_pre_act,
+                        products=products, next_msg=next_msg)
 
     def forward(self, e: Tensor, a: Tensor, angle_index: Tensor, *, activation=None) -> Tuple[Tensor, Tensor]:
         return _public_mp(self.angle_mlp, self.edge_mlp, e, a, angle_index, self.aggr, activation)

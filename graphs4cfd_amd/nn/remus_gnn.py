@@ -83,16 +83,26 @@ class NsRotEquiTreeScaleGNN(GNN):
         a12 = self.angle_encoder12.run_coded([Source(g.angle_attr12)], int(g.angle_attr12.size(0)), SELU)
         a23 = self.angle_encoder23.run_coded([Source(g.angle_attr23)], int(g.angle_attr23.size(0)), SELU)
         a_pending = {1: NONE, 2: NONE, 3: NONE}
-        for op, name, lvl in self._PROGRAM:
+        products = {1: None, 2: None, 3: None}   # first-layer edge-side terms of the next EdgeMP of a level, if already made
+        prog = self._PROGRAM
+        for k, (op, name, lvl) in enumerate(prog):
             block = getattr(self, name)
             if op == "mp":
-                e[lvl], a[lvl] = block.step(e[lvl], a[lvl], aidx[lvl], SELU, a_pre_act=a_pending[lvl])
+                nxt = prog[k + 1] if k + 1 < len(prog) else None
+                if nxt is not None and nxt[0] == "mp" and nxt[2] == lvl:   # same level, consecutive: products ride along
+                    e[lvl], a[lvl], products[lvl] = block.step(e[lvl], a[lvl], aidx[lvl], SELU, a_pre_act=a_pending[lvl],
+                                                               products=products[lvl], next_msg=getattr(self, nxt[1]).angle_mlp)
+                else:
+                    e[lvl], a[lvl] = block.step(e[lvl], a[lvl], aidx[lvl], SELU, a_pre_act=a_pending[lvl], products=products[lvl])
+                    products[lvl] = None
                 a_pending[lvl] = SELU
             elif op == "down":
                 a_x, idx_x = (a12, g.angle_index12) if lvl == 1 else (a23, g.angle_index23)
                 e[lvl + 1] = block(e[lvl], e[lvl + 1], a_x, idx_x, activation="selu")
+                products[lvl + 1] = None
             else:
                 lo, hi = lvl, lvl - 1
+                products[hi] = None
                 e[hi] = block(g.pos, getattr(g, f"y_idx_{lo}{hi}"), getattr(g, f"x_idx_{lo}{hi}"),
                               getattr(g, f"weights_{lo}{hi}"), e[lo], getattr(g, f"edge_index{sfx[lo]}"),
                               getattr(g, f"edgeUnitVectorInverse{sfx[lo]}"), getattr(g, f"coarse_mask{sfx[lo]}"),
