@@ -11,5 +11,6 @@ eager-torch fallback.  Out of scope: training loop, datasets, pl
 """
 from .graph import Graph
 from . import nn, plan, ops, synthetic
+from .ops import mlp_precision, set_mlp_precision      # "fp32" (default) | "bf16" (opt-in bf16-MFMA MLPs)
 
 __version__ = "0.1.0"

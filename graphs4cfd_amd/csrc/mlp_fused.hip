@@ -1463,6 +1463,221 @@ __global__ void pack_layer_kernel(const float *__restrict__ W, int n_out, int k_
     packed[(long long)(kp >> 5) * CHUNK_FLOATS + (U >> 1) * 1024 + (n >> 5) * 256 + (((kp >> 1) & 1) * 32 + (n & 31)) * 4 + (U & 1) * 2 + (kp & 1)] = v;
 }
 
+// ======================================================================================================
+// bf16-MFMA variant (BASELINE config 3: "bf16 edge-MLP MFMA"; opt-in, g4c_mlp_forward_bf16).  Operands are rounded
+// to bf16 (weights at pack time, activations when they are staged in LDS), products accumulate in fp32
+// (v_mfma_f32_32x32x16_bf16: 16x the fp32 MFMA rate), bias / SELU / LayerNorm / the gathered additive terms stay fp32.
+// With the MFMA time gone (8 instructions per 128-k layer and wave) the kernel is bound by what surrounds it, so the
+// structure follows the small-launch kernel: a whole 128-k block per barrier.  Same 32-row tile, 4 waves, one
+// 32-column tile each.  Weight stream (bf16): per 128-k block [column tile][step (16 k)][lane][8 bf16]; every
+// weighted input block is padded to 128 k (pad MFMAs are free here).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int HB = 128 + 8;                 // LDS row stride of a bf16 block (272 B: conflict-free ds_read_b128)
+constexpr int BLOCK_BF16 = 128 * NP;        // bf16 elements of one 128-k block of the weight stream
+
+struct RingB { bf16x8 s[8]; };
+
+// one 128-k block: 8 MFMAs from the bf16 LDS rows at `pa`; slot s is refilled with step s of the NEXT block
+__device__ __forceinline__ void mma_block_bf16(const __bf16 *pa, RingB &g, const __bf16 *wnext, unsigned lo, f32x16 &acc) {
+    bf16x8 a = *reinterpret_cast<const bf16x8 *>(pa);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const bf16x8 an = *reinterpret_cast<const bf16x8 *>(pa + ((s + 1) & 7) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, g.s[s], acc, 0, 0, 0);
+        g.s[s] = *reinterpret_cast<const bf16x8 *>(wnext + s * 512 + lo);
+        __builtin_amdgcn_sched_barrier(0);
+        a = an;
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void mlp_bf16_kernel(const Params p) {
+    constexpr int ROWS = 32, NW = 4;
+    // fp32 final tile [32][132] (for the LayerNorm / store epilogue) aliases the two bf16 block buffers [2][32][136]
+    constexpr int BUF_FLOATS = (2 * ROWS * HB / 2 > ROWS * HS) ? 2 * ROWS * HB / 2 : ROWS * HS;
+    __shared__ __attribute__((aligned(16))) float lds[BUF_FLOATS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
+    float *sH = lds;
+    __bf16 *sB0 = reinterpret_cast<__bf16 *>(lds);
+    __bf16 *sB1 = sB0 + ROWS * HB;
+    int *sRow = reinterpret_cast<int *>(lds + BUF_FLOATS);
+    int *sRowAdd = sRow + G4C_MAX_SRC * ROWS;
+    float *sBias = lds + BUF_FLOATS + 2 * G4C_MAX_SRC * ROWS;
+    float *sGB = sBias + G4C_MAX_LAYERS * NP;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int ct0 = wave;
+
+    int tile;
+    {
+        const int b = blockIdx.x, nt = p.n_tiles;
+        const int q = nt >> 3, r = nt & 7, x = b & 7, j = b >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const long long row0 = p.row_base + (long long)tile * ROWS;
+
+    const __bf16 *w = reinterpret_cast<const __bf16 *>(p.w);
+    const unsigned lo = (unsigned)(ct0 * 4096 + lane * 8);
+    RingB ring;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) ring.s[s] = *reinterpret_cast<const bf16x8 *>(w + s * 512 + lo);
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int e = tid; e < 2 * G4C_MAX_SRC * ROWS; e += 64 * NW) {
+        const int slot = e / ROWS, r = e % ROWS;
+        long long gr = row0 + r;
+        if (gr >= p.M) gr = p.M - 1;
+        const int *ix = nullptr;
+        bool used;
+        if (slot < G4C_MAX_SRC) { used = slot < p.n_src; if (used) ix = p.src[slot].idx; }
+        else { used = slot - G4C_MAX_SRC < p.n_add; if (used) ix = p.add[slot - G4C_MAX_SRC].idx; }
+        if (used) sRow[e] = ix ? ix[gr] : (int)gr;
+    }
+    for (int e = tid; e < p.n_layers * NP; e += 64 * NW) sBias[e] = p.b[e];
+    if (p.gamma) {
+        for (int e = tid; e < NP; e += 64 * NW) {
+            const int ee = e < p.n_out ? e : 0;
+            sGB[e] = p.gamma[ee];
+            sGB[NP + e] = p.beta[ee];
+        }
+    }
+    __syncthreads();
+
+    // this wave's 8 rows of an input block: lane -> row (lane>>3) + 8*wave, 4 floats at column 4*(lane&7) of each 32-k chunk
+    const int grow_l = (lane >> 3) + 8 * wave, c4 = (lane & 7) * 4;
+    f32x4 xp[4];
+    auto gather = [&](int sidx) {
+        const int width = p.src[sidx].width;
+        const float *rp = p.src[sidx].ptr + (long long)sRow[sidx * ROWS + grow_l] * p.src[sidx].ld + p.src[sidx].col0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = q * KC + c4;
+            if (VEC) {
+                xp[q] = *reinterpret_cast<const f32x4 *>(rp + (c < width ? c : 0));
+            } else {
+                const int w1 = width - 1;
+                xp[q][0] = rp[c + 0 < w1 ? c + 0 : w1]; xp[q][1] = rp[c + 1 < w1 ? c + 1 : w1];
+                xp[q][2] = rp[c + 2 < w1 ? c + 2 : w1]; xp[q][3] = rp[c + 3 < w1 ? c + 3 : w1];
+            }
+        }
+    };
+    auto park = [&](__bf16 *dst, int sidx) {
+        const int width = p.src[sidx].width, act = p.src[sidx].pre_act;
+        __bf16 *d = dst + grow_l * HB + c4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = q * KC + c4;
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = (c + e < width) ? xp[q][e] : 0.f;
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = g4c::selu_f(t[e]);
+            }
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (__bf16)t[e];
+            *reinterpret_cast<bf16x4 *>(d + q * KC) = v;
+        }
+    };
+    gather(0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int a = 0; a < p.n_add; ++a) {
+        float t[16];
+        const int col = ct0 * 32 + i;
+        const bool ok = col < p.add[a].width;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
+            t[q] = p.add[a].ptr[(long long)sRowAdd[a * ROWS + row] * p.add[a].ld + (ok ? col : 0)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] += ok ? t[q] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    park(sB0, 0);
+    __syncthreads();
+
+    // ---------------------------------------------------------------- layer 0: one barrier per (padded) 128-k input block
+    const __bf16 *pa0 = sB0 + i * HB + 8 * h, *pa1 = sB1 + i * HB + 8 * h;
+    for (int s = 0; s < p.n_src; ++s) {
+        const bool more = s + 1 < p.n_src;
+        if (more) gather(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        w += BLOCK_BF16;
+        mma_block_bf16((s & 1) ? pa1 : pa0, ring, w, lo, acc);
+        if (more) park((s & 1) ? sB0 : sB1, s + 1);
+        __syncthreads();
+    }
+    // hidden layers ping-pong between the two bf16 buffers, starting with the one layer 0 did not read last
+    int cur = (p.n_src & 1) ? 1 : 0;       // buffer to WRITE next
+    for (int l = 0;; ++l) {
+        const bool last = (l == p.n_layers - 1);
+        const float bv = sBias[l * NP + ct0 * 32 + i];
+        if (last) {
+            // the final tile goes out in fp32 (LayerNorm / store epilogue); sH aliases both bf16 buffers, and every wave
+            // finished reading them at the barrier that ended the previous block
+            float *base = sH + (4 * h) * HS + ct0 * 32 + i;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) base[((q & 3) + 8 * (q >> 2)) * HS] = acc[q] + bv;
+            __syncthreads();
+            break;
+        }
+        {
+            __bf16 *base = (cur ? sB1 : sB0) + (4 * h) * HB + ct0 * 32 + i;
+#pragma unroll
+            for (int q0 = 0; q0 < 16; q0 += 4) {
+                float x[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[q] = g4c::selu_f(acc[q0 + q] + bv);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) base[(q + 2 * q0) * HB] = (__bf16)x[q];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        w += BLOCK_BF16;
+        mma_block_bf16(cur ? pa1 : pa0, ring, w, lo, acc);
+        cur ^= 1;
+        // no barrier needed before the next hidden store: it writes the OTHER buffer ... but the final fp32 tile and the
+        // buffer after next alias what is being read here, so close the block
+        __syncthreads();
+    }
+    split_finish<NW>(p, sH, sGB, wave, lane, row0);
+}
+
+// bf16 image of one layer: W[n_out, k_in] -> [block = 128 k][ct = n/32][step = (k%128)/16][lane = ((k%16)/8)*32 + n%32][e = k%8]
+__global__ void pack_layer_bf16_kernel(const float *__restrict__ W, int n_out, int k_in, PackSegs segs,
+                                       __bf16 *__restrict__ packed, int k_pad) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= k_pad * NP) return;
+    const int kp = gid / NP, n = gid % NP;
+    int k = -1, base_p = 0, base = 0, neg = 0;
+    for (int s = 0; s < segs.n_seg; ++s) {
+        if (kp >= base_p && kp < base_p + segs.wpad[s]) {
+            const int j = kp - base_p;
+            if (j < segs.width[s]) { k = base + j; neg = segs.neg[s]; }
+        }
+        base_p += segs.wpad[s];
+        base += segs.width[s];
+    }
+    float v = 0.f;
+    if (k >= 0 && n < n_out) v = W[(long long)n * k_in + k];
+    if (neg) v = -v;
+    const int kk = kp & 127;
+    packed[(long long)(kp >> 7) * BLOCK_BF16 + (n >> 5) * 4096 + (kk >> 4) * 512 + (((kk >> 3) & 1) * 32 + (n & 31)) * 8 + (kk & 7)] = (__bf16)v;
+}
+
 }  // namespace
 
 extern "C" int g4c_mlp_pack_layer(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
@@ -1488,6 +1703,29 @@ extern "C" int g4c_mlp_pack_layer(const float *W, int32_t n_out, int32_t k_in, c
     const int total = k_pad * NP;
     pack_layer_kernel<<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(W, n_out, k_in, segs, packed, k_pad);
     return g4c::check_launch("g4c_mlp_pack_layer");
+}
+
+extern "C" int g4c_mlp_pack_layer_bf16(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
+                                       const int32_t *seg_negate, int32_t n_seg, void *packed,
+                                       int32_t k_pad, int32_t n_pad, void *stream) {
+    G4C_REQUIRE(W && packed && seg_width, G4C_EINVAL, "g4c_mlp_pack_layer_bf16: null pointer");
+    G4C_REQUIRE(n_seg >= 1 && n_seg <= G4C_MAX_SRC, G4C_EUNSUPPORTED, "g4c_mlp_pack_layer_bf16: %d input blocks (max %d)", n_seg, G4C_MAX_SRC);
+    G4C_REQUIRE(n_out >= 1 && n_out <= NP, G4C_EUNSUPPORTED, "g4c_mlp_pack_layer_bf16: layer width %d unsupported (max 128)", n_out);
+    G4C_REQUIRE(n_pad == NP && k_pad == NP * n_seg, G4C_EINVAL, "g4c_mlp_pack_layer_bf16: n_pad must be 128 and k_pad 128 per input block (got %d, %d)", n_pad, k_pad);
+    PackSegs segs;
+    segs.n_seg = n_seg;
+    int ksum = 0;
+    for (int s = 0; s < n_seg; ++s) {
+        G4C_REQUIRE(seg_width[s] > 0 && seg_width[s] <= NP, G4C_EUNSUPPORTED, "g4c_mlp_pack_layer_bf16: input block %d is %d wide (1..128)", s, seg_width[s]);
+        segs.width[s] = seg_width[s];
+        segs.wpad[s] = NP;
+        segs.neg[s] = seg_negate ? seg_negate[s] : 0;
+        ksum += segs.width[s];
+    }
+    G4C_REQUIRE(ksum == k_in, G4C_EINVAL, "g4c_mlp_pack_layer_bf16: blocks sum to %d columns, weight has %d", ksum, k_in);
+    const int total = k_pad * NP;
+    pack_layer_bf16_kernel<<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(W, n_out, k_in, segs, (__bf16 *)packed, k_pad);
+    return g4c::check_launch("g4c_mlp_pack_layer_bf16");
 }
 
 extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
@@ -1579,11 +1817,20 @@ extern "C" int g4c_mlp_forward_heads(const g4c_mlp_t *mlp, const g4c_src_t *srcs
                       head_w, n_heads, head_out, head_ld, stream);
 }
 
+extern "C" int g4c_mlp_forward_bf16(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                                    float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
+                                    const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream) {
+    return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3216, out, out_ld, out_idx, act, resid, resid_ld, resid_col0,
+                      nullptr, 0, nullptr, 0, stream);
+}
+
 static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                       int64_t row_begin, int64_t row_count, int32_t tile_rows,
                       float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                       const float *resid, int32_t resid_ld, int32_t resid_col0,
                       const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream) {
+    const bool bf16 = (tile_rows == 3216);      // weights: the bf16 stream of g4c_mlp_pack_layer_bf16, input blocks padded to 128 k
+    if (bf16) tile_rows = 324;
     G4C_REQUIRE(tile_rows == 64 || tile_rows == 32 || tile_rows == 322 || tile_rows == 324 || tile_rows == 325 || tile_rows == 644, G4C_EINVAL,
                 "g4c_mlp_forward_rows: tile_rows must be 64, 32, 322 (32 rows / 2 waves), 324 (32 rows / 4 waves) or 325 (324, small-launch variant)");
     G4C_REQUIRE(row_begin >= 0 && row_count >= 0 && row_begin + row_count <= n_rows && row_begin % 32 == 0 && (tile_rows != 644 || row_begin % 64 == 0), G4C_EINVAL,
@@ -1614,7 +1861,8 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         G4C_REQUIRE(g.pre_act == G4C_ACT_NONE || g.pre_act == G4C_ACT_SELU, G4C_EUNSUPPORTED,
                     "g4c_mlp_forward: source %d pre_act %d (only NONE / SELU can be applied on load)", s, g.pre_act);
         Src &d = p.src[nk++];
-        d.ptr = g.ptr; d.idx = g.idx; d.width = g.width; d.wpad = (g.width + KC - 1) / KC * KC; d.ld = g.ld; d.col0 = g.col0;
+        if (bf16) G4C_REQUIRE(g.width <= NP, G4C_EUNSUPPORTED, "g4c_mlp_forward_bf16: input block %d is %d wide (max 128)", s, g.width);
+        d.ptr = g.ptr; d.idx = g.idx; d.width = g.width; d.wpad = bf16 ? NP : (g.width + KC - 1) / KC * KC; d.ld = g.ld; d.col0 = g.col0;
         d.pre_act = g.pre_act;
         d.vec = (g.width % 4 == 0) && (g.ld % 4 == 0) && (g.col0 % 4 == 0) && ((uintptr_t)g.ptr % 16 == 0);
         all_vec = all_vec && d.vec;
@@ -1632,7 +1880,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         G4C_REQUIRE(mlp->n_pad[l] == NP, G4C_EINVAL, "g4c_mlp_forward: layer %d n_pad %d (must be 128)", l, mlp->n_pad[l]);
         if (l > 0) G4C_REQUIRE(mlp->k_pad[l] == NP, G4C_EINVAL, "g4c_mlp_forward: layer %d k_pad %d (must be 128)", l, mlp->k_pad[l]);
         // one contiguous stream: layer l starts where layer l-1 ends
-        if (l > 0) G4C_REQUIRE((const float *)mlp->w[l] == (const float *)mlp->w[l - 1] + (size_t)mlp->k_pad[l - 1] * NP, G4C_EINVAL,
+        if (l > 0) G4C_REQUIRE((const char *)mlp->w[l] == (const char *)mlp->w[l - 1] + (size_t)mlp->k_pad[l - 1] * NP * (bf16 ? 2 : 4), G4C_EINVAL,
                                "g4c_mlp_forward: packed layers must be contiguous (layer %d)", l);
         if (l > 0) G4C_REQUIRE((const float *)mlp->b[l] == (const float *)mlp->b[l - 1] + NP, G4C_EINVAL,
                                "g4c_mlp_forward: padded biases must be contiguous (layer %d)", l);
@@ -1650,6 +1898,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     p.n_heads = n_heads; p.head_ld = head_ld;
     for (int hd = 0; hd < G4C_MAX_HEADS; ++hd) p.head_out[hd] = hd < n_heads ? head_out[hd] : nullptr;
     if (n_heads) {
+        G4C_REQUIRE(!bf16, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads: no bf16 variant");
         G4C_REQUIRE(tile_rows == 324 || tile_rows == 325, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads: tile mode %d has no heads", tile_rows);
         G4C_REQUIRE(p.n_out == NP && !resid && !out_idx && head_ld >= NP, G4C_EINVAL,
                     "g4c_mlp_forward_heads: heads need a 128-wide output without residual / output index (n_out=%d)", p.n_out);
@@ -1674,6 +1923,10 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         p.n_tiles = (int)((row_count + 31) / 32);
         if (all_vec) mlp_split_kernel<2, true><<<dim3(p.n_tiles), dim3(128), 0, st>>>(p);
         else mlp_split_kernel<2, false><<<dim3(p.n_tiles), dim3(128), 0, st>>>(p);
+    } else if (bf16) {
+        p.n_tiles = (int)((row_count + 31) / 32);
+        if (all_vec) mlp_bf16_kernel<true><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
+        else mlp_bf16_kernel<false><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
     } else if (tile_rows == 644) {
         p.n_tiles = (int)((row_count + 63) / 64);
         if (all_vec) mlp_split64_kernel<true><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);

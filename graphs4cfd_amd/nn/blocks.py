@@ -72,7 +72,8 @@ class MLP(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def packed(self, seg_widths: Sequence[int], seg_negate: Sequence[bool]) -> ops.PackedMLP:
-        key = (tuple(seg_widths), tuple(bool(x) for x in seg_negate))
+        prec = ops.mlp_precision()
+        key = (tuple(seg_widths), tuple(bool(x) for x in seg_negate), prec)
         sig = self._signature()
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
@@ -81,7 +82,7 @@ class MLP(nn.Module):
             lin = self._linears()
             ln = getattr(self.MLP, "layer_norm", None)
             pk = ops.PackedMLP([l.weight for l in lin], [l.bias for l in lin],
-                               None if ln is None else (ln.weight, ln.bias, ln.eps), key[0], key[1])
+                               None if ln is None else (ln.weight, ln.bias, ln.eps), key[0], key[1], precision=prec)
             self._packed[key] = (sig, pk)
             hit = self._packed[key]
         return hit[1]
@@ -108,6 +109,8 @@ class MLP(nn.Module):
         Returns None when the launch cannot carry heads (shape envelope / kernel variant): the caller then lets the
         consumer compute its products itself."""
         if self.output_size != 128 or any(int(w) != 128 for w in widths) or not 1 <= len(widths) <= _lib.MAX_HEADS:
+            return None
+        if ops.mlp_precision() != "fp32":
             return None
         key = ("heads", id(consumer), k_cols, tuple(widths), tuple(s.width for s in sources), tuple(s.negate for s in sources))
         sig = (self._signature(), consumer._signature())
@@ -139,18 +142,19 @@ class MLP(nn.Module):
     # -- first-layer hoisting ------------------------------------------------------------------
     def _packed_cols(self, tag: str, a: int, b: int, seg_widths, seg_negate, first_only: bool) -> ops.PackedMLP:
         """Packed variant using only columns [a, b) of the first Linear layer (`first_only`: that layer alone, no bias)."""
-        key = (tag, a, b, tuple(seg_widths), tuple(bool(x) for x in seg_negate))
+        prec = ops.mlp_precision()
+        key = (tag, a, b, tuple(seg_widths), tuple(bool(x) for x in seg_negate), prec)
         sig = self._signature()
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
             lin = self._linears()
             w1 = lin[0].weight.detach()[:, a:b].contiguous()
             if first_only:
-                pk = ops.PackedMLP([w1], [None], None, key[3], key[4])
+                pk = ops.PackedMLP([w1], [None], None, key[3], key[4], precision=prec)
             else:
                 ln = getattr(self.MLP, "layer_norm", None)
                 pk = ops.PackedMLP([w1] + [l.weight for l in lin[1:]], [l.bias for l in lin],
-                                   None if ln is None else (ln.weight, ln.bias, ln.eps), key[3], key[4])
+                                   None if ln is None else (ln.weight, ln.bias, ln.eps), key[3], key[4], precision=prec)
             self._packed[key] = (sig, pk)
             hit = self._packed[key]
         return hit[1]
@@ -163,7 +167,7 @@ class MLP(nn.Module):
         Below HOIST_MIN_ROWS the launch is latency-bound and the extra product launches cost more than the MFMA
         work they save (measured crossover ~25k rows, scripts/sweep_tile_modes.py): one plain fused launch then.
         `products` (from the producer's launch, MLP.run_with_heads): the per-node terms, already multiplied."""
-        if n_rows < HOIST_MIN_ROWS and products is None:
+        if (n_rows < HOIST_MIN_ROWS or ops.mlp_precision() != "fp32") and products is None:   # (bf16 MFMAs are ~free: never hoist)
             return self.run_coded(list(k_sources) + [Source(t, index=idx) for t, idx in gathered], n_rows, act_code, **kw)
         kw_widths = [s.width for s in k_sources]
         off = sum(kw_widths)

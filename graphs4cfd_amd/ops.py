@@ -4,6 +4,7 @@ Nothing here computes on the host or with torch ops."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -181,14 +182,38 @@ def rollout_advance(field: Tensor, pred: Tensor, outputs: Tensor, step: Tensor, 
                                        int(outputs.size(1)), _lib.ptr(step), int(field.size(0)), _lib.stream_handle(dev)))
 
 
+# Arithmetic of the fused MLPs: "fp32" (exact fp32 MFMA, the default and the parity path) or "bf16" (operands rounded to
+# bf16, fp32 accumulation, fp32 bias / SELU / LayerNorm: BASELINE config 3's "bf16 edge-MLP MFMA"; g4c_mlp_forward_bf16).
+_PRECISION = os.environ.get("G4C_MLP_PRECISION", "fp32")
+
+
+def mlp_precision() -> str:
+    return _PRECISION
+
+
+def set_mlp_precision(precision: str) -> str:
+    """Select the arithmetic of every fused MLP launched from now on; returns the previous setting."""
+    global _PRECISION
+    if precision not in ("fp32", "bf16"):
+        raise ValueError(f"unknown MLP precision {precision!r} (fp32 | bf16)")
+    old, _PRECISION = _PRECISION, precision
+    return old
+
+
 class PackedMLP:
     """Device-side packed weights of one MLP for a given input block structure."""
 
     def __init__(self, weights: Sequence[Tensor], biases: Sequence[Tensor], ln: Optional[Tuple[Tensor, Tensor, float]],
-                 seg_widths: Sequence[int], seg_negate: Sequence[bool], heads: Sequence[Tensor] = ()):
+                 seg_widths: Sequence[int], seg_negate: Sequence[bool], heads: Sequence[Tensor] = (),
+                 precision: str = "fp32"):
         """`heads`: bias-free [128, 128] weights applied to the MLP's final output row (g4c_mlp_forward_heads); their
-        packed images continue the weight stream after the last layer."""
+        packed images continue the weight stream after the last layer.  `precision` "bf16": the bf16 stream of
+        g4c_mlp_pack_layer_bf16 (every input block padded to 128 k), consumed by g4c_mlp_forward_bf16."""
         lib = _lib.load()
+        self.precision = precision
+        bf16 = precision == "bf16"
+        if bf16 and heads:
+            raise NotImplementedError("heads in bf16")
         dev = _lib.require_hip(*weights, *[b for b in biases if b is not None], *heads)
         n_layers = len(weights)
         if not 1 <= n_layers <= _lib.MAX_LAYERS:
@@ -200,7 +225,9 @@ class PackedMLP:
         self._keep: List[Tensor] = []
         stream = _lib.stream_handle(dev)
         KC, NP = 32, 128                       # kernel constants: K chunk, computed layer width
-        k_pad0 = sum((s + KC - 1) // KC * KC for s in seg_widths)
+        if bf16 and any(s > NP for s in seg_widths):
+            raise NotImplementedError("bf16 MLP with an input block wider than 128")
+        k_pad0 = NP * len(seg_widths) if bf16 else sum((s + KC - 1) // KC * KC for s in seg_widths)
         k_pads = [k_pad0] + [NP] * (n_layers - 1)
         # one contiguous weight stream (layer after layer, 32-k chunk after chunk) + one chunk of slack:
         # the kernel's register ring prefetches one chunk past the end
@@ -208,7 +235,11 @@ class PackedMLP:
             raise NotImplementedError(f"heads must be at most {_lib.MAX_HEADS} weights of shape [128, 128]")
         if heads and int(weights[-1].size(0)) != NP:
             raise NotImplementedError("heads need a 128-wide MLP output")
-        stream_buf = torch.zeros((sum(k_pads) + NP * len(heads) + KC) * NP, dtype=torch.float32, device=dev)
+        # (bf16: 2-byte elements, one 128-k block of slack)
+        stream_buf = torch.zeros((sum(k_pads) + NP * len(heads) + (NP if bf16 else KC)) * NP,
+                                 dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+        esz = 2 if bf16 else 4
+        pack = lib.g4c_mlp_pack_layer_bf16 if bf16 else lib.g4c_mlp_pack_layer
         bias_buf = torch.zeros(n_layers * NP, dtype=torch.float32, device=dev)
         self._keep += [stream_buf, bias_buf]
         off = 0
@@ -226,9 +257,8 @@ class PackedMLP:
             Wc = W.detach().to(torch.float32).contiguous()
             seg_arr = (C.c_int32 * len(segs))(*segs)
             neg_arr = (C.c_int32 * len(segs))(*negs)
-            wptr = stream_buf.data_ptr() + 4 * off
-            _lib.check(lib.g4c_mlp_pack_layer(_lib.ptr(Wc), n_out, k_in, seg_arr, neg_arr, len(segs), wptr,
-                                              k_pads[l], NP, stream))
+            wptr = stream_buf.data_ptr() + esz * off
+            _lib.check(pack(_lib.ptr(Wc), n_out, k_in, seg_arr, neg_arr, len(segs), wptr, k_pads[l], NP, stream))
             if b is not None:
                 bias_buf[l * NP: l * NP + n_out].copy_(b.detach())
             self.desc.k_pad[l], self.desc.n_pad[l] = k_pads[l], NP
@@ -292,7 +322,15 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
         out = torch.empty((n_rows, packed.n_out), dtype=torch.float32, device=dev)
     args = (_lib.ptr(out), _ld(out), _lib.ptr(out_idx32), act, _lib.ptr(resid), _ld(resid) if resid is not None else 0,
             resid_col0, _lib.stream_handle(dev))
-    if head_outs is not None:
+    if packed.precision == "bf16":
+        if head_outs is not None or tile_mode is not None:
+            raise NotImplementedError("bf16 MLP with heads / a forced tile mode")
+        call = lambda: _lib.check(lib.g4c_mlp_forward_bf16(C.byref(packed.desc), arr, len(sources), n_rows, *args))
+        if KernelTimer.active is None:
+            call()
+        else:
+            _timed("mlp_bf16_kernel", packed.flops_per_row * n_rows, 4.0 * (sum(packed.seg_widths) + packed.n_out) * n_rows, call)
+    elif head_outs is not None:
         if len(head_outs) != packed.n_heads or packed.n_heads == 0:
             raise ValueError(f"{len(head_outs)} head outputs for a packing with {packed.n_heads} heads")
         if out_idx32 is not None or resid is not None or tile_mode is not None:

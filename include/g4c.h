@@ -155,6 +155,18 @@ int g4c_mlp_forward_heads(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /
                           const float *head_w, int32_t n_heads, float *const *head_out /*host*/, int32_t head_ld,
                           void *stream);
 
+/* bf16-MFMA variant (opt-in; BASELINE config 3 "bf16 edge-MLP MFMA"): weights and the activations entering each Linear
+ * are rounded to bf16, products accumulate in fp32 (v_mfma_f32_32x32x16_bf16), bias / SELU / LayerNorm / additive
+ * sources / residual stay fp32.  g4c_mlp_pack_layer_bf16 writes the 2-byte weight stream (every input block padded
+ * to 128 k: k_pad = 128 * n_seg; one 128-k block of slack after the last layer); g4c_mlp_forward_bf16 takes a
+ * g4c_mlp_t whose w[] point into that stream.  Expected deviation from the fp32 path: ~1e-2 on LayerNorm-scale outputs. */
+int g4c_mlp_pack_layer_bf16(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width /*host*/,
+                            const int32_t *seg_negate /*host*/, int32_t n_seg, void *packed,
+                            int32_t k_pad, int32_t n_pad, void *stream);
+int g4c_mlp_forward_bf16(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
+                         int64_t n_rows, float *out, int32_t out_ld, const int32_t *out_idx,
+                         int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
+
 /* ---------------------------------------------------------------- REMuS helpers (HBM-bound)
  * out[e, f] = v[node[e], 2f]*U[e,0] + v[node[e], 2f+1]*U[e,1]
  * (nn/remus_gnn.py:124-126, nn/blocks.py:454). node == NULL reads row e. */

@@ -121,6 +121,55 @@ def test_mlp_kernel_variants_agree(rows):
         torch.testing.assert_close(y.cpu(), torch.selu(ref_v), rtol=2e-4, atol=2e-4, msg=lambda m: f"node mode {mode}: {m}")
 
 
+@pytest.mark.parametrize("rows", [1, 200, 40000])
+def test_mlp_bf16_variant(rows):
+    """Opt-in bf16-MFMA MLPs (BASELINE config 3): against the SAME computation with operands rounded to bf16 where
+    the kernel rounds them (tight), and against the fp32 oracle at the stated bf16 tolerance (1e-2 scale)."""
+    H, n = 128, max(rows // 6, 1)
+    torch.manual_seed(rows + 7)
+    blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H + 3, (H, H, H), True)).to(DEV)
+    e, v = torch.randn(rows, H, device=DEV), torch.randn(n, H, device=DEV)
+    row = torch.randint(0, n, (rows,), device=DEV, dtype=torch.int32)
+    col = torch.randint(0, n, (rows,), device=DEV, dtype=torch.int32)
+    x3 = torch.randn(rows, 3, device=DEV)
+
+    def emulate(mlp, x, first_exact_cols=0):       # bf16-rounded operands, fp32 accumulation (fp64 here), fp32 epilogue
+        lin = mlp._linears()
+        r = lambda t: t.to(torch.bfloat16).double()
+        y = x.double()
+        for li, l in enumerate(lin):
+            y = r(y.float()) @ r(l.weight.detach()).T + l.bias.detach().double()
+            if li < len(lin) - 1:
+                y = torch.selu(y)
+        ln = getattr(mlp.MLP, "layer_norm", None)
+        if ln is not None:
+            y = torch.nn.functional.layer_norm(y.float(), (y.size(-1),), ln.weight, ln.bias, ln.eps).double()
+        return y.float()
+
+    def close_bf16(got, want):
+        # an activation that lands on a bf16 rounding tie may round the other way in the kernel's fp32 epilogue than in
+        # this fp64 emulation: isolated elements move by one bf16 ulp of an operand, everything else agrees to fp32 noise
+        d = (got - want).abs()
+        assert d.mean().item() < 2e-4 and d.max().item() < 2e-2, (d.mean().item(), d.max().item())
+
+    old = ops.set_mlp_precision("bf16")
+    try:
+        # edge MLP, plain 3-block form with SELU-on-load and gathers
+        y = blk.edge_mlp.run_coded([ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(v, index=row), ops.Source(v, index=col)], rows)
+        xin = torch.cat([torch.selu(e), v[row.long()], v[col.long()]], 1)
+        close_bf16(y, emulate(blk.edge_mlp, xin))
+        # node-like MLP with a narrow, unaligned third block and a fused activation
+        y2 = blk.node_mlp.run_coded([ops.Source(e), ops.Source(e), ops.Source(x3)], rows, _lib.ACT_TANH)
+        close_bf16(y2, torch.tanh(emulate(blk.node_mlp, torch.cat([e, e, x3], 1))))
+    finally:
+        ops.set_mlp_precision(old)
+    w = {f"m.{k}": t.cpu() for k, t in blk.edge_mlp.state_dict().items()}
+    ref = O.mlp(xin.cpu(), w, "m")
+    err = (y.cpu() - ref).abs().max().item()
+    assert err < 6e-2, err                          # LayerNorm-scale outputs, three bf16 GEMMs deep
+    assert (y.cpu() - ref).abs().mean().item() < 6e-3
+
+
 @pytest.mark.parametrize("rows", [33, 5000, 40000])
 def test_mlp_heads(rows):
     """g4c_mlp_forward_heads: the node MLP launch also emits W1[:, H:2H] y and W1[:, 2H:] y of the next edge MLP
