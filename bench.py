@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--nodes", type=int, default=100_000)
     ap.add_argument("--model", default="NsThreeScaleGNN")
     ap.add_argument("--hidden", type=int, default=128)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="arithmetic of the fused MLPs: fp32 (default, the parity path and the headline number) or the opt-in bf16-MFMA variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=30.0)
@@ -124,6 +126,9 @@ def main():
     import graphs4cfd_amd as gfd
     from graphs4cfd_amd import ops, synthetic as S
     from graphs4cfd_amd.nn.model import Rollout
+    ops.set_mlp_precision(args.precision)
+    if args.precision != "fp32":       # the MFMA roofline / PMC entries describe the fp32 kernels only
+        args.no_roofline = True
 
     # G4C_BENCH_SAME_GPU=1 (functional check on a single-GPU box only): every rank uses cuda:0 and the gloo transport
     same_gpu = os.environ.get("G4C_BENCH_SAME_GPU", "0") == "1"
@@ -175,7 +180,8 @@ def main():
     result = {
         "metric": "rollout timesteps/s (100k-node 2D mesh)", "value": args.steps / elapsed, "unit": "rollout timesteps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "fp32" else "bf16 MLP operands (fp32 accumulate, bias, SELU, LayerNorm, aggregation)", "data": "synthetic",
         "config": {"workload": f"{args.model} (published arch, H={args.hidden}) rollout on a {args.nodes}-node synthetic 2D mesh, "
                                f"kNN k=6, {levels} grid-clustered scale(s), hipGraph-replayed step",
                    "nodes": args.nodes, "edges": int(graph_cpu.edge_index.size(1)), "mp_layers_per_step": sum(

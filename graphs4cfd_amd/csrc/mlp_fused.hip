@@ -1492,8 +1492,11 @@ __device__ __forceinline__ void mma_block_bf16(const __bf16 *pa, RingB &g, const
     }
 }
 
+#ifndef G4C_BF16_MINW
+#define G4C_BF16_MINW 4
+#endif
 template <bool VEC>
-__global__ __launch_bounds__(256) void mlp_bf16_kernel(const Params p) {
+__global__ __launch_bounds__(256, G4C_BF16_MINW) void mlp_bf16_kernel(const Params p) {
     constexpr int ROWS = 32, NW = 4;
     // fp32 final tile [32][132] (for the LayerNorm / store epilogue) aliases the two bf16 block buffers [2][32][136]
     constexpr int BUF_FLOATS = (2 * ROWS * HB / 2 > ROWS * HS) ? 2 * ROWS * HB / 2 : ROWS * HS;

@@ -9,6 +9,7 @@ from graphs4cfd_amd.nn import blocks as B
 
 ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--rows", type=int, default=600000)
 ap.add_argument("--rounds", type=int, default=15); ap.add_argument("--inner", type=int, default=3)
+ap.add_argument("--precision", default="fp32")
 ap.add_argument("--modes", default="", help="comma list of tile modes: each library is timed once per mode (default: the library's own policy)")
 a = ap.parse_args()
 _modes = [int(m) for m in a.modes.split(",")] if a.modes else [None]
@@ -24,6 +25,7 @@ def load(path):
 
 
 libs = [load(p) for p in a.libs]
+ops.set_mlp_precision(a.precision)
 dev = torch.device("cuda", 0); H = 128
 torch.manual_seed(0)
 _lib._lib = libs[0]
