@@ -1681,6 +1681,280 @@ __global__ void pack_layer_bf16_kernel(const float *__restrict__ W, int n_out, i
     packed[(long long)(kp >> 7) * BLOCK_BF16 + (n >> 5) * 4096 + (kk >> 4) * 512 + (((kk >> 3) & 1) * 32 + (n & 31)) * 8 + (kk & 7)] = (__bf16)v;
 }
 
+// ======================================================================================================
+// fp32-accurate MLP on the bf16 matrix pipe ("bf16x6", opt-in: g4c_mlp_forward_bx6).  Every fp32 operand is split
+// EXACTLY into three bf16 terms x = h + m + l (8 + 8 + 8 significand bits); of the nine partial products the six
+// largest are formed (hh, hm, mh, mm, hl, lh — each exact in fp32) and accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16.  The dropped terms (ml, lm, ll) are <= 2^-23 relative: the same order as ONE fp32 rounding,
+// so the result is as accurate as the fp32-MFMA kernel (tests compare both against fp64), at 6 x 32 = 192 MFMA cycles
+// per 16 k instead of 8 x 64 = 512.  Structure = mlp_bf16_kernel with three operand planes; weights are split at pack
+// time (g4c_mlp_pack_layer_bx6: [128-k block][column tile][16-k step][plane][lane][8], 6 bytes per weight).
+#ifndef G4C_BX6_RING
+#define G4C_BX6_RING 2
+#endif
+constexpr int RD6 = G4C_BX6_RING;              // ring depth in 16-k steps (2 or 4)
+struct Ring6 { bf16x8 h[RD6], m[RD6], l[RD6]; };
+constexpr int STEP6 = 3 * 512;                  // bf16 elements of one 16-k step of one column tile (3 planes)
+constexpr int BLOCK6 = 4 * 8 * STEP6;           // one 128-k block of the bf16x6 stream
+constexpr int PLANE = 32 * HB;                  // one LDS operand plane [32 rows][HB]
+
+// one 128-k block: 8 steps x 6 MFMAs from the three LDS planes at `pa`; ring slot s&3 is refilled 4 steps ahead
+__device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, Ring6 &g, const __bf16 *wcur, unsigned lo, f32x16 &acc) {
+    bf16x8 ah = *reinterpret_cast<const bf16x8 *>(pa), am = *reinterpret_cast<const bf16x8 *>(pa + PLANE),
+           al = *reinterpret_cast<const bf16x8 *>(pa + 2 * PLANE);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int o = ((s + 1) & 7) * 16;
+        const bf16x8 nh = (G4C_ABLATE & 64) ? ah : *reinterpret_cast<const bf16x8 *>(pa + o),
+                     nm = (G4C_ABLATE & 64) ? am : *reinterpret_cast<const bf16x8 *>(pa + PLANE + o),
+                     nl = (G4C_ABLATE & 64) ? al : *reinterpret_cast<const bf16x8 *>(pa + 2 * PLANE + o);
+        __builtin_amdgcn_sched_barrier(0);
+        const int r = s % RD6;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], al, acc, 0, 0, 0);     // small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.l[r], ah, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.m[r], am, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], am, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.m[r], ah, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], ah, acc, 0, 0, 0);
+        const __bf16 *wr = (s + RD6 < 8 ? wcur + (s + RD6) * STEP6 : wcur + BLOCK6 + (s + RD6 - 8) * STEP6) + lo;
+        if (!(G4C_ABLATE & 32)) {
+            g.h[r] = *reinterpret_cast<const bf16x8 *>(wr);
+            g.m[r] = *reinterpret_cast<const bf16x8 *>(wr + 512);
+            g.l[r] = *reinterpret_cast<const bf16x8 *>(wr + 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ah = nh; am = nm; al = nl;
+    }
+}
+
+// exact three-way bf16 split of an fp32 value
+__device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+#ifndef G4C_BX6_MINW
+#define G4C_BX6_MINW 3
+#endif
+template <bool VEC>
+__global__ __launch_bounds__(256, G4C_BX6_MINW) void mlp_bx6_kernel(const Params p) {
+    constexpr int ROWS = 32, NW = 4;
+    // three bf16 operand planes [3][32][136]; the fp32 final tile [32][132] aliases them
+    constexpr int BUF_FLOATS = 3 * PLANE / 2;
+    static_assert(BUF_FLOATS >= ROWS * HS, "final tile must fit");
+    __shared__ __attribute__((aligned(16))) float lds[BUF_FLOATS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
+    float *sH = lds;
+    __bf16 *sB = reinterpret_cast<__bf16 *>(lds);
+    int *sRow = reinterpret_cast<int *>(lds + BUF_FLOATS);
+    int *sRowAdd = sRow + G4C_MAX_SRC * ROWS;
+    float *sBias = lds + BUF_FLOATS + 2 * G4C_MAX_SRC * ROWS;
+    float *sGB = sBias + G4C_MAX_LAYERS * NP;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int ct0 = wave;
+
+    int tile;
+    {
+        const int b = blockIdx.x, nt = p.n_tiles;
+        const int q = nt >> 3, r = nt & 7, x = b & 7, j = b >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const long long row0 = p.row_base + (long long)tile * ROWS;
+
+    const __bf16 *w = reinterpret_cast<const __bf16 *>(p.w);
+    const unsigned lo = (unsigned)(ct0 * 8 * STEP6 + lane * 8);
+    Ring6 ring;
+#pragma unroll
+    for (int s = 0; s < RD6; ++s) {
+        ring.h[s] = *reinterpret_cast<const bf16x8 *>(w + s * STEP6 + lo);
+        ring.m[s] = *reinterpret_cast<const bf16x8 *>(w + s * STEP6 + 512 + lo);
+        ring.l[s] = *reinterpret_cast<const bf16x8 *>(w + s * STEP6 + 1024 + lo);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int e = tid; e < 2 * G4C_MAX_SRC * ROWS; e += 64 * NW) {
+        const int slot = e / ROWS, r = e % ROWS;
+        long long gr = row0 + r;
+        if (gr >= p.M) gr = p.M - 1;
+        const int *ix = nullptr;
+        bool used;
+        if (slot < G4C_MAX_SRC) { used = slot < p.n_src; if (used) ix = p.src[slot].idx; }
+        else { used = slot - G4C_MAX_SRC < p.n_add; if (used) ix = p.add[slot - G4C_MAX_SRC].idx; }
+        if (used) sRow[e] = ix ? ix[gr] : (int)gr;
+    }
+    for (int e = tid; e < p.n_layers * NP; e += 64 * NW) sBias[e] = p.b[e];
+    if (p.gamma) {
+        for (int e = tid; e < NP; e += 64 * NW) {
+            const int ee = e < p.n_out ? e : 0;
+            sGB[e] = p.gamma[ee];
+            sGB[NP + e] = p.beta[ee];
+        }
+    }
+    __syncthreads();
+
+    const int grow_l = (lane >> 3) + 8 * wave, c4 = (lane & 7) * 4;
+    f32x4 xp[4];
+    auto gather = [&](int sidx) {
+        const int width = p.src[sidx].width;
+        const float *rp = p.src[sidx].ptr + (long long)sRow[sidx * ROWS + grow_l] * p.src[sidx].ld + p.src[sidx].col0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = q * KC + c4;
+            if (VEC) {
+                xp[q] = *reinterpret_cast<const f32x4 *>(rp + (c < width ? c : 0));
+            } else {
+                const int w1 = width - 1;
+                xp[q][0] = rp[c + 0 < w1 ? c + 0 : w1]; xp[q][1] = rp[c + 1 < w1 ? c + 1 : w1];
+                xp[q][2] = rp[c + 2 < w1 ? c + 2 : w1]; xp[q][3] = rp[c + 3 < w1 ? c + 3 : w1];
+            }
+        }
+    };
+    auto park = [&](int sidx) {
+        const int width = p.src[sidx].width, act = p.src[sidx].pre_act;
+        __bf16 *d = sB + grow_l * HB + c4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = q * KC + c4;
+            bf16x4 vh, vm, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = (c + e < width) ? xp[q][e] : 0.f;
+                if (act) t = g4c::selu_f(t);
+                __bf16 a, b, cc;
+                split3(t, a, b, cc);
+                vh[e] = a; vm[e] = b; vl[e] = cc;
+            }
+            *reinterpret_cast<bf16x4 *>(d + q * KC) = vh;
+            *reinterpret_cast<bf16x4 *>(d + PLANE + q * KC) = vm;
+            *reinterpret_cast<bf16x4 *>(d + 2 * PLANE + q * KC) = vl;
+        }
+    };
+    gather(0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    // Operands are swapped in the MFMAs (weights as A, activations as B), so the accumulator is TRANSPOSED: this lane
+    // holds sample row i (= lane & 31) and the 16 output features f(q) = 32*ct0 + 8*(q>>2) + 4*h + (q&3): four runs of
+    // four consecutive features -> 16-byte gathers / LDS accesses instead of 16 scalar ones.
+    const int fbase = ct0 * 32 + 4 * h;
+    for (int a = 0; a < p.n_add; ++a) {
+        const float *pr = p.add[a].ptr + (long long)sRowAdd[a * ROWS + i] * p.add[a].ld;
+        const int width = p.add[a].width;
+        const bool vec = ((p.add[a].ld & 3) == 0) && ((width & 3) == 0) && (((uintptr_t)p.add[a].ptr & 15) == 0);
+        f32x4 t[4];
+        if (vec) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int f = fbase + 8 * gq;
+                t[gq] = *reinterpret_cast<const f32x4 *>(pr + (f < width ? f : 0));
+            }
+        } else {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int f = fbase + 8 * gq + e;
+                    t[gq][e] = pr[f < width ? f : 0];
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * gq + e] += (fbase + 8 * gq + e < width) ? t[gq][e] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    park(0);
+    __syncthreads();
+
+    // ---------------------------------------------------------------- layer 0: one (padded) 128-k input block at a time
+    const __bf16 *pa = sB + i * HB + 8 * h;
+    for (int s = 0; s < p.n_src; ++s) {
+        const bool more = s + 1 < p.n_src;
+        if (more) gather(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_block_bx6(pa, ring, w, lo, acc);
+        w += BLOCK6;
+        __syncthreads();                   // everybody is done reading the planes
+        if (more) {
+            park(s + 1);
+            __syncthreads();
+        }
+    }
+    for (int l = 0;; ++l) {
+        const bool last = (l == p.n_layers - 1);
+        if (last) {
+            // final tile in fp32 for the LayerNorm / store epilogue (aliases the operand planes: everybody finished
+            // reading them at the barrier that closed the previous block)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sBias + l * NP + fbase + 8 * gq);
+                f32x4 x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = acc[4 * gq + e] + b4[e];
+                *reinterpret_cast<f32x4 *>(sH + i * HS + fbase + 8 * gq) = x;
+            }
+            __syncthreads();
+            break;
+        }
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sBias + l * NP + fbase + 8 * gq);
+            bf16x4 vh, vm, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = g4c::selu_f(acc[4 * gq + e] + b4[e]);
+                __bf16 a, b, cc;
+                split3(x, a, b, cc);
+                vh[e] = a; vm[e] = b; vl[e] = cc;
+            }
+            __bf16 *d = sB + i * HB + fbase + 8 * gq;
+            *reinterpret_cast<bf16x4 *>(d) = vh;
+            *reinterpret_cast<bf16x4 *>(d + PLANE) = vm;
+            *reinterpret_cast<bf16x4 *>(d + 2 * PLANE) = vl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        mma_block_bx6(pa, ring, w, lo, acc);
+        w += BLOCK6;
+        __syncthreads();
+    }
+    split_finish<NW>(p, sH, sGB, wave, lane, row0);
+}
+
+// bf16x6 image of one layer: three planes (h, m, l) of the exact split of every weight
+__global__ void pack_layer_bx6_kernel(const float *__restrict__ W, int n_out, int k_in, PackSegs segs,
+                                      __bf16 *__restrict__ packed, int k_pad) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= k_pad * NP) return;
+    const int kp = gid / NP, n = gid % NP;
+    int k = -1, base_p = 0, base = 0, neg = 0;
+    for (int s = 0; s < segs.n_seg; ++s) {
+        if (kp >= base_p && kp < base_p + segs.wpad[s]) {
+            const int j = kp - base_p;
+            if (j < segs.width[s]) { k = base + j; neg = segs.neg[s]; }
+        }
+        base_p += segs.wpad[s];
+        base += segs.width[s];
+    }
+    float v = 0.f;
+    if (k >= 0 && n < n_out) v = W[(long long)n * k_in + k];
+    if (neg) v = -v;
+    __bf16 a, b, c;
+    split3(v, a, b, c);
+    const int kk = kp & 127;
+    __bf16 *d = packed + (long long)(kp >> 7) * BLOCK6 + (n >> 5) * 8 * STEP6 + (kk >> 4) * STEP6 + (((kk >> 3) & 1) * 32 + (n & 31)) * 8 + (kk & 7);
+    d[0] = a; d[512] = b; d[1024] = c;
+}
+
 }  // namespace
 
 extern "C" int g4c_mlp_pack_layer(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
@@ -1708,9 +1982,23 @@ extern "C" int g4c_mlp_pack_layer(const float *W, int32_t n_out, int32_t k_in, c
     return g4c::check_launch("g4c_mlp_pack_layer");
 }
 
+static int pack_layer_16(bool six, const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
+                         const int32_t *seg_negate, int32_t n_seg, void *packed, int32_t k_pad, int32_t n_pad, void *stream);
+
 extern "C" int g4c_mlp_pack_layer_bf16(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
                                        const int32_t *seg_negate, int32_t n_seg, void *packed,
                                        int32_t k_pad, int32_t n_pad, void *stream) {
+    return pack_layer_16(false, W, n_out, k_in, seg_width, seg_negate, n_seg, packed, k_pad, n_pad, stream);
+}
+
+extern "C" int g4c_mlp_pack_layer_bx6(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
+                                      const int32_t *seg_negate, int32_t n_seg, void *packed,
+                                      int32_t k_pad, int32_t n_pad, void *stream) {
+    return pack_layer_16(true, W, n_out, k_in, seg_width, seg_negate, n_seg, packed, k_pad, n_pad, stream);
+}
+
+static int pack_layer_16(bool six, const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
+                         const int32_t *seg_negate, int32_t n_seg, void *packed, int32_t k_pad, int32_t n_pad, void *stream) {
     G4C_REQUIRE(W && packed && seg_width, G4C_EINVAL, "g4c_mlp_pack_layer_bf16: null pointer");
     G4C_REQUIRE(n_seg >= 1 && n_seg <= G4C_MAX_SRC, G4C_EUNSUPPORTED, "g4c_mlp_pack_layer_bf16: %d input blocks (max %d)", n_seg, G4C_MAX_SRC);
     G4C_REQUIRE(n_out >= 1 && n_out <= NP, G4C_EUNSUPPORTED, "g4c_mlp_pack_layer_bf16: layer width %d unsupported (max 128)", n_out);
@@ -1727,7 +2015,8 @@ extern "C" int g4c_mlp_pack_layer_bf16(const float *W, int32_t n_out, int32_t k_
     }
     G4C_REQUIRE(ksum == k_in, G4C_EINVAL, "g4c_mlp_pack_layer_bf16: blocks sum to %d columns, weight has %d", ksum, k_in);
     const int total = k_pad * NP;
-    pack_layer_bf16_kernel<<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(W, n_out, k_in, segs, (__bf16 *)packed, k_pad);
+    if (six) pack_layer_bx6_kernel<<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(W, n_out, k_in, segs, (__bf16 *)packed, k_pad);
+    else pack_layer_bf16_kernel<<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(W, n_out, k_in, segs, (__bf16 *)packed, k_pad);
     return g4c::check_launch("g4c_mlp_pack_layer_bf16");
 }
 
@@ -1827,12 +2116,21 @@ extern "C" int g4c_mlp_forward_bf16(const g4c_mlp_t *mlp, const g4c_src_t *srcs,
                       nullptr, 0, nullptr, 0, stream);
 }
 
+extern "C" int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                                   float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
+                                   const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream) {
+    return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3248, out, out_ld, out_idx, act, resid, resid_ld, resid_col0,
+                      nullptr, 0, nullptr, 0, stream);
+}
+
 static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                       int64_t row_begin, int64_t row_count, int32_t tile_rows,
                       float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                       const float *resid, int32_t resid_ld, int32_t resid_col0,
                       const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream) {
-    const bool bf16 = (tile_rows == 3216);      // weights: the bf16 stream of g4c_mlp_pack_layer_bf16, input blocks padded to 128 k
+    const bool bx6 = (tile_rows == 3248);       // weights: the three-plane stream of g4c_mlp_pack_layer_bx6
+    const bool bf16 = (tile_rows == 3216) || bx6;   // 2-byte stream(s), input blocks padded to 128 k
+    const int wbytes = bx6 ? 6 : (bf16 ? 2 : 4);
     if (bf16) tile_rows = 324;
     G4C_REQUIRE(tile_rows == 64 || tile_rows == 32 || tile_rows == 322 || tile_rows == 324 || tile_rows == 325 || tile_rows == 644, G4C_EINVAL,
                 "g4c_mlp_forward_rows: tile_rows must be 64, 32, 322 (32 rows / 2 waves), 324 (32 rows / 4 waves) or 325 (324, small-launch variant)");
@@ -1883,7 +2181,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         G4C_REQUIRE(mlp->n_pad[l] == NP, G4C_EINVAL, "g4c_mlp_forward: layer %d n_pad %d (must be 128)", l, mlp->n_pad[l]);
         if (l > 0) G4C_REQUIRE(mlp->k_pad[l] == NP, G4C_EINVAL, "g4c_mlp_forward: layer %d k_pad %d (must be 128)", l, mlp->k_pad[l]);
         // one contiguous stream: layer l starts where layer l-1 ends
-        if (l > 0) G4C_REQUIRE((const char *)mlp->w[l] == (const char *)mlp->w[l - 1] + (size_t)mlp->k_pad[l - 1] * NP * (bf16 ? 2 : 4), G4C_EINVAL,
+        if (l > 0) G4C_REQUIRE((const char *)mlp->w[l] == (const char *)mlp->w[l - 1] + (size_t)mlp->k_pad[l - 1] * NP * wbytes, G4C_EINVAL,
                                "g4c_mlp_forward: packed layers must be contiguous (layer %d)", l);
         if (l > 0) G4C_REQUIRE((const float *)mlp->b[l] == (const float *)mlp->b[l - 1] + NP, G4C_EINVAL,
                                "g4c_mlp_forward: padded biases must be contiguous (layer %d)", l);
@@ -1926,6 +2224,10 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         p.n_tiles = (int)((row_count + 31) / 32);
         if (all_vec) mlp_split_kernel<2, true><<<dim3(p.n_tiles), dim3(128), 0, st>>>(p);
         else mlp_split_kernel<2, false><<<dim3(p.n_tiles), dim3(128), 0, st>>>(p);
+    } else if (bx6) {
+        p.n_tiles = (int)((row_count + 31) / 32);
+        if (all_vec) mlp_bx6_kernel<true><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
+        else mlp_bx6_kernel<false><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
     } else if (bf16) {
         p.n_tiles = (int)((row_count + 31) / 32);
         if (all_vec) mlp_bf16_kernel<true><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);

@@ -167,7 +167,7 @@ class MLP(nn.Module):
         Below HOIST_MIN_ROWS the launch is latency-bound and the extra product launches cost more than the MFMA
         work they save (measured crossover ~25k rows, scripts/sweep_tile_modes.py): one plain fused launch then.
         `products` (from the producer's launch, MLP.run_with_heads): the per-node terms, already multiplied."""
-        if (n_rows < HOIST_MIN_ROWS or ops.mlp_precision() != "fp32") and products is None:   # (bf16 MFMAs are ~free: never hoist)
+        if (n_rows < HOIST_MIN_ROWS or ops.mlp_precision() == "bf16") and products is None:   # (plain bf16 MFMAs are ~free: never hoist)
             return self.run_coded(list(k_sources) + [Source(t, index=idx) for t, idx in gathered], n_rows, act_code, **kw)
         kw_widths = [s.width for s in k_sources]
         off = sum(kw_widths)

@@ -182,8 +182,9 @@ def rollout_advance(field: Tensor, pred: Tensor, outputs: Tensor, step: Tensor, 
                                        int(outputs.size(1)), _lib.ptr(step), int(field.size(0)), _lib.stream_handle(dev)))
 
 
-# Arithmetic of the fused MLPs: "fp32" (exact fp32 MFMA, the default and the parity path) or "bf16" (operands rounded to
-# bf16, fp32 accumulation, fp32 bias / SELU / LayerNorm: BASELINE config 3's "bf16 edge-MLP MFMA"; g4c_mlp_forward_bf16).
+# Arithmetic of the fused MLPs: "fp32" (fp32 MFMA, the default and the parity path), "bf16x6" (fp32-accurate: exact
+# three-way bf16 split of both operands, six partial products on the bf16 matrix pipe; g4c_mlp_forward_bx6) or "bf16"
+# (operands rounded to bf16, fp32 accumulation / bias / SELU / LayerNorm: BASELINE config 3's "bf16 edge-MLP MFMA").
 _PRECISION = os.environ.get("G4C_MLP_PRECISION", "fp32")
 
 
@@ -194,8 +195,8 @@ def mlp_precision() -> str:
 def set_mlp_precision(precision: str) -> str:
     """Select the arithmetic of every fused MLP launched from now on; returns the previous setting."""
     global _PRECISION
-    if precision not in ("fp32", "bf16"):
-        raise ValueError(f"unknown MLP precision {precision!r} (fp32 | bf16)")
+    if precision not in ("fp32", "bf16", "bf16x6"):
+        raise ValueError(f"unknown MLP precision {precision!r} (fp32 | bf16 | bf16x6)")
     old, _PRECISION = _PRECISION, precision
     return old
 
@@ -211,7 +212,8 @@ class PackedMLP:
         g4c_mlp_pack_layer_bf16 (every input block padded to 128 k), consumed by g4c_mlp_forward_bf16."""
         lib = _lib.load()
         self.precision = precision
-        bf16 = precision == "bf16"
+        bf16 = precision in ("bf16", "bf16x6")       # 2-byte weight stream(s), 128-k input blocks
+        planes = 3 if precision == "bf16x6" else 1
         if bf16 and heads:
             raise NotImplementedError("heads in bf16")
         dev = _lib.require_hip(*weights, *[b for b in biases if b is not None], *heads)
@@ -236,10 +238,10 @@ class PackedMLP:
         if heads and int(weights[-1].size(0)) != NP:
             raise NotImplementedError("heads need a 128-wide MLP output")
         # (bf16: 2-byte elements, one 128-k block of slack)
-        stream_buf = torch.zeros((sum(k_pads) + NP * len(heads) + (NP if bf16 else KC)) * NP,
+        stream_buf = torch.zeros((sum(k_pads) + NP * len(heads) + (NP if bf16 else KC)) * NP * planes,
                                  dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
-        esz = 2 if bf16 else 4
-        pack = lib.g4c_mlp_pack_layer_bf16 if bf16 else lib.g4c_mlp_pack_layer
+        esz = 2 * planes if bf16 else 4
+        pack = {"fp32": lib.g4c_mlp_pack_layer, "bf16": lib.g4c_mlp_pack_layer_bf16, "bf16x6": lib.g4c_mlp_pack_layer_bx6}[precision]
         bias_buf = torch.zeros(n_layers * NP, dtype=torch.float32, device=dev)
         self._keep += [stream_buf, bias_buf]
         off = 0
@@ -322,14 +324,15 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
         out = torch.empty((n_rows, packed.n_out), dtype=torch.float32, device=dev)
     args = (_lib.ptr(out), _ld(out), _lib.ptr(out_idx32), act, _lib.ptr(resid), _ld(resid) if resid is not None else 0,
             resid_col0, _lib.stream_handle(dev))
-    if packed.precision == "bf16":
+    if packed.precision != "fp32":
         if head_outs is not None or tile_mode is not None:
             raise NotImplementedError("bf16 MLP with heads / a forced tile mode")
-        call = lambda: _lib.check(lib.g4c_mlp_forward_bf16(C.byref(packed.desc), arr, len(sources), n_rows, *args))
+        fwd = lib.g4c_mlp_forward_bf16 if packed.precision == "bf16" else lib.g4c_mlp_forward_bx6
+        call = lambda: _lib.check(fwd(C.byref(packed.desc), arr, len(sources), n_rows, *args))
         if KernelTimer.active is None:
             call()
         else:
-            _timed("mlp_bf16_kernel", packed.flops_per_row * n_rows, 4.0 * (sum(packed.seg_widths) + packed.n_out) * n_rows, call)
+            _timed("mlp_bf16_kernel" if packed.precision == "bf16" else "mlp_bx6_kernel", packed.flops_per_row * n_rows, 4.0 * (sum(packed.seg_widths) + packed.n_out) * n_rows, call)
     elif head_outs is not None:
         if len(head_outs) != packed.n_heads or packed.n_heads == 0:
             raise ValueError(f"{len(head_outs)} head outputs for a packing with {packed.n_heads} heads")

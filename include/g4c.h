@@ -167,6 +167,17 @@ int g4c_mlp_forward_bf16(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*
                          int64_t n_rows, float *out, int32_t out_ld, const int32_t *out_idx,
                          int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
 
+/* fp32-accurate variant on the bf16 matrix pipe ("bf16x6", opt-in): both operands of every Linear are split exactly
+ * into three bf16 terms (x = h + m + l), the six largest partial products are accumulated in fp32; dropped terms are
+ * <= 2^-23 relative.  Same contract as the _bf16 pair above with a three-plane stream (6 bytes per weight:
+ * k_pad * n_pad * 3 bf16 per layer, one 128-k block of slack). */
+int g4c_mlp_pack_layer_bx6(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width /*host*/,
+                           const int32_t *seg_negate /*host*/, int32_t n_seg, void *packed,
+                           int32_t k_pad, int32_t n_pad, void *stream);
+int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
+                        int64_t n_rows, float *out, int32_t out_ld, const int32_t *out_idx,
+                        int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
+
 /* ---------------------------------------------------------------- REMuS helpers (HBM-bound)
  * out[e, f] = v[node[e], 2f]*U[e,0] + v[node[e], 2f+1]*U[e,1]
  * (nn/remus_gnn.py:124-126, nn/blocks.py:454). node == NULL reads row e. */
