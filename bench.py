@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--nodes", type=int, default=100_000)
     ap.add_argument("--model", default="NsThreeScaleGNN")
     ap.add_argument("--hidden", type=int, default=128)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x6", "bf16"],
                     help="arithmetic of the fused MLPs: fp32 (default, the parity path and the headline number) or the opt-in bf16-MFMA variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

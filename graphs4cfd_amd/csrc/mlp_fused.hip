@@ -23,6 +23,7 @@
 // MFMA-bound in fp32: 2*K*128 FLOP per row per layer against ~(K_in + N_out)*4 bytes per row.
 #include "g4c_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 // Timing-only ablations, compile-time so that the production kernel has no extra control flow
 // (a runtime switch between two mma_chunk instantiations makes hipcc reconcile the weight-ring
@@ -1696,35 +1697,89 @@ constexpr int RD6 = G4C_BX6_RING;              // ring depth in 16-k steps (2 or
 struct Ring6 { bf16x8 h[RD6], m[RD6], l[RD6]; };
 constexpr int STEP6 = 3 * 512;                  // bf16 elements of one 16-k step of one column tile (3 planes)
 constexpr int BLOCK6 = 4 * 8 * STEP6;           // one 128-k block of the bf16x6 stream
-constexpr int PLANE = 32 * HB;                  // one LDS operand plane [32 rows][HB]
 
-// one 128-k block: 8 steps x 6 MFMAs from the three LDS planes at `pa`; ring slot s&3 is refilled 4 steps ahead
-__device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, Ring6 &g, const __bf16 *wcur, unsigned lo, f32x16 &acc) {
-    bf16x8 ah = *reinterpret_cast<const bf16x8 *>(pa), am = *reinterpret_cast<const bf16x8 *>(pa + PLANE),
-           al = *reinterpret_cast<const bf16x8 *>(pa + 2 * PLANE);
+// one 128-k block for RT row tiles of 32: per 16-k step and row tile 6 MFMAs from the three LDS planes (plane stride
+// `plane`, row-tile stride 32*HB); the weight fragments of a step are shared by the row tiles; ring slot s % RD6 is
+// refilled RD6 steps ahead.  A fragments are double-buffered per (step, row tile) item: the next item's three
+// ds_read_b128 are issued before this item's MFMAs.
+// 16-byte weight-fragment load through a buffer descriptor: 32-bit lane offset (one VGPR for the whole kernel) + wave-uniform
+// byte offset in an SGPR + immediate, instead of a 64-bit VALU address computation (and two address VGPRs) per load.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 ldw(__amdgpu_buffer_rsrc_t rs, unsigned voff_bytes, unsigned soff_bytes) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_bytes, soff_bytes, 0);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int RT>
+__device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6 &g, __amdgpu_buffer_rsrc_t rs, unsigned wofs, unsigned lo_b,
+                                              f32x16 (&acc)[RT]) {
+    bf16x8 ah = *reinterpret_cast<const bf16x8 *>(pa), am = *reinterpret_cast<const bf16x8 *>(pa + plane),
+           al = *reinterpret_cast<const bf16x8 *>(pa + 2 * plane);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const int o = ((s + 1) & 7) * 16;
-        const bf16x8 nh = (G4C_ABLATE & 64) ? ah : *reinterpret_cast<const bf16x8 *>(pa + o),
-                     nm = (G4C_ABLATE & 64) ? am : *reinterpret_cast<const bf16x8 *>(pa + PLANE + o),
-                     nl = (G4C_ABLATE & 64) ? al : *reinterpret_cast<const bf16x8 *>(pa + 2 * PLANE + o);
-        __builtin_amdgcn_sched_barrier(0);
         const int r = s % RD6;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], al, acc, 0, 0, 0);     // small terms first
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.l[r], ah, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.m[r], am, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], am, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.m[r], ah, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], ah, acc, 0, 0, 0);
-        const __bf16 *wr = (s + RD6 < 8 ? wcur + (s + RD6) * STEP6 : wcur + BLOCK6 + (s + RD6 - 8) * STEP6) + lo;
-        if (!(G4C_ABLATE & 32)) {
-            g.h[r] = *reinterpret_cast<const bf16x8 *>(wr);
-            g.m[r] = *reinterpret_cast<const bf16x8 *>(wr + 512);
-            g.l[r] = *reinterpret_cast<const bf16x8 *>(wr + 1024);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int nt = (t + 1) % RT, ns = (t + 1 == RT) ? ((s + 1) & 7) : s;
+            const __bf16 *pn = pa + nt * 32 * HB + ns * 16;
+            const bf16x8 nh = (G4C_ABLATE & 64) ? ah : *reinterpret_cast<const bf16x8 *>(pn),
+                         nm = (G4C_ABLATE & 64) ? am : *reinterpret_cast<const bf16x8 *>(pn + plane),
+                         nl = (G4C_ABLATE & 64) ? al : *reinterpret_cast<const bf16x8 *>(pn + 2 * plane);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(G4C_ABLATE & 128)) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], al, acc[t], 0, 0, 0);     // small terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.l[r], ah, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.m[r], am, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], am, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.m[r], ah, acc[t], 0, 0, 0);
+            } else {      // keep every operand live with one cheap VALU op instead of five MFMAs
+                acc[t][0] += (float)al[0] + (float)am[0] + (float)g.l[r][0] + (float)g.m[r][0];
+            }
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], ah, acc[t], 0, 0, 0);
+            if (t + 1 == RT && !(G4C_ABLATE & 32)) {
+                // slot r gets step s + RD6 (of this block, or of the next one: blocks are BLOCK6 apart; column tiles are
+                // 8 steps apart inside a block, so the next block's first steps are NOT contiguous with this one's last)
+                const unsigned so = wofs + 2u * (unsigned)(s + RD6 < 8 ? (s + RD6) * STEP6 : BLOCK6 + (s + RD6 - 8) * STEP6);
+                g.h[r] = ldw(rs, lo_b, so);
+                g.m[r] = ldw(rs, lo_b + 1024u, so);
+                g.l[r] = ldw(rs, lo_b + 2048u, so);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ah = nh; am = nm; al = nl;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        ah = nh; am = nm; al = nl;
     }
+}
+
+// SELU of four values with the multiplies / fused multiply-adds written as vector math (v_pk_mul_f32 / v_pk_fma_f32):
+// scale*max(x,0) + scale*alpha*(exp(min(x,0)) - 1); the second term is exactly 0 for x >= 0.
+__device__ __forceinline__ f32x4 selu4(f32x4 x) {
+    const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f;
+    const float scale = 1.0507009873554804934193349852946f;
+    f32x4 t, m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { t[e] = fminf(x[e], 0.f); m[e] = fmaxf(x[e], 0.f); }
+    t = t * 1.4426950408889634f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_exp2f(t[e]);
+    return m * scale + (t * sa - sa);
+}
+
+// exact three-way bf16 split of four fp32 values (vector subtractions -> v_pk_add_f32)
+__device__ __forceinline__ void split3x4(f32x4 x, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
+    if (G4C_ABLATE & 512) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = (__bf16)x[e]; m[e] = h[e]; l[e] = h[e]; }
+        return;
+    }
+    f32x4 hf, mf;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h[e] = (__bf16)x[e]; hf[e] = (float)h[e]; }
+    const f32x4 r1 = x - hf;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { m[e] = (__bf16)r1[e]; mf[e] = (float)m[e]; }
+    const f32x4 r2 = r1 - mf;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) l[e] = (__bf16)r2[e];
 }
 
 // exact three-way bf16 split of an fp32 value
@@ -1736,13 +1791,19 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
 }
 
 #ifndef G4C_BX6_MINW
-#define G4C_BX6_MINW 3
+#define G4C_BX6_MINW 4
 #endif
-template <bool VEC>
-__global__ __launch_bounds__(256, G4C_BX6_MINW) void mlp_bx6_kernel(const Params p) {
-    constexpr int ROWS = 32, NW = 4;
-    // three bf16 operand planes [3][32][136]; the fp32 final tile [32][132] aliases them
-    constexpr int BUF_FLOATS = 3 * PLANE / 2;
+// RT = 1: 32-row tile.  RT = 2: 64-row tile — every weight fragment feeds two row tiles (half the L2 -> register weight
+// traffic per row, which is what this kernel stalls on) and every memory round trip of the tile's critical path serves
+// twice the rows.
+// FULL: every weighted input block and every additive block is exactly 128 wide and 16-byte aligned (the MP layers):
+// no column masks anywhere.
+template <int RT, bool VEC, bool FULL>
+__global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kernel(const Params p) {
+    constexpr int ROWS = 32 * RT, NW = 4;
+    constexpr int PLN = ROWS * HB;              // one bf16 operand plane [ROWS][136]
+    // three operand planes; the fp32 final tile [ROWS][132] aliases them
+    constexpr int BUF_FLOATS = 3 * PLN / 2;
     static_assert(BUF_FLOATS >= ROWS * HS, "final tile must fit");
     __shared__ __attribute__((aligned(16))) float lds[BUF_FLOATS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
     float *sH = lds;
@@ -1765,169 +1826,273 @@ __global__ __launch_bounds__(256, G4C_BX6_MINW) void mlp_bx6_kernel(const Params
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
     const long long row0 = p.row_base + (long long)tile * ROWS;
+    G4C_STAMPW(0);
 
-    const __bf16 *w = reinterpret_cast<const __bf16 *>(p.w);
-    const unsigned lo = (unsigned)(ct0 * 8 * STEP6 + lane * 8);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, 0x7fffffff, 0x00020000);
+    const unsigned lo_b = 2u * (unsigned)(ct0 * 8 * STEP6 + lane * 8);    // this lane's byte offset inside a block of the stream
+    unsigned wofs = 0;                                                     // byte offset of the current block (wave-uniform)
     Ring6 ring;
-#pragma unroll
-    for (int s = 0; s < RD6; ++s) {
-        ring.h[s] = *reinterpret_cast<const bf16x8 *>(w + s * STEP6 + lo);
-        ring.m[s] = *reinterpret_cast<const bf16x8 *>(w + s * STEP6 + 512 + lo);
-        ring.l[s] = *reinterpret_cast<const bf16x8 *>(w + s * STEP6 + 1024 + lo);
-    }
-    __builtin_amdgcn_sched_barrier(0);
 
-    for (int e = tid; e < 2 * G4C_MAX_SRC * ROWS; e += 64 * NW) {
+    // this wave's rows of an input block: lane -> row (lane>>3) + 8*wave (+ 32 per row tile), 4 floats at column
+    // 4*(lane&7) of each 32-k chunk.  A block whose rows are not gathered through an index can start right away.
+    const int grow_l = (lane >> 3) + 8 * wave, c4 = (lane & 7) * 4;
+    f32x4 xp[RT][4];
+    auto gather = [&](int sidx, bool direct) __attribute__((always_inline)) {
+        const int width = p.src[sidx].width;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            long long gr;
+            if (direct) { gr = row0 + grow_l + 32 * t; if (gr >= p.M) gr = p.M - 1; }
+            else gr = sRow[sidx * ROWS + grow_l + 32 * t];
+            const float *rp = p.src[sidx].ptr + gr * p.src[sidx].ld + p.src[sidx].col0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = q * KC + c4;
+                if (FULL) {
+                    xp[t][q] = *reinterpret_cast<const f32x4 *>(rp + c);
+                } else if (VEC) {
+                    xp[t][q] = *reinterpret_cast<const f32x4 *>(rp + (c < width ? c : 0));
+                } else {
+                    const int w1 = width - 1;
+                    xp[t][q][0] = rp[c + 0 < w1 ? c + 0 : w1]; xp[t][q][1] = rp[c + 1 < w1 ? c + 1 : w1];
+                    xp[t][q][2] = rp[c + 2 < w1 ? c + 2 : w1]; xp[t][q][3] = rp[c + 3 < w1 ? c + 3 : w1];
+                }
+            }
+        }
+    };
+    auto park_impl = [&](int sidx, auto act_tag) __attribute__((always_inline)) {
+        constexpr bool ACT = decltype(act_tag)::value;
+        const int width = p.src[sidx].width;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            __bf16 *d = sB + (grow_l + 32 * t) * HB + c4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = q * KC + c4;
+                f32x4 v = xp[t][q];
+                if (!FULL) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (c + e < width) ? v[e] : 0.f;
+                }
+                if (ACT) v = selu4(v);
+                bf16x4 vh, vm, vl;
+                split3x4(v, vh, vm, vl);
+                *reinterpret_cast<bf16x4 *>(d + q * KC) = vh;
+                *reinterpret_cast<bf16x4 *>(d + PLN + q * KC) = vm;
+                *reinterpret_cast<bf16x4 *>(d + 2 * PLN + q * KC) = vl;
+                __builtin_amdgcn_sched_barrier(0);      // one group of four at a time: bounds the live temporaries
+            }
+        }
+    };
+    auto park = [&](int sidx) __attribute__((always_inline)) {            // one uniform branch per block, not one per element
+        if (p.src[sidx].pre_act) park_impl(sidx, std::true_type{});
+        else park_impl(sidx, std::false_type{});
+    };
+    // Memory instructions return in order per wave, so the loads that head a dependent chain go FIRST: row indices (the
+    // additive gathers wait for them), then the parameters, then the long-latency streams (weights, directly indexed input).
+    int idx_v[(2 * G4C_MAX_SRC * ROWS + 64 * NW - 1) / (64 * NW)];
+#pragma unroll
+    for (int it = 0; it < (2 * G4C_MAX_SRC * ROWS + 64 * NW - 1) / (64 * NW); ++it) {
+        const int e = tid + it * 64 * NW;
         const int slot = e / ROWS, r = e % ROWS;
         long long gr = row0 + r;
         if (gr >= p.M) gr = p.M - 1;
         const int *ix = nullptr;
-        bool used;
-        if (slot < G4C_MAX_SRC) { used = slot < p.n_src; if (used) ix = p.src[slot].idx; }
-        else { used = slot - G4C_MAX_SRC < p.n_add; if (used) ix = p.add[slot - G4C_MAX_SRC].idx; }
-        if (used) sRow[e] = ix ? ix[gr] : (int)gr;
+        if (slot < G4C_MAX_SRC) { if (slot < p.n_src) ix = p.src[slot].idx; }
+        else { if (slot - G4C_MAX_SRC < p.n_add) ix = p.add[slot - G4C_MAX_SRC].idx; }
+        idx_v[it] = ix ? ix[gr] : (int)gr;
     }
-    for (int e = tid; e < p.n_layers * NP; e += 64 * NW) sBias[e] = p.b[e];
+    float bias_v[(G4C_MAX_LAYERS * NP) / (64 * NW)], gb_v = 0.f;
+#pragma unroll
+    for (int it = 0; it < (G4C_MAX_LAYERS * NP) / (64 * NW); ++it) {
+        const int e = tid + it * 64 * NW;
+        bias_v[it] = p.b[e < p.n_layers * NP ? e : 0];
+    }
     if (p.gamma) {
-        for (int e = tid; e < NP; e += 64 * NW) {
-            const int ee = e < p.n_out ? e : 0;
-            sGB[e] = p.gamma[ee];
-            sGB[NP + e] = p.beta[ee];
-        }
+        const int e = tid & (NP - 1);
+        const int ee = e < p.n_out ? e : 0;
+        gb_v = tid < NP ? p.gamma[ee] : p.beta[ee];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < RD6; ++s) {
+        ring.h[s] = ldw(rs, lo_b, 2u * s * STEP6);
+        ring.m[s] = ldw(rs, lo_b + 1024u, 2u * s * STEP6);
+        ring.l[s] = ldw(rs, lo_b + 2048u, 2u * s * STEP6);
+    }
+    const bool direct0 = (p.src[0].idx == nullptr);
+    if (direct0) gather(0, true);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < (2 * G4C_MAX_SRC * ROWS + 64 * NW - 1) / (64 * NW); ++it) {
+        const int e = tid + it * 64 * NW;
+        if (e < 2 * G4C_MAX_SRC * ROWS) sRow[e] = idx_v[it];
+    }
+#pragma unroll
+    for (int it = 0; it < (G4C_MAX_LAYERS * NP) / (64 * NW); ++it) sBias[tid + it * 64 * NW] = bias_v[it];
+    if (p.gamma) sGB[tid] = gb_v;          // [gamma(128) | beta(128)] = 256 threads
     __syncthreads();
-
-    const int grow_l = (lane >> 3) + 8 * wave, c4 = (lane & 7) * 4;
-    f32x4 xp[4];
-    auto gather = [&](int sidx) {
-        const int width = p.src[sidx].width;
-        const float *rp = p.src[sidx].ptr + (long long)sRow[sidx * ROWS + grow_l] * p.src[sidx].ld + p.src[sidx].col0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = q * KC + c4;
-            if (VEC) {
-                xp[q] = *reinterpret_cast<const f32x4 *>(rp + (c < width ? c : 0));
-            } else {
-                const int w1 = width - 1;
-                xp[q][0] = rp[c + 0 < w1 ? c + 0 : w1]; xp[q][1] = rp[c + 1 < w1 ? c + 1 : w1];
-                xp[q][2] = rp[c + 2 < w1 ? c + 2 : w1]; xp[q][3] = rp[c + 3 < w1 ? c + 3 : w1];
-            }
-        }
-    };
-    auto park = [&](int sidx) {
-        const int width = p.src[sidx].width, act = p.src[sidx].pre_act;
-        __bf16 *d = sB + grow_l * HB + c4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = q * KC + c4;
-            bf16x4 vh, vm, vl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = (c + e < width) ? xp[q][e] : 0.f;
-                if (act) t = g4c::selu_f(t);
-                __bf16 a, b, cc;
-                split3(t, a, b, cc);
-                vh[e] = a; vm[e] = b; vl[e] = cc;
-            }
-            *reinterpret_cast<bf16x4 *>(d + q * KC) = vh;
-            *reinterpret_cast<bf16x4 *>(d + PLANE + q * KC) = vm;
-            *reinterpret_cast<bf16x4 *>(d + 2 * PLANE + q * KC) = vl;
-        }
-    };
-    gather(0);
+    G4C_STAMPW(1);
+    if (!direct0) gather(0, false);
     __builtin_amdgcn_sched_barrier(0);
 
-    f32x16 acc;
+    park(0);          // (before the additive gathers: the input registers are free again while those are in flight)
+    G4C_STAMPW(2);
+    // Operands are swapped in the MFMAs (weights as A, activations as B), so the accumulators are TRANSPOSED: this lane
+    // holds sample row i (= lane & 31, + 32 per row tile) and the 16 output features 32*ct0 + 8*(q>>2) + 4*h + (q&3):
+    // four runs of four consecutive features -> 16-byte gathers / LDS accesses instead of 16 scalar ones.
+    f32x16 acc[RT];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    // Operands are swapped in the MFMAs (weights as A, activations as B), so the accumulator is TRANSPOSED: this lane
-    // holds sample row i (= lane & 31) and the 16 output features f(q) = 32*ct0 + 8*(q>>2) + 4*h + (q&3): four runs of
-    // four consecutive features -> 16-byte gathers / LDS accesses instead of 16 scalar ones.
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
     const int fbase = ct0 * 32 + 4 * h;
     for (int a = 0; a < p.n_add; ++a) {
-        const float *pr = p.add[a].ptr + (long long)sRowAdd[a * ROWS + i] * p.add[a].ld;
         const int width = p.add[a].width;
-        const bool vec = ((p.add[a].ld & 3) == 0) && ((width & 3) == 0) && (((uintptr_t)p.add[a].ptr & 15) == 0);
-        f32x4 t[4];
-        if (vec) {
+        const bool vec = FULL || (((p.add[a].ld & 3) == 0) && ((width & 3) == 0) && (((uintptr_t)p.add[a].ptr & 15) == 0));
+        f32x4 tt[RT][4];
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int f = fbase + 8 * gq;
-                t[gq] = *reinterpret_cast<const f32x4 *>(pr + (f < width ? f : 0));
+        for (int t = 0; t < RT; ++t) {
+            const float *pr = p.add[a].ptr + (long long)sRowAdd[a * ROWS + i + 32 * t] * p.add[a].ld;
+            if (vec) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int f = fbase + 8 * gq;
+                    tt[t][gq] = *reinterpret_cast<const f32x4 *>(pr + ((FULL || f < width) ? f : 0));
+                }
+            } else {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int f = fbase + 8 * gq + e;
+                        tt[t][gq][e] = pr[f < width ? f : 0];
+                    }
             }
-        } else {
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int f = fbase + 8 * gq + e;
-                    t[gq][e] = pr[f < width ? f : 0];
-                }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[4 * gq + e] += (fbase + 8 * gq + e < width) ? t[gq][e] : 0.f;
+                for (int e = 0; e < 4; ++e) acc[t][4 * gq + e] += (FULL || fbase + 8 * gq + e < width) ? tt[t][gq][e] : 0.f;
         __builtin_amdgcn_sched_barrier(0);
     }
-    park(0);
     __syncthreads();
+    G4C_STAMPW(3);
 
     // ---------------------------------------------------------------- layer 0: one (padded) 128-k input block at a time
     const __bf16 *pa = sB + i * HB + 8 * h;
     for (int s = 0; s < p.n_src; ++s) {
         const bool more = s + 1 < p.n_src;
-        if (more) gather(s + 1);
+        if (more && RT == 1) gather(s + 1, false);          // (RT = 2: 32 more live registers would cost a wave per SIMD)
         __builtin_amdgcn_sched_barrier(0);
-        mma_block_bx6(pa, ring, w, lo, acc);
-        w += BLOCK6;
+        mma_block_bx6<RT>(pa, PLN, ring, rs, wofs, lo_b, acc);
+        wofs += 2u * BLOCK6;
         __syncthreads();                   // everybody is done reading the planes
         if (more) {
+            if (RT != 1) gather(s + 1, false);
             park(s + 1);
             __syncthreads();
         }
     }
+    G4C_STAMPW(4);
     for (int l = 0;; ++l) {
         const bool last = (l == p.n_layers - 1);
         if (last) {
             // final tile in fp32 for the LayerNorm / store epilogue (aliases the operand planes: everybody finished
             // reading them at the barrier that closed the previous block)
 #pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sBias + l * NP + fbase + 8 * gq);
+                    f32x4 x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = acc[t][4 * gq + e] + b4[e];
+                    *reinterpret_cast<f32x4 *>(sH + (i + 32 * t) * HS + fbase + 8 * gq) = x;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            __syncthreads();
+            G4C_STAMPW(5 + 2 * l);
+            break;
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sBias + l * NP + fbase + 8 * gq);
                 f32x4 x;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = acc[4 * gq + e] + b4[e];
-                *reinterpret_cast<f32x4 *>(sH + i * HS + fbase + 8 * gq) = x;
+                for (int e = 0; e < 4; ++e) x[e] = acc[t][4 * gq + e];
+                bf16x4 vh, vm, vl;
+                split3x4(selu4(x + b4), vh, vm, vl);
+                __bf16 *d = sB + (i + 32 * t) * HB + fbase + 8 * gq;
+                *reinterpret_cast<bf16x4 *>(d) = vh;
+                *reinterpret_cast<bf16x4 *>(d + PLN) = vm;
+                *reinterpret_cast<bf16x4 *>(d + 2 * PLN) = vl;
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __syncthreads();
-            break;
-        }
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sBias + l * NP + fbase + 8 * gq);
-            bf16x4 vh, vm, vl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x = g4c::selu_f(acc[4 * gq + e] + b4[e]);
-                __bf16 a, b, cc;
-                split3(x, a, b, cc);
-                vh[e] = a; vm[e] = b; vl[e] = cc;
-            }
-            __bf16 *d = sB + i * HB + fbase + 8 * gq;
-            *reinterpret_cast<bf16x4 *>(d) = vh;
-            *reinterpret_cast<bf16x4 *>(d + PLANE) = vm;
-            *reinterpret_cast<bf16x4 *>(d + 2 * PLANE) = vl;
-        }
         __syncthreads();
+        G4C_STAMPW(5 + 2 * l);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-        mma_block_bx6(pa, ring, w, lo, acc);
-        w += BLOCK6;
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+        mma_block_bx6<RT>(pa, PLN, ring, rs, wofs, lo_b, acc);
+        wofs += 2u * BLOCK6;
         __syncthreads();
+        G4C_STAMPW(6 + 2 * l);
     }
-    split_finish<NW>(p, sH, sGB, wave, lane, row0);
+    G4C_STAMPW(12);
+    split_finish<NW, ROWS>(p, sH, sGB, wave, lane, row0);
+    G4C_STAMPW(13);
+    if (p.n_heads) {
+        // heads (see Params): the finished fp32 tile -> three operand planes (they alias it: read everything, barrier,
+        // then overwrite), then one 128-k block per head whose weights continue the stream
+        __syncthreads();
+        f32x4 v[RT][4];
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[t][q] = *reinterpret_cast<const f32x4 *>(sH + (grow_l + 32 * t) * HS + q * KC + c4);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bf16x4 vh, vm, vl;
+                split3x4(v[t][q], vh, vm, vl);
+                __bf16 *d = sB + (grow_l + 32 * t) * HB + q * KC + c4;
+                *reinterpret_cast<bf16x4 *>(d) = vh;
+                *reinterpret_cast<bf16x4 *>(d + PLN) = vm;
+                *reinterpret_cast<bf16x4 *>(d + 2 * PLN) = vl;
+            }
+        __syncthreads();
+        for (int hd = 0; hd < p.n_heads; ++hd) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+            mma_block_bx6<RT>(pa, PLN, ring, rs, wofs, lo_b, acc);
+            wofs += 2u * BLOCK6;
+            float *ho = p.head_out[hd];
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const long long grow = row0 + i + 32 * t;
+                if (grow < p.M) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        f32x4 x;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[e] = acc[t][4 * gq + e];
+                        *reinterpret_cast<f32x4 *>(ho + grow * p.head_ld + fbase + 8 * gq) = x;
+                    }
+                }
+            }
+        }
+    }
 }
 
 // bf16x6 image of one layer: three planes (h, m, l) of the exact split of every weight
@@ -2116,6 +2281,14 @@ extern "C" int g4c_mlp_forward_bf16(const g4c_mlp_t *mlp, const g4c_src_t *srcs,
                       nullptr, 0, nullptr, 0, stream);
 }
 
+extern "C" int g4c_mlp_forward_heads_bx6(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                                         float *out, int32_t out_ld, int32_t act,
+                                         const void *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream) {
+    G4C_REQUIRE(n_heads >= 1 && n_heads <= G4C_MAX_HEADS && head_w && head_out, G4C_EINVAL, "g4c_mlp_forward_heads_bx6: bad heads (n=%d)", n_heads);
+    return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3248, out, out_ld, nullptr, act, nullptr, 0, 0,
+                      (const float *)head_w, n_heads, head_out, head_ld, stream);
+}
+
 extern "C" int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                    float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                                    const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream) {
@@ -2199,12 +2372,13 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     p.n_heads = n_heads; p.head_ld = head_ld;
     for (int hd = 0; hd < G4C_MAX_HEADS; ++hd) p.head_out[hd] = hd < n_heads ? head_out[hd] : nullptr;
     if (n_heads) {
-        G4C_REQUIRE(!bf16, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads: no bf16 variant");
+        G4C_REQUIRE(!bf16 || bx6, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads: no plain-bf16 variant");
+        G4C_REQUIRE((head_ld & 3) == 0 || !bx6, G4C_EINVAL, "g4c_mlp_forward_heads: head outputs need a leading dimension that is a multiple of 4");
         G4C_REQUIRE(tile_rows == 324 || tile_rows == 325, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads: tile mode %d has no heads", tile_rows);
         G4C_REQUIRE(p.n_out == NP && !resid && !out_idx && head_ld >= NP, G4C_EINVAL,
                     "g4c_mlp_forward_heads: heads need a 128-wide output without residual / output index (n_out=%d)", p.n_out);
         const int last = mlp->n_layers - 1;
-        G4C_REQUIRE(head_w == (const float *)mlp->w[last] + (size_t)mlp->k_pad[last] * NP, G4C_EINVAL,
+        G4C_REQUIRE((const char *)head_w == (const char *)mlp->w[last] + (size_t)mlp->k_pad[last] * NP * wbytes, G4C_EINVAL,
                     "g4c_mlp_forward_heads: head weights must continue the packed stream");
         for (int hd = 0; hd < n_heads; ++hd) G4C_REQUIRE(head_out[hd], G4C_EINVAL, "g4c_mlp_forward_heads: null head output %d", hd);
     }
@@ -2225,9 +2399,23 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         if (all_vec) mlp_split_kernel<2, true><<<dim3(p.n_tiles), dim3(128), 0, st>>>(p);
         else mlp_split_kernel<2, false><<<dim3(p.n_tiles), dim3(128), 0, st>>>(p);
     } else if (bx6) {
-        p.n_tiles = (int)((row_count + 31) / 32);
-        if (all_vec) mlp_bx6_kernel<true><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
-        else mlp_bx6_kernel<false><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
+        static const int64_t rt2_rows = getenv("G4C_BX6_RT2_ROWS") ? atoll(getenv("G4C_BX6_RT2_ROWS")) : (1LL << 40);   // measured slower (2 waves per SIMD): off
+        bool full = all_vec;
+        for (int s2 = 0; s2 < p.n_src; ++s2) full = full && p.src[s2].width == NP;
+        for (int a = 0; a < p.n_add; ++a)
+            full = full && p.add[a].width == NP && (p.add[a].ld & 3) == 0 && ((uintptr_t)p.add[a].ptr & 15) == 0;
+        const dim3 blk(256);
+        if (row_count >= rt2_rows) {       // 64-row tiles (tuning only)
+            p.n_tiles = (int)((row_count + 63) / 64);
+            if (full) mlp_bx6_kernel<2, true, true><<<dim3(p.n_tiles), blk, 0, st>>>(p);
+            else if (all_vec) mlp_bx6_kernel<2, true, false><<<dim3(p.n_tiles), blk, 0, st>>>(p);
+            else mlp_bx6_kernel<2, false, false><<<dim3(p.n_tiles), blk, 0, st>>>(p);
+        } else {
+            p.n_tiles = (int)((row_count + 31) / 32);
+            if (full) mlp_bx6_kernel<1, true, true><<<dim3(p.n_tiles), blk, 0, st>>>(p);
+            else if (all_vec) mlp_bx6_kernel<1, true, false><<<dim3(p.n_tiles), blk, 0, st>>>(p);
+            else mlp_bx6_kernel<1, false, false><<<dim3(p.n_tiles), blk, 0, st>>>(p);
+        }
     } else if (bf16) {
         p.n_tiles = (int)((row_count + 31) / 32);
         if (all_vec) mlp_bf16_kernel<true><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);

@@ -72,7 +72,7 @@ class MLP(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def packed(self, seg_widths: Sequence[int], seg_negate: Sequence[bool]) -> ops.PackedMLP:
-        prec = ops.mlp_precision()
+        prec = ops.effective_precision(seg_widths)
         key = (tuple(seg_widths), tuple(bool(x) for x in seg_negate), prec)
         sig = self._signature()
         hit = self._packed.get(key)
@@ -110,9 +110,10 @@ class MLP(nn.Module):
         consumer compute its products itself."""
         if self.output_size != 128 or any(int(w) != 128 for w in widths) or not 1 <= len(widths) <= _lib.MAX_HEADS:
             return None
-        if ops.mlp_precision() != "fp32":
+        prec = ops.effective_precision([s.width for s in sources])
+        if prec == "bf16":
             return None
-        key = ("heads", id(consumer), k_cols, tuple(widths), tuple(s.width for s in sources), tuple(s.negate for s in sources))
+        key = ("heads", id(consumer), k_cols, tuple(widths), tuple(s.width for s in sources), tuple(s.negate for s in sources), prec)
         sig = (self._signature(), consumer._signature())
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
@@ -126,12 +127,11 @@ class MLP(nn.Module):
             if int(w1.size(0)) != 128:
                 return None
             pk = ops.PackedMLP([l.weight for l in lin], [l.bias for l in lin],
-                               None if ln is None else (ln.weight, ln.bias, ln.eps), key[4], key[5], heads=heads)
+                               None if ln is None else (ln.weight, ln.bias, ln.eps), key[4], key[5], heads=heads, precision=prec)
             self._packed[key] = (sig, pk)
             hit = self._packed[key]
         pk = hit[1]
-        arr_mode = ops.mlp_mode(sources, n_rows)
-        if arr_mode not in (324, 325):
+        if prec == "fp32" and ops.mlp_mode(sources, n_rows) not in (324, 325):
             return None
         dev = sources[0].tensor.device
         y = torch.empty((n_rows, 128), dtype=torch.float32, device=dev)
@@ -142,7 +142,7 @@ class MLP(nn.Module):
     # -- first-layer hoisting ------------------------------------------------------------------
     def _packed_cols(self, tag: str, a: int, b: int, seg_widths, seg_negate, first_only: bool) -> ops.PackedMLP:
         """Packed variant using only columns [a, b) of the first Linear layer (`first_only`: that layer alone, no bias)."""
-        prec = ops.mlp_precision()
+        prec = ops.effective_precision(seg_widths)
         key = (tag, a, b, tuple(seg_widths), tuple(bool(x) for x in seg_negate), prec)
         sig = self._signature()
         hit = self._packed.get(key)

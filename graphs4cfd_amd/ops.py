@@ -182,13 +182,24 @@ def rollout_advance(field: Tensor, pred: Tensor, outputs: Tensor, step: Tensor, 
                                        int(outputs.size(1)), _lib.ptr(step), int(field.size(0)), _lib.stream_handle(dev)))
 
 
-# Arithmetic of the fused MLPs: "fp32" (fp32 MFMA, the default and the parity path), "bf16x6" (fp32-accurate: exact
-# three-way bf16 split of both operands, six partial products on the bf16 matrix pipe; g4c_mlp_forward_bx6) or "bf16"
-# (operands rounded to bf16, fp32 accumulation / bias / SELU / LayerNorm: BASELINE config 3's "bf16 edge-MLP MFMA").
-_PRECISION = os.environ.get("G4C_MLP_PRECISION", "fp32")
+# Arithmetic of the fused MLPs — all fp32 in, fp32 out:
+#   "bf16x6" (default)  fp32-accurate products on the bf16 matrix pipe: both operands split EXACTLY into three bf16 terms,
+#                       the six largest partial products accumulated in fp32 (g4c_mlp_forward_bx6); measured error
+#                       against fp64 <= that of the fp32-MFMA kernel (scripts/mlp_accuracy.py, test_mlp_precisions_vs_fp64);
+#                       MLPs outside its envelope (an input block wider than 128) use the fp32 kernels;
+#   "fp32"              v_mfma_f32_32x32x2_f32 (g4c_mlp_forward): the original kernels, every tile variant;
+#   "bf16"              operands ROUNDED to bf16 (~1e-2 deviation): BASELINE config 3's "bf16 edge-MLP MFMA", opt-in only.
+_PRECISION = os.environ.get("G4C_MLP_PRECISION", "bf16x6")
 
 
 def mlp_precision() -> str:
+    return _PRECISION
+
+
+def effective_precision(seg_widths: Sequence[int]) -> str:
+    """Precision an MLP with these input blocks is packed for: the selected one, or fp32 outside the bf16 kernels' envelope."""
+    if _PRECISION != "fp32" and any(int(w) > 128 for w in seg_widths):
+        return "fp32"
     return _PRECISION
 
 
@@ -214,8 +225,8 @@ class PackedMLP:
         self.precision = precision
         bf16 = precision in ("bf16", "bf16x6")       # 2-byte weight stream(s), 128-k input blocks
         planes = 3 if precision == "bf16x6" else 1
-        if bf16 and heads:
-            raise NotImplementedError("heads in bf16")
+        if precision == "bf16" and heads:
+            raise NotImplementedError("heads in plain bf16")
         dev = _lib.require_hip(*weights, *[b for b in biases if b is not None], *heads)
         n_layers = len(weights)
         if not 1 <= n_layers <= _lib.MAX_LAYERS:
@@ -266,13 +277,13 @@ class PackedMLP:
             self.desc.k_pad[l], self.desc.n_pad[l] = k_pads[l], NP
             self.desc.w[l], self.desc.b[l] = wptr, bias_buf.data_ptr() + 4 * l * NP
             off += k_pads[l] * NP
-        self.head_w = stream_buf.data_ptr() + 4 * off if heads else None
         self.n_heads = len(heads)
+        self.head_w = stream_buf.data_ptr() + esz * off if heads else None
         one = (C.c_int32 * 1)(NP)
         zero = (C.c_int32 * 1)(0)
         for W in heads:
             Wc = W.detach().to(torch.float32).contiguous()
-            _lib.check(lib.g4c_mlp_pack_layer(_lib.ptr(Wc), NP, NP, one, zero, 1, stream_buf.data_ptr() + 4 * off, NP, NP, stream))
+            _lib.check(pack(_lib.ptr(Wc), NP, NP, one, zero, 1, stream_buf.data_ptr() + esz * off, NP, NP, stream))
             off += NP * NP
         self.n_out = int(weights[-1].size(0))
         self.desc.n_out = self.n_out
@@ -325,10 +336,21 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
     args = (_lib.ptr(out), _ld(out), _lib.ptr(out_idx32), act, _lib.ptr(resid), _ld(resid) if resid is not None else 0,
             resid_col0, _lib.stream_handle(dev))
     if packed.precision != "fp32":
-        if head_outs is not None or tile_mode is not None:
-            raise NotImplementedError("bf16 MLP with heads / a forced tile mode")
-        fwd = lib.g4c_mlp_forward_bf16 if packed.precision == "bf16" else lib.g4c_mlp_forward_bx6
-        call = lambda: _lib.check(fwd(C.byref(packed.desc), arr, len(sources), n_rows, *args))
+        if tile_mode is not None or (head_outs is not None and packed.precision == "bf16"):
+            raise NotImplementedError("bf16 MLP with a forced tile mode / plain bf16 with heads")
+        if head_outs is not None:
+            if len(head_outs) != packed.n_heads or packed.n_heads == 0:
+                raise ValueError(f"{len(head_outs)} head outputs for a packing with {packed.n_heads} heads")
+            if out_idx32 is not None or resid is not None:
+                raise NotImplementedError("heads with an output index / residual")
+            _lib.require_hip(*head_outs)
+            ho = (C.c_void_p * len(head_outs))(*[h.data_ptr() for h in head_outs])
+            call = lambda: _lib.check(lib.g4c_mlp_forward_heads_bx6(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out),
+                                                                    _ld(out), act, packed.head_w, len(head_outs), ho,
+                                                                    _ld(head_outs[0]), _lib.stream_handle(dev)))
+        else:
+            fwd = lib.g4c_mlp_forward_bf16 if packed.precision == "bf16" else lib.g4c_mlp_forward_bx6
+            call = lambda: _lib.check(fwd(C.byref(packed.desc), arr, len(sources), n_rows, *args))
         if KernelTimer.active is None:
             call()
         else:

@@ -177,6 +177,11 @@ int g4c_mlp_pack_layer_bx6(const float *W, int32_t n_out, int32_t k_in, const in
 int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
                         int64_t n_rows, float *out, int32_t out_ld, const int32_t *out_idx,
                         int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
+/* g4c_mlp_forward_heads for the bf16x6 stream (heads packed with g4c_mlp_pack_layer_bx6 right after the last layer) */
+int g4c_mlp_forward_heads_bx6(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
+                              int64_t n_rows, float *out, int32_t out_ld, int32_t act,
+                              const void *head_w, int32_t n_heads, float *const *head_out /*host*/, int32_t head_ld,
+                              void *stream);
 
 /* ---------------------------------------------------------------- REMuS helpers (HBM-bound)
  * out[e, f] = v[node[e], 2f]*U[e,0] + v[node[e], 2f+1]*U[e,1]

@@ -91,12 +91,13 @@ def test_mlp_row_tails_and_leading_dims(golden):
 
 
 @pytest.mark.parametrize("rows", [1, 33, 1000, 20000])
-def test_mlp_kernel_variants_agree(rows):
+def test_mlp_kernel_variants_agree(rows, monkeypatch):
     """Every kernel variant behind g4c_mlp_forward_rows (64 / 32-row single-wave tiles, 2- and 4-wave column split,
     the small-launch variant 325) computes the same MLP: hoisted edge form (gathered additive terms + SELU-on-load)
     and the two-block node form, against the oracle MLP on the concatenated input."""
     H, n = 128, max(rows // 6, 1)
     torch.manual_seed(rows)
+    monkeypatch.setattr(ops, "_PRECISION", "fp32")      # the tile variants are the fp32-MFMA kernels
     blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
     e, v, agg = torch.randn(rows, H, device=DEV), torch.randn(n, H, device=DEV), torch.randn(n, H, device=DEV)
     row = torch.randint(0, n, (rows,), device=DEV, dtype=torch.int32)
@@ -170,12 +171,14 @@ def test_mlp_bf16_variant(rows):
     assert (y.cpu() - ref).abs().mean().item() < 6e-3
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
 @pytest.mark.parametrize("rows", [33, 5000, 40000])
-def test_mlp_heads(rows):
+def test_mlp_heads(rows, prec, monkeypatch):
     """g4c_mlp_forward_heads: the node MLP launch also emits W1[:, H:2H] y and W1[:, 2H:] y of the next edge MLP
     (both 4-wave split variants: 325 below 16384 rows, 324 above) == separate products of the stored output."""
     H = 128
     torch.manual_seed(rows)
+    monkeypatch.setattr(ops, "_PRECISION", prec)
     blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
     nxt = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
     agg, v = torch.randn(rows, H, device=DEV), torch.randn(rows, H, device=DEV)
@@ -190,6 +193,42 @@ def test_mlp_heads(rows):
     torch.testing.assert_close(pc.cpu(), (y.cpu().double() @ W1[:, 2 * H:].T).float(), rtol=2e-4, atol=2e-4)
     # a launch that cannot carry heads says so instead of computing something else
     assert blk.node_mlp.run_with_heads([ops.Source(agg), ops.Source(v)], rows, _lib.ACT_SELU, nxt.edge_mlp, H, [H, H, H]) is None
+
+
+def test_mlp_precisions_vs_fp64():
+    """The default bf16x6 arithmetic (exact three-way bf16 split, six partial products on the bf16 matrix pipe) is as
+    accurate as the fp32-MFMA kernels: both against an fp64 evaluation of the same edge MLP (gathers, SELU-on-load,
+    LayerNorm); plain bf16 is the only mode that deviates (its stated ~1e-2)."""
+    H, rows = 128, 20000
+    n = rows // 6
+    torch.manual_seed(11)
+    blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
+    e, v = 3.0 * torch.randn(rows, H, device=DEV), torch.randn(n, H, device=DEV)
+    e[::7] *= 1e3                                   # large magnitudes: bf16 keeps the fp32 exponent range
+    e[5::11] *= 1e-4
+    row = torch.randint(0, n, (rows,), device=DEV, dtype=torch.int32)
+    col = torch.randint(0, n, (rows,), device=DEV, dtype=torch.int32)
+    y = torch.cat([e, v[row.long()], v[col.long()]], 1).double()
+    lin = blk.edge_mlp._linears()
+    for li, l in enumerate(lin):
+        y = y @ l.weight.detach().double().T + l.bias.detach().double()
+        if li < len(lin) - 1:
+            y = torch.selu(y)
+    ln = blk.edge_mlp.MLP.layer_norm
+    ref = torch.nn.functional.layer_norm(y, (H,), ln.weight.double(), ln.bias.double(), ln.eps)
+    err = {}
+    old = ops.mlp_precision()
+    try:
+        for prec in ("fp32", "bf16x6", "bf16"):
+            ops.set_mlp_precision(prec)
+            out = blk.edge_mlp.run_coded([ops.Source(e), ops.Source(v, index=row), ops.Source(v, index=col)], rows)
+            d = (out.double() - ref).abs()
+            err[prec] = (d.max().item(), d.mean().item())
+    finally:
+        ops.set_mlp_precision(old)
+    assert err["fp32"][0] < 2e-5 and err["bf16x6"][0] < 2e-5, err
+    assert err["bf16x6"][0] <= 2.0 * err["fp32"][0] + 1e-6 and err["bf16x6"][1] <= 1.5 * err["fp32"][1] + 1e-7, err
+    assert 1e-3 < err["bf16"][0] < 2e-1, err
 
 
 def test_mp_chain_with_and_without_heads(monkeypatch):
