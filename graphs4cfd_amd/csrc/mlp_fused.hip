@@ -1799,7 +1799,7 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
 // FULL: every weighted input block and every additive block is exactly 128 wide and 16-byte aligned (the MP layers):
 // no column masks anywhere.
 template <int RT, bool VEC, bool FULL>
-__global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kernel(const Params p) {
+__global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kernel(const Params p) {
     constexpr int ROWS = 32 * RT, NW = 4;
     constexpr int PLN = ROWS * HB;              // one bf16 operand plane [ROWS][136]
     // three operand planes; the fp32 final tile [ROWS][132] aliases them
