@@ -1715,38 +1715,44 @@ __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6
                                               f32x16 (&acc)[RT]) {
     bf16x8 ah = *reinterpret_cast<const bf16x8 *>(pa), am = *reinterpret_cast<const bf16x8 *>(pa + plane),
            al = *reinterpret_cast<const bf16x8 *>(pa + 2 * plane);
+    // ROLLED over groups of RD6 steps (ring slots are compile-time inside a group): unrolling all 8 steps lets hipcc give
+    // every refill fresh registers, which costs a wave of occupancy
+    unsigned so = wofs + 2u * RD6 * STEP6;          // byte offset of the step that refills slot 0 (RD6 steps ahead)
+#pragma unroll 1
+    for (int j = 0; j < 8 / RD6; ++j) {
+        const __bf16 *pj = pa + j * RD6 * 16;
+        if (j == 8 / RD6 - 1) so = wofs + 2u * BLOCK6;      // the last group refills from the NEXT block's first steps
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int r = s % RD6;
+        for (int r = 0; r < RD6; ++r) {
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const int nt = (t + 1) % RT, ns = (t + 1 == RT) ? ((s + 1) & 7) : s;
-            const __bf16 *pn = pa + nt * 32 * HB + ns * 16;
-            const bf16x8 nh = (G4C_ABLATE & 64) ? ah : *reinterpret_cast<const bf16x8 *>(pn),
-                         nm = (G4C_ABLATE & 64) ? am : *reinterpret_cast<const bf16x8 *>(pn + plane),
-                         nl = (G4C_ABLATE & 64) ? al : *reinterpret_cast<const bf16x8 *>(pn + 2 * plane);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(G4C_ABLATE & 128)) {
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], al, acc[t], 0, 0, 0);     // small terms first
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.l[r], ah, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.m[r], am, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], am, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.m[r], ah, acc[t], 0, 0, 0);
-            } else {      // keep every operand live with one cheap VALU op instead of five MFMAs
-                acc[t][0] += (float)al[0] + (float)am[0] + (float)g.l[r][0] + (float)g.m[r][0];
+            for (int t = 0; t < RT; ++t) {
+                // next (row tile, step) item; after the last step of the block the prefetch wraps to step 0 (unused values)
+                const int nt = (t + 1) % RT, nr = (t + 1 == RT) ? r + 1 : r;
+                const __bf16 *pn = ((nr == RD6 && j == 8 / RD6 - 1) ? pa : pj + nr * 16) + nt * 32 * HB;
+                const bf16x8 nh = (G4C_ABLATE & 64) ? ah : *reinterpret_cast<const bf16x8 *>(pn),
+                             nm = (G4C_ABLATE & 64) ? am : *reinterpret_cast<const bf16x8 *>(pn + plane),
+                             nl = (G4C_ABLATE & 64) ? al : *reinterpret_cast<const bf16x8 *>(pn + 2 * plane);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(G4C_ABLATE & 128)) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], al, acc[t], 0, 0, 0);     // small terms first
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.l[r], ah, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.m[r], am, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], am, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.m[r], ah, acc[t], 0, 0, 0);
+                } else {      // keep every operand live with one cheap VALU op instead of five MFMAs
+                    acc[t][0] += (float)al[0] + (float)am[0] + (float)g.l[r][0] + (float)g.m[r][0];
+                }
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], ah, acc[t], 0, 0, 0);
+                if (t + 1 == RT && !(G4C_ABLATE & 32)) {
+                    g.h[r] = ldw(rs, lo_b, so + 2u * r * STEP6);
+                    g.m[r] = ldw(rs, lo_b + 1024u, so + 2u * r * STEP6);
+                    g.l[r] = ldw(rs, lo_b + 2048u, so + 2u * r * STEP6);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                ah = nh; am = nm; al = nl;
             }
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], ah, acc[t], 0, 0, 0);
-            if (t + 1 == RT && !(G4C_ABLATE & 32)) {
-                // slot r gets step s + RD6 (of this block, or of the next one: blocks are BLOCK6 apart; column tiles are
-                // 8 steps apart inside a block, so the next block's first steps are NOT contiguous with this one's last)
-                const unsigned so = wofs + 2u * (unsigned)(s + RD6 < 8 ? (s + RD6) * STEP6 : BLOCK6 + (s + RD6 - 8) * STEP6);
-                g.h[r] = ldw(rs, lo_b, so);
-                g.m[r] = ldw(rs, lo_b + 1024u, so);
-                g.l[r] = ldw(rs, lo_b + 2048u, so);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            ah = nh; am = nm; al = nl;
         }
+        so += 2u * RD6 * STEP6;
     }
 }
 
