@@ -29,6 +29,10 @@ HOIST_MIN_ROWS = int(os.environ.get("G4C_HOIST_MIN_ROWS", 24576))
 Tensor = torch.Tensor
 
 
+def _ld_of(t: Tensor) -> int:
+    return int(t.stride(0)) if t.dim() == 2 else int(t.numel())
+
+
 def _finish(x: Tensor, activation, code: Optional[int]) -> Tensor:
     """Apply an activation that could not be fused into the kernel epilogue."""
     return x if (activation is None or code is not None) else activation(x)
@@ -102,12 +106,14 @@ class MLP(nn.Module):
         return ops.mlp_forward(pk, sources, n_rows, act_code, **kw)
 
     def run_with_heads(self, sources: Sequence[Source], n_rows: int, act_code: int, consumer: "MLP", k_cols: int,
-                       widths: Sequence[int]) -> Optional[Tuple[Tensor, List[Tensor]]]:
+                       widths: Sequence[int], out: Optional[Tensor] = None,
+                       head_outs: Optional[Sequence[Optional[Tensor]]] = None) -> Optional[Tuple[Tensor, List[Tensor]]]:
         """This MLP on `sources`, plus — from the same launch — the first-layer products `consumer` will need from
         this MLP's output y: [W1c[:, a:b] y for consecutive column blocks [a, b) of `widths` after the first `k_cols`
         columns of consumer's first layer] (see MLP.run_hoisted; g4c_mlp_forward_heads).
         Returns None when the launch cannot carry heads (shape envelope / kernel variant): the caller then lets the
-        consumer compute its products itself."""
+        consumer compute its products itself.  `out` / `head_outs` (entries may be None): caller-provided [n_rows, 128]
+        destinations (row-sliced views of wider buffers are fine)."""
         if self.output_size != 128 or any(int(w) != 128 for w in widths) or not 1 <= len(widths) <= _lib.MAX_HEADS:
             return None
         prec = ops.effective_precision([s.width for s in sources])
@@ -134,8 +140,11 @@ class MLP(nn.Module):
         if prec == "fp32" and ops.mlp_mode(sources, n_rows) not in (324, 325):
             return None
         dev = sources[0].tensor.device
-        y = torch.empty((n_rows, 128), dtype=torch.float32, device=dev)
-        outs = [torch.empty((n_rows, 128), dtype=torch.float32, device=dev) for _ in widths]
+        y = out if out is not None else torch.empty((n_rows, 128), dtype=torch.float32, device=dev)
+        outs = [(head_outs[j] if head_outs is not None and head_outs[j] is not None else
+                 torch.empty((n_rows, 128), dtype=torch.float32, device=dev)) for j in range(len(widths))]
+        if any(_ld_of(t) != _ld_of(outs[0]) for t in outs):        # one leading dimension for all heads (g4c_mlp_forward_heads)
+            return None
         ops.mlp_forward(pk, sources, n_rows, act_code, out=y, head_outs=outs)
         return y, outs
 

@@ -256,14 +256,33 @@ class HipImpl:
         m.node_encoder.run_coded(srcs, mesh.n_own[0], SELU, out=v_out)
         return e
 
+    def hoists(self, n_edges: int) -> bool:
+        """Whether an MP layer with this many local edges multiplies its node-side first-layer terms per node
+        (MLP.run_hoisted) — then the halo exchange can carry those products instead of the latents."""
+        from .nn import blocks as _blocks
+        return n_edges >= _blocks.HOIST_MIN_ROWS and ops.mlp_precision() != "bf16"
+
     def mp(self, name: str, v: torch.Tensor, e: torch.Tensor, e_pending: int, edge_index: torch.Tensor, n_own: int,
-           v_out: torch.Tensor):
+           v_out: torch.Tensor, products=None, next_name: Optional[str] = None, pr_out: Optional[torch.Tensor] = None):
+        """One MP layer on the local sub-mesh.  `products` = (W1r v over own + halo rows, W1c v over own rows) when the
+        previous layer's node launch made them (and the halo rows of the first were exchanged): then `v`'s halo rows are
+        not read at all.  `next_name` / `pr_out`: also emit the NEXT layer's products from this layer's node launch
+        (own rows of `pr_out`, and a fresh tensor).  Returns (e', next products or None)."""
         blk = getattr(self.m, name)
         ep, csr = plan.edge_csr(edge_index, n_own)
-        e_new = blk.edge_mlp.run_hoisted([Source(e, pre_act=e_pending)], [(v, ep.row), (v, ep.col)], ep.n_edges)
+        e_new = blk.edge_mlp.run_hoisted([Source(e, pre_act=e_pending)], [(v, ep.row), (v, ep.col)], ep.n_edges,
+                                         products=products)
         agg = ops.segment_reduce(e_new, csr, blk.aggr == "mean")
-        blk.node_mlp.run_coded([Source(agg), Source(v[:n_own])], n_own, SELU, out=v_out)
-        return e_new
+        srcs = [Source(agg), Source(v[:n_own])]
+        if next_name is not None and pr_out is not None:
+            nxt = getattr(self.m, next_name).edge_mlp
+            w = int(v.size(1))
+            res = blk.node_mlp.run_with_heads(srcs, n_own, SELU, nxt, nxt.input_size - 2 * w, [w, w],
+                                              out=v_out, head_outs=[pr_out[:n_own], None])
+            if res is not None:
+                return e_new, (pr_out, res[1][1])
+        blk.node_mlp.run_coded(srcs, n_own, SELU, out=v_out)
+        return e_new, None
 
     def down(self, name: str, v_own: torch.Tensor, rel: torch.Tensor, parent: torch.Tensor, n_coarse: int, e: torch.Tensor,
              e_pending: int, pool_csr, v_out: torch.Tensor):
@@ -302,9 +321,11 @@ class MusPartitionedForward:
         e = impl.encode(m, v[: m.n_own[0]])
         e_pending = NONE
         stash = []
-        for name in self.program:
+        prod = None               # (W1r v [own + halo rows], W1c v [own rows]) of the next MP layer, when already multiplied
+        for k, name in enumerate(self.program):
             n_own = m.n_own[level - 1]
             if name.startswith("down_mp"):
+                prod = None
                 stash.append((v, e, e_pending))
                 v_c = self._buf(level + 1)
                 e = impl.down(name, v[:n_own], m.rel[level - 1], m.parent[level - 1], m.n_own[level], e, e_pending,
@@ -312,15 +333,25 @@ class MusPartitionedForward:
                 v, e_pending = v_c, NONE
                 level += 1
             elif name.startswith("up_mp"):
+                prod = None
                 v_old, e, e_pending = stash.pop()
                 level -= 1
                 v_f = self._buf(level)
                 impl.up(name, v, v_old[: m.n_own[level - 1]], m.rel[level - 1], m.parent[level - 1], v_f[: m.n_own[level - 1]])
                 v = v_f
             else:
-                self.xch.exchange(v, level)
+                # products ride on the previous layer's node launch when this layer hoists its first layer: then the halo
+                # exchange carries W1r v (same size) and the latents of the halo rows are never needed
+                if prod is not None:
+                    self.xch.exchange(prod[0], level)
+                else:
+                    self.xch.exchange(v, level)
                 v_new = self._buf(level)
-                e = impl.mp(name, v, e, e_pending, m.edge_index[level - 1], n_own, v_new[:n_own])
+                nxt = self.program[k + 1] if k + 1 < len(self.program) else ""
+                n_edges = int(m.edge_index[level - 1].size(1))
+                want_next = nxt.startswith("mp") and impl.hoists(n_edges)
+                e, prod = impl.mp(name, v, e, e_pending, m.edge_index[level - 1], n_own, v_new[:n_own], products=prod,
+                                  next_name=nxt if want_next else None, pr_out=self._buf(level) if want_next else None)
                 v, e_pending = v_new, SELU
         return impl.decode(v[: m.n_own[0]], m.inputs["field"], self.nf)
 

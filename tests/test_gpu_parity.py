@@ -493,11 +493,16 @@ def test_errors():
 
 
 # ------------------------------------------------------------------ node partition on the HIP back-end
-def test_partitioned_hip_forward_two_ranks_in_process():
+@pytest.mark.parametrize("hoist_min_rows", [None, 0])
+def test_partitioned_hip_forward_two_ranks_in_process(hoist_min_rows, monkeypatch):
     """Two 'ranks' on the one GPU of the test box, as two threads with an in-process halo exchange
-    (the RCCL path differs only in the transport; the partition / gloo exchange is tested on CPU)."""
+    (the RCCL path differs only in the transport; the partition / gloo exchange is tested on CPU).
+    hoist_min_rows = 0: every MP layer hoists, so consecutive layers exchange the halo rows of W1r v (emitted by the
+    previous layer's node launch) instead of the latents."""
     import threading
     from graphs4cfd_amd import partition as P
+    if hoist_min_rows is not None:
+        monkeypatch.setattr(B, "HOIST_MIN_ROWS", hoist_min_rows)
     world, levels = 2, 3
     g = S.mus_graph(4000, levels=levels, seed=12)
     torch.manual_seed(13)
@@ -570,6 +575,8 @@ def test_distributed_rollout_two_processes_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "scripts", "dist_check.py"), "--backend", "gloo", "--same-gpu",
            "--nodes", "12000", "--steps", "3"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "max|partitioned - single|" in out.stdout
+    # G4C_HOIST_MIN_ROWS=0: every MP layer hoists, i.e. the halo exchange carries the first-layer products (partition.py)
+    for env in (dict(os.environ), dict(os.environ, G4C_HOIST_MIN_ROWS="0")):
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        assert "max|partitioned - single|" in out.stdout

@@ -46,8 +46,8 @@ def test_partition_invariants():
 class OracleImpl:
     """Test-only arithmetic back-end for MusPartitionedForward (CPU, oracle ops)."""
 
-    def __init__(self, w):
-        self.w = w
+    def __init__(self, w, use_products=False):
+        self.w, self.use_products = w, use_products
 
     def new(self, rows, width, device):
         return torch.zeros(rows, width)
@@ -61,12 +61,38 @@ class OracleImpl:
     def _act(e, pending):
         return F.selu(e) if pending else e
 
-    def mp(self, name, v, e, e_pending, edge_index, n_own, v_out):
+    def hoists(self, n_edges):
+        """Product exchange (MusPartitionedForward): on for this back-end iff `use_products`."""
+        return self.use_products
+
+    def _mlp_tail(self, h, prefix):
+        """O.mlp from after its first Linear: (SELU, Linear)*, LayerNorm."""
+        n = 1
+        while f"{prefix}.MLP.linear_{n + 1}.weight" in self.w:
+            n += 1
+        x = h
+        for i in range(2, n + 1):
+            x = F.linear(F.selu(x), self.w[f"{prefix}.MLP.linear_{i}.weight"], self.w[f"{prefix}.MLP.linear_{i}.bias"])
+        g = self.w.get(f"{prefix}.MLP.layer_norm.weight")
+        return x if g is None else F.layer_norm(x, (x.size(-1),), g, self.w[f"{prefix}.MLP.layer_norm.bias"], 1e-5)
+
+    def mp(self, name, v, e, e_pending, edge_index, n_own, v_out, products=None, next_name=None, pr_out=None):
         row, col = edge_index
-        e_new = O.mlp(torch.cat((self._act(e, e_pending), v[row], v[col]), 1), self.w, f"{name}.edge_mlp")
+        H = v.size(1)
+        if products is None:
+            e_new = O.mlp(torch.cat((self._act(e, e_pending), v[row], v[col]), 1), self.w, f"{name}.edge_mlp")
+        else:       # W1 [e | v_row | v_col] = W1e e + (W1r v)[row] + (W1c v)[col]; the halo rows of W1r v were exchanged
+            W1, b1 = self.w[f"{name}.edge_mlp.MLP.linear_1.weight"], self.w[f"{name}.edge_mlp.MLP.linear_1.bias"]
+            h = self._act(e, e_pending) @ W1[:, :-2 * H].T + products[0][row] + products[1][col] + b1
+            e_new = self._mlp_tail(h, f"{name}.edge_mlp")
         agg = O.scatter(e_new, col, n_own, "mean")
         v_out.copy_(F.selu(O.mlp(torch.cat((agg, v[:n_own]), 1), self.w, f"{name}.node_mlp")))
-        return e_new
+        nxt = None
+        if next_name is not None and pr_out is not None:
+            Wn = self.w[f"{next_name}.edge_mlp.MLP.linear_1.weight"]
+            pr_out[:n_own] = v_out @ Wn[:, -2 * H:-H].T
+            nxt = (pr_out, v_out @ Wn[:, -H:].T)
+        return e_new, nxt
 
     def down(self, name, v_own, rel, parent, n_coarse, e, e_pending, pool_csr, v_out):
         msg = O.mlp(torch.cat((rel, v_own), 1), self.w, f"{name}.down_mlp")
@@ -81,7 +107,7 @@ class OracleImpl:
         return field[:, -nf:] + O.mlp(v_own, self.w, "node_decoder")
 
 
-def _worker(rank, world, port, model_name, levels, out_dir):
+def _worker(rank, world, port, model_name, levels, out_dir, use_products):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -95,7 +121,7 @@ def _worker(rank, world, port, model_name, levels, out_dir):
         w = {k: v.detach() for k, v in model.state_dict().items()}
         parts = P.build_partition(g, levels, world)
         mesh = P.LocalMesh(g, levels, parts[rank], torch.device("cpu"), rank, world)
-        fwd = P.MusPartitionedForward(model._PROGRAM, mesh, OracleImpl(w), P.HaloExchanger(mesh), 32, 3)
+        fwd = P.MusPartitionedForward(model._PROGRAM, mesh, OracleImpl(w, use_products), P.HaloExchanger(mesh), 32, 3)
         with torch.no_grad():
             pred = fwd.forward()
         full = torch.zeros(g.pos.size(0), 3)
@@ -109,11 +135,13 @@ def _worker(rank, world, port, model_name, levels, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model_name,levels", [("NsThreeScaleGNN", 3), ("NsOneScaleGNN", 1)])
-def test_partitioned_forward_matches_global_on_two_gloo_ranks(tmp_path, model_name, levels):
+@pytest.mark.parametrize("model_name,levels,use_products", [("NsThreeScaleGNN", 3, False), ("NsOneScaleGNN", 1, False),
+                                                            ("NsThreeScaleGNN", 3, True)])
+def test_partitioned_forward_matches_global_on_two_gloo_ranks(tmp_path, model_name, levels, use_products):
+    """`use_products`: consecutive MP layers exchange the halo rows of W1r v (made by the previous layer) instead of v."""
     import torch.multiprocessing as mp
-    port = 29600 + (os.getpid() % 300) + levels
-    mp.spawn(_worker, args=(2, port, model_name, levels, str(tmp_path)), nprocs=2, join=True)
+    port = 29600 + (os.getpid() % 300) + levels + 7 * int(use_products)
+    mp.spawn(_worker, args=(2, port, model_name, levels, str(tmp_path), use_products), nprocs=2, join=True)
     r = torch.load(os.path.join(str(tmp_path), "result.pt"))
     assert all(h > 0 for h in r["halo"][0]), "the test mesh must actually have halos on every level"
     torch.testing.assert_close(r["full"], r["ref"], rtol=1e-4, atol=1e-4)
