@@ -213,6 +213,7 @@ class HaloExchanger:
     def __init__(self, mesh: LocalMesh, group=None):
         self.mesh, self.group = mesh, group
         self._send_buf: Dict[tuple, torch.Tensor] = {}
+        self._send_cat: Dict[int, Optional[torch.Tensor]] = {}
 
     def exchange(self, v: torch.Tensor, level: int) -> None:
         m = self.mesh
@@ -225,15 +226,16 @@ class HaloExchanger:
         buf = self._send_buf.get(key)
         if buf is None:
             buf = self._send_buf[key] = torch.empty((max(n_send, 1), width), dtype=v.dtype, device=v.device)
-        off = 0
-        for q, idx in enumerate(m.send_idx32[level - 1]):
-            k = m.send_counts[level - 1][q]
-            if k:
-                if v.is_cuda:
-                    ops.copy_cols(v, buf[off:off + k], 0, scol0=0, width=width, idx32=idx, n_rows=k)
-                else:   # CPU tests (gloo): host logic only
-                    buf[off:off + k] = v[idx.long()]
-                off += k
+        # one pack launch: the per-peer send lists are concatenated in peer order (= the order all_to_all_single splits)
+        cat = self._send_cat.get(level)
+        if cat is None:
+            parts = [idx for q, idx in enumerate(m.send_idx32[level - 1]) if m.send_counts[level - 1][q]]
+            cat = self._send_cat[level] = torch.cat(parts) if parts else None
+        if n_send:
+            if v.is_cuda:
+                ops.copy_cols(v, buf[:n_send], 0, scol0=0, width=width, idx32=cat, n_rows=n_send)
+            else:   # CPU tests (gloo): host logic only
+                buf[:n_send] = v[cat.long()]
         recv = v[m.n_own[level - 1]:]
         dist.all_to_all_single(recv, buf[:n_send], output_split_sizes=m.recv_counts[level - 1],
                                input_split_sizes=m.send_counts[level - 1], group=self.group)
