@@ -97,6 +97,11 @@ struct Params {
     int n_heads;
     float *head_out[G4C_MAX_HEADS];
     int head_ld;
+    // fused aggregation (bf16x6 kernel): tiles of whole CSR segments (g4c_plan_tiles) instead of fixed 32-row tiles; after
+    // the store, the tile's segments are summed / averaged from the LDS copy of the output rows into agg[segment, :]
+    const int *tile_rows, *tile_seg, *seg_off;
+    float *agg;
+    int agg_ld, agg_mean;
 };
 
 template <int RT> struct Acc { f32x16 t[RT][4]; };
@@ -651,7 +656,9 @@ __device__ __forceinline__ void mma_chunk_n(const float *pa, RingN<NCT> &g, cons
 // LayerNorm / activation / store of a finished 32-row tile held in sH; rows split over the NW waves of the workgroup.
 // Shared by the column-split kernels.  Needs: all waves' last-layer columns visible in sH (barrier done by the caller).
 template <int NW, int ROWS = 32>
-__device__ __forceinline__ void split_finish(const Params &p, float *sH, const float *sGB, int wave, int lane, long long row0) {
+__device__ __forceinline__ void split_finish(const Params &p, float *sH, const float *sGB, int wave, int lane, long long row0,
+                                             long long mlim = -1) {
+    if (mlim < 0) mlim = p.M;          // rows >= mlim are not stored (mlim < p.M: tiles of whole segments)
     const int i = lane & 31, h = lane >> 5;
     // ---------------------------------------------------------------- LayerNorm / activation: rows split over the waves
     // wave w owns rows [w*RPW, (w+1)*RPW); lane = part * RPW + row_local, each part = NC consecutive columns
@@ -722,7 +729,7 @@ __device__ __forceinline__ void split_finish(const Params &p, float *sH, const f
         for (int r = h; r < RPW; r += 2) {
             const int row = wave * RPW + r;
             const long long grow = row0 + row;
-            if (grow < p.M) {
+            if (grow < mlim) {
                 const long long orow = p.out_idx ? p.out_idx[grow] : grow;
                 const f32x4 t = *reinterpret_cast<const f32x4 *>(sH + row * HS + 4 * i);
                 *reinterpret_cast<f32x4 *>(p.out + orow * p.out_ld + 4 * i) = t;
@@ -733,7 +740,7 @@ __device__ __forceinline__ void split_finish(const Params &p, float *sH, const f
             const int r = e / n_out, c = e - r * n_out;
             const int row = wave * RPW + r;
             const long long grow = row0 + row;
-            if (grow < p.M) {
+            if (grow < mlim) {
                 const long long orow = p.out_idx ? p.out_idx[grow] : grow;
                 float y = sH[row * HS + c];
                 if (p.resid) y += p.resid[grow * p.resid_ld + p.resid_col0 + c];
@@ -1770,22 +1777,40 @@ __device__ __forceinline__ f32x4 selu4(f32x4 x) {
     return m * scale + (t * sa - sa);
 }
 
-// exact three-way bf16 split of four fp32 values (vector subtractions -> v_pk_add_f32)
+// exact three-way bf16 split of four fp32 values.  Two values at a time: ONE v_cvt_pk_bf16_f32 gives both bf16 terms, and
+// their fp32 values come back with a shift / a mask of that packed word (instead of one extra conversion per element);
+// the remainders are vector subtractions (v_pk_add_f32).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(f32x2 x, f32x2 &back) {
+    bf16x2 b;
+    b[0] = (__bf16)x[0]; b[1] = (__bf16)x[1];
+    const unsigned u = __builtin_bit_cast(unsigned, b);
+    back[0] = __builtin_bit_cast(float, u << 16);
+    back[1] = __builtin_bit_cast(float, u & 0xffff0000u);
+    return u;
+}
 __device__ __forceinline__ void split3x4(f32x4 x, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
     if (G4C_ABLATE & 512) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { h[e] = (__bf16)x[e]; m[e] = h[e]; l[e] = h[e]; }
         return;
     }
-    f32x4 hf, mf;
+    unsigned hu[2], mu[2], lu[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { h[e] = (__bf16)x[e]; hf[e] = (float)h[e]; }
-    const f32x4 r1 = x - hf;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { m[e] = (__bf16)r1[e]; mf[e] = (float)m[e]; }
-    const f32x4 r2 = r1 - mf;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) l[e] = (__bf16)r2[e];
+    for (int j = 0; j < 2; ++j) {
+        f32x2 v, hf, mf, lf;
+        v[0] = x[2 * j]; v[1] = x[2 * j + 1];
+        hu[j] = pack_bf16(v, hf);
+        const f32x2 r1 = v - hf;
+        mu[j] = pack_bf16(r1, mf);
+        const f32x2 r2 = r1 - mf;
+        lu[j] = pack_bf16(r2, lf);
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 hh, mm, ll;
+    hh[0] = hu[0]; hh[1] = hu[1]; mm[0] = mu[0]; mm[1] = mu[1]; ll[0] = lu[0]; ll[1] = lu[1];
+    h = __builtin_bit_cast(bf16x4, hh); m = __builtin_bit_cast(bf16x4, mm); l = __builtin_bit_cast(bf16x4, ll);
 }
 
 // exact three-way bf16 split of an fp32 value
@@ -1831,7 +1856,8 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
         const int q = nt >> 3, r = nt & 7, x = b & 7, j = b >> 3;
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
-    const long long row0 = p.row_base + (long long)tile * ROWS;
+    long long row0 = p.row_base + (long long)tile * ROWS, mlim = p.M;
+    if (p.tile_rows) { row0 = p.tile_rows[tile]; mlim = p.tile_rows[tile + 1]; }      // tile of whole segments (<= ROWS rows)
     G4C_STAMPW(0);
 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, 0x7fffffff, 0x00020000);
@@ -1848,7 +1874,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             long long gr;
-            if (direct) { gr = row0 + grow_l + 32 * t; if (gr >= p.M) gr = p.M - 1; }
+            if (direct) { gr = row0 + grow_l + 32 * t; if (gr >= mlim) gr = mlim - 1; }
             else gr = sRow[sidx * ROWS + grow_l + 32 * t];
             const float *rp = p.src[sidx].ptr + gr * p.src[sidx].ld + p.src[sidx].col0;
 #pragma unroll
@@ -1902,7 +1928,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
         const int e = tid + it * 64 * NW;
         const int slot = e / ROWS, r = e % ROWS;
         long long gr = row0 + r;
-        if (gr >= p.M) gr = p.M - 1;
+        if (gr >= mlim) gr = mlim - 1;
         const int *ix = nullptr;
         if (slot < G4C_MAX_SRC) { if (slot < p.n_src) ix = p.src[slot].idx; }
         else { if (slot - G4C_MAX_SRC < p.n_add) ix = p.add[slot - G4C_MAX_SRC].idx; }
@@ -2052,8 +2078,22 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
         G4C_STAMPW(6 + 2 * l);
     }
     G4C_STAMPW(12);
-    split_finish<NW, ROWS>(p, sH, sGB, wave, lane, row0);
+    split_finish<NW, ROWS>(p, sH, sGB, wave, lane, row0, mlim);
     G4C_STAMPW(13);
+    if (p.agg) {
+        // aggregation of the targets whose messages this tile holds (rows in CSR order): same summation order and the
+        // same mean formula as segment_reduce_kernel, so the result is bit-identical to the separate launch
+        __syncthreads();
+        const int s0 = p.tile_seg[tile], s1 = p.tile_seg[tile + 1];
+        const int col = tid & (NP - 1);
+        for (int sg = s0 + (tid >> 7); sg < s1; sg += (64 * NW) >> 7) {
+            const int b = p.seg_off[sg] - (int)row0, e = p.seg_off[sg + 1] - (int)row0;
+            float a = 0.f;
+            for (int r = b; r < e; ++r) a += sH[r * HS + col];
+            if (p.agg_mean) a /= (float)((e - b) > 1 ? (e - b) : 1);
+            p.agg[(long long)sg * p.agg_ld + col] = a;
+        }
+    }
     if (p.n_heads) {
         // heads (see Params): the finished fp32 tile -> three operand planes (they alias it: read everything, barrier,
         // then overwrite), then one 128-k block per head whose weights continue the stream
@@ -2087,7 +2127,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 const long long grow = row0 + i + 32 * t;
-                if (grow < p.M) {
+                if (grow < mlim) {
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         f32x4 x;
@@ -2256,11 +2296,19 @@ extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int3
     return rc;
 }
 
+struct AggArgs {           // fused aggregation (g4c_mlp_forward_bx6_agg); all null / 0 otherwise
+    const int32_t *tile_rows, *tile_seg, *seg_off;
+    int32_t n_tiles;
+    float *out;
+    int32_t out_ld, mean;
+};
+
 static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                       int64_t row_begin, int64_t row_count, int32_t tile_rows,
                       float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                       const float *resid, int32_t resid_ld, int32_t resid_col0,
-                      const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream);
+                      const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream,
+                      const AggArgs *agg = nullptr);
 
 extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                     int64_t row_begin, int64_t row_count, int32_t tile_rows,
@@ -2295,6 +2343,16 @@ extern "C" int g4c_mlp_forward_heads_bx6(const g4c_mlp_t *mlp, const g4c_src_t *
                       (const float *)head_w, n_heads, head_out, head_ld, stream);
 }
 
+extern "C" int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                                       float *out, int32_t out_ld, int32_t act,
+                                       const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,
+                                       float *agg, int32_t agg_ld, int32_t agg_mean, void *stream) {
+    G4C_REQUIRE(tile_rows && tile_seg && seg_off && agg && n_tiles >= 0 && agg_ld >= NP, G4C_EINVAL, "g4c_mlp_forward_bx6_agg: bad aggregation plan");
+    const AggArgs a{tile_rows, tile_seg, seg_off, n_tiles, agg, agg_ld, agg_mean};
+    return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3248, out, out_ld, nullptr, act, nullptr, 0, 0,
+                      nullptr, 0, nullptr, 0, stream, &a);
+}
+
 extern "C" int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                    float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                                    const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream) {
@@ -2306,7 +2364,8 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
                       int64_t row_begin, int64_t row_count, int32_t tile_rows,
                       float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                       const float *resid, int32_t resid_ld, int32_t resid_col0,
-                      const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream) {
+                      const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream,
+                      const AggArgs *agg) {
     const bool bx6 = (tile_rows == 3248);       // weights: the three-plane stream of g4c_mlp_pack_layer_bx6
     const bool bf16 = (tile_rows == 3216) || bx6;   // 2-byte stream(s), input blocks padded to 128 k
     const int wbytes = bx6 ? 6 : (bf16 ? 2 : 4);
@@ -2375,6 +2434,12 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     p.M = n_rows;
     p.out = out; p.out_ld = out_ld; p.out_idx = out_idx; p.act = act;
     p.resid = resid; p.resid_ld = resid_ld; p.resid_col0 = resid_col0;
+    p.tile_rows = p.tile_seg = p.seg_off = nullptr; p.agg = nullptr; p.agg_ld = 0; p.agg_mean = 0;
+    if (agg) {
+        G4C_REQUIRE(bx6 && mlp->n_out == NP && !out_idx && !resid, G4C_EUNSUPPORTED, "g4c_mlp_forward_bx6_agg: needs the bf16x6 kernel and a plain 128-wide output");
+        p.tile_rows = agg->tile_rows; p.tile_seg = agg->tile_seg; p.seg_off = agg->seg_off;
+        p.agg = agg->out; p.agg_ld = agg->out_ld; p.agg_mean = agg->mean;
+    }
     p.n_heads = n_heads; p.head_ld = head_ld;
     for (int hd = 0; hd < G4C_MAX_HEADS; ++hd) p.head_out[hd] = hd < n_heads ? head_out[hd] : nullptr;
     if (n_heads) {
@@ -2411,7 +2476,13 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         for (int a = 0; a < p.n_add; ++a)
             full = full && p.add[a].width == NP && (p.add[a].ld & 3) == 0 && ((uintptr_t)p.add[a].ptr & 15) == 0;
         const dim3 blk(256);
-        if (row_count >= rt2_rows) {       // 64-row tiles (tuning only)
+        if (agg) {                          // tiles of whole segments, at most 32 rows each
+            p.n_tiles = agg->n_tiles;
+            if (p.n_tiles == 0) return G4C_OK;
+            if (full) mlp_bx6_kernel<1, true, true><<<dim3(p.n_tiles), blk, 0, st>>>(p);
+            else if (all_vec) mlp_bx6_kernel<1, true, false><<<dim3(p.n_tiles), blk, 0, st>>>(p);
+            else mlp_bx6_kernel<1, false, false><<<dim3(p.n_tiles), blk, 0, st>>>(p);
+        } else if (row_count >= rt2_rows) {       // 64-row tiles (tuning only)
             p.n_tiles = (int)((row_count + 63) / 64);
             if (full) mlp_bx6_kernel<2, true, true><<<dim3(p.n_tiles), blk, 0, st>>>(p);
             else if (all_vec) mlp_bx6_kernel<2, true, false><<<dim3(p.n_tiles), blk, 0, st>>>(p);

@@ -29,6 +29,31 @@ extern "C" int g4c_plan_csr(const int64_t *keys, int64_t n, int64_t n_seg, int32
     return G4C_OK;
 }
 
+// Tiles of whole segments: tile t covers segments [tile_seg[t], tile_seg[t+1]) = rows [tile_rows[t], tile_rows[t+1]), at
+// most max_rows rows (greedy, in order; empty segments ride along).  Lets the edge-MLP kernel reduce the messages of the
+// targets it has just computed (g4c_mlp_forward_bx6_agg).  Returns the tile count, -1 if a segment exceeds max_rows (then
+// the caller keeps the separate g4c_segment_reduce launch), or a negative G4C_E* code.
+extern "C" int64_t g4c_plan_tiles(const int32_t *off, int32_t n_seg, int32_t max_rows, int32_t *tile_rows, int32_t *tile_seg,
+                                  int64_t capacity) {
+    G4C_REQUIRE(off && tile_rows && tile_seg && n_seg >= 0 && max_rows > 0 && capacity >= 1, G4C_EINVAL, "g4c_plan_tiles: bad arguments");
+    int64_t nt = 0;
+    int32_t s = 0;
+    tile_rows[0] = off[0];
+    tile_seg[0] = 0;
+    while (s < n_seg) {
+        const int32_t r0 = off[s];
+        int32_t e = s;
+        while (e < n_seg && off[e + 1] - r0 <= max_rows) ++e;
+        if (e == s) return -1;                          // one segment alone is larger than a tile
+        G4C_REQUIRE(nt + 1 < capacity, G4C_EINVAL, "g4c_plan_tiles: capacity %lld too small", (long long)capacity);
+        ++nt;
+        tile_rows[nt] = off[e];
+        tile_seg[nt] = e;
+        s = e;
+    }
+    return nt;
+}
+
 extern "C" int64_t g4c_plan_pool_edge(const int64_t *idx_hr_to_lr, int64_t n_hr, const int64_t *edge_index,
                                       int64_t n_edges, int64_t *coarse_edge_index, int32_t *perm, int32_t *off,
                                       int64_t *n_kept) {

@@ -284,9 +284,11 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
         raise ValueError(f"unsupported aggr {aggr!r}")
     ep, csr = plan.edge_csr(index, int(v.size(0)))
     senders = v if v_src is None else v_src
+    # the aggregation rides on the edge launch when the kernel can reduce the tile it has just computed
+    # (ops.mlp_forward(agg=...)); otherwise that call runs g4c_segment_reduce right after the launch
+    agg = torch.empty((csr.n_seg, msg_mlp.output_size), dtype=torch.float32, device=e.device)
     e_new = msg_mlp.run_hoisted([Source(e, pre_act=e_pre_act)], [(senders, ep.row), (v, ep.col)], ep.n_edges,
-                                products=products)
-    agg = ops.segment_reduce(e_new, csr, aggr == "mean")
+                                products=products, agg=(csr, agg, aggr == "mean"))
     if next_msg is not None:
         nxt = None
         if ep.n_edges >= HOIST_MIN_ROWS:     # the consumer will hoist: give it its node-side terms from this launch

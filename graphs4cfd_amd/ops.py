@@ -192,6 +192,13 @@ def rollout_advance(field: Tensor, pred: Tensor, outputs: Tensor, step: Tensor, 
 _PRECISION = os.environ.get("G4C_MLP_PRECISION", "bf16x6")
 
 
+# Fused aggregation in the edge-MLP launch (g4c_mlp_forward_bx6_agg).  Bit-identical to the separate g4c_segment_reduce, but
+# the launch then runs on tiles of WHOLE segments: with in-degree 6 (or 5) a 32-row tile holds 30 rows, i.e. 6.7 % more tiles,
+# which eats what the saved HBM pass gains (measured +0.8 % on the 100k-node rollout).  Off by default; worth it when the
+# degree divides 32.
+FUSE_AGG = os.environ.get("G4C_FUSE_AGG", "0") == "1"
+
+
 def mlp_precision() -> str:
     return _PRECISION
 
@@ -320,10 +327,12 @@ def mlp_mode(sources: Sequence[Source], n_rows: int) -> int:
 def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: int = _lib.ACT_NONE,
                 out: Optional[Tensor] = None, out_idx32: Optional[Tensor] = None,
                 resid: Optional[Tensor] = None, resid_col0: int = 0, tile_mode: Optional[int] = None,
-                head_outs: Optional[Sequence[Tensor]] = None) -> Tensor:
+                head_outs: Optional[Sequence[Tensor]] = None, agg: Optional[Tuple[CsrPlan, Tensor, bool]] = None) -> Tensor:
     """One fused MLP launch (g4c_mlp_forward).  `tile_mode` (tests / tuning) runs every row through
     g4c_mlp_forward_rows with that kernel variant instead of the library's own choice.
-    `head_outs` ([n_rows, 128] tensors, one per head of `packed`): g4c_mlp_forward_heads."""
+    `head_outs` ([n_rows, 128] tensors, one per head of `packed`): g4c_mlp_forward_heads.
+    `agg` = (csr, out [n_seg, 128], mean): also aggregate the output rows over the segments of `csr` (rows must be in segment
+    order) — inside the launch when the kernel can (g4c_mlp_forward_bx6_agg), otherwise with a g4c_segment_reduce afterwards."""
     lib = _lib.load()
     dev = _lib.require_hip(*[s.tensor for s in sources], *[s.index for s in sources], out, out_idx32, resid)
     if dev != packed.device:
@@ -335,7 +344,25 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
         out = torch.empty((n_rows, packed.n_out), dtype=torch.float32, device=dev)
     args = (_lib.ptr(out), _ld(out), _lib.ptr(out_idx32), act, _lib.ptr(resid), _ld(resid) if resid is not None else 0,
             resid_col0, _lib.stream_handle(dev))
-    if packed.precision != "fp32":
+    if agg is not None:
+        csr, agg_out, agg_mean = agg
+        tiles = csr.tiles() if (FUSE_AGG and packed.precision == "bf16x6" and packed.n_out == 128 and head_outs is None and tile_mode is None
+                                and out_idx32 is None and resid is None and n_rows == csr.n) else None
+        if tiles is None:        # not fusable here: the plain launch, then the separate reduction
+            y = mlp_forward(packed, sources, n_rows, act, out, out_idx32, resid, resid_col0, tile_mode, head_outs)
+            segment_reduce(y, csr, agg_mean, out=agg_out)
+            return y
+        _lib.require_hip(agg_out)
+        t_rows, t_seg, nt = tiles
+        call = lambda: _lib.check(lib.g4c_mlp_forward_bx6_agg(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out), _ld(out), act,
+                                                              _lib.ptr(t_rows), _lib.ptr(t_seg), _lib.ptr(csr.off), nt, _lib.ptr(agg_out),
+                                                              _ld(agg_out), 1 if agg_mean else 0, _lib.stream_handle(dev)))
+        if KernelTimer.active is None:
+            call()
+        else:
+            _timed("mlp_bx6_kernel", packed.flops_per_row * n_rows,
+                   4.0 * ((sum(packed.seg_widths) + packed.n_out) * n_rows + packed.n_out * csr.n_seg), call)
+    elif packed.precision != "fp32":
         if tile_mode is not None or (head_outs is not None and packed.precision == "bf16"):
             raise NotImplementedError("bf16 MLP with a forced tile mode / plain bf16 with heads")
         if head_outs is not None:

@@ -272,9 +272,9 @@ class HipImpl:
         (own rows of `pr_out`, and a fresh tensor).  Returns (e', next products or None)."""
         blk = getattr(self.m, name)
         ep, csr = plan.edge_csr(edge_index, n_own)
+        agg = torch.empty((csr.n_seg, blk.edge_mlp.output_size), dtype=torch.float32, device=e.device)
         e_new = blk.edge_mlp.run_hoisted([Source(e, pre_act=e_pending)], [(v, ep.row), (v, ep.col)], ep.n_edges,
-                                         products=products)
-        agg = ops.segment_reduce(e_new, csr, blk.aggr == "mean")
+                                         products=products, agg=(csr, agg, blk.aggr == "mean"))
         srcs = [Source(agg), Source(v[:n_own])]
         if next_name is not None and pr_out is not None:
             nxt = getattr(self.m, next_name).edge_mlp

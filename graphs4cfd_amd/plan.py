@@ -32,6 +32,24 @@ class CsrPlan:
     n: int
     n_seg: int
     max_deg: int
+    _tiles: object = False         # cache of tiles(): False = not built yet, None = not tileable
+
+    def tiles(self, max_rows: int = 32):
+        """(tile_rows int32 [T+1], tile_seg int32 [T+1], T) on the device: tiles of whole segments of at most `max_rows`
+        rows (g4c_plan_tiles), for the edge-MLP launch that also aggregates (ops.mlp_forward(agg=...)); None when the rows
+        are not in segment order or a segment is longer than a tile."""
+        if self._tiles is False:
+            self._tiles = None
+            if self.perm is None and self.n > 0 and 0 < self.max_deg <= max_rows:
+                lib = _lib.load()
+                off = np.ascontiguousarray(self.off.detach().cpu().numpy().astype(np.int32))
+                cap = self.n_seg + 2
+                rows, seg = np.empty(cap, np.int32), np.empty(cap, np.int32)
+                nt = int(lib.g4c_plan_tiles(off.ctypes.data, self.n_seg, max_rows, rows.ctypes.data, seg.ctypes.data, cap))
+                if nt > 0:
+                    dev = self.off.device
+                    self._tiles = (torch.from_numpy(rows[: nt + 1].copy()).to(dev), torch.from_numpy(seg[: nt + 1].copy()).to(dev), nt)
+        return self._tiles
 
 
 @dataclass

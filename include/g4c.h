@@ -177,6 +177,18 @@ int g4c_mlp_pack_layer_bx6(const float *W, int32_t n_out, int32_t k_in, const in
 int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
                         int64_t n_rows, float *out, int32_t out_ld, const int32_t *out_idx,
                         int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
+/* Edge MLP + aggregation in one launch.  g4c_plan_tiles (host) cuts the CSR-ordered rows into tiles of whole segments
+ * (<= max_rows rows; -1 if a segment is longer): tile t = segments [tile_seg[t], tile_seg[t+1]) = rows
+ * [tile_rows[t], tile_rows[t+1]).  g4c_mlp_forward_bx6_agg runs the MLP on those tiles (max_rows must be 32) and, from
+ * the on-chip copy of each tile's output rows, writes agg[s, :] = sum or mean (agg_mean) of the rows of segment s —
+ * same order and formula as g4c_segment_reduce, i.e. the `scatter(e', col, reduce)` of nn/blocks.py:183 without
+ * re-reading e' from HBM.  tile_rows / tile_seg / seg_off are device int32 arrays. */
+int64_t g4c_plan_tiles(const int32_t *off /*host*/, int32_t n_seg, int32_t max_rows, int32_t *tile_rows /*host, out*/,
+                       int32_t *tile_seg /*host, out*/, int64_t capacity);
+int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
+                            int64_t n_rows, float *out, int32_t out_ld, int32_t act,
+                            const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,
+                            float *agg, int32_t agg_ld, int32_t agg_mean, void *stream);
 /* g4c_mlp_forward_heads for the bf16x6 stream (heads packed with g4c_mlp_pack_layer_bx6 right after the last layer) */
 int g4c_mlp_forward_heads_bx6(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
                               int64_t n_rows, float *out, int32_t out_ld, int32_t act,

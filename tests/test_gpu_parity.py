@@ -195,6 +195,46 @@ def test_mlp_heads(rows, prec, monkeypatch):
     assert blk.node_mlp.run_with_heads([ops.Source(agg), ops.Source(v)], rows, _lib.ACT_SELU, nxt.edge_mlp, H, [H, H, H]) is None
 
 
+@pytest.mark.parametrize("case", ["knn6", "ragged", "unsorted", "long_segment"])
+def test_edge_mlp_with_fused_aggregation(case, monkeypatch):
+    """ops.mlp_forward(agg=...): the edge launch also reduces its output rows per target (g4c_mlp_forward_bx6_agg on tiles
+    of whole segments) == the plain launch followed by g4c_segment_reduce, bit for bit; inputs the fused kernel cannot
+    take (rows not in segment order, a segment longer than a tile) go through the separate reduction transparently."""
+    H, n = 128, 700
+    torch.manual_seed(21)
+    monkeypatch.setattr(ops, "FUSE_AGG", True)
+    if case == "knn6":
+        col = torch.arange(n).repeat_interleave(6)
+    elif case == "ragged":                          # degrees 0..9 incl. empty targets at both ends
+        deg = torch.randint(0, 10, (n,)); deg[0] = 0; deg[-1] = 0; deg[5:9] = 0
+        col = torch.arange(n).repeat_interleave(deg)
+    elif case == "unsorted":
+        col = torch.randint(0, n, (4000,))
+    else:
+        deg = torch.full((n,), 3); deg[17] = 40
+        col = torch.arange(n).repeat_interleave(deg)
+    E = int(col.numel())
+    row = torch.randint(0, n, (E,))
+    edge_index = torch.stack([row, col]).to(DEV)
+    blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
+    v, e = torch.randn(n, H, device=DEV), torch.randn(E, H, device=DEV)
+    ep, csr = plan.edge_csr(edge_index, n)
+    assert (csr.tiles() is not None) == (case in ("knn6", "ragged"))
+    srcs = [ops.Source(e), ops.Source(v, index=ep.row), ops.Source(v, index=ep.col)]
+    pk = blk.edge_mlp.packed([H, H, H], [False] * 3)
+    for mean in (True, False):
+        agg = torch.full((n, H), float("nan"), device=DEV)
+        y = ops.mlp_forward(pk, srcs, E, agg=(csr, agg, mean))
+        y_ref = ops.mlp_forward(pk, srcs, E)
+        agg_ref = ops.segment_reduce(y_ref, csr, mean)
+        assert torch.equal(y, y_ref) and torch.equal(agg, agg_ref)
+        # and against an independent dense reduction
+        dense = torch.zeros(n, H, device=DEV).index_add_(0, col.to(DEV), y_ref)
+        if mean:
+            dense /= torch.bincount(col, minlength=n).clamp(min=1).to(DEV)[:, None]
+        torch.testing.assert_close(agg, dense, rtol=1e-5, atol=1e-5)
+
+
 def test_mlp_precisions_vs_fp64():
     """The default bf16x6 arithmetic (exact three-way bf16 split, six partial products on the bf16 matrix pipe) is as
     accurate as the fp32-MFMA kernels: both against an fp64 evaluation of the same edge MLP (gathers, SELU-on-load,
