@@ -172,6 +172,27 @@ def mask_index32(mask: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def restricted_level(mask_l: torch.Tensor, edge_index_l: torch.Tensor, mask_prev: Optional[torch.Tensor]):
+    """Static part of a gMuS-GNN down-sampling (nn/mugs_gnn.py:101-104,251-255 + `restriction`, nn/blocks.py:9-32):
+    `mask_l` / `mask_prev` are the boolean masks of the new / current level over LEVEL-1 node ids, `edge_index_l` the new
+    level's edges in level-1 ids.  Returns (keep32: rows of the current level that survive, edge_index in compact ids)."""
+    key = _Cache.key(mask_l, edge_index_l) + (None if mask_prev is None else _Cache.key(mask_prev),)
+    out = _index_plans.get(key)
+    if out is None:
+        _lib.require_hip(mask_l, edge_index_l)
+        n1 = int(mask_l.size(0))
+        lut = torch.full((n1,), -1, dtype=torch.long, device=mask_l.device)
+        lut[mask_l] = torch.arange(int(mask_l.sum()), dtype=torch.long, device=mask_l.device)
+        keep = mask_l if mask_prev is None else mask_l[mask_prev]
+        keep32 = keep.nonzero().reshape(-1).to(torch.int32).contiguous()
+        ei = lut[edge_index_l].contiguous()
+        if bool((ei < 0).any()):
+            raise ValueError("edge_index of a coarse level references nodes outside its coarse_mask")
+        held = (mask_l, edge_index_l) + (() if mask_prev is None else (mask_prev,))
+        out = _index_plans.put(key, held, (keep32, ei))
+    return out
+
+
 def segments_of_sorted(index: torch.Tensor, n_seg: Optional[int] = None) -> CsrPlan:
     """CSR plan for an index vector (knn_interpolate's y_idx; any `scatter` index)."""
     key = _Cache.key(index) + (n_seg,)

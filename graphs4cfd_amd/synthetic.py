@@ -170,6 +170,64 @@ def knn_interp_weights(pos_x: torch.Tensor, pos_y: torch.Tensor, k: int):
     return y_idx, x_idx, w
 
 
+# ------------------------------------------------------------------------------ gMuS-GNN graphs
+MUGS_LAYERS = {
+    "NsTwoGuillardScaleGNN": ("mp111 mp112 mp113 mp114 mp21 mp22 mp23 mp24 mp121 mp122 mp123 mp124", ("mp121",)),
+    "NsThreeGuillardScaleGNN": ("mp111 mp112 mp113 mp114 mp211 mp212 mp31 mp32 mp33 mp34 mp221 mp222 mp121 mp122 mp123 mp124",
+                                ("mp221", "mp121")),
+    "NsFourGuillardScaleGNN": ("mp111 mp112 mp113 mp114 mp211 mp212 mp311 mp312 mp41 mp42 mp43 mp44 mp321 mp322 mp221 mp222 "
+                               "mp121 mp122 mp123 mp124", ("mp321", "mp221", "mp121")),
+}
+
+
+def mugs_arch(model: str, hidden: int = 128, nf: int = 3, node_in: int = 5, dim: int = 2) -> dict:
+    """arch dict of a gMuS-GNN class with the published layout (nn/mugs_gnn.py:15-42): the first MP after every
+    up-sampling takes node latents [interpolated | stashed] = 2H wide."""
+    H = hidden
+    layers, wide = MUGS_LAYERS[model]
+    levels = {"NsTwoGuillardScaleGNN": 2, "NsThreeGuillardScaleGNN": 3, "NsFourGuillardScaleGNN": 4}[model]
+    arch = {"edge_encoder": (dim, (H, H, H), False), "node_encoder": (node_in, (H, H, H), False)}
+    for l in range(2, levels + 1):
+        arch[f"edge_encoder{l}"] = (dim, (H, H, H), False)
+    for name in layers.split():
+        vw = 2 * H if name in wide else H
+        arch[name] = ((H + 2 * vw, (H, H, H), True), (H + vw, (H, H, H), True))
+    arch["decoder"] = (H, (H, H, nf), False)
+    return arch
+
+
+def mugs_graph(n: int, levels: int = 2, k: int = 6, seed: int = 0, nf: int = 3) -> Graph:
+    """Synthetic gMuS-GNN input with the attribute layout of `GuillardCoarseningAndConnectKNN` + `BuildKnnInterpWeights`
+    (transforms/mugs.py:32-89, interpolate.py:133-155): kNN level 1, node-nested Guillard coarsening, kNN per coarse level
+    (edge_index{l} in level-1 ids), interpolation indices / weights between consecutive levels."""
+    gen = torch.Generator().manual_seed(seed)
+    pos = torch.rand(n, 2, generator=gen)
+    g = Graph(pos=pos)
+    r = 2.0 * float(n) ** -0.5
+    g.edge_index, ea = connect_knn(pos, k)
+    g.edge_attr = ea / (2 * r)
+    masks = [torch.ones(n, dtype=torch.bool)]
+    ei_local = g.edge_index
+    for l in range(2, levels + 1):
+        prev = masks[-1]
+        cm = torch.zeros(n, dtype=torch.bool)
+        cm[prev] = guillard_coarsening(ei_local, int(prev.sum()))
+        idx = cm.nonzero().reshape(-1)
+        if idx.numel() <= k:
+            raise ValueError(f"level {l} has only {idx.numel()} nodes (need > k = {k}): use a larger mesh")
+        ei_local, ea = connect_knn(pos[idx], k)
+        setattr(g, f"coarse_mask{l}", cm)
+        setattr(g, f"edge_index{l}", idx[ei_local])
+        setattr(g, f"edge_attr{l}", ea / (2 * r * 2 ** (l - 1)))
+        y, x, w = knn_interp_weights(pos[cm], pos[prev], k)
+        setattr(g, f"y_idx_{l}{l - 1}", y); setattr(g, f"x_idx_{l}{l - 1}", x); setattr(g, f"weights_{l}{l - 1}", w)
+        masks.append(cm)
+    g.field = torch.randn(n, nf, generator=gen)
+    g.glob = torch.rand(n, 1, generator=gen)
+    g.omega = (torch.rand(n, 1, generator=gen) > 0.9).float()
+    return g
+
+
 def remus_graph(n: int, k: int = 5, seed: int = 0, scale: Optional[Sequence[float]] = None,
                 pos: Optional[torch.Tensor] = None) -> Graph:
     """Synthetic 3-level REMuS-GNN input: `BuildRemusGraph(num_levels=3, k, scale_edge_length)` +

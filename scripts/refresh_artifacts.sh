@@ -19,5 +19,7 @@ hipcc -w --offload-arch=gfx950 -O3 -o /tmp/mfma_peak scripts/micro/mfma_peak.hip
   timeout 300 python bench.py --model NsTwoScaleGNN --nodes 10000 --steps 50 --no-cpu-baseline --no-roofline | tail -1
   timeout 300 python bench.py --model NsFourScaleGNN --nodes 100000 --steps 20 --no-cpu-baseline --no-roofline | tail -1
   timeout 300 python scripts/bench_remus.py 2>&1 | tail -3
+  timeout 300 python scripts/bench_mugs.py 2>&1 | tail -2
+  timeout 300 python bench.py --precision fp32 --steps 20 --no-cpu-baseline | tail -1
 } > $A/${TAG}_side_configs.log 2>&1
 rm -rf $A/prof; ls -la $A

@@ -290,6 +290,61 @@ def gen_mus_models():
     save("models_mus.pt", out)
 
 
+MUGS_LAYERS = {
+    "NsTwoGuillardScaleGNN": (["mp111", "mp112", "mp113", "mp114", "mp21", "mp22", "mp23", "mp24", "mp121", "mp122", "mp123", "mp124"],
+                              ["mp121"]),
+    "NsThreeGuillardScaleGNN": (["mp111", "mp112", "mp113", "mp114", "mp211", "mp212", "mp31", "mp32", "mp33", "mp34", "mp221", "mp222",
+                                 "mp121", "mp122", "mp123", "mp124"], ["mp221", "mp121"]),
+    "NsFourGuillardScaleGNN": (["mp111", "mp112", "mp113", "mp114", "mp211", "mp212", "mp311", "mp312", "mp41", "mp42", "mp43", "mp44",
+                                "mp321", "mp322", "mp221", "mp222", "mp121", "mp122", "mp123", "mp124"], ["mp321", "mp221", "mp121"]),
+}
+
+
+def mugs_arch(cls_name, H, nf=3, node_in=5, d=2):
+    """arch dict of the gMuS-GNN classes (nn/mugs_gnn.py docstrings): the first MP after every up-sampling takes node
+    features [interpolated | stashed] = 2H wide."""
+    layers, wide = MUGS_LAYERS[cls_name]
+    levels = {"NsTwoGuillardScaleGNN": 2, "NsThreeGuillardScaleGNN": 3, "NsFourGuillardScaleGNN": 4}[cls_name]
+    arch = {"edge_encoder": (d, (H, H, H), False), "node_encoder": (node_in, (H, H, H), False)}
+    for l in range(2, levels + 1):
+        arch[f"edge_encoder{l}"] = (d, (H, H, H), False)
+    for name in layers:
+        vw = 2 * H if name in wide else H
+        arch[name] = ((H + 2 * vw, (H, H, H), True), (H + vw, (H, H, H), True))
+    arch["decoder"] = (H, (H, H, nf), False)
+    return arch
+
+
+def gen_mugs_models():
+    """gMuS-GNN family (nn/mugs_gnn.py:11-490) on graphs built by the reference's own
+    GuillardCoarseningAndConnectKNN + BuildKnnInterpWeights (transforms/mugs.py:32-89, interpolate.py:133-155)."""
+    out = {}
+    H = 32
+    for i, (cls, levels) in enumerate([("NsTwoGuillardScaleGNN", 2), ("NsThreeGuillardScaleGNN", 3), ("NsFourGuillardScaleGNN", 4)]):
+        torch.manual_seed(500 + i)
+        n = (500, 900, 3000)[i]          # the 4-level case needs > k nodes on its coarsest level
+        g = gfd.Graph(pos=torch.rand(n, 2))
+        g = gfd.transforms.GuillardCoarseningAndConnectKNN(k=(6,) * levels, period=None,
+                                                           scale_edge_attr=(0.1, 0.2, 0.4, 0.8)[:levels])(g)
+        g = gfd.transforms.BuildKnnInterpWeights(6)(g)
+        g.batch = torch.zeros(n, dtype=torch.long)       # forward() slices graph.batch (nn/mugs_gnn.py:103); solve() sets the same
+        g.field = torch.randn(n, 3)
+        g.glob = torch.rand(n, 1)
+        g.omega = (torch.rand(n, 1) > 0.9).float()
+        arch = mugs_arch(cls, H)
+        torch.manual_seed(520 + i)
+        model = getattr(gfd.nn, cls)(arch=arch)
+        gi = graph_dict(g)
+        with torch.no_grad():
+            model.eval()
+            y = model.forward(g, 0)
+        y3 = model.solve(g, 3)
+        out[cls] = dict(ref="nn/mugs_gnn.py forward + nn/model.py:303-327 solve", arch=arch, weights=sd(model), graph=gi,
+                        forward=y, solve3=y3, num_params=model.num_params)
+        assert torch.equal(g.field, gi["field"])
+    save("models_mugs.pt", out)
+
+
 def gen_rollout():
     # a8: solve / shift_and_replace incl. n_in = 2 history window (model.py:303-327)
     out = {}
@@ -369,6 +424,7 @@ def gen_transforms():
 if __name__ == "__main__":
     gen_blocks()
     gen_mus_models()
+    gen_mugs_models()
     gen_rollout()
     gen_remus_model()
     gen_checkpoint()

@@ -394,6 +394,37 @@ def test_mus_models(golden, cls):
     assert g.field is before["field"]
 
 
+@pytest.mark.parametrize("cls", sorted(S.MUGS_LAYERS))
+def test_mugs_models(golden, cls):
+    """gMuS-GNN classes on the HIP blocks vs the reference's forward / solve (graphs from its own transforms)."""
+    c = golden("models_mugs.pt")[cls]
+    model = getattr(gfd.nn, cls)(arch=c["arch"], device=DEV)
+    model.load_state_dict(c["weights"])
+    assert model.num_params == c["num_params"]
+    g = gfd.Graph(**cu(c["graph"]))
+    before = {k: v for k, v in g.to_dict().items()}
+    with torch.no_grad():
+        y = model.forward(g)
+    torch.testing.assert_close(y.cpu(), c["forward"], **FWD)
+    assert all(g.to_dict()[k] is v for k, v in before.items()), "forward must leave the Graph untouched"
+    torch.testing.assert_close(model.solve(g, 3).cpu(), c["solve3"], rtol=1e-3, atol=1e-3)
+
+
+def test_mugs_three_scale_h128_vs_oracle():
+    """Production width: heads between consecutive layers, the 2H-wide first layer after each up-sampling on the
+    fp32-MFMA kernels, hipGraph-captured rollout == eager."""
+    g = S.mugs_graph(9000, levels=3, seed=8)
+    torch.manual_seed(9)
+    model = gfd.nn.NsThreeGuillardScaleGNN(arch=S.mugs_arch("NsThreeGuillardScaleGNN", 128), device=DEV)
+    w = {k: v.cpu() for k, v in model.state_dict().items()}
+    ref = O.mugs_forward("NsThreeGuillardScaleGNN", g.to_dict(), w, 3)
+    gd = g.clone().to(DEV)
+    with torch.no_grad():
+        y = model.forward(gd)
+    torch.testing.assert_close(y.cpu(), ref, **FWD)
+    torch.testing.assert_close(model.solve(gd, 3, capture=True), model.solve(gd, 3, capture=False), rtol=0, atol=0)
+
+
 def test_remus_model(golden):
     c = golden("model_remus.pt")
     model = gfd.nn.NsRotEquiTreeScaleGNN(arch=c["arch"], device=DEV)

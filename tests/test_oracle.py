@@ -125,6 +125,14 @@ def test_mus_models(golden, cls):
     torch.testing.assert_close(O.mus_solve(cls, c["graph"], c["weights"], 3, nf), c["solve3"], rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("cls", sorted(O.MUGS_PROGRAMS))
+def test_mugs_models(golden, cls):
+    """gMuS-GNN family against the reference's own forward / solve on graphs from its own transforms."""
+    c = golden("models_mugs.pt")[cls]
+    torch.testing.assert_close(O.mugs_forward(cls, c["graph"], c["weights"], 3), c["forward"], rtol=1e-4, atol=5e-5)
+    torch.testing.assert_close(O.mugs_solve(cls, c["graph"], c["weights"], 3, 3), c["solve3"], rtol=1e-4, atol=2e-4)
+
+
 def test_remus_model(golden):
     c = golden("model_remus.pt")
     torch.testing.assert_close(O.remus_forward(c["graph"], c["weights"]), c["forward"], rtol=1e-4, atol=5e-5)
