@@ -10,7 +10,7 @@ Compute runs in hand-written HIP kernels (libg4c.so, C-ABI in include/g4c.h); th
 eager-torch fallback.  Out of scope: training loop, datasets, plotting, augmentation.
 """
 from .graph import Graph
-from . import nn, plan, ops, synthetic
+from . import nn, plan, ops, synthetic, transforms
 from .ops import mlp_precision, set_mlp_precision      # "fp32" (default) | "bf16" (opt-in bf16-MFMA MLPs)
 
 __version__ = "0.1.0"
