@@ -1717,6 +1717,9 @@ __device__ __forceinline__ bf16x8 ldw(__amdgpu_buffer_rsrc_t rs, unsigned voff_b
     return __builtin_bit_cast(bf16x8, v);
 }
 
+#ifndef G4C_BX6_TUNE
+#define G4C_BX6_TUNE 0      // tuning bits: 1 = s_setprio around the MFMAs, 2 = no sched_barriers in the MFMA loop
+#endif
 template <int RT>
 __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6 &g, __amdgpu_buffer_rsrc_t rs, unsigned wofs, unsigned lo_b,
                                               f32x16 (&acc)[RT]) {
@@ -1739,7 +1742,8 @@ __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6
                 const bf16x8 nh = (G4C_ABLATE & 64) ? ah : *reinterpret_cast<const bf16x8 *>(pn),
                              nm = (G4C_ABLATE & 64) ? am : *reinterpret_cast<const bf16x8 *>(pn + plane),
                              nl = (G4C_ABLATE & 64) ? al : *reinterpret_cast<const bf16x8 *>(pn + 2 * plane);
-                __builtin_amdgcn_sched_barrier(0);
+                if (!(G4C_BX6_TUNE & 2)) __builtin_amdgcn_sched_barrier(0);
+                if (G4C_BX6_TUNE & 1) __builtin_amdgcn_s_setprio(1);
                 if (!(G4C_ABLATE & 128)) {
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], al, acc[t], 0, 0, 0);     // small terms first
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.l[r], ah, acc[t], 0, 0, 0);
@@ -1750,12 +1754,13 @@ __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6
                     acc[t][0] += (float)al[0] + (float)am[0] + (float)g.l[r][0] + (float)g.m[r][0];
                 }
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], ah, acc[t], 0, 0, 0);
+                if (G4C_BX6_TUNE & 1) __builtin_amdgcn_s_setprio(0);
                 if (t + 1 == RT && !(G4C_ABLATE & 32)) {
                     g.h[r] = ldw(rs, lo_b, so + 2u * r * STEP6);
                     g.m[r] = ldw(rs, lo_b + 1024u, so + 2u * r * STEP6);
                     g.l[r] = ldw(rs, lo_b + 2048u, so + 2u * r * STEP6);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (!(G4C_BX6_TUNE & 2)) __builtin_amdgcn_sched_barrier(0);
                 ah = nh; am = nm; al = nl;
             }
         }
