@@ -1756,9 +1756,10 @@ __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], ah, acc[t], 0, 0, 0);
                 if (G4C_BX6_TUNE & 1) __builtin_amdgcn_s_setprio(0);
                 if (t + 1 == RT && !(G4C_ABLATE & 32)) {
-                    g.h[r] = ldw(rs, lo_b, so + 2u * r * STEP6);
-                    g.m[r] = ldw(rs, lo_b + 1024u, so + 2u * r * STEP6);
-                    g.l[r] = ldw(rs, lo_b + 2048u, so + 2u * r * STEP6);
+                    const unsigned sx = (G4C_ABLATE & 1024) ? 0u : so + 2u * r * STEP6;     // (1024: always the same 3 KB -> L1 hits)
+                    g.h[r] = ldw(rs, lo_b, sx);
+                    g.m[r] = ldw(rs, lo_b + 1024u, sx);
+                    g.l[r] = ldw(rs, lo_b + 2048u, sx);
                 }
                 if (!(G4C_BX6_TUNE & 2)) __builtin_amdgcn_sched_barrier(0);
                 ah = nh; am = nm; al = nl;
