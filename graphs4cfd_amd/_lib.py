@@ -57,8 +57,6 @@ _SIGNATURES = {
                                             C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "g4c_mlp_pack_layer": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                      C.c_int32, C.c_int32, C.c_void_p]),
-    "g4c_mlp_pack_layer_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
-                                          C.c_int32, C.c_int32, C.c_void_p]),
     "g4c_mlp_forward_bf16": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_void_p,
                                        C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "g4c_mlp_pack_layer_bx6": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,

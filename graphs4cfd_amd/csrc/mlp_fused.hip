@@ -1471,223 +1471,9 @@ __global__ void pack_layer_kernel(const float *__restrict__ W, int n_out, int k_
     packed[(long long)(kp >> 5) * CHUNK_FLOATS + (U >> 1) * 1024 + (n >> 5) * 256 + (((kp >> 1) & 1) * 32 + (n & 31)) * 4 + (U & 1) * 2 + (kp & 1)] = v;
 }
 
-// ======================================================================================================
-// bf16-MFMA variant (BASELINE config 3: "bf16 edge-MLP MFMA"; opt-in, g4c_mlp_forward_bf16).  Operands are rounded
-// to bf16 (weights at pack time, activations when they are staged in LDS), products accumulate in fp32
-// (v_mfma_f32_32x32x16_bf16: 16x the fp32 MFMA rate), bias / SELU / LayerNorm / the gathered additive terms stay fp32.
-// With the MFMA time gone (8 instructions per 128-k layer and wave) the kernel is bound by what surrounds it, so the
-// structure follows the small-launch kernel: a whole 128-k block per barrier.  Same 32-row tile, 4 waves, one
-// 32-column tile each.  Weight stream (bf16): per 128-k block [column tile][step (16 k)][lane][8 bf16]; every
-// weighted input block is padded to 128 k (pad MFMAs are free here).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int HB = 128 + 8;                 // LDS row stride of a bf16 block (272 B: conflict-free ds_read_b128)
-constexpr int BLOCK_BF16 = 128 * NP;        // bf16 elements of one 128-k block of the weight stream
-
-struct RingB { bf16x8 s[8]; };
-
-// one 128-k block: 8 MFMAs from the bf16 LDS rows at `pa`; slot s is refilled with step s of the NEXT block
-__device__ __forceinline__ void mma_block_bf16(const __bf16 *pa, RingB &g, const __bf16 *wnext, unsigned lo, f32x16 &acc) {
-    bf16x8 a = *reinterpret_cast<const bf16x8 *>(pa);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const bf16x8 an = *reinterpret_cast<const bf16x8 *>(pa + ((s + 1) & 7) * 16);
-        __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, g.s[s], acc, 0, 0, 0);
-        g.s[s] = *reinterpret_cast<const bf16x8 *>(wnext + s * 512 + lo);
-        __builtin_amdgcn_sched_barrier(0);
-        a = an;
-    }
-}
-
-#ifndef G4C_BF16_MINW
-#define G4C_BF16_MINW 4
-#endif
-template <bool VEC>
-__global__ __launch_bounds__(256, G4C_BF16_MINW) void mlp_bf16_kernel(const Params p) {
-    constexpr int ROWS = 32, NW = 4;
-    // fp32 final tile [32][132] (for the LayerNorm / store epilogue) aliases the two bf16 block buffers [2][32][136]
-    constexpr int BUF_FLOATS = (2 * ROWS * HB / 2 > ROWS * HS) ? 2 * ROWS * HB / 2 : ROWS * HS;
-    __shared__ __attribute__((aligned(16))) float lds[BUF_FLOATS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
-    float *sH = lds;
-    __bf16 *sB0 = reinterpret_cast<__bf16 *>(lds);
-    __bf16 *sB1 = sB0 + ROWS * HB;
-    int *sRow = reinterpret_cast<int *>(lds + BUF_FLOATS);
-    int *sRowAdd = sRow + G4C_MAX_SRC * ROWS;
-    float *sBias = lds + BUF_FLOATS + 2 * G4C_MAX_SRC * ROWS;
-    float *sGB = sBias + G4C_MAX_LAYERS * NP;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 31, h = lane >> 5;
-    const int ct0 = wave;
-
-    int tile;
-    {
-        const int b = blockIdx.x, nt = p.n_tiles;
-        const int q = nt >> 3, r = nt & 7, x = b & 7, j = b >> 3;
-        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-    }
-    const long long row0 = p.row_base + (long long)tile * ROWS;
-
-    const __bf16 *w = reinterpret_cast<const __bf16 *>(p.w);
-    const unsigned lo = (unsigned)(ct0 * 4096 + lane * 8);
-    RingB ring;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) ring.s[s] = *reinterpret_cast<const bf16x8 *>(w + s * 512 + lo);
-    __builtin_amdgcn_sched_barrier(0);
-
-    for (int e = tid; e < 2 * G4C_MAX_SRC * ROWS; e += 64 * NW) {
-        const int slot = e / ROWS, r = e % ROWS;
-        long long gr = row0 + r;
-        if (gr >= p.M) gr = p.M - 1;
-        const int *ix = nullptr;
-        bool used;
-        if (slot < G4C_MAX_SRC) { used = slot < p.n_src; if (used) ix = p.src[slot].idx; }
-        else { used = slot - G4C_MAX_SRC < p.n_add; if (used) ix = p.add[slot - G4C_MAX_SRC].idx; }
-        if (used) sRow[e] = ix ? ix[gr] : (int)gr;
-    }
-    for (int e = tid; e < p.n_layers * NP; e += 64 * NW) sBias[e] = p.b[e];
-    if (p.gamma) {
-        for (int e = tid; e < NP; e += 64 * NW) {
-            const int ee = e < p.n_out ? e : 0;
-            sGB[e] = p.gamma[ee];
-            sGB[NP + e] = p.beta[ee];
-        }
-    }
-    __syncthreads();
-
-    // this wave's 8 rows of an input block: lane -> row (lane>>3) + 8*wave, 4 floats at column 4*(lane&7) of each 32-k chunk
-    const int grow_l = (lane >> 3) + 8 * wave, c4 = (lane & 7) * 4;
-    f32x4 xp[4];
-    auto gather = [&](int sidx) {
-        const int width = p.src[sidx].width;
-        const float *rp = p.src[sidx].ptr + (long long)sRow[sidx * ROWS + grow_l] * p.src[sidx].ld + p.src[sidx].col0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = q * KC + c4;
-            if (VEC) {
-                xp[q] = *reinterpret_cast<const f32x4 *>(rp + (c < width ? c : 0));
-            } else {
-                const int w1 = width - 1;
-                xp[q][0] = rp[c + 0 < w1 ? c + 0 : w1]; xp[q][1] = rp[c + 1 < w1 ? c + 1 : w1];
-                xp[q][2] = rp[c + 2 < w1 ? c + 2 : w1]; xp[q][3] = rp[c + 3 < w1 ? c + 3 : w1];
-            }
-        }
-    };
-    auto park = [&](__bf16 *dst, int sidx) {
-        const int width = p.src[sidx].width, act = p.src[sidx].pre_act;
-        __bf16 *d = dst + grow_l * HB + c4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = q * KC + c4;
-            float t[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) t[e] = (c + e < width) ? xp[q][e] : 0.f;
-            if (act) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = g4c::selu_f(t[e]);
-            }
-            bf16x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (__bf16)t[e];
-            *reinterpret_cast<bf16x4 *>(d + q * KC) = v;
-        }
-    };
-    gather(0);
-    __builtin_amdgcn_sched_barrier(0);
-
-    f32x16 acc;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    for (int a = 0; a < p.n_add; ++a) {
-        float t[16];
-        const int col = ct0 * 32 + i;
-        const bool ok = col < p.add[a].width;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-            t[q] = p.add[a].ptr[(long long)sRowAdd[a * ROWS + row] * p.add[a].ld + (ok ? col : 0)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] += ok ? t[q] : 0.f;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    park(sB0, 0);
-    __syncthreads();
-
-    // ---------------------------------------------------------------- layer 0: one barrier per (padded) 128-k input block
-    const __bf16 *pa0 = sB0 + i * HB + 8 * h, *pa1 = sB1 + i * HB + 8 * h;
-    for (int s = 0; s < p.n_src; ++s) {
-        const bool more = s + 1 < p.n_src;
-        if (more) gather(s + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        w += BLOCK_BF16;
-        mma_block_bf16((s & 1) ? pa1 : pa0, ring, w, lo, acc);
-        if (more) park((s & 1) ? sB0 : sB1, s + 1);
-        __syncthreads();
-    }
-    // hidden layers ping-pong between the two bf16 buffers, starting with the one layer 0 did not read last
-    int cur = (p.n_src & 1) ? 1 : 0;       // buffer to WRITE next
-    for (int l = 0;; ++l) {
-        const bool last = (l == p.n_layers - 1);
-        const float bv = sBias[l * NP + ct0 * 32 + i];
-        if (last) {
-            // the final tile goes out in fp32 (LayerNorm / store epilogue); sH aliases both bf16 buffers, and every wave
-            // finished reading them at the barrier that ended the previous block
-            float *base = sH + (4 * h) * HS + ct0 * 32 + i;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) base[((q & 3) + 8 * (q >> 2)) * HS] = acc[q] + bv;
-            __syncthreads();
-            break;
-        }
-        {
-            __bf16 *base = (cur ? sB1 : sB0) + (4 * h) * HB + ct0 * 32 + i;
-#pragma unroll
-            for (int q0 = 0; q0 < 16; q0 += 4) {
-                float x[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) x[q] = g4c::selu_f(acc[q0 + q] + bv);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) base[(q + 2 * q0) * HB] = (__bf16)x[q];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-        w += BLOCK_BF16;
-        mma_block_bf16(cur ? pa1 : pa0, ring, w, lo, acc);
-        cur ^= 1;
-        // no barrier needed before the next hidden store: it writes the OTHER buffer ... but the final fp32 tile and the
-        // buffer after next alias what is being read here, so close the block
-        __syncthreads();
-    }
-    split_finish<NW>(p, sH, sGB, wave, lane, row0);
-}
-
-// bf16 image of one layer: W[n_out, k_in] -> [block = 128 k][ct = n/32][step = (k%128)/16][lane = ((k%16)/8)*32 + n%32][e = k%8]
-__global__ void pack_layer_bf16_kernel(const float *__restrict__ W, int n_out, int k_in, PackSegs segs,
-                                       __bf16 *__restrict__ packed, int k_pad) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= k_pad * NP) return;
-    const int kp = gid / NP, n = gid % NP;
-    int k = -1, base_p = 0, base = 0, neg = 0;
-    for (int s = 0; s < segs.n_seg; ++s) {
-        if (kp >= base_p && kp < base_p + segs.wpad[s]) {
-            const int j = kp - base_p;
-            if (j < segs.width[s]) { k = base + j; neg = segs.neg[s]; }
-        }
-        base_p += segs.wpad[s];
-        base += segs.width[s];
-    }
-    float v = 0.f;
-    if (k >= 0 && n < n_out) v = W[(long long)n * k_in + k];
-    if (neg) v = -v;
-    const int kk = kp & 127;
-    packed[(long long)(kp >> 7) * BLOCK_BF16 + (n >> 5) * 4096 + (kk >> 4) * 512 + (((kk >> 3) & 1) * 32 + (n & 31)) * 8 + (kk & 7)] = (__bf16)v;
-}
+constexpr int HB = 128 + 8;                 // LDS row stride of a bf16 operand plane (272 B: conflict-free ds_read_b128)
 
 // ======================================================================================================
 // fp32-accurate MLP on the bf16 matrix pipe ("bf16x6", opt-in: g4c_mlp_forward_bx6).  Every fp32 operand is split
@@ -1695,8 +1481,10 @@ __global__ void pack_layer_bf16_kernel(const float *__restrict__ W, int n_out, i
 // largest are formed (hh, hm, mh, mm, hl, lh — each exact in fp32) and accumulated in fp32 by
 // v_mfma_f32_32x32x16_bf16.  The dropped terms (ml, lm, ll) are <= 2^-23 relative: the same order as ONE fp32 rounding,
 // so the result is as accurate as the fp32-MFMA kernel (tests compare both against fp64), at 6 x 32 = 192 MFMA cycles
-// per 16 k instead of 8 x 64 = 512.  Structure = mlp_bf16_kernel with three operand planes; weights are split at pack
-// time (g4c_mlp_pack_layer_bx6: [128-k block][column tile][16-k step][plane][lane][8], 6 bytes per weight).
+// per 16 k instead of 8 x 64 = 512.  A whole 128-k block is staged per barrier pair; weights are split at pack time
+// (g4c_mlp_pack_layer_bx6: [128-k block][column tile][16-k step][plane][lane][8], 6 bytes per weight).
+// Template parameter SP = 3: the above.  SP = 1: only the leading terms (operands ROUNDED to bf16, one product) — the
+// opt-in "bf16" mode of BASELINE config 3 ("bf16 edge-MLP MFMA", ~1e-2 deviation) on the same stream and structure.
 #ifndef G4C_BX6_RING
 #define G4C_BX6_RING 2
 #endif
@@ -1720,11 +1508,11 @@ __device__ __forceinline__ bf16x8 ldw(__amdgpu_buffer_rsrc_t rs, unsigned voff_b
 #ifndef G4C_BX6_TUNE
 #define G4C_BX6_TUNE 0      // tuning bits: 1 = s_setprio around the MFMAs, 2 = no sched_barriers in the MFMA loop
 #endif
-template <int RT>
+template <int RT, int SP>
 __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6 &g, __amdgpu_buffer_rsrc_t rs, unsigned wofs, unsigned lo_b,
                                               f32x16 (&acc)[RT]) {
-    bf16x8 ah = *reinterpret_cast<const bf16x8 *>(pa), am = *reinterpret_cast<const bf16x8 *>(pa + plane),
-           al = *reinterpret_cast<const bf16x8 *>(pa + 2 * plane);
+    bf16x8 ah = *reinterpret_cast<const bf16x8 *>(pa), am = ah, al = ah;
+    if (SP == 3) { am = *reinterpret_cast<const bf16x8 *>(pa + plane); al = *reinterpret_cast<const bf16x8 *>(pa + 2 * plane); }
     // ROLLED over groups of RD6 steps (ring slots are compile-time inside a group): unrolling all 8 steps lets hipcc give
     // every refill fresh registers, which costs a wave of occupancy
     unsigned so = wofs + 2u * RD6 * STEP6;          // byte offset of the step that refills slot 0 (RD6 steps ahead)
@@ -1740,17 +1528,17 @@ __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6
                 const int nt = (t + 1) % RT, nr = (t + 1 == RT) ? r + 1 : r;
                 const __bf16 *pn = ((nr == RD6 && j == 8 / RD6 - 1) ? pa : pj + nr * 16) + nt * 32 * HB;
                 const bf16x8 nh = (G4C_ABLATE & 64) ? ah : *reinterpret_cast<const bf16x8 *>(pn),
-                             nm = (G4C_ABLATE & 64) ? am : *reinterpret_cast<const bf16x8 *>(pn + plane),
-                             nl = (G4C_ABLATE & 64) ? al : *reinterpret_cast<const bf16x8 *>(pn + 2 * plane);
+                             nm = (SP == 1 || (G4C_ABLATE & 64)) ? am : *reinterpret_cast<const bf16x8 *>(pn + plane),
+                             nl = (SP == 1 || (G4C_ABLATE & 64)) ? al : *reinterpret_cast<const bf16x8 *>(pn + 2 * plane);
                 if (!(G4C_BX6_TUNE & 2)) __builtin_amdgcn_sched_barrier(0);
                 if (G4C_BX6_TUNE & 1) __builtin_amdgcn_s_setprio(1);
-                if (!(G4C_ABLATE & 128)) {
+                if (SP == 3 && !(G4C_ABLATE & 128)) {
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], al, acc[t], 0, 0, 0);     // small terms first
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.l[r], ah, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.m[r], am, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], am, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.m[r], ah, acc[t], 0, 0, 0);
-                } else {      // keep every operand live with one cheap VALU op instead of five MFMAs
+                } else if (SP == 3) {      // (ablation) keep every operand live with one cheap VALU op instead of five MFMAs
                     acc[t][0] += (float)al[0] + (float)am[0] + (float)g.l[r][0] + (float)g.m[r][0];
                 }
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], ah, acc[t], 0, 0, 0);
@@ -1758,8 +1546,7 @@ __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6
                 if (t + 1 == RT && !(G4C_ABLATE & 32)) {
                     const unsigned sx = (G4C_ABLATE & 1024) ? 0u : so + 2u * r * STEP6;     // (1024: always the same 3 KB -> L1 hits)
                     g.h[r] = ldw(rs, lo_b, sx);
-                    g.m[r] = ldw(rs, lo_b + 1024u, sx);
-                    g.l[r] = ldw(rs, lo_b + 2048u, sx);
+                    if (SP == 3) { g.m[r] = ldw(rs, lo_b + 1024u, sx); g.l[r] = ldw(rs, lo_b + 2048u, sx); }
                 }
                 if (!(G4C_BX6_TUNE & 2)) __builtin_amdgcn_sched_barrier(0);
                 ah = nh; am = nm; al = nl;
@@ -1796,8 +1583,9 @@ __device__ __forceinline__ unsigned pack_bf16(f32x2 x, f32x2 &back) {
     back[1] = __builtin_bit_cast(float, u & 0xffff0000u);
     return u;
 }
+template <int SP = 3>
 __device__ __forceinline__ void split3x4(f32x4 x, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
-    if (G4C_ABLATE & 512) {
+    if (SP == 1 || (G4C_ABLATE & 512)) {          // SP == 1: round to bf16 (only h is stored)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { h[e] = (__bf16)x[e]; m[e] = h[e]; l[e] = h[e]; }
         return;
@@ -1835,7 +1623,7 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
 // twice the rows.
 // FULL: every weighted input block and every additive block is exactly 128 wide and 16-byte aligned (the MP layers):
 // no column masks anywhere.
-template <int RT, bool VEC, bool FULL>
+template <int RT, bool VEC, bool FULL, int SP>
 __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kernel(const Params p) {
     constexpr int ROWS = 32 * RT, NW = 4;
     constexpr int PLN = ROWS * HB;              // one bf16 operand plane [ROWS][136]
@@ -1914,10 +1702,12 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
                 }
                 if (ACT) v = selu4(v);
                 bf16x4 vh, vm, vl;
-                split3x4(v, vh, vm, vl);
+                split3x4<SP>(v, vh, vm, vl);
                 *reinterpret_cast<bf16x4 *>(d + q * KC) = vh;
-                *reinterpret_cast<bf16x4 *>(d + PLN + q * KC) = vm;
-                *reinterpret_cast<bf16x4 *>(d + 2 * PLN + q * KC) = vl;
+                if (SP == 3) {
+                    *reinterpret_cast<bf16x4 *>(d + PLN + q * KC) = vm;
+                    *reinterpret_cast<bf16x4 *>(d + 2 * PLN + q * KC) = vl;
+                }
                 __builtin_amdgcn_sched_barrier(0);      // one group of four at a time: bounds the live temporaries
             }
         }
@@ -1955,8 +1745,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
 #pragma unroll
     for (int s = 0; s < RD6; ++s) {
         ring.h[s] = ldw(rs, lo_b, 2u * s * STEP6);
-        ring.m[s] = ldw(rs, lo_b + 1024u, 2u * s * STEP6);
-        ring.l[s] = ldw(rs, lo_b + 2048u, 2u * s * STEP6);
+        if (SP == 3) { ring.m[s] = ldw(rs, lo_b + 1024u, 2u * s * STEP6); ring.l[s] = ldw(rs, lo_b + 2048u, 2u * s * STEP6); }
     }
     const bool direct0 = (p.src[0].idx == nullptr);
     if (direct0) gather(0, true);
@@ -2026,7 +1815,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
         const bool more = s + 1 < p.n_src;
         if (more && RT == 1) gather(s + 1, false);          // (RT = 2: 32 more live registers would cost a wave per SIMD)
         __builtin_amdgcn_sched_barrier(0);
-        mma_block_bx6<RT>(pa, PLN, ring, rs, wofs, lo_b, acc);
+        mma_block_bx6<RT, SP>(pa, PLN, ring, rs, wofs, lo_b, acc);
         wofs += 2u * BLOCK6;
         __syncthreads();                   // everybody is done reading the planes
         if (more) {
@@ -2065,11 +1854,13 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = acc[t][4 * gq + e];
                 bf16x4 vh, vm, vl;
-                split3x4(selu4(x + b4), vh, vm, vl);
+                split3x4<SP>(selu4(x + b4), vh, vm, vl);
                 __bf16 *d = sB + (i + 32 * t) * HB + fbase + 8 * gq;
                 *reinterpret_cast<bf16x4 *>(d) = vh;
-                *reinterpret_cast<bf16x4 *>(d + PLN) = vm;
-                *reinterpret_cast<bf16x4 *>(d + 2 * PLN) = vl;
+                if (SP == 3) {
+                    *reinterpret_cast<bf16x4 *>(d + PLN) = vm;
+                    *reinterpret_cast<bf16x4 *>(d + 2 * PLN) = vl;
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         __syncthreads();
@@ -2078,7 +1869,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
-        mma_block_bx6<RT>(pa, PLN, ring, rs, wofs, lo_b, acc);
+        mma_block_bx6<RT, SP>(pa, PLN, ring, rs, wofs, lo_b, acc);
         wofs += 2u * BLOCK6;
         __syncthreads();
         G4C_STAMPW(6 + 2 * l);
@@ -2115,11 +1906,13 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 bf16x4 vh, vm, vl;
-                split3x4(v[t][q], vh, vm, vl);
+                split3x4<SP>(v[t][q], vh, vm, vl);
                 __bf16 *d = sB + (grow_l + 32 * t) * HB + q * KC + c4;
                 *reinterpret_cast<bf16x4 *>(d) = vh;
-                *reinterpret_cast<bf16x4 *>(d + PLN) = vm;
-                *reinterpret_cast<bf16x4 *>(d + 2 * PLN) = vl;
+                if (SP == 3) {
+                    *reinterpret_cast<bf16x4 *>(d + PLN) = vm;
+                    *reinterpret_cast<bf16x4 *>(d + 2 * PLN) = vl;
+                }
             }
         __syncthreads();
         for (int hd = 0; hd < p.n_heads; ++hd) {
@@ -2127,7 +1920,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
-            mma_block_bx6<RT>(pa, PLN, ring, rs, wofs, lo_b, acc);
+            mma_block_bx6<RT, SP>(pa, PLN, ring, rs, wofs, lo_b, acc);
             wofs += 2u * BLOCK6;
             float *ho = p.head_out[hd];
 #pragma unroll
@@ -2202,12 +1995,6 @@ extern "C" int g4c_mlp_pack_layer(const float *W, int32_t n_out, int32_t k_in, c
 static int pack_layer_16(bool six, const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
                          const int32_t *seg_negate, int32_t n_seg, void *packed, int32_t k_pad, int32_t n_pad, void *stream);
 
-extern "C" int g4c_mlp_pack_layer_bf16(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
-                                       const int32_t *seg_negate, int32_t n_seg, void *packed,
-                                       int32_t k_pad, int32_t n_pad, void *stream) {
-    return pack_layer_16(false, W, n_out, k_in, seg_width, seg_negate, n_seg, packed, k_pad, n_pad, stream);
-}
-
 extern "C" int g4c_mlp_pack_layer_bx6(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
                                       const int32_t *seg_negate, int32_t n_seg, void *packed,
                                       int32_t k_pad, int32_t n_pad, void *stream) {
@@ -2232,9 +2019,8 @@ static int pack_layer_16(bool six, const float *W, int32_t n_out, int32_t k_in, 
     }
     G4C_REQUIRE(ksum == k_in, G4C_EINVAL, "g4c_mlp_pack_layer_bf16: blocks sum to %d columns, weight has %d", ksum, k_in);
     const int total = k_pad * NP;
-    if (six) pack_layer_bx6_kernel<<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(W, n_out, k_in, segs, (__bf16 *)packed, k_pad);
-    else pack_layer_bf16_kernel<<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(W, n_out, k_in, segs, (__bf16 *)packed, k_pad);
-    return g4c::check_launch("g4c_mlp_pack_layer_bf16");
+    pack_layer_bx6_kernel<<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(W, n_out, k_in, segs, (__bf16 *)packed, k_pad);
+    return g4c::check_launch("g4c_mlp_pack_layer_bx6");
 }
 
 extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
@@ -2372,9 +2158,10 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
                       const float *resid, int32_t resid_ld, int32_t resid_col0,
                       const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream,
                       const AggArgs *agg) {
-    const bool bx6 = (tile_rows == 3248);       // weights: the three-plane stream of g4c_mlp_pack_layer_bx6
-    const bool bf16 = (tile_rows == 3216) || bx6;   // 2-byte stream(s), input blocks padded to 128 k
-    const int wbytes = bx6 ? 6 : (bf16 ? 2 : 4);
+    const bool round1 = (tile_rows == 3216);     // operands rounded to bf16: only the leading plane of the stream is used
+    const bool bx6 = (tile_rows == 3248) || round1;   // weights: the three-plane stream of g4c_mlp_pack_layer_bx6
+    const bool bf16 = bx6;                       // input blocks padded to 128 k
+    const int wbytes = bx6 ? 6 : 4;
     if (bf16) tile_rows = 324;
     G4C_REQUIRE(tile_rows == 64 || tile_rows == 32 || tile_rows == 322 || tile_rows == 324 || tile_rows == 325 || tile_rows == 644, G4C_EINVAL,
                 "g4c_mlp_forward_rows: tile_rows must be 64, 32, 322 (32 rows / 2 waves), 324 (32 rows / 4 waves) or 325 (324, small-launch variant)");
@@ -2449,7 +2236,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     p.n_heads = n_heads; p.head_ld = head_ld;
     for (int hd = 0; hd < G4C_MAX_HEADS; ++hd) p.head_out[hd] = hd < n_heads ? head_out[hd] : nullptr;
     if (n_heads) {
-        G4C_REQUIRE(!bf16 || bx6, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads: no plain-bf16 variant");
+        G4C_REQUIRE(!round1, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads: no rounded-bf16 variant");
         G4C_REQUIRE((head_ld & 3) == 0 || !bx6, G4C_EINVAL, "g4c_mlp_forward_heads: head outputs need a leading dimension that is a multiple of 4");
         G4C_REQUIRE(tile_rows == 324 || tile_rows == 325, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads: tile mode %d has no heads", tile_rows);
         G4C_REQUIRE(p.n_out == NP && !resid && !out_idx && head_ld >= NP, G4C_EINVAL,
@@ -2482,27 +2269,19 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         for (int a = 0; a < p.n_add; ++a)
             full = full && p.add[a].width == NP && (p.add[a].ld & 3) == 0 && ((uintptr_t)p.add[a].ptr & 15) == 0;
         const dim3 blk(256);
-        if (agg) {                          // tiles of whole segments, at most 32 rows each
-            p.n_tiles = agg->n_tiles;
-            if (p.n_tiles == 0) return G4C_OK;
-            if (full) mlp_bx6_kernel<1, true, true><<<dim3(p.n_tiles), blk, 0, st>>>(p);
-            else if (all_vec) mlp_bx6_kernel<1, true, false><<<dim3(p.n_tiles), blk, 0, st>>>(p);
-            else mlp_bx6_kernel<1, false, false><<<dim3(p.n_tiles), blk, 0, st>>>(p);
-        } else if (row_count >= rt2_rows) {       // 64-row tiles (tuning only)
-            p.n_tiles = (int)((row_count + 63) / 64);
-            if (full) mlp_bx6_kernel<2, true, true><<<dim3(p.n_tiles), blk, 0, st>>>(p);
-            else if (all_vec) mlp_bx6_kernel<2, true, false><<<dim3(p.n_tiles), blk, 0, st>>>(p);
-            else mlp_bx6_kernel<2, false, false><<<dim3(p.n_tiles), blk, 0, st>>>(p);
-        } else {
-            p.n_tiles = (int)((row_count + 31) / 32);
-            if (full) mlp_bx6_kernel<1, true, true><<<dim3(p.n_tiles), blk, 0, st>>>(p);
-            else if (all_vec) mlp_bx6_kernel<1, true, false><<<dim3(p.n_tiles), blk, 0, st>>>(p);
-            else mlp_bx6_kernel<1, false, false><<<dim3(p.n_tiles), blk, 0, st>>>(p);
-        }
-    } else if (bf16) {
-        p.n_tiles = (int)((row_count + 31) / 32);
-        if (all_vec) mlp_bf16_kernel<true><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
-        else mlp_bf16_kernel<false><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
+        const bool rt2 = !agg && row_count >= rt2_rows;      // 64-row tiles (tuning only)
+        p.n_tiles = agg ? agg->n_tiles : (int)((row_count + (rt2 ? 63 : 31)) / (rt2 ? 64 : 32));
+        if (p.n_tiles == 0) return G4C_OK;
+        const dim3 grid(p.n_tiles);
+#define G4C_BX6_LAUNCH(RT, SP)                                                                         \
+        do {                                                                                           \
+            if (full) mlp_bx6_kernel<RT, true, true, SP><<<grid, blk, 0, st>>>(p);                     \
+            else if (all_vec) mlp_bx6_kernel<RT, true, false, SP><<<grid, blk, 0, st>>>(p);            \
+            else mlp_bx6_kernel<RT, false, false, SP><<<grid, blk, 0, st>>>(p);                        \
+        } while (0)
+        if (round1) { if (rt2) G4C_BX6_LAUNCH(2, 1); else G4C_BX6_LAUNCH(1, 1); }
+        else { if (rt2) G4C_BX6_LAUNCH(2, 3); else G4C_BX6_LAUNCH(1, 3); }
+#undef G4C_BX6_LAUNCH
     } else if (tile_rows == 644) {
         p.n_tiles = (int)((row_count + 63) / 64);
         if (all_vec) mlp_split64_kernel<true><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);

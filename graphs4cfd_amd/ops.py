@@ -227,11 +227,11 @@ class PackedMLP:
                  precision: str = "fp32"):
         """`heads`: bias-free [128, 128] weights applied to the MLP's final output row (g4c_mlp_forward_heads); their
         packed images continue the weight stream after the last layer.  `precision` "bf16": the bf16 stream of
-        g4c_mlp_pack_layer_bf16 (every input block padded to 128 k), consumed by g4c_mlp_forward_bf16."""
+        g4c_mlp_pack_layer_bx6 (every input block padded to 128 k; "bf16" uses the same stream, leading plane only)."""
         lib = _lib.load()
         self.precision = precision
-        bf16 = precision in ("bf16", "bf16x6")       # 2-byte weight stream(s), 128-k input blocks
-        planes = 3 if precision == "bf16x6" else 1
+        bf16 = precision in ("bf16", "bf16x6")       # three-plane bf16 weight stream, 128-k input blocks ("bf16" reads plane 0 only)
+        planes = 3
         if precision == "bf16" and heads:
             raise NotImplementedError("heads in plain bf16")
         dev = _lib.require_hip(*weights, *[b for b in biases if b is not None], *heads)
@@ -259,7 +259,7 @@ class PackedMLP:
         stream_buf = torch.zeros((sum(k_pads) + NP * len(heads) + (NP if bf16 else KC)) * NP * planes,
                                  dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
         esz = 2 * planes if bf16 else 4
-        pack = {"fp32": lib.g4c_mlp_pack_layer, "bf16": lib.g4c_mlp_pack_layer_bf16, "bf16x6": lib.g4c_mlp_pack_layer_bx6}[precision]
+        pack = lib.g4c_mlp_pack_layer_bx6 if bf16 else lib.g4c_mlp_pack_layer
         bias_buf = torch.zeros(n_layers * NP, dtype=torch.float32, device=dev)
         self._keep += [stream_buf, bias_buf]
         off = 0
@@ -381,7 +381,7 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
         if KernelTimer.active is None:
             call()
         else:
-            _timed("mlp_bf16_kernel" if packed.precision == "bf16" else "mlp_bx6_kernel", packed.flops_per_row * n_rows, 4.0 * (sum(packed.seg_widths) + packed.n_out) * n_rows, call)
+            _timed("mlp_bx6_kernel", packed.flops_per_row * n_rows, 4.0 * (sum(packed.seg_widths) + packed.n_out) * n_rows, call)
     elif head_outs is not None:
         if len(head_outs) != packed.n_heads or packed.n_heads == 0:
             raise ValueError(f"{len(head_outs)} head outputs for a packing with {packed.n_heads} heads")

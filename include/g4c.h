@@ -155,28 +155,24 @@ int g4c_mlp_forward_heads(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /
                           const float *head_w, int32_t n_heads, float *const *head_out /*host*/, int32_t head_ld,
                           void *stream);
 
-/* bf16-MFMA variant (opt-in; BASELINE config 3 "bf16 edge-MLP MFMA"): weights and the activations entering each Linear
- * are rounded to bf16, products accumulate in fp32 (v_mfma_f32_32x32x16_bf16), bias / SELU / LayerNorm / additive
- * sources / residual stay fp32.  g4c_mlp_pack_layer_bf16 writes the 2-byte weight stream (every input block padded
- * to 128 k: k_pad = 128 * n_seg; one 128-k block of slack after the last layer); g4c_mlp_forward_bf16 takes a
- * g4c_mlp_t whose w[] point into that stream.  Expected deviation from the fp32 path: ~1e-2 on LayerNorm-scale outputs. */
-int g4c_mlp_pack_layer_bf16(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width /*host*/,
-                            const int32_t *seg_negate /*host*/, int32_t n_seg, void *packed,
-                            int32_t k_pad, int32_t n_pad, void *stream);
-int g4c_mlp_forward_bf16(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
-                         int64_t n_rows, float *out, int32_t out_ld, const int32_t *out_idx,
-                         int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
-
 /* fp32-accurate variant on the bf16 matrix pipe ("bf16x6", opt-in): both operands of every Linear are split exactly
  * into three bf16 terms (x = h + m + l), the six largest partial products are accumulated in fp32; dropped terms are
- * <= 2^-23 relative.  Same contract as the _bf16 pair above with a three-plane stream (6 bytes per weight:
- * k_pad * n_pad * 3 bf16 per layer, one 128-k block of slack). */
+ * <= 2^-23 relative.  g4c_mlp_pack_layer_bx6 writes the three-plane weight stream (6 bytes per weight: k_pad * n_pad * 3
+ * bf16 per layer, every input block padded to 128 k: k_pad = 128 * n_seg; one 128-k block of slack after the last
+ * layer); g4c_mlp_forward_bx6 takes a g4c_mlp_t whose w[] point into that stream. */
 int g4c_mlp_pack_layer_bx6(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width /*host*/,
                            const int32_t *seg_negate /*host*/, int32_t n_seg, void *packed,
                            int32_t k_pad, int32_t n_pad, void *stream);
 int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
                         int64_t n_rows, float *out, int32_t out_ld, const int32_t *out_idx,
                         int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
+/* Rounded-bf16 variant (opt-in only; BASELINE config 3 "bf16 edge-MLP MFMA"): the same stream and kernel structure, but
+ * only the LEADING bf16 term of every operand is used (one product per multiply-add): weights and the activations
+ * entering each Linear are rounded to bf16, accumulation / bias / SELU / LayerNorm / additive sources / residual stay
+ * fp32.  Expected deviation from the fp32 result: ~1e-2 on LayerNorm-scale outputs. */
+int g4c_mlp_forward_bf16(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
+                         int64_t n_rows, float *out, int32_t out_ld, const int32_t *out_idx,
+                         int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
 /* Edge MLP + aggregation in one launch.  g4c_plan_tiles (host) cuts the CSR-ordered rows into tiles of whole segments
  * (<= max_rows rows; -1 if a segment is longer): tile t = segments [tile_seg[t], tile_seg[t+1]) = rows
  * [tile_rows[t], tile_rows[t+1]).  g4c_mlp_forward_bx6_agg runs the MLP on those tiles (max_rows must be 32) and, from

@@ -28,7 +28,7 @@ def t(f, reps=5):
     return statistics.median(ts)
 
 
-for prec in ("fp32", "bf16"):
+for prec in ("fp32", "bf16x6", "bf16"):
     ops.set_mlp_precision(prec)
     te = t(lambda: blk.edge_mlp.run_hoisted([ops.Source(e)], [(v, row), (v, col)], rows, 0, out=out_e))
     t3 = t(lambda: blk.edge_mlp.run_coded([ops.Source(e), ops.Source(v, index=row), ops.Source(v, index=col)], rows, 0, out=out_e))
