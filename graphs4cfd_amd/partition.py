@@ -251,12 +251,25 @@ class HipImpl:
     def new(self, rows: int, width: int, device) -> torch.Tensor:
         return torch.empty((rows, width), dtype=torch.float32, device=device)
 
-    def encode(self, mesh: LocalMesh, v_out: torch.Tensor):
+    def _node_launch(self, mlp, srcs, n_own: int, act: int, v_out: torch.Tensor, next_name: Optional[str],
+                     pr_out: Optional[torch.Tensor]):
+        """`mlp` -> v_out (own rows); when `next_name` is the MP layer that consumes v_out and hoists its first layer, the
+        same launch also emits its products (own rows of `pr_out`, and W1c v as a fresh tensor).  Returns them or None."""
+        if next_name is not None and pr_out is not None:
+            nxt = getattr(self.m, next_name).edge_mlp
+            w = int(v_out.size(1))
+            res = mlp.run_with_heads(srcs, n_own, act, nxt, nxt.input_size - 2 * w, [w, w], out=v_out,
+                                     head_outs=[pr_out[:n_own], None])
+            if res is not None:
+                return pr_out, res[1][1]
+        mlp.run_coded(srcs, n_own, act, out=v_out)
+        return None
+
+    def encode(self, mesh: LocalMesh, v_out: torch.Tensor, next_name: Optional[str] = None, pr_out: Optional[torch.Tensor] = None):
         m = self.m
         e = m.edge_encoder.run_coded([Source(mesh.edge_attr)], int(mesh.edge_attr.size(0)), SELU)
         srcs = [Source(mesh.inputs[k]) for k in ("field", "loc", "glob", "omega") if k in mesh.inputs]
-        m.node_encoder.run_coded(srcs, mesh.n_own[0], SELU, out=v_out)
-        return e
+        return e, self._node_launch(m.node_encoder, srcs, mesh.n_own[0], SELU, v_out, next_name, pr_out)
 
     def hoists(self, n_edges: int) -> bool:
         """Whether an MP layer with this many local edges multiplies its node-side first-layer terms per node
@@ -275,16 +288,7 @@ class HipImpl:
         agg = torch.empty((csr.n_seg, blk.edge_mlp.output_size), dtype=torch.float32, device=e.device)
         e_new = blk.edge_mlp.run_hoisted([Source(e, pre_act=e_pending)], [(v, ep.row), (v, ep.col)], ep.n_edges,
                                          products=products, agg=(csr, agg, blk.aggr == "mean"))
-        srcs = [Source(agg), Source(v[:n_own])]
-        if next_name is not None and pr_out is not None:
-            nxt = getattr(self.m, next_name).edge_mlp
-            w = int(v.size(1))
-            res = blk.node_mlp.run_with_heads(srcs, n_own, SELU, nxt, nxt.input_size - 2 * w, [w, w],
-                                              out=v_out, head_outs=[pr_out[:n_own], None])
-            if res is not None:
-                return e_new, (pr_out, res[1][1])
-        blk.node_mlp.run_coded(srcs, n_own, SELU, out=v_out)
-        return e_new, None
+        return e_new, self._node_launch(blk.node_mlp, [Source(agg), Source(v[:n_own])], n_own, SELU, v_out, next_name, pr_out)
 
     def down(self, name: str, v_own: torch.Tensor, rel: torch.Tensor, parent: torch.Tensor, n_coarse: int, e: torch.Tensor,
              e_pending: int, pool_csr, v_out: torch.Tensor):
@@ -295,10 +299,10 @@ class HipImpl:
         return ops.segment_reduce(e, pool_csr, True, src_act=e_pending)
 
     def up(self, name: str, v_coarse: torch.Tensor, v_old_own: torch.Tensor, rel: torch.Tensor, parent: torch.Tensor,
-           v_out: torch.Tensor):
+           v_out: torch.Tensor, next_name: Optional[str] = None, pr_out: Optional[torch.Tensor] = None):
         blk = getattr(self.m, name)
-        blk.up_mlp.run_coded([Source(rel, negate=True), Source(v_coarse, plan.index32(parent)), Source(v_old_own)],
-                             int(v_old_own.size(0)), TANH, out=v_out)
+        srcs = [Source(rel, negate=True), Source(v_coarse, plan.index32(parent)), Source(v_old_own)]
+        return self._node_launch(blk.up_mlp, srcs, int(v_old_own.size(0)), TANH, v_out, next_name, pr_out)
 
     def decode(self, v_own: torch.Tensor, field: torch.Tensor, nf: int) -> torch.Tensor:
         return self.m.node_decoder.run_coded([Source(v_own)], int(v_own.size(0)), NONE, resid=field,
@@ -320,10 +324,16 @@ class MusPartitionedForward:
         m, impl = self.mesh, self.impl
         level = 1
         v = self._buf(1)
-        e = impl.encode(m, v[: m.n_own[0]])
+
+        def wants(k: int, lvl: int) -> bool:      # program entry k is an MP layer that will hoist its first layer
+            return (k < len(self.program) and self.program[k].startswith("mp")
+                    and impl.hoists(int(m.edge_index[lvl - 1].size(1))))
+
+        # (W1r v [own + halo rows], W1c v [own rows]) of the next MP layer, when the launch producing v already made them
+        w0 = wants(0, 1)
+        e, prod = impl.encode(m, v[: m.n_own[0]], self.program[0] if w0 else None, self._buf(1) if w0 else None)
         e_pending = NONE
         stash = []
-        prod = None               # (W1r v [own + halo rows], W1c v [own rows]) of the next MP layer, when already multiplied
         for k, name in enumerate(self.program):
             n_own = m.n_own[level - 1]
             if name.startswith("down_mp"):
@@ -335,11 +345,12 @@ class MusPartitionedForward:
                 v, e_pending = v_c, NONE
                 level += 1
             elif name.startswith("up_mp"):
-                prod = None
                 v_old, e, e_pending = stash.pop()
                 level -= 1
                 v_f = self._buf(level)
-                impl.up(name, v, v_old[: m.n_own[level - 1]], m.rel[level - 1], m.parent[level - 1], v_f[: m.n_own[level - 1]])
+                wn = wants(k + 1, level)
+                prod = impl.up(name, v, v_old[: m.n_own[level - 1]], m.rel[level - 1], m.parent[level - 1], v_f[: m.n_own[level - 1]],
+                               self.program[k + 1] if wn else None, self._buf(level) if wn else None)
                 v = v_f
             else:
                 # products ride on the previous layer's node launch when this layer hoists its first layer: then the halo

@@ -52,10 +52,18 @@ class OracleImpl:
     def new(self, rows, width, device):
         return torch.zeros(rows, width)
 
-    def encode(self, mesh, v_out):
+    def _products(self, v_out, n_own, next_name, pr_out):
+        if next_name is None or pr_out is None:
+            return None
+        H = v_out.size(1)
+        Wn = self.w[f"{next_name}.edge_mlp.MLP.linear_1.weight"]
+        pr_out[:n_own] = v_out @ Wn[:, -2 * H:-H].T
+        return pr_out, v_out @ Wn[:, -H:].T
+
+    def encode(self, mesh, v_out, next_name=None, pr_out=None):
         x = torch.cat([mesh.inputs[k] for k in ("field", "loc", "glob", "omega") if k in mesh.inputs], 1)
         v_out.copy_(F.selu(O.mlp(x, self.w, "node_encoder")))
-        return F.selu(O.mlp(mesh.edge_attr, self.w, "edge_encoder"))
+        return F.selu(O.mlp(mesh.edge_attr, self.w, "edge_encoder")), self._products(v_out, v_out.size(0), next_name, pr_out)
 
     @staticmethod
     def _act(e, pending):
@@ -87,12 +95,7 @@ class OracleImpl:
             e_new = self._mlp_tail(h, f"{name}.edge_mlp")
         agg = O.scatter(e_new, col, n_own, "mean")
         v_out.copy_(F.selu(O.mlp(torch.cat((agg, v[:n_own]), 1), self.w, f"{name}.node_mlp")))
-        nxt = None
-        if next_name is not None and pr_out is not None:
-            Wn = self.w[f"{next_name}.edge_mlp.MLP.linear_1.weight"]
-            pr_out[:n_own] = v_out @ Wn[:, -2 * H:-H].T
-            nxt = (pr_out, v_out @ Wn[:, -H:].T)
-        return e_new, nxt
+        return e_new, self._products(v_out, n_own, next_name, pr_out)
 
     def down(self, name, v_own, rel, parent, n_coarse, e, e_pending, pool_csr, v_out):
         msg = O.mlp(torch.cat((rel, v_own), 1), self.w, f"{name}.down_mlp")
@@ -100,8 +103,9 @@ class OracleImpl:
         seg = torch.repeat_interleave(torch.arange(pool_csr.n_seg), (pool_csr.off[1:] - pool_csr.off[:-1]).long())
         return O.scatter(self._act(e, e_pending)[pool_csr.perm.long()], seg, pool_csr.n_seg, "mean")
 
-    def up(self, name, v_coarse, v_old_own, rel, parent, v_out):
+    def up(self, name, v_coarse, v_old_own, rel, parent, v_out, next_name=None, pr_out=None):
         v_out.copy_(torch.tanh(O.mlp(torch.cat((-rel, v_coarse[parent], v_old_own), 1), self.w, f"{name}.up_mlp")))
+        return self._products(v_out, v_out.size(0), next_name, pr_out)
 
     def decode(self, v_own, field, nf):
         return field[:, -nf:] + O.mlp(v_own, self.w, "node_decoder")
