@@ -11,6 +11,7 @@
 // [+ E*4 when a permutation is read].  For W = 128 one message row is 512 B = 32 lanes x float4,
 // a wave covers two destination rows per load instruction and keeps up to UNROLL rows in flight.
 #include "g4c_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -115,7 +116,10 @@ extern "C" int g4c_segment_reduce(const float *src, int32_t src_ld, const int32_
             src, src_ld, perm, off, n_seg, width, mean, src_act, act, out, out_ld);
         return g4c::check_launch("g4c_segment_reduce");
     }
-    const int q = width / 4;
+    static const int force_lpr = getenv("G4C_SEG_LPR") ? atoi(getenv("G4C_SEG_LPR")) : 0;     // tuning only
+    int q = width / 4;
+    if (force_lpr == 16 && q > 16) q = 16;
+    if (force_lpr == 8 && q > 8) q = 8;
     if (q > 16) {
         const long long total = (long long)n_seg * 32;
         segment_reduce_kernel<32><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(
