@@ -18,6 +18,7 @@ OK, EINVAL, ELAUNCH, EUNSUPPORTED = 0, -1, -2, -3
 ACT_NONE, ACT_SELU, ACT_TANH = 0, 1, 2
 MAX_SRC, MAX_LAYERS = 4, 4
 MAX_HEADS = 2
+NARROW_MAX = 8
 
 _ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "selu": ACT_SELU, "tanh": ACT_TANH}
 
@@ -36,7 +37,8 @@ def act_code(activation) -> Optional[int]:
 
 class g4c_src_t(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("idx", C.c_void_p), ("width", C.c_int32), ("ld", C.c_int32),
-                ("col0", C.c_int32), ("pre_act", C.c_int32), ("additive", C.c_int32), ("reserved", C.c_int32)]
+                ("col0", C.c_int32), ("pre_act", C.c_int32), ("additive", C.c_int32), ("reserved", C.c_int32),
+                ("w", C.c_void_p)]
 
 
 class g4c_mlp_t(C.Structure):

@@ -64,6 +64,12 @@ struct Src {
     int width, wpad, ld, col0, vec, pre_act;
 };
 
+struct NarSrc {          // narrow input block multiplied on the VALUs (g4c_src_t.additive == 2): rows = the tile's own rows
+    const float *ptr;    // first used column of row 0
+    const float *w;      // fp32 [width][128]
+    int width, ld;
+};
+
 struct AddSrc {          // pre-multiplied first-layer term, gathered per row and added to the layer-0 output
     const float *ptr;
     const int *idx;
@@ -102,6 +108,9 @@ struct Params {
     const int *tile_rows, *tile_seg, *seg_off;
     float *agg;
     int agg_ld, agg_mean;
+    // narrow input blocks of the first layer, multiplied in fp32 on the vector ALUs (bf16x6 kernel)
+    NarSrc nar[G4C_MAX_SRC];
+    int n_nar;
 };
 
 template <int RT> struct Acc { f32x16 t[RT][4]; };
@@ -1747,7 +1756,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
         ring.h[s] = ldw(rs, lo_b, 2u * s * STEP6);
         if (SP == 3) { ring.m[s] = ldw(rs, lo_b + 1024u, 2u * s * STEP6); ring.l[s] = ldw(rs, lo_b + 2048u, 2u * s * STEP6); }
     }
-    const bool direct0 = (p.src[0].idx == nullptr);
+    const bool direct0 = p.n_src > 0 && (p.src[0].idx == nullptr);
     if (direct0) gather(0, true);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1760,10 +1769,10 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
     if (p.gamma) sGB[tid] = gb_v;          // [gamma(128) | beta(128)] = 256 threads
     __syncthreads();
     G4C_STAMPW(1);
-    if (!direct0) gather(0, false);
+    if (!direct0 && p.n_src > 0) gather(0, false);
     __builtin_amdgcn_sched_barrier(0);
 
-    park(0);          // (before the additive gathers: the input registers are free again while those are in flight)
+    if (p.n_src > 0) park(0);          // (before the additive gathers: the input registers are free again while those are in flight)
     G4C_STAMPW(2);
     // Operands are swapped in the MFMAs (weights as A, activations as B), so the accumulators are TRANSPOSED: this lane
     // holds sample row i (= lane & 31, + 32 per row tile) and the 16 output features 32*ct0 + 8*(q>>2) + 4*h + (q&3):
@@ -1805,6 +1814,26 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[t][4 * gq + e] += (FULL || fbase + 8 * gq + e < width) ? tt[t][gq][e] : 0.f;
         __builtin_amdgcn_sched_barrier(0);
+    }
+    // narrow input blocks (2..8 columns): x[row, k] * W1^T[k, :] in fp32 on the vector ALUs — a padded 128-k block of
+    // six-product MFMAs for 2 columns of input would cost 48 MFMAs per wave; this costs 16 FMAs per column
+    for (int a = 0; a < p.n_nar; ++a) {
+        const float *wn = p.nar[a].w + fbase;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            long long gr = row0 + i + 32 * t;
+            if (gr >= mlim) gr = mlim - 1;
+            const float *xr = p.nar[a].ptr + gr * p.nar[a].ld;
+            for (int kk = 0; kk < p.nar[a].width; ++kk) {
+                const float x = xr[kk];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wn + kk * NP + 8 * gq);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[t][4 * gq + e] = fmaf(x, w4[e], acc[t][4 * gq + e]);
+                }
+            }
+        }
     }
     __syncthreads();
     G4C_STAMPW(3);
@@ -2180,10 +2209,20 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     bool all_vec = true, deep_ok = true;
     int nk = 0;
     p.n_add = 0;
+    p.n_nar = 0;
     for (int s = 0; s < n_src; ++s) {
         const g4c_src_t &g = srcs[s];
         G4C_REQUIRE(g.ptr && g.width > 0 && g.ld >= g.col0 + g.width && g.col0 >= 0, G4C_EINVAL,
                     "g4c_mlp_forward: bad source %d (width=%d ld=%d col0=%d)", s, g.width, g.ld, g.col0);
+        if (g.additive == 2) {
+            G4C_REQUIRE(bx6, G4C_EUNSUPPORTED, "g4c_mlp_forward: narrow sources (additive == 2) need the bf16x6 kernels");
+            G4C_REQUIRE(g.width <= G4C_NARROW_MAX && !g.idx && g.pre_act == G4C_ACT_NONE && g.w && ((uintptr_t)g.w & 15) == 0, G4C_EINVAL,
+                        "g4c_mlp_forward: bad narrow source %d (width %d <= %d, no index, no pre_act, 16-byte aligned weights)", s,
+                        g.width, G4C_NARROW_MAX);
+            NarSrc &a = p.nar[p.n_nar++];
+            a.ptr = g.ptr + g.col0; a.w = g.w; a.width = g.width; a.ld = g.ld;
+            continue;
+        }
         if (g.additive) {
             G4C_REQUIRE(g.pre_act == G4C_ACT_NONE && g.width <= NP, G4C_EINVAL, "g4c_mlp_forward: bad additive source %d", s);
             AddSrc &a = p.add[p.n_add++];
@@ -2201,9 +2240,11 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         deep_ok = deep_ok && d.vec && g.width == NP;
         kp += d.wpad;
     }
-    G4C_REQUIRE(nk >= 1, G4C_EINVAL, "g4c_mlp_forward: no input block goes through the weights");
+    G4C_REQUIRE(nk >= 1 || p.n_nar >= 1, G4C_EINVAL, "g4c_mlp_forward: no input block goes through the weights");
     p.n_src = nk;
-    for (int s = nk; s < G4C_MAX_SRC; ++s) p.src[s] = p.src[0];
+    if (nk == 0) p.src[0] = Src{nullptr, nullptr, 0, 0, 0, 0, 1, 0};
+    for (int s = (nk ? nk : 1); s < G4C_MAX_SRC; ++s) p.src[s] = p.src[0];
+    for (int s = p.n_nar; s < G4C_MAX_SRC; ++s) p.nar[s] = NarSrc{nullptr, nullptr, 0, 0};
     for (int s = p.n_add; s < G4C_MAX_SRC; ++s) p.add[s] = AddSrc{nullptr, nullptr, 0, 0};
     G4C_REQUIRE(kp == mlp->k_pad[0], G4C_EINVAL, "g4c_mlp_forward: sources give %d padded columns, layer 1 packed for %d", kp, mlp->k_pad[0]);
     p.n_layers = mlp->n_layers;

@@ -29,6 +29,12 @@ HOIST_MIN_ROWS = int(os.environ.get("G4C_HOIST_MIN_ROWS", 24576))
 Tensor = torch.Tensor
 
 
+def _narrow_flags(sources: Sequence[Source]) -> List[bool]:
+    """Input blocks the bf16x6 kernels multiply on the vector ALUs instead of padding them to a 128-k matrix block:
+    at most 8 columns, read row-for-row (no gather index) and without an activation on load."""
+    return [s.width <= _lib.NARROW_MAX and s.index is None and s.pre_act == _lib.ACT_NONE and not s.additive for s in sources]
+
+
 def _ld_of(t: Tensor) -> int:
     return int(t.stride(0)) if t.dim() == 2 else int(t.numel())
 
@@ -75,9 +81,10 @@ class MLP(nn.Module):
     def _signature(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def packed(self, seg_widths: Sequence[int], seg_negate: Sequence[bool]) -> ops.PackedMLP:
+    def packed(self, seg_widths: Sequence[int], seg_negate: Sequence[bool], narrow: Optional[Sequence[bool]] = None) -> ops.PackedMLP:
         prec = ops.effective_precision(seg_widths)
-        key = (tuple(seg_widths), tuple(bool(x) for x in seg_negate), prec)
+        narrow = tuple(bool(x) for x in narrow) if (narrow is not None and prec != "fp32") else (False,) * len(seg_widths)
+        key = (tuple(seg_widths), tuple(bool(x) for x in seg_negate), prec, narrow)
         sig = self._signature()
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
@@ -86,7 +93,7 @@ class MLP(nn.Module):
             lin = self._linears()
             ln = getattr(self.MLP, "layer_norm", None)
             pk = ops.PackedMLP([l.weight for l in lin], [l.bias for l in lin],
-                               None if ln is None else (ln.weight, ln.bias, ln.eps), key[0], key[1], precision=prec)
+                               None if ln is None else (ln.weight, ln.bias, ln.eps), key[0], key[1], precision=prec, narrow=narrow)
             self._packed[key] = (sig, pk)
             hit = self._packed[key]
         return hit[1]
@@ -97,12 +104,12 @@ class MLP(nn.Module):
         code = _lib.act_code(activation)
         if code is None and resid is not None:
             raise NotImplementedError("a residual after a non-fusable activation")
-        pk = self.packed([s.width for s in sources], [s.negate for s in sources])
+        pk = self.packed([s.width for s in sources], [s.negate for s in sources], _narrow_flags(sources))
         y = ops.mlp_forward(pk, sources, n_rows, _lib.ACT_NONE if code is None else code, out, out_idx32, resid, resid_col0)
         return _finish(y, activation, code)
 
     def run_coded(self, sources: Sequence[Source], n_rows: int, act_code: int = _lib.ACT_NONE, **kw) -> Tensor:
-        pk = self.packed([s.width for s in sources], [s.negate for s in sources])
+        pk = self.packed([s.width for s in sources], [s.negate for s in sources], _narrow_flags(sources))
         return ops.mlp_forward(pk, sources, n_rows, act_code, **kw)
 
     def run_with_heads(self, sources: Sequence[Source], n_rows: int, act_code: int, consumer: "MLP", k_cols: int,
@@ -119,7 +126,8 @@ class MLP(nn.Module):
         prec = ops.effective_precision([s.width for s in sources])
         if prec == "bf16":
             return None
-        key = ("heads", id(consumer), k_cols, tuple(widths), tuple(s.width for s in sources), tuple(s.negate for s in sources), prec)
+        narrow = tuple(_narrow_flags(sources)) if prec != "fp32" else (False,) * len(sources)
+        key = ("heads", id(consumer), k_cols, tuple(widths), tuple(s.width for s in sources), tuple(s.negate for s in sources), prec, narrow)
         sig = (self._signature(), consumer._signature())
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
@@ -133,7 +141,8 @@ class MLP(nn.Module):
             if int(w1.size(0)) != 128:
                 return None
             pk = ops.PackedMLP([l.weight for l in lin], [l.bias for l in lin],
-                               None if ln is None else (ln.weight, ln.bias, ln.eps), key[4], key[5], heads=heads, precision=prec)
+                               None if ln is None else (ln.weight, ln.bias, ln.eps), key[4], key[5], heads=heads, precision=prec,
+                               narrow=narrow)
             self._packed[key] = (sig, pk)
             hit = self._packed[key]
         pk = hit[1]

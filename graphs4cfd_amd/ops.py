@@ -224,13 +224,22 @@ class PackedMLP:
 
     def __init__(self, weights: Sequence[Tensor], biases: Sequence[Tensor], ln: Optional[Tuple[Tensor, Tensor, float]],
                  seg_widths: Sequence[int], seg_negate: Sequence[bool], heads: Sequence[Tensor] = (),
-                 precision: str = "fp32"):
+                 precision: str = "fp32", narrow: Optional[Sequence[bool]] = None):
         """`heads`: bias-free [128, 128] weights applied to the MLP's final output row (g4c_mlp_forward_heads); their
         packed images continue the weight stream after the last layer.  `precision` "bf16": the bf16 stream of
-        g4c_mlp_pack_layer_bx6 (every input block padded to 128 k; "bf16" uses the same stream, leading plane only)."""
+        g4c_mlp_pack_layer_bx6 (every input block padded to 128 k; "bf16" uses the same stream, leading plane only).
+        `narrow[s]` (bf16x6 / bf16 only): input block s (<= 8 columns, read without index or activation) is multiplied in
+        fp32 on the vector ALUs by its rows of the first layer's weight (g4c_src_t.additive == 2) instead of being padded
+        to a 128-k block of the matrix-pipe stream."""
         lib = _lib.load()
         self.precision = precision
-        bf16 = precision in ("bf16", "bf16x6")       # three-plane bf16 weight stream, 128-k input blocks ("bf16" reads plane 0 only)
+        bf16 = precision in ("bf16", "bf16x6")
+        narrow = tuple(bool(x) for x in narrow) if narrow is not None else (False,) * len(seg_widths)
+        if any(narrow) and not bf16:
+            raise NotImplementedError("narrow input blocks need the bf16x6 kernels")
+        if any(nw and w > _lib.NARROW_MAX for nw, w in zip(narrow, seg_widths)):
+            raise ValueError(f"a narrow input block has more than {_lib.NARROW_MAX} columns")
+        self.narrow = narrow       # three-plane bf16 weight stream, 128-k input blocks ("bf16" reads plane 0 only)
         planes = 3
         if precision == "bf16" and heads:
             raise NotImplementedError("heads in plain bf16")
@@ -247,7 +256,8 @@ class PackedMLP:
         KC, NP = 32, 128                       # kernel constants: K chunk, computed layer width
         if bf16 and any(s > NP for s in seg_widths):
             raise NotImplementedError("bf16 MLP with an input block wider than 128")
-        k_pad0 = NP * len(seg_widths) if bf16 else sum((s + KC - 1) // KC * KC for s in seg_widths)
+        wide = [j for j in range(len(seg_widths)) if not narrow[j]]            # the blocks that go through the packed stream
+        k_pad0 = NP * len(wide) if bf16 else sum((s + KC - 1) // KC * KC for s in seg_widths)
         k_pads = [k_pad0] + [NP] * (n_layers - 1)
         # one contiguous weight stream (layer after layer, 32-k chunk after chunk) + one chunk of slack:
         # the kernel's register ring prefetches one chunk past the end
@@ -269,16 +279,33 @@ class PackedMLP:
                 raise NotImplementedError(f"layer width {n_out} > 128 is outside the fused-MLP kernel envelope")
             if l == 0:
                 segs, negs = list(seg_widths), [1 if x else 0 for x in seg_negate]
+                self.narrow_w = {}
+                if any(narrow):          # fp32 rows of W1^T for the narrow blocks; the stream gets the remaining columns only
+                    col0s = [sum(seg_widths[:j]) for j in range(len(seg_widths))]
+                    W32 = W.detach().to(torch.float32)
+                    for j in range(len(seg_widths)):
+                        if narrow[j]:
+                            rows = torch.zeros((seg_widths[j], NP), dtype=torch.float32, device=dev)
+                            rows[:, :n_out] = W32[:, col0s[j]:col0s[j] + seg_widths[j]].T * (-1.0 if seg_negate[j] else 1.0)
+                            self.narrow_w[j] = rows.contiguous()
+                            self._keep.append(self.narrow_w[j])
+                    if wide:
+                        W = torch.cat([W32[:, col0s[j]:col0s[j] + seg_widths[j]] for j in wide], dim=1)
+                        segs, negs = [seg_widths[j] for j in wide], [1 if seg_negate[j] else 0 for j in wide]
+                        k_in = int(W.size(1))
+                    else:
+                        W = None
             else:
                 prev = int(weights[l - 1].size(0))
                 if k_in != prev:
                     raise ValueError(f"layer {l + 1} expects {k_in} inputs, previous layer gives {prev}")
                 segs, negs = [k_in], [0]
-            Wc = W.detach().to(torch.float32).contiguous()
-            seg_arr = (C.c_int32 * len(segs))(*segs)
-            neg_arr = (C.c_int32 * len(segs))(*negs)
             wptr = stream_buf.data_ptr() + esz * off
-            _lib.check(pack(_lib.ptr(Wc), n_out, k_in, seg_arr, neg_arr, len(segs), wptr, k_pads[l], NP, stream))
+            if W is not None:            # (None: every input block of the first layer is narrow, nothing to stream)
+                Wc = W.detach().to(torch.float32).contiguous()
+                seg_arr = (C.c_int32 * len(segs))(*segs)
+                neg_arr = (C.c_int32 * len(segs))(*negs)
+                _lib.check(pack(_lib.ptr(Wc), n_out, k_in, seg_arr, neg_arr, len(segs), wptr, k_pads[l], NP, stream))
             if b is not None:
                 bias_buf[l * NP: l * NP + n_out].copy_(b.detach())
             self.desc.k_pad[l], self.desc.n_pad[l] = k_pads[l], NP
@@ -340,6 +367,16 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
     if tuple(s.width for s in sources if not s.additive) != packed.seg_widths:
         raise ValueError(f"input blocks {[s.width for s in sources if not s.additive]} do not match packed layout {packed.seg_widths}")
     arr = _src_array(sources)
+    if any(packed.narrow):
+        j = 0
+        for a, src in zip(arr, sources):
+            if src.additive:
+                continue
+            if packed.narrow[j]:
+                if src.index is not None or src.pre_act != _lib.ACT_NONE:
+                    raise ValueError("a narrow input block cannot be gathered through an index or activated on load")
+                a.additive, a.w = 2, packed.narrow_w[j].data_ptr()
+            j += 1
     if out is None:
         out = torch.empty((n_rows, packed.n_out), dtype=torch.float32, device=dev)
     args = (_lib.ptr(out), _ld(out), _lib.ptr(out_idx32), act, _lib.ptr(resid), _ld(resid) if resid is not None else 0,

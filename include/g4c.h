@@ -35,6 +35,7 @@ extern "C" {
 #define G4C_MAX_SRC 4
 #define G4C_MAX_LAYERS 4
 #define G4C_MAX_HEADS 2
+#define G4C_NARROW_MAX 8
 
 int g4c_version(void);
 const char *g4c_last_error(void);
@@ -96,8 +97,14 @@ typedef struct {
                            1: a term ALREADY multiplied by its block of the first layer's weights, at the row count of
                            the tensor it was gathered from; row idx[r] is added to row r of the first layer's output.
                            Linearity: W1 [e | v[row] | v[col]] = W1e e + (W1r v)[row] + (W1c v)[col], so the node-side
-                           products cost N rows instead of E (nn/blocks.py:181, :328, :373). */
+                           products cost N rows instead of E (nn/blocks.py:181, :328, :373).
+                           2 (bf16x6 kernels only): a NARROW column block (width <= G4C_NARROW_MAX, idx == NULL, no pre_act)
+                           multiplied in fp32 on the vector ALUs by its rows of the first layer's weight, `w`, instead of
+                           being padded to a 128-k block of the matrix-pipe stream (the 2..5-wide encoder / DownMP / UpMP
+                           inputs: nn/mus_gnn.py:71,176-177, nn/blocks.py:229,285); such blocks are NOT part of the packed
+                           stream (k_pad[0] counts the other blocks only). */
     int32_t reserved;
+    const float *w;     /* additive == 2: fp32 [width][128] = W1^T rows of this block (sign folded in), zero padded */
 } g4c_src_t;
 
 typedef struct {

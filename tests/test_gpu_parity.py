@@ -134,12 +134,19 @@ def test_mlp_bf16_variant(rows):
     col = torch.randint(0, n, (rows,), device=DEV, dtype=torch.int32)
     x3 = torch.randn(rows, 3, device=DEV)
 
-    def emulate(mlp, x, first_exact_cols=0):       # bf16-rounded operands, fp32 accumulation (fp64 here), fp32 epilogue
+    def emulate(mlp, x, exact_from=None):       # bf16-rounded operands, fp32 accumulation (fp64 here), fp32 epilogue
+        """`exact_from`: first-layer input columns from there on form a NARROW block, which the kernel multiplies in fp32
+        on the vector ALUs (not rounded)."""
         lin = mlp._linears()
         r = lambda t: t.to(torch.bfloat16).double()
         y = x.double()
         for li, l in enumerate(lin):
-            y = r(y.float()) @ r(l.weight.detach()).T + l.bias.detach().double()
+            W = l.weight.detach()
+            if li == 0 and exact_from is not None:
+                y = (r(y[:, :exact_from].float()) @ r(W[:, :exact_from]).T + y[:, exact_from:] @ W[:, exact_from:].double().T
+                     + l.bias.detach().double())
+            else:
+                y = r(y.float()) @ r(W).T + l.bias.detach().double()
             if li < len(lin) - 1:
                 y = torch.selu(y)
         ln = getattr(mlp.MLP, "layer_norm", None)
@@ -161,7 +168,7 @@ def test_mlp_bf16_variant(rows):
         close_bf16(y, emulate(blk.edge_mlp, xin))
         # node-like MLP with a narrow, unaligned third block and a fused activation
         y2 = blk.node_mlp.run_coded([ops.Source(e), ops.Source(e), ops.Source(x3)], rows, _lib.ACT_TANH)
-        close_bf16(y2, torch.tanh(emulate(blk.node_mlp, torch.cat([e, e, x3], 1))))
+        close_bf16(y2, torch.tanh(emulate(blk.node_mlp, torch.cat([e, e, x3], 1), exact_from=2 * H)))
     finally:
         ops.set_mlp_precision(old)
     w = {f"m.{k}": t.cpu() for k, t in blk.edge_mlp.state_dict().items()}
@@ -233,6 +240,31 @@ def test_edge_mlp_with_fused_aggregation(case, monkeypatch):
         if mean:
             dense /= torch.bincount(col, minlength=n).clamp(min=1).to(DEV)[:, None]
         torch.testing.assert_close(agg, dense, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows", [1, 77, 5000])
+def test_mlp_narrow_input_blocks(rows):
+    """Narrow input blocks (g4c_src_t.additive == 2: the 2..5-wide encoder / DownMP / UpMP inputs) are multiplied in fp32
+    on the vector ALUs instead of being padded to 128-k matrix blocks: all-narrow first layers (edge encoder), narrow +
+    wide mixes with a folded sign (UpMP), strided views, vs the oracle MLP on the concatenated input."""
+    H = 128
+    torch.manual_seed(rows + 3)
+    enc = B.MLP(2, (H, H, H), False).to(DEV)
+    node_enc = B.MLP(5, (H, H, H), False).to(DEV)
+    up = B.MLP(2 + 2 * H, (H, H, H), True).to(DEV)
+    ea = torch.randn(rows, 2, device=DEV)
+    buf = torch.randn(rows, 9, device=DEV)                       # field | glob | omega as column views of one buffer
+    field, glob, omega = buf[:, 1:4], buf[:, 5:6], buf[:, 8:9]
+    a, b = torch.randn(rows, H, device=DEV), torch.randn(rows, H, device=DEV)
+    w = lambda m: {f"m.{k}": t.cpu() for k, t in m.state_dict().items()}
+    y = enc.run_coded([ops.Source(ea)], rows, _lib.ACT_SELU)
+    torch.testing.assert_close(y.cpu(), torch.selu(O.mlp(ea.cpu(), w(enc), "m")), **BLOCK)
+    y = node_enc.run_coded([ops.Source(field), ops.Source(glob), ops.Source(omega)], rows, _lib.ACT_SELU)
+    torch.testing.assert_close(y.cpu(), torch.selu(O.mlp(torch.cat([field, glob, omega], 1).cpu(), w(node_enc), "m")), **BLOCK)
+    y = up.run_coded([ops.Source(ea, negate=True), ops.Source(a), ops.Source(b)], rows, _lib.ACT_TANH)
+    torch.testing.assert_close(y.cpu(), torch.tanh(O.mlp(torch.cat([-ea, a, b], 1).cpu(), w(up), "m")), **BLOCK)
+    pk = up.packed([2, H, H], [True, False, False], [True, False, False])
+    assert (pk.narrow == (True, False, False)) == (ops.mlp_precision() != "fp32")
 
 
 def test_mlp_precisions_vs_fp64():
