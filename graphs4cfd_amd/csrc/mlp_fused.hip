@@ -62,6 +62,8 @@ struct Src {
     const float *ptr;
     const int *idx;
     int width, wpad, ld, col0, vec, pre_act;
+    const int *seg_off;      // bf16x6 kernel: row r = sum / mean of rows [seg_off[r], seg_off[r+1]) (aggregation on load)
+    int seg_mean;
 };
 
 struct NarSrc {          // narrow input block multiplied on the VALUs (g4c_src_t.additive == 2): rows = the tile's own rows
@@ -1624,6 +1626,9 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
     l = (__bf16)(r1 - (float)m);
 }
 
+#ifndef G4C_SEG_INFLIGHT
+#define G4C_SEG_INFLIGHT 6       // rows of a segment in flight per column chunk when a source is aggregated on load
+#endif
 #ifndef G4C_BX6_MINW
 #define G4C_BX6_MINW 4
 #endif
@@ -1674,6 +1679,48 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
     f32x4 xp[RT][4];
     auto gather = [&](int sidx, bool direct) __attribute__((always_inline)) {
         const int width = p.src[sidx].width;
+        if (p.src[sidx].seg_off) {
+            // aggregation on load: this lane's row is the sum / mean of a CSR segment of the source's rows, added in
+            // order (bit-identical to segment_reduce_kernel); four rows in flight per column chunk
+            const int *so = p.src[sidx].seg_off;
+            const int ld = p.src[sidx].ld;
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                long long gr = row0 + grow_l + 32 * t;
+                if (gr >= mlim) gr = mlim - 1;
+                const int b = so[gr], e = so[gr + 1];
+                const float *rp = p.src[sidx].ptr + p.src[sidx].col0 + c4;
+                // one 32-column chunk at a time, G4C_SEG_INFLIGHT rows of it in flight (bounded registers; the row order
+                // of the additions is the segment order whichever way the loads are batched)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    for (int r = b; r < e; r += G4C_SEG_INFLIGHT) {
+                        f32x4 v[G4C_SEG_INFLIGHT];
+#pragma unroll
+                        for (int u = 0; u < G4C_SEG_INFLIGHT; ++u) {
+                            const int rr = (r + u < e) ? r + u : e - 1;
+                            v[u] = *reinterpret_cast<const f32x4 *>(rp + (long long)rr * ld + q * KC);
+                        }
+#pragma unroll
+                        for (int u = 0; u < G4C_SEG_INFLIGHT; ++u) {
+                            const bool on = r + u < e;
+#pragma unroll
+                            for (int el = 0; el < 4; ++el) a[el] += on ? v[u][el] : 0.f;
+                        }
+                    }
+                    xp[t][q] = a;
+                }
+                if (p.src[sidx].seg_mean) {
+                    const float cnt = (float)((e - b) > 1 ? (e - b) : 1);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int el = 0; el < 4; ++el) xp[t][q][el] /= cnt;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             long long gr;
@@ -2235,6 +2282,10 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         if (bf16) G4C_REQUIRE(g.width <= NP, G4C_EUNSUPPORTED, "g4c_mlp_forward_bf16: input block %d is %d wide (max 128)", s, g.width);
         d.ptr = g.ptr; d.idx = g.idx; d.width = g.width; d.wpad = bf16 ? NP : (g.width + KC - 1) / KC * KC; d.ld = g.ld; d.col0 = g.col0;
         d.pre_act = g.pre_act;
+        d.seg_off = g.seg_off; d.seg_mean = g.seg_mean;
+        if (g.seg_off)
+            G4C_REQUIRE(bx6 && !g.idx && g.width == NP && g.ld % 4 == 0 && g.col0 % 4 == 0 && (uintptr_t)g.ptr % 16 == 0, G4C_EUNSUPPORTED,
+                        "g4c_mlp_forward: aggregation on load needs the bf16x6 kernels and a 128-wide aligned block without gather index");
         d.vec = (g.width % 4 == 0) && (g.ld % 4 == 0) && (g.col0 % 4 == 0) && ((uintptr_t)g.ptr % 16 == 0);
         all_vec = all_vec && d.vec;
         deep_ok = deep_ok && d.vec && g.width == NP;
@@ -2242,7 +2293,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     }
     G4C_REQUIRE(nk >= 1 || p.n_nar >= 1, G4C_EINVAL, "g4c_mlp_forward: no input block goes through the weights");
     p.n_src = nk;
-    if (nk == 0) p.src[0] = Src{nullptr, nullptr, 0, 0, 0, 0, 1, 0};
+    if (nk == 0) p.src[0] = Src{nullptr, nullptr, 0, 0, 0, 0, 1, 0, nullptr, 0};
     for (int s = (nk ? nk : 1); s < G4C_MAX_SRC; ++s) p.src[s] = p.src[0];
     for (int s = p.n_nar; s < G4C_MAX_SRC; ++s) p.nar[s] = NarSrc{nullptr, nullptr, 0, 0};
     for (int s = p.n_add; s < G4C_MAX_SRC; ++s) p.add[s] = AddSrc{nullptr, nullptr, 0, 0};

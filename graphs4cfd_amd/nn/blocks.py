@@ -293,21 +293,29 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
         raise ValueError(f"unsupported aggr {aggr!r}")
     ep, csr = plan.edge_csr(index, int(v.size(0)))
     senders = v if v_src is None else v_src
-    # the aggregation rides on the edge launch when the kernel can reduce the tile it has just computed
-    # (ops.mlp_forward(agg=...)); otherwise that call runs g4c_segment_reduce right after the launch
-    agg = torch.empty((csr.n_seg, msg_mlp.output_size), dtype=torch.float32, device=e.device)
-    e_new = msg_mlp.run_hoisted([Source(e, pre_act=e_pre_act)], [(senders, ep.row), (v, ep.col)], ep.n_edges,
-                                products=products, agg=(csr, agg, aggr == "mean"))
+    mean = aggr == "mean"
+    if ops.can_aggregate_on_load(csr, msg_mlp.output_size, [msg_mlp.output_size, int(v.size(1))]) and not ops.FUSE_AGG:
+        # the node launch averages each target's messages while it gathers its input (g4c_src_t.seg_off): no separate
+        # aggregation pass, no aggregate written to / re-read from HBM
+        e_new = msg_mlp.run_hoisted([Source(e, pre_act=e_pre_act)], [(senders, ep.row), (v, ep.col)], ep.n_edges, products=products)
+        agg_src = Source(e_new, segments=csr, seg_mean=mean)
+    else:
+        # (G4C_FUSE_AGG: the aggregation rides on the EDGE launch when the kernel can reduce the tile it has just computed,
+        # ops.mlp_forward(agg=...); otherwise that call runs g4c_segment_reduce right after the launch)
+        agg = torch.empty((csr.n_seg, msg_mlp.output_size), dtype=torch.float32, device=e.device)
+        e_new = msg_mlp.run_hoisted([Source(e, pre_act=e_pre_act)], [(senders, ep.row), (v, ep.col)], ep.n_edges,
+                                    products=products, agg=(csr, agg, mean))
+        agg_src = Source(agg)
     if next_msg is not None:
         nxt = None
         if ep.n_edges >= HOIST_MIN_ROWS:     # the consumer will hoist: give it its node-side terms from this launch
             w = int(v.size(1))
-            nxt = upd_mlp.run_with_heads([Source(agg), Source(v)], int(v.size(0)), act_code, next_msg,
+            nxt = upd_mlp.run_with_heads([agg_src, Source(v)], int(v.size(0)), act_code, next_msg,
                                          next_msg.input_size - 2 * w, [w, w])
         if nxt is None:
-            return upd_mlp.run_coded([Source(agg), Source(v)], int(v.size(0)), act_code), e_new, None
+            return upd_mlp.run_coded([agg_src, Source(v)], int(v.size(0)), act_code), e_new, None
         return nxt[0], e_new, nxt[1]
-    v_new = upd_mlp.run_coded([Source(agg), Source(v)], int(v.size(0)), act_code)
+    v_new = upd_mlp.run_coded([agg_src, Source(v)], int(v.size(0)), act_code)
     return v_new, e_new
 
 

@@ -75,10 +75,11 @@ def _ld(t: Tensor) -> int:
 class Source:
     """One column block of a virtually concatenated MLP input."""
 
-    __slots__ = ("tensor", "index", "col0", "width", "negate", "pre_act", "additive")
+    __slots__ = ("tensor", "index", "col0", "width", "negate", "pre_act", "additive", "segments", "seg_mean")
 
     def __init__(self, tensor: Tensor, index: Optional[Tensor] = None, col0: int = 0, width: Optional[int] = None,
-                 negate: bool = False, pre_act: int = _lib.ACT_NONE, additive: bool = False):
+                 negate: bool = False, pre_act: int = _lib.ACT_NONE, additive: bool = False,
+                 segments: Optional[CsrPlan] = None, seg_mean: bool = True):
         self.tensor = _f32_2d(tensor, "source")
         self.index = index          # int32 gather index or None
         self.col0 = col0
@@ -86,6 +87,12 @@ class Source:
         self.negate = negate        # folded into the packed weights
         self.pre_act = pre_act      # activation applied while loading (producer stored the raw tensor)
         self.additive = additive    # already multiplied by its block of the first layer: gathered and added, not multiplied
+        # aggregation on load (bf16x6 kernels): row r of the block = sum / mean of the tensor's rows in segment r of this
+        # CSR plan (rows in segment order), i.e. scatter(tensor, col, reduce) without materialising it
+        self.segments = segments
+        self.seg_mean = seg_mean
+        if segments is not None and (segments.perm is not None or index is not None or additive or self.width != 128):
+            raise ValueError("aggregation on load needs rows in segment order, no gather index and a 128-wide block")
 
 
 def segment_reduce(src: Tensor, csr: CsrPlan, mean: bool, act: int = _lib.ACT_NONE, out: Optional[Tensor] = None,
@@ -197,6 +204,14 @@ _PRECISION = os.environ.get("G4C_MLP_PRECISION", "bf16x6")
 # which eats what the saved HBM pass gains (measured +0.8 % on the 100k-node rollout).  Off by default; worth it when the
 # degree divides 32.
 FUSE_AGG = os.environ.get("G4C_FUSE_AGG", "0") == "1"
+# Aggregation on load (g4c_src_t.seg_off): the node-MLP launch averages each target's messages while it gathers its input,
+# instead of a separate g4c_segment_reduce pass (bit-identical values; no tile-alignment constraint, unlike FUSE_AGG).
+AGG_ON_LOAD = os.environ.get("G4C_AGG_ON_LOAD", "1") == "1"
+
+
+def can_aggregate_on_load(csr: CsrPlan, width: int, consumer_widths: Sequence[int]) -> bool:
+    """`consumer_widths`: input blocks of the MLP that would aggregate while loading (it must run on the bf16x6 kernels)."""
+    return (AGG_ON_LOAD and effective_precision(consumer_widths) != "fp32" and csr.perm is None and width == 128 and csr.n > 0)
 
 
 def mlp_precision() -> str:
@@ -340,6 +355,8 @@ def _src_array(sources: Sequence[Source]):
         a.ptr, a.idx, a.width, a.ld, a.col0, a.pre_act = (s.tensor.data_ptr(), _lib.ptr(s.index), s.width, _ld(s.tensor),
                                                           s.col0, s.pre_act)
         a.additive = 1 if s.additive else 0
+        if s.segments is not None:
+            a.seg_off, a.seg_mean = _lib.ptr(s.segments.off), 1 if s.seg_mean else 0
     return arr
 
 

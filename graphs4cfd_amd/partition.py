@@ -285,10 +285,16 @@ class HipImpl:
         (own rows of `pr_out`, and a fresh tensor).  Returns (e', next products or None)."""
         blk = getattr(self.m, name)
         ep, csr = plan.edge_csr(edge_index, n_own)
-        agg = torch.empty((csr.n_seg, blk.edge_mlp.output_size), dtype=torch.float32, device=e.device)
-        e_new = blk.edge_mlp.run_hoisted([Source(e, pre_act=e_pending)], [(v, ep.row), (v, ep.col)], ep.n_edges,
-                                         products=products, agg=(csr, agg, blk.aggr == "mean"))
-        return e_new, self._node_launch(blk.node_mlp, [Source(agg), Source(v[:n_own])], n_own, SELU, v_out, next_name, pr_out)
+        mean = blk.aggr == "mean"
+        if ops.can_aggregate_on_load(csr, blk.edge_mlp.output_size, [blk.edge_mlp.output_size, int(v.size(1))]) and not ops.FUSE_AGG:
+            e_new = blk.edge_mlp.run_hoisted([Source(e, pre_act=e_pending)], [(v, ep.row), (v, ep.col)], ep.n_edges, products=products)
+            agg_src = Source(e_new, segments=csr, seg_mean=mean)
+        else:
+            agg = torch.empty((csr.n_seg, blk.edge_mlp.output_size), dtype=torch.float32, device=e.device)
+            e_new = blk.edge_mlp.run_hoisted([Source(e, pre_act=e_pending)], [(v, ep.row), (v, ep.col)], ep.n_edges,
+                                             products=products, agg=(csr, agg, mean))
+            agg_src = Source(agg)
+        return e_new, self._node_launch(blk.node_mlp, [agg_src, Source(v[:n_own])], n_own, SELU, v_out, next_name, pr_out)
 
     def down(self, name: str, v_own: torch.Tensor, rel: torch.Tensor, parent: torch.Tensor, n_coarse: int, e: torch.Tensor,
              e_pending: int, pool_csr, v_out: torch.Tensor):

@@ -103,8 +103,12 @@ typedef struct {
                            being padded to a 128-k block of the matrix-pipe stream (the 2..5-wide encoder / DownMP / UpMP
                            inputs: nn/mus_gnn.py:71,176-177, nn/blocks.py:229,285); such blocks are NOT part of the packed
                            stream (k_pad[0] counts the other blocks only). */
-    int32_t reserved;
+    int32_t seg_mean;   /* with seg_off: 1 = mean over the segment (divided by max(count, 1)), 0 = sum */
     const float *w;     /* additive == 2: fp32 [width][128] = W1^T rows of this block (sign folded in), zero padded */
+    const int32_t *seg_off; /* bf16x6 kernels, additive == 0, idx == NULL, width 128: row r of this block is the sum / mean of rows
+                           [seg_off[r], seg_off[r+1]) of ptr — the aggregation `scatter(e', col, reduce)` (nn/blocks.py:183) done
+                           while the node MLP gathers its input, in the order and with the formula of g4c_segment_reduce, instead
+                           of a separate pass that writes and re-reads the aggregate. */
 } g4c_src_t;
 
 typedef struct {

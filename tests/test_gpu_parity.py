@@ -267,6 +267,31 @@ def test_mlp_narrow_input_blocks(rows):
     assert (pk.narrow == (True, False, False)) == (ops.mlp_precision() != "fp32")
 
 
+@pytest.mark.parametrize("case", ["knn6", "ragged"])
+def test_node_mlp_aggregates_on_load(case):
+    """g4c_src_t.seg_off: the node MLP averages / sums each target's messages while gathering its input == the separate
+    g4c_segment_reduce followed by the plain launch, bit for bit (degrees 0..40 incl. empty targets and a long segment)."""
+    H, n = 128, 900
+    torch.manual_seed(31)
+    if case == "knn6":
+        col = torch.arange(n).repeat_interleave(6)
+    else:
+        deg = torch.randint(0, 10, (n,)); deg[0] = 0; deg[-1] = 0; deg[7:11] = 0; deg[100] = 40
+        col = torch.arange(n).repeat_interleave(deg)
+    E = int(col.numel())
+    edge_index = torch.stack([torch.randint(0, n, (E,)), col]).to(DEV)
+    ep, csr = plan.edge_csr(edge_index, n)
+    blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
+    e_new, v = torch.randn(E, H, device=DEV), torch.randn(n, H, device=DEV)
+    if ops.mlp_precision() == "fp32":
+        pytest.skip("aggregation on load is a feature of the bf16x6 kernels")
+    for mean in (True, False):
+        y = blk.node_mlp.run_coded([ops.Source(e_new, segments=csr, seg_mean=mean), ops.Source(v)], n, _lib.ACT_SELU)
+        agg = ops.segment_reduce(e_new, csr, mean)
+        y_ref = blk.node_mlp.run_coded([ops.Source(agg), ops.Source(v)], n, _lib.ACT_SELU)
+        assert torch.equal(y, y_ref)
+
+
 def test_mlp_precisions_vs_fp64():
     """The default bf16x6 arithmetic (exact three-way bf16 split, six partial products on the bf16 matrix pipe) is as
     accurate as the fp32-MFMA kernels: both against an fp64 evaluation of the same edge MLP (gathers, SELU-on-load,
