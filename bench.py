@@ -91,7 +91,11 @@ def pmc_traffic():
         sel = [v for name, v in k.items() if name.startswith(prefix)]
         n = sum(v["dispatches"] for v in sel)
         return sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in sel) / n if n else None
-    return {"avg": avg, "scatter": avg("segment_reduce_kernel")}, os.path.relpath(files[-1], ROOT)
+    def largest(prefix):
+        sel = [v.get("hbm_bytes_largest_launch") for name, v in k.items() if name.startswith(prefix) and v.get("hbm_bytes_largest_launch")]
+        return max(sel) if sel else None
+    # (the level-1 aggregation = the largest segment-reduce dispatches of the profiled bench run)
+    return {"avg": avg, "scatter": largest("segment_reduce_kernel") or avg("segment_reduce_kernel")}, os.path.relpath(files[-1], ROOT)
 
 
 def reference_flop_per_step(model, g, S):
