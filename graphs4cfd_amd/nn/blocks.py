@@ -386,7 +386,7 @@ class DownMP(nn.Module):
                 item.reset_parameters()
 
     def pool(self, graph: Graph, field: Tensor, edge_index: Tensor, edge_attr: Tensor, activation=None,
-             e_pre_act: int = _lib.ACT_NONE):
+             e_pre_act: int = _lib.ACT_NONE, target_major: bool = False):
         """Functional core: returns (field_l, edge_index_l, edge_attr_l) without touching the Graph.
         `e_pre_act`: activation still pending on `edge_attr` (applied while pooling)."""
         h, l = self.hr_graph_idx, self.lr_graph_idx
@@ -396,7 +396,8 @@ class DownMP(nn.Module):
         code = _lib.act_code(activation)
         pooled = ops.segment_reduce(m, csr, True, _lib.ACT_NONE if code is None else code)
         pooled = _finish(pooled, activation, code)
-        pp = plan.pool_edge_plan(getattr(graph, f'idx{h}_to_idx{l}'), edge_index)
+        # (target_major: the models' internal coarse edge order, see plan.pool_edge_plan; the public forward keeps `coalesce` order)
+        pp = plan.pool_edge_plan(getattr(graph, f'idx{h}_to_idx{l}'), edge_index, target_major)
         ea_l = ops.segment_reduce(edge_attr, pp.csr, True, src_act=e_pre_act)
         return pooled, pp.edge_index, ea_l
 

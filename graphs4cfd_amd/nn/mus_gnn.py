@@ -83,7 +83,7 @@ class _MuSGNN(GNN):
             block = getattr(self, name)
             if name.startswith("down_mp"):
                 stash.append((v, edge_index, e, e_pending))
-                v, edge_index, e = block.pool(graph, v, edge_index, e, torch.tanh, e_pre_act=e_pending)
+                v, edge_index, e = block.pool(graph, v, edge_index, e, torch.tanh, e_pre_act=e_pending, target_major=True)
                 e_pending, products = NONE, None
             elif name.startswith("up_mp"):
                 v_old, edge_index, e, e_pending = stash.pop()

@@ -228,9 +228,27 @@ def cluster_plan(cluster: torch.Tensor, mask: torch.Tensor) -> CsrPlan:
     return plan
 
 
-def pool_edge_plan(idx_hr_to_lr: torch.Tensor, edge_index: torch.Tensor) -> PoolEdgePlan:
-    key = _Cache.key(idx_hr_to_lr, edge_index)
+def pool_edge_plan(idx_hr_to_lr: torch.Tensor, edge_index: torch.Tensor, target_major: bool = False) -> PoolEdgePlan:
+    """Static part of `pool_edge` (nn/blocks.py:51-68).  `target_major=False`: coarse edges in torch_geometric `coalesce`
+    order (sorted by (row, col)) — the public `pool_edge`.  `target_major=True` (the models' internal use): the same
+    edges grouped by TARGET (stable, i.e. by (col, row)): the reference never exposes the coarse edge order
+    (SURVEY.md appendix A.2), and in this order the coarse MP layers need no permutation and can aggregate on load."""
+    key = _Cache.key(idx_hr_to_lr, edge_index) + (bool(target_major),)
     plan = _pool_plans.get(key)
+    if plan is None and target_major:
+        base = pool_edge_plan(idx_hr_to_lr, edge_index, False)
+        dev = base.edge_index.device
+        ei = base.edge_index.cpu().numpy()
+        off = base.csr.off.cpu().numpy().astype(np.int64)
+        perm = base.csr.perm.cpu().numpy()
+        order = np.argsort(ei[1], kind="stable")
+        deg = np.diff(off)[order]
+        off_new = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+        perm_new = (np.concatenate([perm[off[c]:off[c + 1]] for c in order]) if order.size else perm[:0]).astype(np.int32)
+        csr = CsrPlan(perm=torch.from_numpy(perm_new).to(dev), off=torch.from_numpy(off_new).to(dev), n=base.csr.n,
+                      n_seg=base.n_coarse, max_deg=base.csr.max_deg)
+        plan = PoolEdgePlan(edge_index=torch.from_numpy(np.ascontiguousarray(ei[:, order])).to(dev), csr=csr, n_coarse=base.n_coarse)
+        _pool_plans.put(key, (idx_hr_to_lr, edge_index), plan)
     if plan is None:
         lib = _lib.load()
         dev = _lib.require_hip(idx_hr_to_lr, edge_index)
