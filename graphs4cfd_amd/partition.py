@@ -154,8 +154,15 @@ class LocalMesh:
         # node inputs of owned level-1 nodes (the reference's concat order: field, loc, glob, omega)
         self.inputs = {k: getattr(graph, k)[own1].contiguous().to(device) for k in ("field", "loc", "glob", "omega")
                        if hasattr(graph, k)}
-        # per level: owned edges in local ids (+ the input edge_attr at level 1)
-        self.edge_index = [t(p.edge_index) for p in parts]
+        # per level: owned edges in local ids (+ the input edge_attr at level 1).  The coarse levels' edges (whose order nothing
+        # observes: their latents are produced by this mesh's own pool_edge plan) are grouped by target, so that the coarse MP
+        # layers need no CSR permutation and can aggregate on load; level 1 keeps the Graph's order (already target-grouped
+        # for kNN meshes, and aligned with edge_attr).
+        self._edge_index_np = [p.edge_index for p in parts]
+        for l in range(1, levels):
+            ei = parts[l].edge_index
+            self._edge_index_np[l] = np.ascontiguousarray(ei[:, np.argsort(ei[1], kind="stable")])
+        self.edge_index = [t(a) for a in self._edge_index_np]
         self.edge_attr = graph.edge_attr[torch.from_numpy(p1.edge_ids)].contiguous().to(device)
         # inter-level maps for owned fine nodes -> local coarse id, relative positions, pooling of edges
         self.parent, self.rel, self.parent_full = [], [], []
@@ -186,11 +193,11 @@ class LocalMesh:
             fine, coarse = self.parts[l - 1], self.parts[l]
             par_own, par_halo = self.parent_full[l - 1]
             par = np.concatenate([par_own, par_halo])
-            fe = fine.edge_index
+            fe = self._edge_index_np[l - 1]          # (the order the latents of that level are stored in)
             cr, cc = par[fe[0]], par[fe[1]]
             keep = np.nonzero((cr != cc) & (cr >= 0))[0]
             # local coarse edges, keyed like the local coarse edge list
-            ce = coarse.edge_index
+            ce = self._edge_index_np[l]
             n_loc = coarse.n_own + coarse.n_halo
             key_c = ce[0] * n_loc + ce[1]
             order_c = np.argsort(key_c, kind="stable")
