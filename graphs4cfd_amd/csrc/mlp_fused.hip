@@ -1626,6 +1626,9 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
     l = (__bf16)(r1 - (float)m);
 }
 
+#ifndef G4C_SEG_CHUNKS
+#define G4C_SEG_CHUNKS 1
+#endif
 #ifndef G4C_SEG_INFLIGHT
 #define G4C_SEG_INFLIGHT 6       // rows of a segment in flight per column chunk when a source is aggregated on load
 #endif
@@ -1690,26 +1693,33 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
                 if (gr >= mlim) gr = mlim - 1;
                 const int b = so[gr], e = so[gr + 1];
                 const float *rp = p.src[sidx].ptr + p.src[sidx].col0 + c4;
-                // one 32-column chunk at a time, G4C_SEG_INFLIGHT rows of it in flight (bounded registers; the row order
-                // of the additions is the segment order whichever way the loads are batched)
+                // G4C_SEG_CHUNKS 32-column chunks at a time, G4C_SEG_INFLIGHT rows of each in flight (bounded registers; the
+                // row order of the additions is the segment order whichever way the loads are batched)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                for (int q0 = 0; q0 < 4; q0 += G4C_SEG_CHUNKS) {
+                    f32x4 a[G4C_SEG_CHUNKS];
+#pragma unroll
+                    for (int qq = 0; qq < G4C_SEG_CHUNKS; ++qq) a[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
                     for (int r = b; r < e; r += G4C_SEG_INFLIGHT) {
-                        f32x4 v[G4C_SEG_INFLIGHT];
+                        f32x4 v[G4C_SEG_INFLIGHT][G4C_SEG_CHUNKS];
 #pragma unroll
                         for (int u = 0; u < G4C_SEG_INFLIGHT; ++u) {
                             const int rr = (r + u < e) ? r + u : e - 1;
-                            v[u] = *reinterpret_cast<const f32x4 *>(rp + (long long)rr * ld + q * KC);
+#pragma unroll
+                            for (int qq = 0; qq < G4C_SEG_CHUNKS; ++qq)
+                                v[u][qq] = *reinterpret_cast<const f32x4 *>(rp + (long long)rr * ld + (q0 + qq) * KC);
                         }
 #pragma unroll
                         for (int u = 0; u < G4C_SEG_INFLIGHT; ++u) {
                             const bool on = r + u < e;
 #pragma unroll
-                            for (int el = 0; el < 4; ++el) a[el] += on ? v[u][el] : 0.f;
+                            for (int qq = 0; qq < G4C_SEG_CHUNKS; ++qq)
+#pragma unroll
+                                for (int el = 0; el < 4; ++el) a[qq][el] += on ? v[u][qq][el] : 0.f;
                         }
                     }
-                    xp[t][q] = a;
+#pragma unroll
+                    for (int qq = 0; qq < G4C_SEG_CHUNKS; ++qq) xp[t][q0 + qq] = a[qq];
                 }
                 if (p.src[sidx].seg_mean) {
                     const float cnt = (float)((e - b) > 1 ? (e - b) : 1);
