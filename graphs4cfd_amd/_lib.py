@@ -38,7 +38,7 @@ def act_code(activation) -> Optional[int]:
 class g4c_src_t(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("idx", C.c_void_p), ("width", C.c_int32), ("ld", C.c_int32),
                 ("col0", C.c_int32), ("pre_act", C.c_int32), ("additive", C.c_int32), ("seg_mean", C.c_int32),
-                ("w", C.c_void_p), ("seg_off", C.c_void_p)]
+                ("w", C.c_void_p), ("seg_off", C.c_void_p), ("seg_perm", C.c_void_p)]
 
 
 class g4c_mlp_t(C.Structure):

@@ -64,6 +64,7 @@ struct Src {
     int width, wpad, ld, col0, vec, pre_act;
     const int *seg_off;      // bf16x6 kernel: row r = sum / mean of rows [seg_off[r], seg_off[r+1]) (aggregation on load)
     int seg_mean;
+    const int *seg_perm;     // optional row indirection of those positions
 };
 
 struct NarSrc {          // narrow input block multiplied on the VALUs (g4c_src_t.additive == 2): rows = the tile's own rows
@@ -1685,8 +1686,8 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
         if (p.src[sidx].seg_off) {
             // aggregation on load: this lane's row is the sum / mean of a CSR segment of the source's rows, added in
             // order (bit-identical to segment_reduce_kernel); four rows in flight per column chunk
-            const int *so = p.src[sidx].seg_off;
-            const int ld = p.src[sidx].ld;
+            const int *so = p.src[sidx].seg_off, *sp = p.src[sidx].seg_perm;
+            const int ld = p.src[sidx].ld, sact = p.src[sidx].pre_act;
 #pragma unroll
             for (int t = 0; t < RT; ++t) {
                 long long gr = row0 + grow_l + 32 * t;
@@ -1704,10 +1705,17 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
                         f32x4 v[G4C_SEG_INFLIGHT][G4C_SEG_CHUNKS];
 #pragma unroll
                         for (int u = 0; u < G4C_SEG_INFLIGHT; ++u) {
-                            const int rr = (r + u < e) ? r + u : e - 1;
+                            int rr = (r + u < e) ? r + u : e - 1;
+                            if (sp) rr = sp[rr];
 #pragma unroll
                             for (int qq = 0; qq < G4C_SEG_CHUNKS; ++qq)
                                 v[u][qq] = *reinterpret_cast<const f32x4 *>(rp + (long long)rr * ld + (q0 + qq) * KC);
+                        }
+                        if (sact) {          // the pending activation of the stored rows applies BEFORE the reduction
+#pragma unroll
+                            for (int u = 0; u < G4C_SEG_INFLIGHT; ++u)
+#pragma unroll
+                                for (int qq = 0; qq < G4C_SEG_CHUNKS; ++qq) v[u][qq] = selu4(v[u][qq]);
                         }
 #pragma unroll
                         for (int u = 0; u < G4C_SEG_INFLIGHT; ++u) {
@@ -1779,7 +1787,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
         }
     };
     auto park = [&](int sidx) __attribute__((always_inline)) {            // one uniform branch per block, not one per element
-        if (p.src[sidx].pre_act) park_impl(sidx, std::true_type{});
+        if (p.src[sidx].pre_act && !p.src[sidx].seg_off) park_impl(sidx, std::true_type{});
         else park_impl(sidx, std::false_type{});
     };
     // Memory instructions return in order per wave, so the loads that head a dependent chain go FIRST: row indices (the
@@ -2292,7 +2300,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         if (bf16) G4C_REQUIRE(g.width <= NP, G4C_EUNSUPPORTED, "g4c_mlp_forward_bf16: input block %d is %d wide (max 128)", s, g.width);
         d.ptr = g.ptr; d.idx = g.idx; d.width = g.width; d.wpad = bf16 ? NP : (g.width + KC - 1) / KC * KC; d.ld = g.ld; d.col0 = g.col0;
         d.pre_act = g.pre_act;
-        d.seg_off = g.seg_off; d.seg_mean = g.seg_mean;
+        d.seg_off = g.seg_off; d.seg_mean = g.seg_mean; d.seg_perm = g.seg_off ? g.seg_perm : nullptr;
         if (g.seg_off)
             G4C_REQUIRE(bx6 && !g.idx && g.width == NP && g.ld % 4 == 0 && g.col0 % 4 == 0 && (uintptr_t)g.ptr % 16 == 0, G4C_EUNSUPPORTED,
                         "g4c_mlp_forward: aggregation on load needs the bf16x6 kernels and a 128-wide aligned block without gather index");
@@ -2303,7 +2311,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     }
     G4C_REQUIRE(nk >= 1 || p.n_nar >= 1, G4C_EINVAL, "g4c_mlp_forward: no input block goes through the weights");
     p.n_src = nk;
-    if (nk == 0) p.src[0] = Src{nullptr, nullptr, 0, 0, 0, 0, 1, 0, nullptr, 0};
+    if (nk == 0) p.src[0] = Src{nullptr, nullptr, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr};
     for (int s = (nk ? nk : 1); s < G4C_MAX_SRC; ++s) p.src[s] = p.src[0];
     for (int s = p.n_nar; s < G4C_MAX_SRC; ++s) p.nar[s] = NarSrc{nullptr, nullptr, 0, 0};
     for (int s = p.n_add; s < G4C_MAX_SRC; ++s) p.add[s] = AddSrc{nullptr, nullptr, 0, 0};

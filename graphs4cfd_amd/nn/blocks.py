@@ -294,16 +294,17 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
     ep, csr = plan.edge_csr(index, int(v.size(0)))
     senders = v if v_src is None else v_src
     mean = aggr == "mean"
+    e_src = e if isinstance(e, Source) else Source(e, pre_act=e_pre_act)      # (a Source: DownMP.pool(lazy_edges=True))
     if ops.can_aggregate_on_load(csr, msg_mlp.output_size, [msg_mlp.output_size, int(v.size(1))]) and not ops.FUSE_AGG:
         # the node launch averages each target's messages while it gathers its input (g4c_src_t.seg_off): no separate
         # aggregation pass, no aggregate written to / re-read from HBM
-        e_new = msg_mlp.run_hoisted([Source(e, pre_act=e_pre_act)], [(senders, ep.row), (v, ep.col)], ep.n_edges, products=products)
+        e_new = msg_mlp.run_hoisted([e_src], [(senders, ep.row), (v, ep.col)], ep.n_edges, products=products)
         agg_src = Source(e_new, segments=csr, seg_mean=mean)
     else:
         # (G4C_FUSE_AGG: the aggregation rides on the EDGE launch when the kernel can reduce the tile it has just computed,
         # ops.mlp_forward(agg=...); otherwise that call runs g4c_segment_reduce right after the launch)
-        agg = torch.empty((csr.n_seg, msg_mlp.output_size), dtype=torch.float32, device=e.device)
-        e_new = msg_mlp.run_hoisted([Source(e, pre_act=e_pre_act)], [(senders, ep.row), (v, ep.col)], ep.n_edges,
+        agg = torch.empty((csr.n_seg, msg_mlp.output_size), dtype=torch.float32, device=v.device)
+        e_new = msg_mlp.run_hoisted([e_src], [(senders, ep.row), (v, ep.col)], ep.n_edges,
                                     products=products, agg=(csr, agg, mean))
         agg_src = Source(agg)
     if next_msg is not None:
@@ -386,7 +387,7 @@ class DownMP(nn.Module):
                 item.reset_parameters()
 
     def pool(self, graph: Graph, field: Tensor, edge_index: Tensor, edge_attr: Tensor, activation=None,
-             e_pre_act: int = _lib.ACT_NONE, target_major: bool = False):
+             e_pre_act: int = _lib.ACT_NONE, target_major: bool = False, lazy_edges: bool = False):
         """Functional core: returns (field_l, edge_index_l, edge_attr_l) without touching the Graph.
         `e_pre_act`: activation still pending on `edge_attr` (applied while pooling)."""
         h, l = self.hr_graph_idx, self.lr_graph_idx
@@ -398,6 +399,11 @@ class DownMP(nn.Module):
         pooled = _finish(pooled, activation, code)
         # (target_major: the models' internal coarse edge order, see plan.pool_edge_plan; the public forward keeps `coalesce` order)
         pp = plan.pool_edge_plan(getattr(graph, f'idx{h}_to_idx{l}'), edge_index, target_major)
+        if lazy_edges and ops.AGG_ON_LOAD and ops.effective_precision([int(edge_attr.size(1))]) != "fp32" and int(edge_attr.size(1)) == 128:
+            # (optional, G4C_LAZY_POOL=1; off by default: measured neutral at 100k nodes and -0.7 % at 12.5k in a same-box A/B) the
+            # pooled coarse edge latents are not materialised: the first coarse edge MLP forms them while it gathers its
+            # input (a Source that _mp_step takes in place of the tensor)
+            return pooled, pp.edge_index, Source(edge_attr, pre_act=e_pre_act, segments=pp.csr, seg_mean=True)
         ea_l = ops.segment_reduce(edge_attr, pp.csr, True, src_act=e_pre_act)
         return pooled, pp.edge_index, ea_l
 

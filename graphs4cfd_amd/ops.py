@@ -88,11 +88,12 @@ class Source:
         self.pre_act = pre_act      # activation applied while loading (producer stored the raw tensor)
         self.additive = additive    # already multiplied by its block of the first layer: gathered and added, not multiplied
         # aggregation on load (bf16x6 kernels): row r of the block = sum / mean of the tensor's rows in segment r of this
-        # CSR plan (rows in segment order), i.e. scatter(tensor, col, reduce) without materialising it
+        # CSR plan (through its permutation, if any; `pre_act` then applies to the rows before they are added), i.e.
+        # scatter(pre_act(tensor), col, reduce) without materialising it
         self.segments = segments
         self.seg_mean = seg_mean
-        if segments is not None and (segments.perm is not None or index is not None or additive or self.width != 128):
-            raise ValueError("aggregation on load needs rows in segment order, no gather index and a 128-wide block")
+        if segments is not None and (index is not None or additive or self.width != 128):
+            raise ValueError("aggregation on load needs a 128-wide block without gather index")
 
 
 def segment_reduce(src: Tensor, csr: CsrPlan, mean: bool, act: int = _lib.ACT_NONE, out: Optional[Tensor] = None,
@@ -211,7 +212,9 @@ AGG_ON_LOAD = os.environ.get("G4C_AGG_ON_LOAD", "1") == "1"
 
 def can_aggregate_on_load(csr: CsrPlan, width: int, consumer_widths: Sequence[int]) -> bool:
     """`consumer_widths`: input blocks of the MLP that would aggregate while loading (it must run on the bf16x6 kernels)."""
-    return (AGG_ON_LOAD and effective_precision(consumer_widths) != "fp32" and csr.perm is None and width == 128 and csr.n > 0)
+    # (rows in segment order only: through a permutation the kernel supports it too — Source(segments=csr with perm) — but the
+    # extra dependent index round trip in the consumer's prologue gives back what the separate reduction costs; measured neutral)
+    return AGG_ON_LOAD and effective_precision(consumer_widths) != "fp32" and csr.perm is None and width == 128 and csr.n > 0
 
 
 def mlp_precision() -> str:
@@ -356,7 +359,7 @@ def _src_array(sources: Sequence[Source]):
                                                           s.col0, s.pre_act)
         a.additive = 1 if s.additive else 0
         if s.segments is not None:
-            a.seg_off, a.seg_mean = _lib.ptr(s.segments.off), 1 if s.seg_mean else 0
+            a.seg_off, a.seg_mean, a.seg_perm = _lib.ptr(s.segments.off), 1 if s.seg_mean else 0, _lib.ptr(s.segments.perm)
     return arr
 
 

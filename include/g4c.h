@@ -108,7 +108,11 @@ typedef struct {
     const int32_t *seg_off; /* bf16x6 kernels, additive == 0, idx == NULL, width 128: row r of this block is the sum / mean of rows
                            [seg_off[r], seg_off[r+1]) of ptr — the aggregation `scatter(e', col, reduce)` (nn/blocks.py:183) done
                            while the node MLP gathers its input, in the order and with the formula of g4c_segment_reduce, instead
-                           of a separate pass that writes and re-reads the aggregate. */
+                           of a separate pass that writes and re-reads the aggregate.  `pre_act` is then applied to every
+                           source row BEFORE it is added (g4c_segment_reduce's src_act). */
+    const int32_t *seg_perm; /* with seg_off: NULL = the segment's rows are [seg_off[r], seg_off[r+1]) themselves; else those are
+                           positions in seg_perm, which holds the row numbers (pool_edge's fine -> coarse edge plan,
+                           nn/blocks.py:67: the pooled coarse edge latents are formed while the first coarse edge MLP gathers them). */
 } g4c_src_t;
 
 typedef struct {

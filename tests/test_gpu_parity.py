@@ -290,6 +290,19 @@ def test_node_mlp_aggregates_on_load(case):
         agg = ops.segment_reduce(e_new, csr, mean)
         y_ref = blk.node_mlp.run_coded([ops.Source(agg), ops.Source(v)], n, _lib.ACT_SELU)
         assert torch.equal(y, y_ref)
+    # through a permutation and with the pending activation of the stored rows (pool_edge's fine -> coarse plan, DownMP)
+    g = S.mus_graph(1500, levels=2, seed=4).to(DEV)
+    pp = plan.pool_edge_plan(g.idx1_to_idx2, g.edge_index, True)
+    assert pp.csr.perm is not None
+    e_f = torch.randn(g.edge_index.size(1), H, device=DEV)
+    lazy = ops.Source(e_f, pre_act=_lib.ACT_SELU, segments=pp.csr, seg_mean=True)
+    x2 = torch.randn(pp.n_coarse, H, device=DEV)
+    y = blk.node_mlp.run_coded([lazy, ops.Source(x2)], pp.n_coarse, _lib.ACT_NONE)
+    pooled = ops.segment_reduce(e_f, pp.csr, True, src_act=_lib.ACT_SELU)
+    torch.testing.assert_close(pooled, torch.zeros_like(pooled).index_add_(
+        0, torch.repeat_interleave(torch.arange(pp.n_coarse, device=DEV), (pp.csr.off[1:] - pp.csr.off[:-1]).long()),
+        torch.selu(e_f)[pp.csr.perm.long()]) / (pp.csr.off[1:] - pp.csr.off[:-1]).clamp(min=1)[:, None], rtol=1e-5, atol=1e-5)
+    assert torch.equal(y, blk.node_mlp.run_coded([ops.Source(pooled), ops.Source(x2)], pp.n_coarse, _lib.ACT_NONE))
 
 
 def test_mlp_precisions_vs_fp64():
