@@ -163,6 +163,17 @@ class LocalMesh:
             ei = parts[l].edge_index
             self._edge_index_np[l] = np.ascontiguousarray(ei[:, np.argsort(ei[1], kind="stable")])
         self.edge_index = [t(a) for a in self._edge_index_np]
+        # owned edges split by where their SENDER lives: interior (owned sender: computable before the halo exchange has
+        # landed) / boundary (halo sender).  int32 row lists + the matching sender / target lists, for the overlapped MP layer.
+        self.sub = []
+        for l in range(levels):
+            ei = self._edge_index_np[l]
+            interior = ei[0] < parts[l].n_own
+            ent = {}
+            for tag, mask in (("int", interior), ("bnd", ~interior)):
+                ids = np.nonzero(mask)[0].astype(np.int32)
+                ent[tag] = (t(ids), t(ei[0][ids].astype(np.int32)), t(ei[1][ids].astype(np.int32)))
+            self.sub.append(ent)
         self.edge_attr = graph.edge_attr[torch.from_numpy(p1.edge_ids)].contiguous().to(device)
         # inter-level maps for owned fine nodes -> local coarse id, relative positions, pooling of edges
         self.parent, self.rel, self.parent_full = [], [], []
@@ -221,6 +232,31 @@ class HaloExchanger:
         self.mesh, self.group = mesh, group
         self._send_buf: Dict[tuple, torch.Tensor] = {}
         self._send_cat: Dict[int, Optional[torch.Tensor]] = {}
+        self._side = None
+
+    def exchange_async(self, v: torch.Tensor, level: int):
+        """`exchange` on a side stream (ordered after everything enqueued so far on the current stream); returns a handle for
+        `wait`.  Lets the caller enqueue work that does not read the halo rows in between (HipImpl.mp: the interior edges)."""
+        if not v.is_cuda:
+            self.exchange(v, level)
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=v.device)
+        cur = torch.cuda.current_stream(v.device)
+        start = torch.cuda.Event()
+        start.record(cur)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(start)
+            self.exchange(v, level)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        if not torch.cuda.is_current_stream_capturing():
+            v.record_stream(self._side)
+        return done
+
+    def wait(self, handle) -> None:
+        if handle is not None:
+            torch.cuda.current_stream().wait_event(handle)
 
     def exchange(self, v: torch.Tensor, level: int) -> None:
         m = self.mesh
@@ -251,6 +287,8 @@ class HaloExchanger:
 # ------------------------------------------------------------------------------------- compute back-ends
 class HipImpl:
     """Arithmetic of the partitioned forward on the HIP kernels (the product path)."""
+
+    overlaps = True     # mp() takes `overlap=` (interior edges while the halo exchange is in flight)
 
     def __init__(self, model):
         self.m = model
@@ -285,7 +323,8 @@ class HipImpl:
         return n_edges >= _blocks.HOIST_MIN_ROWS and ops.mlp_precision() != "bf16"
 
     def mp(self, name: str, v: torch.Tensor, e: torch.Tensor, e_pending: int, edge_index: torch.Tensor, n_own: int,
-           v_out: torch.Tensor, products=None, next_name: Optional[str] = None, pr_out: Optional[torch.Tensor] = None):
+           v_out: torch.Tensor, products=None, next_name: Optional[str] = None, pr_out: Optional[torch.Tensor] = None,
+           overlap=None):
         """One MP layer on the local sub-mesh.  `products` = (W1r v over own + halo rows, W1c v over own rows) when the
         previous layer's node launch made them (and the halo rows of the first were exchanged): then `v`'s halo rows are
         not read at all.  `next_name` / `pr_out`: also emit the NEXT layer's products from this layer's node launch
@@ -293,6 +332,25 @@ class HipImpl:
         blk = getattr(self.m, name)
         ep, csr = plan.edge_csr(edge_index, n_own)
         mean = blk.aggr == "mean"
+        if overlap is not None:
+            # `overlap` = (start, wait, subsets): the halo exchange of products[0] runs on a side stream while the edges whose
+            # sender is owned are computed; the edges with a halo sender follow once it has landed.  Same arithmetic per
+            # edge as the single launch (each edge row is independent), written into one tensor through out_idx.
+            start, wait, sub = overlap
+            handle = start()
+            e_new = torch.empty((ep.n_edges, blk.edge_mlp.output_size), dtype=torch.float32, device=e.device)
+            for tag in ("int", "bnd"):
+                ids, row, col = sub[tag]
+                if tag == "bnd":
+                    wait(handle)
+                if int(ids.numel()):
+                    blk.edge_mlp.run_hoisted([Source(e, index=ids, pre_act=e_pending)], [(v, row), (v, col)], int(ids.numel()),
+                                             products=products, out=e_new, out_idx32=ids)
+            if ops.can_aggregate_on_load(csr, blk.edge_mlp.output_size, [blk.edge_mlp.output_size, int(v.size(1))]):
+                agg_src = Source(e_new, segments=csr, seg_mean=mean)
+            else:
+                agg_src = Source(ops.segment_reduce(e_new, csr, mean))
+            return e_new, self._node_launch(blk.node_mlp, [agg_src, Source(v[:n_own])], n_own, SELU, v_out, next_name, pr_out)
         if ops.can_aggregate_on_load(csr, blk.edge_mlp.output_size, [blk.edge_mlp.output_size, int(v.size(1))]) and not ops.FUSE_AGG:
             e_new = blk.edge_mlp.run_hoisted([Source(e, pre_act=e_pending)], [(v, ep.row), (v, ep.col)], ep.n_edges, products=products)
             agg_src = Source(e_new, segments=csr, seg_mean=mean)
@@ -328,6 +386,9 @@ class MusPartitionedForward:
 
     def __init__(self, program: Sequence[str], mesh: LocalMesh, impl, exchanger: HaloExchanger, width: int, nf: int):
         self.program, self.mesh, self.impl, self.xch, self.width, self.nf = tuple(program), mesh, impl, exchanger, width, nf
+        import os
+        # overlap every product exchange with the interior edges of the layer that consumes it (G4C_DIST_OVERLAP=0: off)
+        self.overlap = os.environ.get("G4C_DIST_OVERLAP", "1") != "0"
 
     def _buf(self, level: int) -> torch.Tensor:
         m = self.mesh
@@ -368,7 +429,11 @@ class MusPartitionedForward:
             else:
                 # products ride on the previous layer's node launch when this layer hoists its first layer: then the halo
                 # exchange carries W1r v (same size) and the latents of the halo rows are never needed
-                if prod is not None:
+                overlap = None
+                if prod is not None and self.overlap and m.world > 1 and getattr(impl, "overlaps", False) and hasattr(self.xch, "exchange_async"):
+                    pr = prod[0]
+                    overlap = (lambda pr=pr, level=level: self.xch.exchange_async(pr, level), self.xch.wait, m.sub[level - 1])
+                elif prod is not None:
                     self.xch.exchange(prod[0], level)
                 else:
                     self.xch.exchange(v, level)
@@ -376,8 +441,9 @@ class MusPartitionedForward:
                 nxt = self.program[k + 1] if k + 1 < len(self.program) else ""
                 n_edges = int(m.edge_index[level - 1].size(1))
                 want_next = nxt.startswith("mp") and impl.hoists(n_edges)
+                kw = {"overlap": overlap} if overlap is not None else {}
                 e, prod = impl.mp(name, v, e, e_pending, m.edge_index[level - 1], n_own, v_new[:n_own], products=prod,
-                                  next_name=nxt if want_next else None, pr_out=self._buf(level) if want_next else None)
+                                  next_name=nxt if want_next else None, pr_out=self._buf(level) if want_next else None, **kw)
                 v, e_pending = v_new, SELU
         return impl.decode(v[: m.n_own[0]], m.inputs["field"], self.nf)
 

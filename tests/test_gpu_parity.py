@@ -673,7 +673,14 @@ def test_partitioned_hip_forward_two_ranks_in_process(hoist_min_rows, monkeypatc
             torch.cuda.synchronize()
             barrier.wait()
 
-    preds, errors = [None] * world, []
+        def exchange_async(self, v, level):     # the interior / boundary launches of HipImpl.mp, synchronous transport
+            self.exchange(v, level)
+            overlapped.append(level)
+
+        def wait(self, handle):
+            pass
+
+    preds, errors, overlapped = [None] * world, [], []
 
     def run(r):
         try:
@@ -692,6 +699,42 @@ def test_partitioned_hip_forward_two_ranks_in_process(hoist_min_rows, monkeypatc
     for r in range(world):
         full[meshes[r].owned_global[0]] = preds[r]
     torch.testing.assert_close(full, ref, **FWD)
+    assert bool(overlapped) == (hoist_min_rows == 0)
+
+
+def test_overlapped_exchange_in_hipgraph_equals_eager_sequential(monkeypatch):
+    """Rank 0 of 2 with a stand-in transport (halo rows <- a fixed function of the packed send rows).  The overlapped step
+    (exchange on a side stream, interior edges meanwhile, boundary edges after) captured into a hipGraph and replayed
+    equals the eager step with one edge launch after a blocking exchange, bit for bit (every edge row is independent)."""
+    import torch.distributed as dist
+    from graphs4cfd_amd import partition as P
+    monkeypatch.setattr(B, "HOIST_MIN_ROWS", 0)
+    calls = []
+
+    def stand_in(recv, send, output_split_sizes=None, input_split_sizes=None, group=None):
+        calls.append(torch.cuda.current_stream().cuda_stream)
+        pick = torch.arange(recv.size(0), device=recv.device) % send.size(0)
+        recv.copy_(torch.index_select(send, 0, pick))
+
+    monkeypatch.setattr(dist, "all_to_all_single", stand_in)
+    g = S.mus_graph(6000, levels=3, seed=21)
+    torch.manual_seed(22)
+    model = gfd.nn.NsThreeScaleGNN(arch=S.mus_arch("NsThreeScaleGNN", 128), device=DEV)
+    outs = {}
+    for overlap, capture in ((False, False), (True, False), (True, True)):
+        monkeypatch.setenv("G4C_DIST_OVERLAP", "1" if overlap else "0")
+        dr = P.DistributedRollout(model, g, 4, 0, 2, DEV, capture=capture)
+        assert dr.fwd.overlap == overlap and min(dr.mesh.n_halo) > 0
+        del calls[:]
+        dr.run(4)
+        torch.cuda.synchronize()
+        assert dr.capture == capture and (dr._hipgraph is not None) == capture
+        main = torch.cuda.current_stream().cuda_stream
+        assert overlap == any(c != main for c in calls[:20])      # first (eager) step: the exchange ran on the side stream
+        outs[(overlap, capture)] = dr.outputs.clone()
+    assert torch.isfinite(outs[(False, False)]).all()
+    assert torch.equal(outs[(True, False)], outs[(False, False)])
+    assert torch.equal(outs[(True, True)], outs[(False, False)])
 
 
 def test_distributed_rollout_single_rank_equals_rollout():

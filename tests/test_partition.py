@@ -48,6 +48,7 @@ class OracleImpl:
 
     def __init__(self, w, use_products=False):
         self.w, self.use_products = w, use_products
+        self.overlaps, self.overlapped = use_products, 0     # product exchange -> also the interior/boundary split
 
     def new(self, rows, width, device):
         return torch.zeros(rows, width)
@@ -84,10 +85,26 @@ class OracleImpl:
         g = self.w.get(f"{prefix}.MLP.layer_norm.weight")
         return x if g is None else F.layer_norm(x, (x.size(-1),), g, self.w[f"{prefix}.MLP.layer_norm.bias"], 1e-5)
 
-    def mp(self, name, v, e, e_pending, edge_index, n_own, v_out, products=None, next_name=None, pr_out=None):
+    def mp(self, name, v, e, e_pending, edge_index, n_own, v_out, products=None, next_name=None, pr_out=None, overlap=None):
         row, col = edge_index
         H = v.size(1)
-        if products is None:
+        if overlap is not None:     # interior edges before the exchange has been waited for, boundary edges after
+            start, wait, sub = overlap
+            W1, b1 = self.w[f"{name}.edge_mlp.MLP.linear_1.weight"], self.w[f"{name}.edge_mlp.MLP.linear_1.bias"]
+            ea = self._act(e, e_pending)
+            e_new = torch.full((row.numel(), self.w[f"{name}.edge_mlp.MLP.linear_1.bias"].numel()), float("nan"))
+            handle = start()
+            for tag in ("int", "bnd"):
+                ids, r, c = (t.long() for t in sub[tag])
+                if tag == "bnd":
+                    wait(handle)
+                assert torch.equal(r, row[ids]) and torch.equal(c, col[ids])
+                assert bool((r < n_own).all()) if tag == "int" else bool((r >= n_own).all())
+                h = ea[ids] @ W1[:, :-2 * H].T + products[0][r] + products[1][c] + b1
+                e_new[ids] = self._mlp_tail(h, f"{name}.edge_mlp")
+            assert not torch.isnan(e_new).any()                    # the two subsets cover every owned edge
+            self.overlapped += 1
+        elif products is None:
             e_new = O.mlp(torch.cat((self._act(e, e_pending), v[row], v[col]), 1), self.w, f"{name}.edge_mlp")
         else:       # W1 [e | v_row | v_col] = W1e e + (W1r v)[row] + (W1c v)[col]; the halo rows of W1r v were exchanged
             W1, b1 = self.w[f"{name}.edge_mlp.MLP.linear_1.weight"], self.w[f"{name}.edge_mlp.MLP.linear_1.bias"]
@@ -125,9 +142,11 @@ def _worker(rank, world, port, model_name, levels, out_dir, use_products):
         w = {k: v.detach() for k, v in model.state_dict().items()}
         parts = P.build_partition(g, levels, world)
         mesh = P.LocalMesh(g, levels, parts[rank], torch.device("cpu"), rank, world)
-        fwd = P.MusPartitionedForward(model._PROGRAM, mesh, OracleImpl(w, use_products), P.HaloExchanger(mesh), 32, 3)
+        impl = OracleImpl(w, use_products)
+        fwd = P.MusPartitionedForward(model._PROGRAM, mesh, impl, P.HaloExchanger(mesh), 32, 3)
         with torch.no_grad():
             pred = fwd.forward()
+        assert not use_products or impl.overlapped > 0      # the interior/boundary path ran
         full = torch.zeros(g.pos.size(0), 3)
         full[mesh.owned_global[0]] = pred
         dist.all_reduce(full)
