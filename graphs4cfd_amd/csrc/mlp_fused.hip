@@ -1642,19 +1642,24 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
 // FULL: every weighted input block and every additive block is exactly 128 wide and 16-byte aligned (the MP layers):
 // no column masks anywhere.
 template <int RT, bool VEC, bool FULL, int SP>
-__global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kernel(const Params p) {
+__global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kernel(const Params p) {
     constexpr int ROWS = 32 * RT, NW = 4;
     constexpr int PLN = ROWS * HB;              // one bf16 operand plane [ROWS][136]
     // three operand planes; the fp32 final tile [ROWS][132] aliases them
     constexpr int BUF_FLOATS = 3 * PLN / 2;
     static_assert(BUF_FLOATS >= ROWS * HS, "final tile must fit");
-    __shared__ __attribute__((aligned(16))) float lds[BUF_FLOATS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
+    // RT = 2 keeps three workgroups per CU (<= 54.6 KB of LDS each): two index slots per kind (the launcher checks) and the
+    // biases read from global memory (L1 hits) instead of an LDS copy
+    constexpr int NSLOT = RT == 2 ? 2 : G4C_MAX_SRC;
+    constexpr bool LDS_BIAS = RT == 1;
+    constexpr int BIAS_FLOATS = LDS_BIAS ? G4C_MAX_LAYERS * NP : 0;
+    __shared__ __attribute__((aligned(16))) float lds[BUF_FLOATS + 2 * NSLOT * ROWS + BIAS_FLOATS + 2 * NP];
     float *sH = lds;
     __bf16 *sB = reinterpret_cast<__bf16 *>(lds);
     int *sRow = reinterpret_cast<int *>(lds + BUF_FLOATS);
-    int *sRowAdd = sRow + G4C_MAX_SRC * ROWS;
-    float *sBias = lds + BUF_FLOATS + 2 * G4C_MAX_SRC * ROWS;
-    float *sGB = sBias + G4C_MAX_LAYERS * NP;
+    int *sRowAdd = sRow + NSLOT * ROWS;
+    float *sBias = lds + BUF_FLOATS + 2 * NSLOT * ROWS;
+    float *sGB = sBias + BIAS_FLOATS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1792,23 +1797,23 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
     };
     // Memory instructions return in order per wave, so the loads that head a dependent chain go FIRST: row indices (the
     // additive gathers wait for them), then the parameters, then the long-latency streams (weights, directly indexed input).
-    int idx_v[(2 * G4C_MAX_SRC * ROWS + 64 * NW - 1) / (64 * NW)];
+    int idx_v[(2 * NSLOT * ROWS + 64 * NW - 1) / (64 * NW)];
 #pragma unroll
-    for (int it = 0; it < (2 * G4C_MAX_SRC * ROWS + 64 * NW - 1) / (64 * NW); ++it) {
+    for (int it = 0; it < (2 * NSLOT * ROWS + 64 * NW - 1) / (64 * NW); ++it) {
         const int e = tid + it * 64 * NW;
         const int slot = e / ROWS, r = e % ROWS;
         long long gr = row0 + r;
         if (gr >= mlim) gr = mlim - 1;
         const int *ix = nullptr;
-        if (slot < G4C_MAX_SRC) { if (slot < p.n_src) ix = p.src[slot].idx; }
-        else { if (slot - G4C_MAX_SRC < p.n_add) ix = p.add[slot - G4C_MAX_SRC].idx; }
+        if (slot < NSLOT) { if (slot < p.n_src) ix = p.src[slot].idx; }
+        else { if (slot - NSLOT < p.n_add) ix = p.add[slot - NSLOT].idx; }
         idx_v[it] = ix ? ix[gr] : (int)gr;
     }
     float bias_v[(G4C_MAX_LAYERS * NP) / (64 * NW)], gb_v = 0.f;
 #pragma unroll
     for (int it = 0; it < (G4C_MAX_LAYERS * NP) / (64 * NW); ++it) {
         const int e = tid + it * 64 * NW;
-        bias_v[it] = p.b[e < p.n_layers * NP ? e : 0];
+        bias_v[it] = LDS_BIAS ? p.b[e < p.n_layers * NP ? e : 0] : 0.f;
     }
     if (p.gamma) {
         const int e = tid & (NP - 1);
@@ -1825,12 +1830,14 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
     if (direct0) gather(0, true);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int it = 0; it < (2 * G4C_MAX_SRC * ROWS + 64 * NW - 1) / (64 * NW); ++it) {
+    for (int it = 0; it < (2 * NSLOT * ROWS + 64 * NW - 1) / (64 * NW); ++it) {
         const int e = tid + it * 64 * NW;
-        if (e < 2 * G4C_MAX_SRC * ROWS) sRow[e] = idx_v[it];
+        if (e < 2 * NSLOT * ROWS) sRow[e] = idx_v[it];
     }
+    if (LDS_BIAS) {
 #pragma unroll
-    for (int it = 0; it < (G4C_MAX_LAYERS * NP) / (64 * NW); ++it) sBias[tid + it * 64 * NW] = bias_v[it];
+        for (int it = 0; it < (G4C_MAX_LAYERS * NP) / (64 * NW); ++it) sBias[tid + it * 64 * NW] = bias_v[it];
+    }
     if (p.gamma) sGB[tid] = gb_v;          // [gamma(128) | beta(128)] = 256 threads
     __syncthreads();
     G4C_STAMPW(1);
@@ -1928,7 +1935,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sBias + l * NP + fbase + 8 * gq);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>((LDS_BIAS ? sBias : p.b) + l * NP + fbase + 8 * gq);
                     f32x4 x;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[e] = acc[t][4 * gq + e] + b4[e];
@@ -1943,7 +1950,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 2) void mlp_bx6_kerne
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sBias + l * NP + fbase + 8 * gq);
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>((LDS_BIAS ? sBias : p.b) + l * NP + fbase + 8 * gq);
                 f32x4 x;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = acc[t][4 * gq + e];
@@ -2379,7 +2386,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         for (int a = 0; a < p.n_add; ++a)
             full = full && p.add[a].width == NP && (p.add[a].ld & 3) == 0 && ((uintptr_t)p.add[a].ptr & 15) == 0;
         const dim3 blk(256);
-        const bool rt2 = !agg && row_count >= rt2_rows;      // 64-row tiles (tuning only)
+        const bool rt2 = !agg && row_count >= rt2_rows && p.n_src <= 2 && p.n_add <= 2;      // 64-row tiles (tuning only)
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + (rt2 ? 63 : 31)) / (rt2 ? 64 : 32));
         if (p.n_tiles == 0) return G4C_OK;
         const dim3 grid(p.n_tiles);
