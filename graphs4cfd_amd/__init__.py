@@ -7,10 +7,12 @@ Drop-in for the hot-path slice of `import graphs4cfd as gfd`:
     out = model.solve(graph, n_out)          # graph: gfd.Graph with the reference's attribute layout
 
 Compute runs in hand-written HIP kernels (libg4c.so, C-ABI in include/g4c.h); there is no CPU or
-eager-torch fallback.  Out of scope: training loop, datasets, plotting, augmentation.
+eager-torch fallback.  Training (`model.fit`, `gfd.nn.TrainConfig`, `gfd.nn.GraphLoss`, `gfd.DataLoader`) runs the same fused
+forward recorded for autograd (autograd.py).  Out of scope: datasets, plotting, augmentation.
 """
 from .graph import Graph
 from . import nn, plan, ops, synthetic, transforms
+from .loader import DataLoader, Collater
 from .ops import mlp_precision, set_mlp_precision      # "fp32" (default) | "bf16" (opt-in bf16-MFMA MLPs)
 
 __version__ = "0.1.0"

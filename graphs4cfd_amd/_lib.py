@@ -92,6 +92,18 @@ _SIGNATURES = {
                                C.c_int32, C.c_int64, C.c_void_p]),
     "g4c_copy_cols": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_int64, C.c_void_p]),
+    # training path (train_ops.hip)
+    "g4c_train_gather": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                   C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    "g4c_act_grad": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                               C.c_int32, C.c_int64, C.c_void_p]),
+    "g4c_layernorm_grad_partials": (C.c_int32, [C.c_int64]),
+    "g4c_layernorm_grad": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                     C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_void_p]),
+    "g4c_colsum_partials": (C.c_int32, [C.c_int64]),
+    "g4c_colsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "g4c_segment_broadcast": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_int32, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -1,0 +1,264 @@
+"""Training path: autograd for the fused blocks.
+
+The reference trains through torch autograd over `cat` / index / `nn.Linear` / SELU / LayerNorm / `scatter`
+(GNN.fit, nn/model.py:152-301; blocks nn/blocks.py:117-290), keeping every intermediate of every block alive between
+the passes (per MP layer at 100k nodes: the [E, 3H] concatenation, three [E, H] hidden tensors, ...).
+
+Here the forward of a block stays ONE fused launch (g4c_mlp_forward / g4c_segment_reduce) and only the block's inputs
+and output are kept.  The backward of a block
+
+  * rebuilds its concatenated input with g4c_train_gather and its hidden activations with rocBLAS GEMMs (plain library
+    GEMMs) + g4c_activation_inplace,
+  * runs LayerNorm / activation adjoints in train_ops.hip (g4c_layernorm_grad, g4c_act_grad), bias gradients with
+    g4c_colsum, weight / input gradients with rocBLAS,
+  * sends the input gradient back through the gathers as deterministic segmented sums on the CSR plan of the gather index
+    (g4c_segment_reduce — the adjoint of an index gather is the scatter the reference's autograd does with atomics), and
+    through aggregations with g4c_segment_broadcast.
+
+No atomics anywhere: two runs of a training step produce bit-identical gradients.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+from torch import Tensor
+
+from . import _lib, ops, plan
+from .ops import Source, _ld
+
+
+# ------------------------------------------------------------------------------------- kernel wrappers
+def _buf(rows: int, cols: int, dev) -> Tensor:
+    return torch.empty((rows, cols), dtype=torch.float32, device=dev)
+
+
+def train_gather(src: Tensor, dst: Tensor, dcol0: int, scol0: int, width: int, idx32: Optional[Tensor], pre_act: int,
+                 negate: bool, n_rows: int) -> None:
+    lib = _lib.load()
+    dev = _lib.require_hip(src, dst, idx32)
+    _lib.check(lib.g4c_train_gather(_lib.ptr(src), _ld(src), scol0, _lib.ptr(idx32), pre_act, 1 if negate else 0, _lib.ptr(dst),
+                                    _ld(dst), dcol0, width, n_rows, _lib.stream_handle(dev)))
+
+
+def act_grad(dy: Tensor, ref: Tensor, act: int, from_input: bool, out: Optional[Tensor] = None) -> Tensor:
+    """dy * act'(.) with `ref` the activation's output (from_input False) or input (True)."""
+    if act == _lib.ACT_NONE:
+        return dy
+    lib = _lib.load()
+    dev = _lib.require_hip(dy, ref)
+    if out is None:
+        out = _buf(int(dy.size(0)), int(dy.size(1)), dev)
+    _lib.check(lib.g4c_act_grad(_lib.ptr(dy), _ld(dy), _lib.ptr(ref), _ld(ref), 1 if from_input else 0, act, _lib.ptr(out),
+                                _ld(out), int(dy.size(1)), int(dy.size(0)), _lib.stream_handle(dev)))
+    return out
+
+
+def colsum(x: Tensor) -> Tensor:
+    lib = _lib.load()
+    dev = _lib.require_hip(x)
+    rows, width = int(x.size(0)), int(x.size(1))
+    scratch = _buf(int(lib.g4c_colsum_partials(rows)), width, dev)
+    out = torch.empty(width, dtype=torch.float32, device=dev)
+    _lib.check(lib.g4c_colsum(_lib.ptr(x), _ld(x), width, rows, _lib.ptr(scratch), _lib.ptr(out), _lib.stream_handle(dev)))
+    return out
+
+
+def layernorm_grad(z: Tensor, gamma: Tensor, dy: Tensor, eps: float):
+    """(dz, dgamma, dbeta) of y = LayerNorm(z) * gamma + beta."""
+    lib = _lib.load()
+    dev = _lib.require_hip(z, gamma, dy)
+    rows, width = int(z.size(0)), int(z.size(1))
+    dz = _buf(rows, width, dev)
+    partial = _buf(int(lib.g4c_layernorm_grad_partials(rows)), 2 * width, dev)
+    _lib.check(lib.g4c_layernorm_grad(_lib.ptr(z), _ld(z), _lib.ptr(gamma), _lib.ptr(dy), _ld(dy), _lib.ptr(dz), _ld(dz),
+                                      _lib.ptr(partial), width, rows, float(eps), _lib.stream_handle(dev)))
+    gb = colsum(partial)
+    return dz, gb[:width], gb[width:]
+
+
+def segment_broadcast(dout: Tensor, csr, mean: bool, n_src_rows: int) -> Tensor:
+    lib = _lib.load()
+    dev = _lib.require_hip(dout, csr.off, csr.perm)
+    width = int(dout.size(1))
+    full = csr.perm is None and csr.n == n_src_rows
+    dsrc = _buf(n_src_rows, width, dev) if full else torch.zeros((n_src_rows, width), dtype=torch.float32, device=dev)
+    _lib.check(lib.g4c_segment_broadcast(_lib.ptr(dout), _ld(dout), _lib.ptr(csr.off), _lib.ptr(csr.perm), csr.n_seg, width,
+                                         1 if mean else 0, _lib.ptr(dsrc), _ld(dsrc), _lib.stream_handle(dev)))
+    return dsrc
+
+
+def _dense(t: Tensor) -> Tensor:
+    return t if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------- fused MLP
+class _Spec:
+    """Non-tensor arguments of one fused-MLP call."""
+    __slots__ = ("packed", "meta", "n_rows", "act", "resid_col0", "has_resid", "n_layers", "has_ln", "eps")
+
+
+class _FusedMLP(torch.autograd.Function):
+    """y = act(LN(MLP(cat(sources)))) (+ resid): forward = the fused launch, backward = recompute (module docstring)."""
+
+    @staticmethod
+    def forward(ctx, spec: _Spec, *tensors: Tensor):
+        n_src = len(spec.meta)
+        srcs = []
+        for t, m in zip(tensors[:n_src], spec.meta):
+            srcs.append(Source(t, index=m["index"], col0=m["col0"], width=m["width"], negate=m["negate"], pre_act=m["pre_act"],
+                               segments=m["segments"], seg_mean=m["seg_mean"]))
+        resid = tensors[n_src] if spec.has_resid else None
+        y = ops.mlp_forward(spec.packed, srcs, spec.n_rows, spec.act, resid=resid, resid_col0=spec.resid_col0)
+        ctx.spec = spec
+        ctx.save_for_backward(y, *tensors)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        spec: _Spec = ctx.spec
+        y, *tensors = ctx.saved_tensors
+        n_src, L = len(spec.meta), spec.n_layers
+        src_t = tensors[:n_src]
+        pos = n_src
+        resid = None
+        if spec.has_resid:
+            resid = tensors[pos]
+            pos += 1
+        W = tensors[pos:pos + L]
+        b = tensors[pos + L:pos + 2 * L]
+        gamma = tensors[pos + 2 * L] if spec.has_ln else None
+        dev = dy.device
+        M = spec.n_rows
+        dy = _dense(dy)
+        needs = ctx.needs_input_grad          # index 0 is `spec`
+
+        # ---- recompute: concatenated input, hidden activations, last pre-norm rows
+        k0 = sum(m["width"] for m in spec.meta)
+        X = _buf(M, k0, dev)
+        c0 = 0
+        aggs: List[Optional[Tensor]] = []
+        for t, m in zip(src_t, spec.meta):
+            if m["segments"] is not None:         # aggregation on load: the block is the segment mean of the source's rows
+                blk = ops.segment_reduce(t, m["segments"], m["seg_mean"], src_act=m["pre_act"])
+                train_gather(blk, X, c0, 0, m["width"], None, _lib.ACT_NONE, m["negate"], M)
+            else:
+                train_gather(t, X, c0, m["col0"], m["width"], m["index"], m["pre_act"], m["negate"], M)
+            c0 += m["width"]
+        acts = [X]
+        for l in range(L - 1):
+            a = torch.addmm(b[l], acts[-1], W[l].t())
+            ops.activation_(a, _lib.ACT_SELU)
+            acts.append(a)
+        # ---- output side: activation, residual, LayerNorm
+        g = dy
+        d_resid = None
+        if spec.has_resid and needs[1 + n_src]:
+            d_resid = torch.zeros_like(resid)
+            d_resid[:, spec.resid_col0:spec.resid_col0 + dy.size(1)] = dy
+        if spec.act != _lib.ACT_NONE:
+            out_act = y if resid is None else y - resid[:, spec.resid_col0:spec.resid_col0 + y.size(1)]
+            g = act_grad(g, _dense(out_act), spec.act, False)
+        d_gamma = d_beta = None
+        if spec.has_ln:
+            z_last = torch.addmm(b[L - 1], acts[-1], W[L - 1].t())
+            g, d_gamma, d_beta = layernorm_grad(z_last, gamma, g, spec.eps)
+        # ---- layers, last to first
+        dW: List[Optional[Tensor]] = [None] * L
+        db: List[Optional[Tensor]] = [None] * L
+        need_dx = any(needs[1 + j] for j in range(n_src))
+        for l in range(L - 1, -1, -1):
+            dW[l] = torch.mm(g.t(), acts[l])
+            db[l] = colsum(g)
+            if l > 0:
+                g = torch.mm(g, W[l])
+                g = act_grad(g, acts[l], _lib.ACT_SELU, False, out=g)
+            elif need_dx:
+                g = torch.mm(g, W[0])
+        # ---- back through the column blocks of the input
+        d_src: List[Optional[Tensor]] = [None] * n_src
+        c0 = 0
+        for j, (t, m) in enumerate(zip(src_t, spec.meta)):
+            w = m["width"]
+            if needs[1 + j]:
+                gx = g[:, c0:c0 + w]
+                if m["negate"]:
+                    gx = -gx
+                n_t = int(t.size(0))
+                if m["segments"] is not None:
+                    gt = segment_broadcast(gx, m["segments"], m["seg_mean"], n_t)
+                elif m["index"] is not None:
+                    gt = ops.segment_reduce(gx, plan.gather_csr(m["index"], n_t), False)
+                else:
+                    gt = gx
+                if m["pre_act"] != _lib.ACT_NONE:
+                    gt = act_grad(_dense(gt), t[:, m["col0"]:m["col0"] + w], m["pre_act"], True)
+                if m["col0"] == 0 and w == int(t.size(1)):
+                    d_src[j] = gt
+                else:
+                    full = torch.zeros_like(t)
+                    full[:, m["col0"]:m["col0"] + w] = gt
+                    d_src[j] = full
+            c0 += w
+        grads = [None] + d_src + ([d_resid] if spec.has_resid else []) + dW + db
+        if spec.has_ln:
+            grads += [d_gamma, d_beta]
+        return tuple(grads)
+
+
+def wants_grad(packed, sources: Sequence[Source], resid: Optional[Tensor]) -> bool:
+    if not torch.is_grad_enabled():
+        return False
+    if any(s.tensor.requires_grad for s in sources) or (resid is not None and resid.requires_grad):
+        return True
+    params = getattr(packed, "params", None)
+    if params is None:
+        return False
+    weights, biases, ln = params
+    flat = list(weights) + list(biases) + ([ln[0], ln[1]] if ln is not None else [])
+    return any(p is not None and p.requires_grad for p in flat)
+
+
+def mlp(packed, sources: Sequence[Source], n_rows: int, act: int, resid: Optional[Tensor], resid_col0: int) -> Tensor:
+    """Differentiable form of ops.mlp_forward (called by it when gradients are wanted)."""
+    if any(s.additive for s in sources):
+        raise NotImplementedError("pre-multiplied (additive) input blocks are an inference-only optimisation")
+    if packed.params is None or packed.heads_params:
+        raise NotImplementedError("this packed MLP carries no parameter references / has heads: inference only")
+    weights, biases, ln = packed.params
+    spec = _Spec()
+    spec.packed, spec.n_rows, spec.act = packed, int(n_rows), int(act)
+    spec.resid_col0, spec.has_resid = int(resid_col0), resid is not None
+    spec.n_layers, spec.has_ln, spec.eps = len(weights), ln is not None, (float(ln[2]) if ln is not None else 0.0)
+    spec.meta = [dict(index=s.index, col0=s.col0, width=s.width, negate=s.negate, pre_act=s.pre_act, segments=s.segments,
+                      seg_mean=s.seg_mean) for s in sources]
+    tensors = [s.tensor for s in sources] + ([resid] if resid is not None else []) + list(weights) + list(biases)
+    if ln is not None:
+        tensors += [ln[0], ln[1]]
+    return _FusedMLP.apply(spec, *tensors)
+
+
+# ------------------------------------------------------------------------------------- segmented reduction
+class _SegmentReduce(torch.autograd.Function):
+    """out[s] = act(sum | mean of src_act(src[perm[p]]) over segment s) — scatter(…, reduce) of nn/blocks.py:183,231 and the
+    feature part of pool_edge (:67)."""
+
+    @staticmethod
+    def forward(ctx, src: Tensor, csr, mean: bool, act: int, src_act: int):
+        out = ops.segment_reduce(src, csr, mean, act, src_act=src_act)
+        ctx.csr, ctx.mean, ctx.act, ctx.src_act = csr, mean, act, src_act
+        ctx.save_for_backward(src, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        src, out = ctx.saved_tensors
+        g = act_grad(_dense(dout), out, ctx.act, False)
+        gs = segment_broadcast(_dense(g), ctx.csr, ctx.mean, int(src.size(0)))
+        if ctx.src_act != _lib.ACT_NONE:
+            gs = act_grad(gs, _dense(src), ctx.src_act, True, out=gs)
+        return gs, None, None, None, None
+
+
+def segment_reduce(src: Tensor, csr, mean: bool, act: int, src_act: int) -> Tensor:
+    return _SegmentReduce.apply(src, csr, mean, act, src_act)

@@ -1,0 +1,226 @@
+// Backward-pass kernels of the training path (gfx950).  All HBM-bound: one pass over their operands, coalesced rows,
+// deterministic reductions (no atomics), so two runs of a training step give bit-identical gradients.
+// The dense contractions of the backward pass (dW = dZ^T A, dA = dZ W) are plain GEMMs and go to rocBLAS from the host
+// side (graphs4cfd_amd/autograd.py); everything around them is here.
+//
+// Reference being differentiated: graphs4cfd/nn/blocks.py:117-144 (MLP), :175-186 (GNBlock), :219-237 (DownMP),
+// :265-290 (UpMP); the reference relies on torch autograd over cat / index / Linear / SELU / LayerNorm / scatter.
+#include "g4c_common.h"
+
+namespace {
+
+using g4c::apply_act;
+
+// d act(x) / dx given either the activation's output (from_input = 0) or its input (from_input = 1)
+__device__ __forceinline__ float act_slope(float ref, int act, int from_input) {
+    const float alpha = 1.6732632423543772848170429916717f;
+    const float scale = 1.0507009873554804934193349852946f;
+    if (act == G4C_ACT_SELU) {
+        const float y = from_input ? g4c::selu_f(ref) : ref;
+        return y > 0.f ? scale : y + scale * alpha;              // x <= 0: d/dx scale*alpha*(e^x - 1) = y + scale*alpha
+    }
+    if (act == G4C_ACT_TANH) {
+        const float y = from_input ? g4c::tanh_f(ref) : ref;
+        return 1.f - y * y;
+    }
+    return 1.f;
+}
+
+__global__ __launch_bounds__(256) void train_gather_kernel(const float *__restrict__ src, int src_ld, int scol0,
+                                                           const int *__restrict__ idx, int pre_act, float sign,
+                                                           float *__restrict__ dst, int dst_ld, int dcol0, int width,
+                                                           long long n_rows) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long r = t / width;
+    const int c = (int)(t - r * width);
+    if (r >= n_rows) return;
+    const long long sr = idx ? (long long)idx[r] : r;
+    dst[r * dst_ld + dcol0 + c] = sign * apply_act(src[sr * src_ld + scol0 + c], pre_act);
+}
+
+__global__ __launch_bounds__(256) void act_grad_kernel(const float *__restrict__ dy, int dy_ld, const float *__restrict__ ref,
+                                                       int ref_ld, int from_input, int act, float *__restrict__ dz, int dz_ld,
+                                                       int width, long long n_rows) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long r = t / width;
+    const int c = (int)(t - r * width);
+    if (r >= n_rows) return;
+    dz[r * dz_ld + c] = dy[r * dy_ld + c] * act_slope(ref[r * ref_ld + c], act, from_input);
+}
+
+// LayerNorm backward, one wave per row (width <= 256: up to 4 columns per lane), 4 rows per workgroup iteration.
+//   xhat = (z - mean) * rstd;  g = dy * gamma;  dz = rstd * (g - mean(g) - xhat * mean(g * xhat))
+// dgamma / dbeta: every workgroup keeps running column sums over its rows and writes one partial row
+// [dgamma(width) | dbeta(width)]; g4c_colsum adds the partial rows in a fixed order.
+constexpr int LN_MAXC = 4;
+__global__ __launch_bounds__(256) void layernorm_grad_kernel(const float *__restrict__ z, int z_ld, const float *__restrict__ gamma,
+                                                             const float *__restrict__ dy, int dy_ld, float *__restrict__ dz,
+                                                             int dz_ld, float *__restrict__ partial, int width,
+                                                             long long n_rows, float eps) {
+    __shared__ float red[4][2 * 64 * LN_MAXC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[LN_MAXC], db[LN_MAXC], gam[LN_MAXC];
+#pragma unroll
+    for (int j = 0; j < LN_MAXC; ++j) {
+        dg[j] = db[j] = 0.f;
+        const int c = lane + 64 * j;
+        gam[j] = c < width ? gamma[c] : 0.f;
+    }
+    const float inv_w = 1.f / (float)width;
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < n_rows; r += (long long)gridDim.x * 4) {
+        float zv[LN_MAXC], gy[LN_MAXC], s = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXC; ++j) {
+            const int c = lane + 64 * j;
+            zv[j] = c < width ? z[r * z_ld + c] : 0.f;
+            gy[j] = c < width ? dy[r * dy_ld + c] : 0.f;
+            s += zv[j];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * inv_w;
+        float var = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXC; ++j) {
+            const int c = lane + 64 * j;
+            const float d = c < width ? zv[j] - mean : 0.f;
+            var += d * d;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+        const float rstd = rsqrtf(var * inv_w + eps);
+        float m1 = 0.f, m2 = 0.f, xh[LN_MAXC];
+#pragma unroll
+        for (int j = 0; j < LN_MAXC; ++j) {
+            const int c = lane + 64 * j;
+            xh[j] = c < width ? (zv[j] - mean) * rstd : 0.f;
+            const float g = gy[j] * gam[j];
+            m1 += g;
+            m2 += g * xh[j];
+            dg[j] += gy[j] * xh[j];
+            db[j] += gy[j];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+        m1 *= inv_w; m2 *= inv_w;
+#pragma unroll
+        for (int j = 0; j < LN_MAXC; ++j) {
+            const int c = lane + 64 * j;
+            if (c < width) dz[r * dz_ld + c] = rstd * (gy[j] * gam[j] - m1 - xh[j] * m2);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LN_MAXC; ++j) { red[wave][lane + 64 * j] = dg[j]; red[wave][64 * LN_MAXC + lane + 64 * j] = db[j]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * width; c += 256) {
+        const int k = c < width ? c : 64 * LN_MAXC + (c - width);
+        partial[(long long)blockIdx.x * 2 * width + c] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    }
+}
+
+// column sums of x[n_rows, width]: stage 1, workgroup g adds rows g*chunk .. (g+1)*chunk in order (thread = column, so
+// a workgroup reads whole rows: coalesced); stage 2 adds the partial rows in order.
+__global__ __launch_bounds__(256) void colsum_stage_kernel(const float *__restrict__ x, int ld, int width, long long n_rows,
+                                                           long long chunk, float *__restrict__ out, int out_ld) {
+    const long long r0 = (long long)blockIdx.x * chunk;
+    const long long r1 = r0 + chunk < n_rows ? r0 + chunk : n_rows;
+    for (int c = threadIdx.x; c < width; c += 256) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        long long r = r0;
+        for (; r + 3 < r1; r += 4) {
+            s0 += x[r * ld + c]; s1 += x[(r + 1) * ld + c]; s2 += x[(r + 2) * ld + c]; s3 += x[(r + 3) * ld + c];
+        }
+        for (; r < r1; ++r) s0 += x[r * ld + c];
+        out[(long long)blockIdx.x * out_ld + c] = (s0 + s1) + (s2 + s3);
+    }
+}
+
+// adjoint of the segmented sum / mean: every row of a segment receives the segment's gradient (/ max(count, 1))
+__global__ __launch_bounds__(256) void segment_broadcast_kernel(const float *__restrict__ dout, int dout_ld,
+                                                                const int *__restrict__ off, const int *__restrict__ perm,
+                                                                int n_seg, int width, int mean, float *__restrict__ dsrc,
+                                                                int dsrc_ld) {
+    const int lane = threadIdx.x & 63;
+    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seg >= n_seg) return;
+    const int b = off[seg], e = off[seg + 1];
+    const float scale = mean ? 1.f / (float)(e - b > 1 ? e - b : 1) : 1.f;
+    for (int c = lane; c < width; c += 64) {
+        const float g = dout[(long long)seg * dout_ld + c] * scale;
+        for (int p = b; p < e; ++p) {
+            const long long r = perm ? (long long)perm[p] : (long long)p;
+            dsrc[r * dsrc_ld + c] = g;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int g4c_train_gather(const float *src, int32_t src_ld, int32_t scol0, const int32_t *idx, int32_t pre_act,
+                                int32_t negate, float *dst, int32_t dst_ld, int32_t dcol0, int32_t width, int64_t n_rows,
+                                void *stream) {
+    G4C_REQUIRE(src && dst, G4C_EINVAL, "g4c_train_gather: null pointer");
+    G4C_REQUIRE(width > 0 && n_rows >= 0 && scol0 >= 0 && dcol0 >= 0 && src_ld >= scol0 + width && dst_ld >= dcol0 + width &&
+                    pre_act >= 0 && pre_act <= 2,
+                G4C_EINVAL, "g4c_train_gather: bad arguments width=%d src_ld=%d dst_ld=%d pre_act=%d", width, src_ld, dst_ld, pre_act);
+    if (n_rows == 0) return G4C_OK;
+    const long long total = n_rows * width;
+    train_gather_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        src, src_ld, scol0, idx, pre_act, negate ? -1.f : 1.f, dst, dst_ld, dcol0, width, n_rows);
+    return g4c::check_launch("g4c_train_gather");
+}
+
+extern "C" int g4c_act_grad(const float *dy, int32_t dy_ld, const float *ref, int32_t ref_ld, int32_t from_input, int32_t act,
+                            float *dz, int32_t dz_ld, int32_t width, int64_t n_rows, void *stream) {
+    G4C_REQUIRE(dy && ref && dz, G4C_EINVAL, "g4c_act_grad: null pointer");
+    G4C_REQUIRE(width > 0 && n_rows >= 0 && dy_ld >= width && ref_ld >= width && dz_ld >= width && act >= 0 && act <= 2, G4C_EINVAL,
+                "g4c_act_grad: bad arguments width=%d lds=%d,%d,%d act=%d", width, dy_ld, ref_ld, dz_ld, act);
+    if (n_rows == 0) return G4C_OK;
+    const long long total = n_rows * width;
+    act_grad_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        dy, dy_ld, ref, ref_ld, from_input, act, dz, dz_ld, width, n_rows);
+    return g4c::check_launch("g4c_act_grad");
+}
+
+extern "C" int32_t g4c_layernorm_grad_partials(int64_t n_rows) {
+    const long long want = (n_rows + 63) / 64;       // >= 16 rows per wave before a second workgroup pays off
+    return (int32_t)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+}
+
+extern "C" int g4c_layernorm_grad(const float *z, int32_t z_ld, const float *gamma, const float *dy, int32_t dy_ld, float *dz,
+                                  int32_t dz_ld, float *partial, int32_t width, int64_t n_rows, float eps, void *stream) {
+    G4C_REQUIRE(z && gamma && dy && dz && partial, G4C_EINVAL, "g4c_layernorm_grad: null pointer");
+    G4C_REQUIRE(width > 0 && width <= 64 * LN_MAXC && n_rows >= 0 && z_ld >= width && dy_ld >= width && dz_ld >= width,
+                G4C_EUNSUPPORTED, "g4c_layernorm_grad: width %d (max %d) / leading dimensions", width, 64 * LN_MAXC);
+    const int n_wg = g4c_layernorm_grad_partials(n_rows);
+    layernorm_grad_kernel<<<dim3(n_wg), dim3(256), 0, (hipStream_t)stream>>>(z, z_ld, gamma, dy, dy_ld, dz, dz_ld, partial, width,
+                                                                              n_rows, eps);
+    return g4c::check_launch("g4c_layernorm_grad");
+}
+
+extern "C" int32_t g4c_colsum_partials(int64_t n_rows) {
+    const long long want = (n_rows + 255) / 256;
+    return (int32_t)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+}
+
+extern "C" int g4c_colsum(const float *x, int32_t ld, int32_t width, int64_t n_rows, float *scratch, float *out, void *stream) {
+    G4C_REQUIRE(x && scratch && out, G4C_EINVAL, "g4c_colsum: null pointer");
+    G4C_REQUIRE(width > 0 && n_rows >= 0 && ld >= width, G4C_EINVAL, "g4c_colsum: bad sizes width=%d ld=%d", width, ld);
+    const int g = g4c_colsum_partials(n_rows);
+    const long long chunk = (n_rows + g - 1) / g;
+    hipStream_t s = (hipStream_t)stream;
+    colsum_stage_kernel<<<dim3(g), dim3(256), 0, s>>>(x, ld, width, n_rows, chunk > 0 ? chunk : 1, scratch, width);
+    colsum_stage_kernel<<<dim3(1), dim3(256), 0, s>>>(scratch, width, width, g, g, out, width);
+    return g4c::check_launch("g4c_colsum");
+}
+
+extern "C" int g4c_segment_broadcast(const float *dout, int32_t dout_ld, const int32_t *off, const int32_t *perm, int32_t n_seg,
+                                     int32_t width, int32_t mean, float *dsrc, int32_t dsrc_ld, void *stream) {
+    G4C_REQUIRE(dout && off && dsrc, G4C_EINVAL, "g4c_segment_broadcast: null pointer");
+    G4C_REQUIRE(width > 0 && n_seg >= 0 && dout_ld >= width && dsrc_ld >= width, G4C_EINVAL,
+                "g4c_segment_broadcast: bad sizes width=%d dout_ld=%d dsrc_ld=%d", width, dout_ld, dsrc_ld);
+    if (n_seg == 0) return G4C_OK;
+    segment_broadcast_kernel<<<dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(
+        dout, dout_ld, off, perm, n_seg, width, mean, dsrc, dsrc_ld);
+    return g4c::check_launch("g4c_segment_broadcast");
+}

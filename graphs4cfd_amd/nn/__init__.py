@@ -3,4 +3,5 @@ from . import blocks
 from .mus_gnn import *
 from .mugs_gnn import NsTwoGuillardScaleGNN, NsThreeGuillardScaleGNN, NsFourGuillardScaleGNN
 from .remus_gnn import NsRotEquiTreeScaleGNN
-from .model import GNN, collate
+from .model import GNN, TrainConfig, collate
+from .losses import GraphLoss

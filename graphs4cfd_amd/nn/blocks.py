@@ -123,6 +123,8 @@ class MLP(nn.Module):
         destinations (row-sliced views of wider buffers are fine)."""
         if self.output_size != 128 or any(int(w) != 128 for w in widths) or not 1 <= len(widths) <= _lib.MAX_HEADS:
             return None
+        if ops.grad_mode():          # recorded for autograd: the plain launches are the differentiable ones
+            return None
         prec = ops.effective_precision([s.width for s in sources])
         if prec == "bf16":
             return None
@@ -185,7 +187,7 @@ class MLP(nn.Module):
         Below HOIST_MIN_ROWS the launch is latency-bound and the extra product launches cost more than the MFMA
         work they save (measured crossover ~25k rows, scripts/sweep_tile_modes.py): one plain fused launch then.
         `products` (from the producer's launch, MLP.run_with_heads): the per-node terms, already multiplied."""
-        if (n_rows < HOIST_MIN_ROWS or ops.mlp_precision() == "bf16") and products is None:   # (plain bf16 MFMAs are ~free: never hoist)
+        if (n_rows < HOIST_MIN_ROWS or ops.mlp_precision() == "bf16" or ops.grad_mode()) and products is None:   # (plain bf16 MFMAs are ~free: never hoist)
             return self.run_coded(list(k_sources) + [Source(t, index=idx) for t, idx in gathered], n_rows, act_code, **kw)
         kw_widths = [s.width for s in k_sources]
         off = sum(kw_widths)
@@ -300,6 +302,9 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
         # aggregation pass, no aggregate written to / re-read from HBM
         e_new = msg_mlp.run_hoisted([e_src], [(senders, ep.row), (v, ep.col)], ep.n_edges, products=products)
         agg_src = Source(e_new, segments=csr, seg_mean=mean)
+    elif ops.grad_mode():
+        e_new = msg_mlp.run_hoisted([e_src], [(senders, ep.row), (v, ep.col)], ep.n_edges)
+        agg_src = Source(ops.segment_reduce(e_new, csr, mean))
     else:
         # (G4C_FUSE_AGG: the aggregation rides on the EDGE launch when the kernel can reduce the tile it has just computed,
         # ops.mlp_forward(agg=...); otherwise that call runs g4c_segment_reduce right after the launch)
@@ -326,6 +331,8 @@ def _public_mp(msg_mlp: MLP, upd_mlp: MLP, v, e, index, aggr, activation, v_src=
     if activation is not None:
         if code is None:
             v_new, e_new = activation(v_new), activation(e_new)
+        elif ops.grad_mode():                  # (out of place: e_new is an autograd output)
+            e_new = torch.nn.functional.selu(e_new) if code == _lib.ACT_SELU else (torch.tanh(e_new) if code == _lib.ACT_TANH else e_new)
         else:
             ops.activation_(e_new, code)
     return v_new, e_new

@@ -2,8 +2,9 @@
 
 Mirrors the inference-side surface of the reference's graphs4cfd/nn/model.py: constructor
 `(arch, weights, checkpoint, device)`, `load_model` (:112-130), `solve` (:303-321),
-`shift_and_replace` (:323-327), `save_checkpoint` (:329-349), `num_params` (:351-354).  The training
-loop (`fit`, `TrainConfig`, :14-82,152-301) is out of scope.
+`shift_and_replace` (:323-327), `save_checkpoint` (:329-349), `num_params` (:351-354), and the training side:
+`TrainConfig` (:14-82), `fit` (:152-301), `grad_norm2` (:356-362) — the forward of a training step is the same fused
+launches, recorded for autograd (../autograd.py).
 
 `solve` keeps the whole rollout on the device: the history-window shift and the write into
 `outputs[:, nf*t:nf*(t+1)]` are one kernel reading the step index from device memory, so a step has no
@@ -12,7 +13,8 @@ host synchronisation and can be captured once in a hipGraph and replayed (`captu
 from __future__ import annotations
 
 import os
-from typing import List, Optional, Union
+import contextlib
+from typing import Callable, List, Optional, Union
 
 import torch
 from torch import nn
@@ -40,6 +42,32 @@ def collate(graphs: List[Graph]) -> Graph:
     merged = {k: (torch.cat(v, dim=-1 if "index" in k else 0) if isinstance(v, list) else v) for k, v in out.items()}
     merged["batch"] = torch.cat(batch)
     return Graph(**merged)
+
+
+class TrainConfig():
+    r"""Training configuration of a model (reference: nn/model.py:14-82; same fields, same defaults, dict-style access).
+
+    name, folder, checkpoint (resume from), tensor_board (log dir or None), chk_interval (epochs), training_loss /
+    validation_loss (callables `(graph, pred, target)`), epochs, num_steps (rollout lengths, advanced when the monitored
+    loss falls below `add_steps['tolerance']`), batch_size, lr, grad_clip ({'epoch', 'limit'} or None), scheduler
+    ({'factor', 'patience', 'loss'} or None), stopping (minimum lr), mixed_precision, device."""
+
+    def __init__(self, name: str, folder: str = './', checkpoint: Union[None, str] = None, tensor_board: Union[None, str] = None,
+                 chk_interval: int = 1, training_loss: Callable = None, validation_loss: Callable = None, epochs: int = 1,
+                 num_steps: Union[int, List[int]] = [1], add_steps: dict = {'tolerance': 0, 'loss': 'training'},
+                 batch_size: int = 1, lr: float = 1e-3, grad_clip: Union[None, dict] = None, scheduler: Union[None, dict] = None,
+                 stopping: float = 0., mixed_precision: bool = False, device: Optional[torch.device] = None):
+        self.name, self.folder, self.checkpoint, self.tensor_board, self.chk_interval = name, folder, checkpoint, tensor_board, chk_interval
+        self.training_loss, self.validation_loss, self.epochs = training_loss, validation_loss, epochs
+        self.num_steps = [num_steps] if isinstance(num_steps, int) else num_steps
+        self.add_steps, self.batch_size, self.lr, self.grad_clip, self.scheduler = add_steps, batch_size, lr, grad_clip, scheduler
+        self.stopping, self.mixed_precision, self.device = stopping, mixed_precision, device
+
+    def __repr__(self):
+        return repr(self.__dict__)
+
+    def __getitem__(self, key):
+        return self.__dict__.get(key)
 
 
 class GNN(nn.Module):
@@ -98,6 +126,140 @@ class GNN(nn.Module):
                                     "pass checkpoint=<path to .chk> instead")
         return path
 
+    # ---------------------------------------------------------------------------------- training
+    def fit(self, train_config: TrainConfig, train_loader, val_loader=None):
+        """Trains the model (reference: nn/model.py:152-301 — same loop: Adam, optional ReduceLROnPlateau, gradient clipping,
+        one optimiser step per rollout step with the prediction fed back detached, validation over the longest rollout,
+        checkpoints in the reference's `.chk` format, rollout length advanced when the monitored loss passes the tolerance).
+
+        Differences, all deliberate: `scheduler=None` / `tensor_board=None` work (the reference dereferences both
+        unconditionally, :279,:299); `mixed_precision` needs no loss scaling here — gradients and accumulations are fp32
+        whatever `ops.set_mlp_precision` says the MLP products run in — so the flag only prints a note."""
+        from torch import optim
+        if train_config['device'] is not None and torch.device(train_config['device']) != self.device:
+            self.to(train_config['device'])
+        criterion = train_config['training_loss']
+        steps_list = list(train_config['num_steps'])
+        max_n_out = steps_list[-1]
+        num_steps = iter(steps_list)
+        n_out = next(num_steps)
+        sch_cfg = train_config['scheduler']
+
+        def new_scheduler(opt):
+            if sch_cfg is None or sch_cfg.get('patience') is None:
+                return None
+            return optim.lr_scheduler.ReduceLROnPlateau(opt, factor=sch_cfg['factor'], patience=sch_cfg['patience'], eps=0.)
+
+        checkpoint, scheduler = None, None
+        if train_config['checkpoint'] is not None and os.path.exists(train_config['checkpoint']):
+            print("Training from an existing check-point:", train_config['checkpoint'])
+            checkpoint = torch.load(train_config['checkpoint'], map_location=self.device, weights_only=False)
+            self.load_state_dict(checkpoint['weights'])
+            optimiser = optim.Adam(self.parameters(), lr=checkpoint['lr'])
+            optimiser.load_state_dict(checkpoint['optimiser'])
+            scheduler = new_scheduler(optimiser)
+            if scheduler is not None and 'scheduler' in checkpoint:
+                scheduler.load_state_dict(checkpoint['scheduler'])
+            while n_out < checkpoint['n_out']:
+                n_out = next(num_steps)
+            initial_epoch = checkpoint['epoch'] + 1
+        else:
+            if train_config['checkpoint'] is not None:
+                print("Not matching check-point file:", train_config['checkpoint'])
+            print('Training from randomly initialised weights')
+            optimiser = optim.Adam(self.parameters(), lr=train_config['lr'])
+            scheduler = new_scheduler(optimiser)
+            initial_epoch = 1
+        path = os.path.join(train_config["folder"], train_config["name"] + ".chk")
+        if os.path.exists(path):
+            print('Renaming', path, 'to:', path + '.bck')
+            os.rename(path, path + '.bck')
+        writer = None
+        if train_config['tensor_board'] is not None:
+            from torch.utils.tensorboard import SummaryWriter
+            writer = SummaryWriter(os.path.join(train_config["tensor_board"], train_config["name"]))
+        if train_config['mixed_precision']:
+            print(f"mixed_precision: MLP products run in ops.mlp_precision() = {ops.mlp_precision()!r}; gradients stay fp32, no loss scaling")
+        print(f'Training on device: {self.device}')
+        print(f'Number of trainable parameters: {self.num_params}')
+        self.history = []
+        for epoch in range(initial_epoch, train_config['epochs'] + 1):
+            if optimiser.param_groups[0]['lr'] < train_config['stopping']:
+                print(f"The learning rate is smaller than {train_config['stopping']}. Stopping training.")
+                self.save_checkpoint(path, n_out, epoch, optimiser, scheduler=scheduler)
+                break
+            print(f"Hyperparameters: n_out = {n_out}, lr = {optimiser.param_groups[0]['lr']}")
+            self.train()
+            training_loss, gradients_norm, iteration = 0., 0., -1
+            for iteration, data in enumerate(train_loader):
+                data = data.to(self.device)
+                pred = None
+                for t in range(n_out):
+                    if t > 0:
+                        data.field = self.shift_and_replace(data.field, pred.detach())
+                    pred = self.forward(data, t)
+                    loss = criterion(data, pred, data.target[:, self.num_fields * t:self.num_fields * (t + 1)])
+                    loss.backward()
+                    training_loss += loss.item() / n_out
+                    gradients_norm += self.grad_norm2() / n_out
+                    if train_config['grad_clip'] is not None and epoch > train_config['grad_clip']["epoch"]:
+                        nn.utils.clip_grad_norm_(self.parameters(), train_config['grad_clip']["limit"])
+                    optimiser.step()
+                    optimiser.zero_grad()
+            training_loss /= (iteration + 1)
+            gradients_norm /= (iteration + 1)
+            print(f"Epoch: {epoch:4d}, Training   loss: {training_loss:.4e}, Gradients: {gradients_norm:.4e}")
+            validation_loss = None
+            if val_loader is not None:
+                validation_criterion = train_config['validation_loss']
+                self.eval()
+                with torch.no_grad():
+                    validation_loss = 0.
+                    for iteration, data in enumerate(val_loader):
+                        data = data.to(self.device)
+                        for t in range(max_n_out):
+                            if t > 0:
+                                data.field = self.shift_and_replace(data.field, pred)
+                            pred = self.forward(data, t)
+                            validation_loss += validation_criterion(
+                                data, pred, data.target[:, self.num_fields * t:self.num_fields * (t + 1)]).item() / max_n_out
+                    validation_loss /= (iteration + 1)
+                    print(f"Epoch: {epoch:4d}, Validation loss: {validation_loss:.4e}")
+            self.history.append({'epoch': epoch, 'n_out': n_out, 'training_loss': training_loss, 'validation_loss': validation_loss,
+                                 'gradients_norm': gradients_norm, 'lr': optimiser.param_groups[0]['lr']})
+            if writer is not None:
+                writer.add_scalar('Loss/train', training_loss, epoch)
+                if val_loader:
+                    writer.add_scalar('Loss/test', validation_loss, epoch)
+
+            def monitored(which: str):
+                if which[:2] == 'tr':
+                    return training_loss
+                if which[:3] == 'val':
+                    if validation_loss is None:
+                        raise ValueError("a validation loss is monitored but no val_loader was given")
+                    return validation_loss
+                raise NameError(f"Invalid loss selector {which!r} (expected 'training' or 'validation').")
+
+            if scheduler is not None:
+                scheduler.step(monitored(sch_cfg['loss']))
+            if not epoch % train_config["chk_interval"]:
+                print('Saving check-point in:', path)
+                self.save_checkpoint(path, n_out, epoch, optimiser, scheduler=scheduler)
+            if monitored(train_config['add_steps']['loss']) < train_config['add_steps']['tolerance'] and n_out < max_n_out:
+                n_out = next(num_steps)
+                optimiser = optim.Adam(self.parameters(), lr=train_config["lr"])
+                scheduler = new_scheduler(optimiser)
+        if writer is not None:
+            writer.close()
+        print("Finished training")
+        return
+
+    def grad_norm2(self):
+        """L2 norm of the gradients (nn/model.py:356-362), with one device->host transfer instead of one per parameter."""
+        sq = [p.grad.detach().pow(2).sum() for p in self.parameters() if p.requires_grad and p.grad is not None]
+        return float(torch.stack(sq).sum().sqrt()) if sq else 0.0
+
     # ---------------------------------------------------------------------------------- rollout
     def solve(self, graph: Union[Graph, List[Graph]], n_out: int, *, capture: Optional[bool] = None) -> torch.Tensor:
         """Evaluate the model on the graph for n_out time-steps. Returns [N, num_fields*n_out].
@@ -117,6 +279,13 @@ class GNN(nn.Module):
             with Rollout(self, graph, n_out, capture=capture) as ro:
                 ro.run(n_out)
                 return ro.outputs
+
+    def _require_inference(self, why: str) -> None:
+        """Model families whose launches are not recorded for autograd call this first: a forward with gradients enabled
+        would silently return a tensor cut off from the parameters."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(f"{type(self).__name__}.forward with gradients enabled: {why}; "
+                                      "wrap inference in torch.no_grad() (solve() does)")
 
     def shift_and_replace(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         """Shift the fields in x by num_fields and replace the last num_fields with y (nn/model.py:323-327).

@@ -55,6 +55,7 @@ class _MuGSGNN(GNN):
         self.to(self.device)
 
     def forward(self, graph: Graph, t: Optional[int] = None) -> torch.Tensor:
+        self._require_inference("the training path (autograd.py) covers the MuS-GNN family")
         g = graph
         field0 = g.field
         n = int(field0.size(0))

@@ -67,6 +67,7 @@ class NsRotEquiTreeScaleGNN(GNN):
         self.to(self.device)
 
     def forward(self, graph: Graph, t: Optional[int] = None) -> torch.Tensor:
+        self._require_inference("the training path (autograd.py) covers the MuS-GNN family")
         g = graph
         sfx = {1: "", 2: "2", 3: "3"}
         nfeat = int(g.field.size(1)) // 2

@@ -99,6 +99,11 @@ class Source:
 def segment_reduce(src: Tensor, csr: CsrPlan, mean: bool, act: int = _lib.ACT_NONE, out: Optional[Tensor] = None,
                    src_act: int = _lib.ACT_NONE) -> Tensor:
     """out[s] = act(sum|mean of src_act(src[perm[p]]) over the plan's segments) (g4c_segment_reduce)."""
+    if torch.is_grad_enabled() and src.requires_grad:
+        if out is not None:
+            raise NotImplementedError("segment_reduce(out=...) is not differentiable")
+        from . import autograd as _ag
+        return _ag.segment_reduce(src, csr, mean, act, src_act)
     lib = _lib.load()
     src = _f32_2d(src, "src")
     dev = _lib.require_hip(src, csr.off, csr.perm)
@@ -208,6 +213,12 @@ FUSE_AGG = os.environ.get("G4C_FUSE_AGG", "0") == "1"
 # Aggregation on load (g4c_src_t.seg_off): the node-MLP launch averages each target's messages while it gathers its input,
 # instead of a separate g4c_segment_reduce pass (bit-identical values; no tile-alignment constraint, unlike FUSE_AGG).
 AGG_ON_LOAD = os.environ.get("G4C_AGG_ON_LOAD", "1") == "1"
+
+
+def grad_mode() -> bool:
+    """True when calls are being recorded for autograd: the block / model code then keeps to the plain forms of the
+    launches (no heads, no pre-multiplied products, no in-place epilogues), which are the differentiable ones."""
+    return torch.is_grad_enabled()
 
 
 def can_aggregate_on_load(csr: CsrPlan, width: int, consumer_widths: Sequence[int]) -> bool:
@@ -350,6 +361,9 @@ class PackedMLP:
             self.desc.ln_gamma, self.desc.ln_beta, self.desc.ln_eps = None, None, 0.0
         self.seg_widths = tuple(seg_widths)
         self.device = dev
+        # the parameter tensors this image was packed from (the training path differentiates with respect to them: autograd.py)
+        self.params = (list(weights), list(biases), ln)
+        self.heads_params = bool(heads)
 
 
 def _src_array(sources: Sequence[Source]):
@@ -379,7 +393,15 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
     g4c_mlp_forward_rows with that kernel variant instead of the library's own choice.
     `head_outs` ([n_rows, 128] tensors, one per head of `packed`): g4c_mlp_forward_heads.
     `agg` = (csr, out [n_seg, 128], mean): also aggregate the output rows over the segments of `csr` (rows must be in segment
-    order) — inside the launch when the kernel can (g4c_mlp_forward_bx6_agg), otherwise with a g4c_segment_reduce afterwards."""
+    order) — inside the launch when the kernel can (g4c_mlp_forward_bx6_agg), otherwise with a g4c_segment_reduce afterwards.
+    With gradients enabled and a differentiable input / parameter, the call is recorded for autograd (autograd.py)."""
+    if torch.is_grad_enabled():
+        from . import autograd as _ag
+        if _ag.wants_grad(packed, sources, resid):
+            if out is not None or out_idx32 is not None or head_outs is not None or agg is not None or tile_mode is not None:
+                raise NotImplementedError("out= / heads / fused aggregation are inference-only forms of mlp_forward; "
+                                          "call under torch.no_grad() or use the plain form")
+            return _ag.mlp(packed, sources, n_rows, act, resid, resid_col0)
     lib = _lib.load()
     dev = _lib.require_hip(*[s.tensor for s in sources], *[s.index for s in sources], out, out_idx32, resid)
     if dev != packed.device:

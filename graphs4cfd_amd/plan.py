@@ -162,6 +162,16 @@ def index32(index: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gather_csr(index: torch.Tensor, n_rows: int) -> CsrPlan:
+    """Cached CSR plan grouping the positions of a gather index by the row they read (adjoint of `x[index]`: the
+    training path sums the gradient rows of each group in order, autograd.py)."""
+    key = _Cache.key(index) + ("gather_csr", n_rows)
+    out = _index_plans.get(key)
+    if out is None:
+        out = _index_plans.put(key, (index,), build_csr(index, n_rows, index.device))
+    return out
+
+
 def mask_index32(mask: torch.Tensor) -> torch.Tensor:
     """Cached int32 positions of the True entries of a boolean node mask (coarse_mask{l})."""
     key = _Cache.key(mask) + ("nonzero",)

@@ -238,6 +238,38 @@ int g4c_activation_inplace(float *x, int64_t n, int32_t act, void *stream);
 int g4c_copy_cols(const float *src, int32_t src_ld, int32_t scol0, const int32_t *idx,
                   float *dst, int32_t dst_ld, int32_t dcol0, int32_t width, int64_t n_rows, void *stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Training path: the backward pass of the fused blocks.  The reference differentiates
+ * cat / index / nn.Linear / SELU / LayerNorm / scatter with torch autograd (GNN.fit, nn/model.py:152-301); here the forward
+ * is the fused launch above, the backward recomputes the block's activations (nothing but the block's inputs and output is
+ * kept between the passes) with rocBLAS for the plain GEMMs and these kernels for everything else.  All reductions run
+ * in a fixed order: gradients are bit-reproducible.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* dst[r, dcol0 : dcol0+width] = (negate ? -1 : 1) * pre_act(src[idx ? idx[r] : r, scol0 : scol0+width]): one column block
+ * of the concatenated MLP input (nn/blocks.py:181,185,229,285), recomputed for the backward pass. */
+int g4c_train_gather(const float *src, int32_t src_ld, int32_t scol0, const int32_t *idx, int32_t pre_act, int32_t negate,
+                     float *dst, int32_t dst_ld, int32_t dcol0, int32_t width, int64_t n_rows, void *stream);
+
+/* dz = dy * act'(.)  — `ref` holds the activation's OUTPUT (from_input = 0) or its INPUT (from_input = 1).  dz may alias dy. */
+int g4c_act_grad(const float *dy, int32_t dy_ld, const float *ref, int32_t ref_ld, int32_t from_input, int32_t act,
+                 float *dz, int32_t dz_ld, int32_t width, int64_t n_rows, void *stream);
+
+/* LayerNorm backward (nn/blocks.py:141, eps 1e-5, affine): dz from the pre-norm rows z, gamma and dy; `partial` receives
+ * g4c_layernorm_grad_partials(n_rows) rows of [dgamma(width) | dbeta(width)] partial sums — add them with g4c_colsum. */
+int32_t g4c_layernorm_grad_partials(int64_t n_rows);
+int g4c_layernorm_grad(const float *z, int32_t z_ld, const float *gamma, const float *dy, int32_t dy_ld, float *dz,
+                       int32_t dz_ld, float *partial, int32_t width, int64_t n_rows, float eps, void *stream);
+
+/* out[c] = sum_r x[r, c] (bias gradients; the LayerNorm partials).  `scratch`: g4c_colsum_partials(n_rows) * width floats. */
+int32_t g4c_colsum_partials(int64_t n_rows);
+int g4c_colsum(const float *x, int32_t ld, int32_t width, int64_t n_rows, float *scratch, float *out, void *stream);
+
+/* Adjoint of g4c_segment_reduce: dsrc[perm ? perm[p] : p] = dout[s] (/ max(count_s, 1) if mean) for p in segment s.
+ * Rows of dsrc that belong to no segment are left untouched (zero them first when perm is not a full permutation). */
+int g4c_segment_broadcast(const float *dout, int32_t dout_ld, const int32_t *off, const int32_t *perm, int32_t n_seg,
+                          int32_t width, int32_t mean, float *dsrc, int32_t dsrc_ld, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,14 @@ from oracle import g4c_oracle as O
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
+
+
+@pytest.fixture(autouse=True)
+def _inference():
+    """This file covers the inference path (every launch form, including the inference-only ones: out=, heads, fused
+    aggregation, explicit kernel variants).  The training path has its own file (test_gpu_train.py)."""
+    with torch.no_grad():
+        yield
 BLOCK = dict(rtol=1e-4, atol=1e-4)
 FWD = dict(rtol=5e-4, atol=5e-4)
 

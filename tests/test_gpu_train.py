@@ -1,0 +1,254 @@
+"""GPU parity of the training path (autograd.py + train_ops.hip) against torch autograd over the oracle's restatement of
+the reference blocks (the reference itself differentiates these ops with torch autograd: nn/model.py:232-236).
+Tolerances: gradients are sums over up to ~1e5 rows of O(1) terms in fp32 — compared relative to the largest entry of each
+gradient tensor (rtol 2e-4 of that scale), far below anything an optimiser step can see."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pytestmark = pytest.mark.gpu
+
+import graphs4cfd_amd as gfd                      # noqa: E402
+from graphs4cfd_amd import _lib, ops, plan, synthetic as S       # noqa: E402
+from graphs4cfd_amd.nn import blocks as B         # noqa: E402
+from oracle import g4c_oracle as O                # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def close(a, b, rel=2e-4, what=""):
+    scale = max(float(b.abs().max()), 1e-6)
+    err = float((a - b).abs().max())
+    assert err <= rel * scale, f"{what}: max |diff| {err:.3e} vs scale {scale:.3e}"
+
+
+# ------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("act", [_lib.ACT_SELU, _lib.ACT_TANH])
+@pytest.mark.parametrize("from_input", [False, True])
+def test_act_grad(act, from_input):
+    from graphs4cfd_amd import autograd as A
+    torch.manual_seed(0)
+    x = torch.randn(777, 96, device=DEV, requires_grad=True)
+    y = F.selu(x) if act == _lib.ACT_SELU else torch.tanh(x)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    got = A.act_grad(dy, x.detach() if from_input else y.detach(), act, from_input)
+    close(got, x.grad, 1e-5, "act_grad")
+
+
+@pytest.mark.parametrize("rows,width", [(1, 128), (333, 128), (5000, 32), (70000, 128), (100, 200)])
+def test_layernorm_grad_and_colsum(rows, width):
+    from graphs4cfd_amd import autograd as A
+    torch.manual_seed(1)
+    z = (torch.randn(rows, width, device=DEV) * 2 + 0.3).requires_grad_(True)
+    gamma = torch.randn(width, device=DEV, requires_grad=True)
+    beta = torch.randn(width, device=DEV, requires_grad=True)
+    dy = torch.randn(rows, width, device=DEV)
+    F.layer_norm(z, (width,), gamma, beta, 1e-5).backward(dy)
+    dz, dg, db = A.layernorm_grad(z.detach(), gamma.detach(), dy, 1e-5)
+    close(dz, z.grad, 2e-5, "dz")
+    close(dg, gamma.grad, 1e-4, "dgamma")
+    close(db, beta.grad, 1e-4, "dbeta")
+    close(A.colsum(dy), dy.double().sum(0).float(), 1e-5, "colsum")
+    # fixed summation order: bit-reproducible
+    assert torch.equal(A.colsum(dy), A.colsum(dy))
+    assert torch.equal(A.layernorm_grad(z.detach(), gamma.detach(), dy, 1e-5)[1], dg)
+
+
+def test_segment_reduce_autograd_with_permutation_and_activations():
+    torch.manual_seed(2)
+    n, n_seg, w = 4000, 700, 128
+    key = torch.randint(0, n_seg + 1, (n,))                 # key == n_seg: dropped rows (pool_edge's self loops)
+    csr = plan.build_csr(key, n_seg + 1, DEV, drop_last_segment=True)
+    src = torch.randn(n, w, device=DEV, requires_grad=True)
+    out = ops.segment_reduce(src, csr, True, _lib.ACT_TANH, src_act=_lib.ACT_SELU)
+    dy = torch.randn_like(out)
+    out.backward(dy)
+    ref_src = src.detach().clone().requires_grad_(True)
+    keep = (key < n_seg).to(DEV)
+    k = key.to(DEV)[keep]
+    s = torch.zeros(n_seg, w, device=DEV).index_add_(0, k, F.selu(ref_src)[keep])
+    cnt = torch.zeros(n_seg, device=DEV).index_add_(0, k, torch.ones_like(k, dtype=torch.float32)).clamp(min=1)
+    ref = torch.tanh(s / cnt[:, None])
+    ref.backward(dy)
+    close(out.detach(), ref.detach(), 1e-5, "forward")
+    close(src.grad, ref_src.grad, 1e-5, "d src")
+
+
+# ------------------------------------------------------------------ one fused MLP with every kind of input block
+def test_fused_mlp_gradients_all_source_kinds():
+    torch.manual_seed(3)
+    M, n_a, n_b, H = 3000, 500, 3000, 128
+    mlp = B.MLP(2 + H + H + 3, (H, H, H), True).to(DEV)
+    rel = torch.randn(M, 2, device=DEV, requires_grad=True)                       # narrow, negated
+    a = torch.randn(n_a, H, device=DEV, requires_grad=True)                       # gathered through an index, activated on load
+    b = torch.randn(n_b, H + 5, device=DEV, requires_grad=True)                   # column window of a wider tensor
+    c = torch.randn(M, 3, device=DEV, requires_grad=True)
+    idx = torch.randint(0, n_a, (M,), device=DEV)
+    resid = torch.randn(M, H + 2, device=DEV, requires_grad=True)
+    srcs = [ops.Source(rel, negate=True), ops.Source(a, plan.index32(idx), pre_act=_lib.ACT_SELU),
+            ops.Source(b, col0=5, width=H), ops.Source(c)]
+    y = mlp.run(srcs, M, activation=torch.tanh, resid=resid, resid_col0=2)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    got = {n: p.grad.clone() for n, p in mlp.named_parameters()}
+    got_in = [t.grad.clone() for t in (rel, a, b, c, resid)]
+    for p in mlp.parameters():
+        p.grad = None
+    ins = [t.detach().clone().requires_grad_(True) for t in (rel, a, b, c, resid)]
+    x = torch.cat((-ins[0], F.selu(ins[1])[idx], ins[2][:, 5:5 + H], ins[3]), 1)
+    ref = torch.tanh(mlp.MLP(x)) + ins[4][:, 2:2 + H]
+    close(y.detach(), ref.detach(), 1e-4, "forward")
+    ref.backward(dy)
+    for n, p in mlp.named_parameters():
+        close(got[n], p.grad, what=n)
+    for name, g, t in zip(("rel", "a", "b", "c", "resid"), got_in, ins):
+        close(g, t.grad, what=name)
+
+
+@pytest.mark.parametrize("activation", [None, "selu", torch.tanh])
+def test_gnblock_public_forward_gradients(activation):
+    """GNBlock.forward(v, e, edge_index) (nn/blocks.py:175-186) under autograd: gradients of both outputs with respect to
+    v, e and every parameter."""
+    torch.manual_seed(5)
+    n, H = 1500, 128
+    g = S.mus_graph(n, levels=1, seed=9)
+    ei = g.edge_index.to(DEV)
+    blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
+    v = torch.randn(n, H, device=DEV, requires_grad=True)
+    e = torch.randn(ei.size(1), H, device=DEV, requires_grad=True)
+    v1, e1 = blk.forward(v, e, ei, activation=activation)
+    dv, de = torch.randn_like(v1), torch.randn_like(e1)
+    torch.autograd.backward([v1, e1], [dv, de])
+    got = {k: p.grad.clone() for k, p in blk.named_parameters()}
+    got_v, got_e = v.grad.clone(), e.grad.clone()
+    for p in blk.parameters():
+        p.grad = None
+    f = {None: lambda x: x, "selu": F.selu, torch.tanh: torch.tanh}[activation]
+    v2, e2 = v.detach().clone().requires_grad_(True), e.detach().clone().requires_grad_(True)
+    row, col = ei
+    e_ref = blk.edge_mlp.MLP(torch.cat((e2, v2[row], v2[col]), 1))
+    agg = torch.zeros(n, H, device=DEV).index_add_(0, col, e_ref)
+    cnt = torch.zeros(n, device=DEV).index_add_(0, col, torch.ones(col.numel(), device=DEV)).clamp(min=1)
+    v_ref = blk.node_mlp.MLP(torch.cat((agg / cnt[:, None], v2), 1))
+    torch.autograd.backward([f(v_ref), f(e_ref)], [dv, de])
+    close(v1.detach(), f(v_ref).detach(), 1e-4, "v'")
+    close(e1.detach(), f(e_ref).detach(), 1e-4, "e'")
+    close(got_v, v2.grad, what="dv")
+    close(got_e, e2.grad, what="de")
+    for k, p in blk.named_parameters():
+        close(got[k], p.grad, what=k)
+
+
+def _model_and_oracle_grads(model_name, levels, nodes, hidden, seed):
+    g = S.mus_graph(nodes, levels=levels, seed=seed)
+    torch.manual_seed(seed + 1)
+    model = getattr(gfd.nn, model_name)(arch=S.mus_arch(model_name, hidden), device=DEV)
+    target = torch.randn(nodes, 3, device=DEV)
+    gd = g.clone().to(DEV)
+    model.train()
+    pred = model.forward(gd)
+    loss = F.mse_loss(pred, target)
+    loss.backward()
+    got = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    w = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    pred_ref = O.mus_forward(model_name, g.to_dict(), w, 3)
+    loss_ref = F.mse_loss(pred_ref, target.cpu())
+    loss_ref.backward()
+    return model, float(loss), float(loss_ref), got, {k: v.grad for k, v in w.items()}
+
+
+@pytest.mark.parametrize("model_name,levels,hidden", [("NsOneScaleGNN", 1, 128), ("NsThreeScaleGNN", 3, 128), ("NsTwoScaleGNN", 2, 32)])
+def test_model_parameter_gradients_match_oracle_autograd(model_name, levels, hidden):
+    model, loss, loss_ref, got, ref = _model_and_oracle_grads(model_name, levels, 2500, hidden, 7)
+    assert abs(loss - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref))
+    assert set(got) == set(ref)
+    worst = 0.0
+    for k in ref:
+        scale = max(float(ref[k].abs().max()), 1e-7)
+        worst = max(worst, float((got[k].cpu() - ref[k]).abs().max()) / scale)
+    assert worst < 2e-3, worst
+
+
+def test_training_step_is_bit_reproducible_and_rollout_still_matches():
+    """Deterministic reductions: two backward passes give identical gradients; and the inference path (hoisting, heads,
+    hipGraph) of the same model is unaffected by having trained (packed weights follow the parameter versions)."""
+    g_cpu = S.mus_graph(3000, levels=2, seed=3)
+    g = g_cpu.clone().to(DEV)
+    torch.manual_seed(4)
+    model = gfd.nn.NsTwoScaleGNN(arch=S.mus_arch("NsTwoScaleGNN", 128), device=DEV)
+    target = torch.randn(3000, 3, device=DEV)
+    grads = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        F.mse_loss(model.forward(g), target).backward()
+        grads.append([p.grad.clone() for p in model.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*grads))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt.step()
+    with torch.no_grad():
+        a = model.forward(g)
+    w = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = O.mus_forward("NsTwoScaleGNN", g_cpu.to_dict(), w, 3)
+    torch.testing.assert_close(a.cpu(), ref, rtol=5e-4, atol=5e-4)
+
+
+# ------------------------------------------------------------------ the training loop (nn/model.py:152-301)
+def _dataset(n_graphs, nodes, n_out, seed=0):
+    """A list of synthetic meshes with a smooth target: `target[:, 3t:3t+3]` = the field advanced t+1 times by a fixed
+    linear map of (field, glob) — learnable, so the loss must fall."""
+    data = []
+    for i in range(n_graphs):
+        g = S.mus_graph(nodes, levels=1, seed=seed + i)     # level-1 edges only: the coarse levels are a batch-level transform
+        f, tgt = g.field, []
+        for _ in range(n_out):
+            f = 0.9 * f + 0.1 * g.glob
+            tgt.append(f)
+        g.target = torch.cat(tgt, 1)
+        data.append(g)
+    return data
+
+
+def test_fit_reduces_the_loss_checkpoints_and_resumes(tmp_path, capsys):
+    torch.manual_seed(0)
+    model = gfd.nn.NsTwoScaleGNN(arch=S.mus_arch("NsTwoScaleGNN", 32), device=DEV)
+    # as in the reference's examples (examples/training/NsMuSGNN/*.py): GridClustering runs on the collated batch
+    coarsen = gfd.transforms.GridClustering(S.default_cells(700, 2, 2))
+    train = gfd.DataLoader(_dataset(4, 700, 2), batch_size=2, shuffle=False, transform=coarsen)
+    val = gfd.DataLoader(_dataset(2, 700, 2, seed=50), batch_size=1, transform=coarsen)
+    cfg = gfd.nn.TrainConfig(name="m", folder=str(tmp_path), epochs=6, num_steps=[1, 2], add_steps={'tolerance': 1e9, 'loss': 'training'},
+                             training_loss=gfd.nn.GraphLoss(lambda_d=0.25), validation_loss=gfd.nn.GraphLoss(), lr=2e-3,
+                             grad_clip={'epoch': 0, 'limit': 1.0}, scheduler={'factor': 0.5, 'patience': 2, 'loss': 'validation'},
+                             batch_size=2, device=DEV)
+    model.fit(cfg, train, val)
+    h = model.history
+    assert [r['n_out'] for r in h] == [1, 2, 2, 2, 2, 2]           # tolerance passed after the first epoch: longer rollouts
+    assert h[-1]['training_loss'] < 0.6 * h[1]['training_loss']
+    assert h[-1]['validation_loss'] < h[1]['validation_loss']
+    assert all(r['gradients_norm'] > 0 for r in h)
+    chk = torch.load(os.path.join(tmp_path, "m.chk"), weights_only=False)
+    assert set(chk) >= {'arch', 'weights', 'optimiser', 'n_out', 'lr', 'epoch', 'scheduler'} and chk['epoch'] == 6 and chk['n_out'] == 2
+    # the checkpoint is a model file of the reference's format ...
+    again = gfd.nn.NsTwoScaleGNN(checkpoint=os.path.join(tmp_path, "m.chk"), device=DEV)
+    g = coarsen(_dataset(1, 700, 2, seed=99)[0])
+    assert torch.equal(again.solve(g.clone(), 2), model.solve(g.clone(), 2))
+    # ... and training resumes from it (epoch 7 only)
+    cfg2 = gfd.nn.TrainConfig(name="m2", folder=str(tmp_path), checkpoint=os.path.join(tmp_path, "m.chk"), epochs=7, num_steps=[1, 2],
+                              training_loss=gfd.nn.GraphLoss(), lr=2e-3, device=DEV)
+    again.fit(cfg2, train)
+    assert [r['epoch'] for r in again.history] == [7] and again.history[0]['n_out'] == 2
+    assert again.history[0]['training_loss'] < h[1]['training_loss']
+
+
+def test_remus_and_mugs_refuse_a_forward_that_autograd_cannot_see():
+    g = S.mugs_graph(1500, levels=2, seed=1).to(DEV)
+    model = gfd.nn.NsTwoGuillardScaleGNN(arch=S.mugs_arch("NsTwoGuillardScaleGNN", 32), device=DEV)
+    with pytest.raises(NotImplementedError):
+        model.forward(g)
+    with torch.no_grad():
+        assert torch.isfinite(model.forward(g)).all()
