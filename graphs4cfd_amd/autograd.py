@@ -28,6 +28,32 @@ from . import _lib, ops, plan
 from .ops import Source, _ld
 
 
+# ------------------------------------------------------------------------------------- optional phase timing
+PROFILE = None       # set to {} (scripts/bench_train.py --phases): per-phase lists of HIP event pairs of the backward pass
+
+
+class _phase:
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            PROFILE.setdefault(self.name, []).append((self.a, b))
+        return False
+
+
+def profile_summary() -> dict:
+    torch.cuda.synchronize()
+    return {k: sum(a.elapsed_time(b) for a, b in v) for k, v in (PROFILE or {}).items()}
+
+
 # ------------------------------------------------------------------------------------- kernel wrappers
 def _buf(rows: int, cols: int, dev) -> Tensor:
     return torch.empty((rows, cols), dtype=torch.float32, device=dev)
@@ -88,6 +114,27 @@ def segment_broadcast(dout: Tensor, csr, mean: bool, n_src_rows: int) -> Tensor:
     return dsrc
 
 
+WGRAD_CHUNK = 4096      # rows per split of a weight-gradient GEMM
+
+
+def weight_grad(g: Tensor, a: Tensor) -> Tensor:
+    """dW = g^T a for g [M, N], a [M, K] with M >> N, K: one [N, K] output tile and a contraction over up to millions of
+    rows is the worst shape for a library GEMM (a single tile's worth of parallelism).  Split the rows into chunks, contract
+    them as ONE strided-batched rocBLAS GEMM (no copies: the batch is a view), and add the per-chunk results in a fixed
+    order with g4c_colsum."""
+    M, N, K = int(g.size(0)), int(g.size(1)), int(a.size(1))
+    nb = M // WGRAD_CHUNK
+    if nb < 2 or not (g.is_contiguous() and a.is_contiguous()):
+        return torch.mm(g.t(), a)
+    m_main = nb * WGRAD_CHUNK
+    tail = M > m_main
+    part = torch.empty((nb + (1 if tail else 0), N, K), dtype=torch.float32, device=g.device)
+    torch.bmm(g[:m_main].view(nb, WGRAD_CHUNK, N).transpose(1, 2), a[:m_main].view(nb, WGRAD_CHUNK, K), out=part[:nb])
+    if tail:
+        torch.mm(g[m_main:].t(), a[m_main:], out=part[nb])
+    return colsum(part.view(part.size(0), N * K)).view(N, K)
+
+
 def _dense(t: Tensor) -> Tensor:
     return t if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous()
 
@@ -137,18 +184,20 @@ class _FusedMLP(torch.autograd.Function):
         k0 = sum(m["width"] for m in spec.meta)
         X = _buf(M, k0, dev)
         c0 = 0
-        aggs: List[Optional[Tensor]] = []
-        for t, m in zip(src_t, spec.meta):
-            if m["segments"] is not None:         # aggregation on load: the block is the segment mean of the source's rows
-                blk = ops.segment_reduce(t, m["segments"], m["seg_mean"], src_act=m["pre_act"])
-                train_gather(blk, X, c0, 0, m["width"], None, _lib.ACT_NONE, m["negate"], M)
-            else:
-                train_gather(t, X, c0, m["col0"], m["width"], m["index"], m["pre_act"], m["negate"], M)
-            c0 += m["width"]
+        with _phase("recompute: gather"):
+            for t, m in zip(src_t, spec.meta):
+                if m["segments"] is not None:         # aggregation on load: the block is the segment mean of the source's rows
+                    blk = ops.segment_reduce(t, m["segments"], m["seg_mean"], src_act=m["pre_act"])
+                    train_gather(blk, X, c0, 0, m["width"], None, _lib.ACT_NONE, m["negate"], M)
+                else:
+                    train_gather(t, X, c0, m["col0"], m["width"], m["index"], m["pre_act"], m["negate"], M)
+                c0 += m["width"]
         acts = [X]
         for l in range(L - 1):
-            a = torch.addmm(b[l], acts[-1], W[l].t())
-            ops.activation_(a, _lib.ACT_SELU)
+            with _phase("recompute: GEMM (rocBLAS)"):
+                a = torch.addmm(b[l], acts[-1], W[l].t())
+            with _phase("recompute: SELU"):
+                ops.activation_(a, _lib.ACT_SELU)
             acts.append(a)
         # ---- output side: activation, residual, LayerNorm
         g = dy
@@ -158,23 +207,31 @@ class _FusedMLP(torch.autograd.Function):
             d_resid[:, spec.resid_col0:spec.resid_col0 + dy.size(1)] = dy
         if spec.act != _lib.ACT_NONE:
             out_act = y if resid is None else y - resid[:, spec.resid_col0:spec.resid_col0 + y.size(1)]
-            g = act_grad(g, _dense(out_act), spec.act, False)
+            with _phase("activation adjoint"):
+                g = act_grad(g, _dense(out_act), spec.act, False)
         d_gamma = d_beta = None
         if spec.has_ln:
-            z_last = torch.addmm(b[L - 1], acts[-1], W[L - 1].t())
-            g, d_gamma, d_beta = layernorm_grad(z_last, gamma, g, spec.eps)
+            with _phase("recompute: GEMM (rocBLAS)"):
+                z_last = torch.addmm(b[L - 1], acts[-1], W[L - 1].t())
+            with _phase("LayerNorm adjoint"):
+                g, d_gamma, d_beta = layernorm_grad(z_last, gamma, g, spec.eps)
         # ---- layers, last to first
         dW: List[Optional[Tensor]] = [None] * L
         db: List[Optional[Tensor]] = [None] * L
         need_dx = any(needs[1 + j] for j in range(n_src))
         for l in range(L - 1, -1, -1):
-            dW[l] = torch.mm(g.t(), acts[l])
-            db[l] = colsum(g)
+            with _phase("dW GEMM (rocBLAS)"):
+                dW[l] = weight_grad(g, acts[l])
+            with _phase("bias column sums"):
+                db[l] = colsum(g)
             if l > 0:
-                g = torch.mm(g, W[l])
-                g = act_grad(g, acts[l], _lib.ACT_SELU, False, out=g)
+                with _phase("dX GEMM (rocBLAS)"):
+                    g = torch.mm(g, W[l])
+                with _phase("activation adjoint"):
+                    g = act_grad(g, acts[l], _lib.ACT_SELU, False, out=g)
             elif need_dx:
-                g = torch.mm(g, W[0])
+                with _phase("dX GEMM (rocBLAS)"):
+                    g = torch.mm(g, W[0])
         # ---- back through the column blocks of the input
         d_src: List[Optional[Tensor]] = [None] * n_src
         c0 = 0
@@ -185,14 +242,15 @@ class _FusedMLP(torch.autograd.Function):
                 if m["negate"]:
                     gx = -gx
                 n_t = int(t.size(0))
-                if m["segments"] is not None:
-                    gt = segment_broadcast(gx, m["segments"], m["seg_mean"], n_t)
-                elif m["index"] is not None:
-                    gt = ops.segment_reduce(gx, plan.gather_csr(m["index"], n_t), False)
-                else:
-                    gt = gx
-                if m["pre_act"] != _lib.ACT_NONE:
-                    gt = act_grad(_dense(gt), t[:, m["col0"]:m["col0"] + w], m["pre_act"], True)
+                with _phase("input adjoint: gather / aggregation"):
+                    if m["segments"] is not None:
+                        gt = segment_broadcast(gx, m["segments"], m["seg_mean"], n_t)
+                    elif m["index"] is not None:
+                        gt = ops.segment_reduce(gx, plan.gather_csr(m["index"], n_t), False)
+                    else:
+                        gt = gx
+                    if m["pre_act"] != _lib.ACT_NONE:
+                        gt = act_grad(_dense(gt), t[:, m["col0"]:m["col0"] + w], m["pre_act"], True)
                 if m["col0"] == 0 and w == int(t.size(1)):
                     d_src[j] = gt
                 else:

@@ -118,20 +118,36 @@ __global__ __launch_bounds__(256) void layernorm_grad_kernel(const float *__rest
     }
 }
 
-// column sums of x[n_rows, width]: stage 1, workgroup g adds rows g*chunk .. (g+1)*chunk in order (thread = column, so
-// a workgroup reads whole rows: coalesced); stage 2 adds the partial rows in order.
+// column sums of x[n_rows, width].  Stage 1: workgroup (g, cb) adds rows g*chunk .. (g+1)*chunk of column block cb in a fixed
+// order — a 256-thread workgroup covers RPI = 256 / min(width, 256) rows at a time (thread = (row offset, column), so every
+// wave reads whole contiguous row pieces), eight loads in flight per thread; the RPI partial sums of a column are then added
+// in order through LDS.  Stage 2 adds the partial rows, again in order.
 __global__ __launch_bounds__(256) void colsum_stage_kernel(const float *__restrict__ x, int ld, int width, long long n_rows,
                                                            long long chunk, float *__restrict__ out, int out_ld) {
+    __shared__ float red[256];
+    const int wb = width < 256 ? width : 256;                 // columns handled by this workgroup
+    const int rpi = 256 / wb;                                 // rows per iteration
+    const int roff = threadIdx.x / wb, cl = threadIdx.x - roff * wb;
+    const int c = blockIdx.y * 256 + cl;
     const long long r0 = (long long)blockIdx.x * chunk;
     const long long r1 = r0 + chunk < n_rows ? r0 + chunk : n_rows;
-    for (int c = threadIdx.x; c < width; c += 256) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        long long r = r0;
-        for (; r + 3 < r1; r += 4) {
-            s0 += x[r * ld + c]; s1 += x[(r + 1) * ld + c]; s2 += x[(r + 2) * ld + c]; s3 += x[(r + 3) * ld + c];
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    if (roff < rpi && c < width) {
+        long long r = r0 + roff;
+        for (; r + 7LL * rpi < r1; r += 8LL * rpi) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += x[(r + (long long)u * rpi) * ld + c];
         }
-        for (; r < r1; ++r) s0 += x[r * ld + c];
-        out[(long long)blockIdx.x * out_ld + c] = (s0 + s1) + (s2 + s3);
+        for (; r < r1; r += rpi) s[0] += x[r * ld + c];
+    }
+    red[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (roff == 0 && c < width) {
+        float t = red[cl];
+        for (int j = 1; j < rpi; ++j) t += red[j * wb + cl];
+        out[(long long)blockIdx.x * out_ld + c] = t;
     }
 }
 
@@ -199,7 +215,7 @@ extern "C" int g4c_layernorm_grad(const float *z, int32_t z_ld, const float *gam
 }
 
 extern "C" int32_t g4c_colsum_partials(int64_t n_rows) {
-    const long long want = (n_rows + 255) / 256;
+    const long long want = (n_rows + 127) / 128;
     return (int32_t)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
 }
 
@@ -209,8 +225,9 @@ extern "C" int g4c_colsum(const float *x, int32_t ld, int32_t width, int64_t n_r
     const int g = g4c_colsum_partials(n_rows);
     const long long chunk = (n_rows + g - 1) / g;
     hipStream_t s = (hipStream_t)stream;
-    colsum_stage_kernel<<<dim3(g), dim3(256), 0, s>>>(x, ld, width, n_rows, chunk > 0 ? chunk : 1, scratch, width);
-    colsum_stage_kernel<<<dim3(1), dim3(256), 0, s>>>(scratch, width, width, g, g, out, width);
+    const unsigned cb = (unsigned)((width + 255) / 256);
+    colsum_stage_kernel<<<dim3(g, cb), dim3(256), 0, s>>>(x, ld, width, n_rows, chunk > 0 ? chunk : 1, scratch, width);
+    colsum_stage_kernel<<<dim3(1, cb), dim3(256), 0, s>>>(scratch, width, width, g, g, out, width);
     return g4c::check_launch("g4c_colsum");
 }
 

@@ -421,7 +421,38 @@ def gen_transforms():
     save("transforms.pt", out)
 
 
+def gen_training():
+    # GNN.fit's inner loop (nn/model.py:226-236): train-mode forward, GraphLoss (nn/losses.py:10-16), backward; then the
+    # second rollout step on the fed-back detached prediction (:229-230).  Gradients of every parameter, both steps.
+    H = 32
+    g = mus_graph(400, 6, [0.10, 0.20], seed=60)
+    g.omega[::7] = 1.0                                   # make sure the Dirichlet term of the loss is active
+    arch = mus_arch("NsThreeScaleGNN", H, 3, 5)
+    torch.manual_seed(600)
+    model = gfd.nn.NsThreeScaleGNN(arch=arch)
+    g.target = torch.randn(400, 6)
+    gi = graph_dict(g)
+    criterion = gfd.nn.GraphLoss(lambda_d=0.5)
+    model.train()
+    steps = []
+    pred = None
+    for t in range(2):
+        if t > 0:
+            g.field = model.shift_and_replace(g.field, pred.detach())
+        model.zero_grad()
+        pred = model.forward(g, t)
+        loss = criterion(g, pred, g.target[:, 3 * t:3 * (t + 1)])
+        loss.backward()
+        steps.append(dict(loss=loss.detach().clone(), pred=pred.detach().clone(), grad_norm2=model.grad_norm2(),
+                          grads={k: p.grad.detach().clone() for k, p in model.named_parameters()}))
+    save("training.pt", dict(ref="nn/model.py:226-236 + nn/losses.py:10-16", arch=arch, weights=sd(model), graph=gi,
+                             lambda_d=0.5, steps=steps))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "training":      # (adds one fixture without rewriting the others)
+        gen_training()
+        sys.exit(0)
     gen_blocks()
     gen_mus_models()
     gen_mugs_models()
@@ -429,3 +460,4 @@ if __name__ == "__main__":
     gen_remus_model()
     gen_checkpoint()
     gen_transforms()
+    gen_training()

@@ -198,6 +198,30 @@ def test_training_step_is_bit_reproducible_and_rollout_still_matches():
     torch.testing.assert_close(a.cpu(), ref, rtol=5e-4, atol=5e-4)
 
 
+def test_training_steps_against_reference_golden():
+    """The HIP training path against the REFERENCE's recorded loss / gradients (tests/golden/training.pt: its own train-mode
+    forward, GraphLoss with the Dirichlet term, backward; second step on the fed-back prediction)."""
+    c = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "training.pt"), weights_only=False)
+    model = gfd.nn.NsThreeScaleGNN(arch=c["arch"], device=DEV)
+    model.load_state_dict(c["weights"])
+    g = gfd.Graph(**c["graph"]).to(DEV)
+    crit = gfd.nn.GraphLoss(lambda_d=c["lambda_d"])
+    model.train()
+    pred = None
+    for t, ref in enumerate(c["steps"]):
+        if t > 0:
+            g.field = model.shift_and_replace(g.field, pred.detach())
+        model.zero_grad()
+        pred = model.forward(g, t)
+        loss = crit(g, pred, g.target[:, 3 * t:3 * (t + 1)])
+        loss.backward()
+        assert abs(float(loss) - float(ref["loss"])) <= 1e-4 * float(ref["loss"])
+        close(pred.detach().cpu(), ref["pred"], 5e-4, "prediction")
+        for k, p in model.named_parameters():
+            close(p.grad.cpu(), ref["grads"][k], 2e-3, k)
+        assert abs(model.grad_norm2() - ref["grad_norm2"]) <= 1e-3 * ref["grad_norm2"]
+
+
 # ------------------------------------------------------------------ the training loop (nn/model.py:152-301)
 def _dataset(n_graphs, nodes, n_out, seed=0):
     """A list of synthetic meshes with a smooth target: `target[:, 3t:3t+3]` = the field advanced t+1 times by a fixed

@@ -139,6 +139,22 @@ def test_remus_model(golden):
     torch.testing.assert_close(O.remus_solve(c["graph"], c["weights"], 3), c["solve3"], rtol=1e-4, atol=2e-4)
 
 
+def test_training_steps_against_reference_autograd(golden):
+    """the oracle's loss and parameter gradients for two rollout steps of GNN.fit's inner loop against the
+    reference's own (train-mode forward + GraphLoss + backward, recorded by make_golden.py gen_training)."""
+    c = golden("training.pt")
+    steps = O.training_steps("NsThreeScaleGNN", c["graph"], c["weights"], 2, 3, c["lambda_d"])
+    for (loss, pred, grads), ref in zip(steps, c["steps"]):
+        torch.testing.assert_close(loss, ref["loss"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(pred, ref["pred"], rtol=1e-4, atol=5e-5)
+        assert set(grads) == set(ref["grads"])
+        for k in grads:
+            scale = float(ref["grads"][k].abs().max())
+            assert float((grads[k] - ref["grads"][k]).abs().max()) <= 1e-4 * scale + 1e-9, k
+        norm = float(torch.sqrt(sum((v ** 2).sum() for v in grads.values())))
+        assert abs(norm - ref["grad_norm2"]) <= 1e-4 * ref["grad_norm2"]
+
+
 def test_rollouts(golden):
     r = golden("rollout.pt")
     c = r["two_scale"]
