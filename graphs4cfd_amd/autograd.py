@@ -320,3 +320,106 @@ class _SegmentReduce(torch.autograd.Function):
 
 def segment_reduce(src: Tensor, csr, mean: bool, act: int, src_act: int) -> Tensor:
     return _SegmentReduce.apply(src, csr, mean, act, src_act)
+
+
+# ------------------------------------------------------------------------------------- gathers / interpolation / projections
+# (gMuS-GNN and REMuS-GNN: nn/mugs_gnn.py restriction + knn_interpolate, nn/blocks.py:34-48,88-114,408-456).  Forward: the
+# inference kernels.  The adjoints are linear maps with static coefficients: an elementwise product (torch) followed, where rows
+# were gathered, by the deterministic segmented sum on the CSR plan of the gather index (g4c_segment_reduce).
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, idx32: Tensor):
+        out = _buf(int(idx32.numel()), int(x.size(1)), x.device)
+        ops.copy_cols(x, out, 0, idx32=idx32)
+        ctx.idx32, ctx.n = idx32, int(x.size(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        return ops.segment_reduce(_dense(dout), plan.gather_csr(ctx.idx32, ctx.n), False), None
+
+
+def gather_rows(x: Tensor, idx32: Tensor) -> Tensor:
+    return _GatherRows.apply(x, idx32)
+
+
+def _segment_coefficients(w: Tensor, csr) -> Tensor:
+    """w_p / sum of w over p's segment, [n, 1] (static per interpolation plan; cached on the plan)."""
+    hit = getattr(csr, "_coef", None)
+    if hit is None or hit[0] != (w.data_ptr(), w._version):
+        deg = (csr.off[1:] - csr.off[:-1]).long()
+        seg = torch.repeat_interleave(torch.arange(csr.n_seg, device=w.device), deg)
+        wf = w.reshape(-1).float()
+        tot = torch.zeros(csr.n_seg, dtype=torch.float32, device=w.device).index_add_(0, seg, wf)
+        csr._coef = ((w.data_ptr(), w._version), (wf / tot[seg]).reshape(-1, 1).contiguous())
+        hit = csr._coef
+    return hit[1]
+
+
+class _WeightedSegmentMean(torch.autograd.Function):
+    """knn_interpolate (nn/blocks.py:34-48): out[s] = sum_p w_p x[x_idx[p]] / sum_p w_p over segment s; with `out_idx32` the
+    result rows land at those positions of a zero [n_out, F] tensor (UpEdgeMP's masked write, nn/blocks.py:437-441)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, x_idx32: Tensor, w: Tensor, csr, n_out: int, out_idx32: Optional[Tensor]):
+        width = int(x.size(1))
+        out = (torch.zeros if out_idx32 is not None else torch.empty)((n_out, width), dtype=torch.float32, device=x.device)
+        ops.weighted_segment_mean(x, x_idx32, w, csr, out, out_idx32)
+        ctx.args = (x_idx32, w, csr, out_idx32, int(x.size(0)))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        x_idx32, w, csr, out_idx32, n_x = ctx.args
+        d = _dense(dout)
+        if out_idx32 is not None:
+            rows = _buf(csr.n_seg, int(d.size(1)), d.device)
+            ops.copy_cols(d, rows, 0, idx32=out_idx32)
+            d = rows
+        tmp = segment_broadcast(d, csr, False, csr.n)
+        tmp.mul_(_segment_coefficients(w, csr))
+        return ops.segment_reduce(tmp, plan.gather_csr(x_idx32, n_x), False), None, None, None, None, None
+
+
+def weighted_segment_mean(x: Tensor, x_idx32: Tensor, w: Tensor, csr, n_out: Optional[int] = None,
+                          out_idx32: Optional[Tensor] = None) -> Tensor:
+    return _WeightedSegmentMean.apply(x, x_idx32, w, csr, csr.n_seg if n_out is None else int(n_out), out_idx32)
+
+
+class _ProjectToEdges(torch.autograd.Function):
+    """(v[node].view(E, F, 2) * unit[:, None]).sum(-1) (nn/blocks.py:449-451)."""
+
+    @staticmethod
+    def forward(ctx, v: Tensor, node32: Optional[Tensor], unit: Tensor, n_edges: int, n_feat: int):
+        ctx.args = (node32, unit, n_edges, n_feat, int(v.size(0)))
+        return ops.project_to_edges(v, node32, unit, n_edges, n_feat)
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        node32, unit, n_edges, n_feat, n_v = ctx.args
+        tmp = (dout.unsqueeze(2) * unit.unsqueeze(1)).reshape(n_edges, 2 * n_feat)
+        dv = tmp if node32 is None else ops.segment_reduce(tmp, plan.gather_csr(node32, n_v), False)
+        return dv, None, None, None, None
+
+
+def project_to_edges(v: Tensor, node32: Optional[Tensor], unit: Tensor, n_edges: int, n_feat: int) -> Tensor:
+    return _ProjectToEdges.apply(v, node32, unit, n_edges, n_feat)
+
+
+class _EdgeScalarToNodeVector(torch.autograd.Function):
+    """Uinv [n, 2, k] @ e.view(n, k, F), feature-major flatten (nn/blocks.py:111-114)."""
+
+    @staticmethod
+    def forward(ctx, e: Tensor, unit_inv: Tensor, n_nodes: int, k: int):
+        ctx.args = (unit_inv, n_nodes, k, int(e.size(1)))
+        return ops.edge_scalar_to_node_vector(e, unit_inv, n_nodes, k)
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        unit_inv, n, k, f = ctx.args
+        g = dout.reshape(n, f, 2).transpose(1, 2)                          # [n, 2, F]
+        return torch.bmm(unit_inv.transpose(1, 2), g).reshape(n * k, f), None, None, None
+
+
+def edge_scalar_to_node_vector(e: Tensor, unit_inv: Tensor, n_nodes: int, k: int) -> Tensor:
+    return _EdgeScalarToNodeVector.apply(e, unit_inv, n_nodes, k)

@@ -525,7 +525,11 @@ class UpEdgeMP(nn.Module):
         v2 = edgeScalarToNodeVector(edge_attr2, edge_index2, edgeUnitVectorInverse=edgeUnitVectorInverse2,
                                     coarse_mask=coarse_mask2)
         # 2- interpolate to the nodes of level 1, written at their level-1 numbering
-        if coarse_mask1 is None:
+        if ops.grad_mode() and v2.requires_grad:       # (recorded for autograd: the interpolation returns the full tensor)
+            from .. import autograd as _ag
+            v1 = _ag.weighted_segment_mean(v2, plan.index32(x_idx_21), weights_21, plan.segments_of_sorted(y_idx_21), n_total,
+                                           None if coarse_mask1 is None else plan.mask_index32(coarse_mask1))
+        elif coarse_mask1 is None:
             v1 = torch.empty(n_total, 2 * nfeat, dtype=torch.float32, device=pos.device)
             knn_interpolate(v2, y_idx_21, x_idx_21, weights_21, out=v1)
         else:

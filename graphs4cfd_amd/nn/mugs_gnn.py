@@ -55,7 +55,6 @@ class _MuGSGNN(GNN):
         self.to(self.device)
 
     def forward(self, graph: Graph, t: Optional[int] = None) -> torch.Tensor:
-        self._require_inference("the training path (autograd.py) covers the MuS-GNN family")
         g = graph
         field0 = g.field
         n = int(field0.size(0))
@@ -85,17 +84,26 @@ class _MuGSGNN(GNN):
                 stash[level] = (v, edge_index, e, e_pending)
                 keep32, edge_index = plan.restricted_level(getattr(g, f"coarse_mask{l}"), getattr(g, f"edge_index{l}"),
                                                            getattr(g, f"coarse_mask{level}") if level > 1 else None)
-                v_c = torch.empty((int(keep32.numel()), int(v.size(1))), dtype=torch.float32, device=v.device)
-                ops.copy_cols(v, v_c, 0, idx32=keep32)
+                if ops.grad_mode() and v.requires_grad:
+                    from .. import autograd as _ag
+                    v_c = _ag.gather_rows(v, keep32)
+                else:
+                    v_c = torch.empty((int(keep32.numel()), int(v.size(1))), dtype=torch.float32, device=v.device)
+                    ops.copy_cols(v, v_c, 0, idx32=keep32)
                 v, e, e_pending, level, products = v_c, e_enc[l], NONE, l, None
             else:                                     # "up{hi}{lo}"
                 hi, lo = int(name[2]), int(name[3])
                 v_old, edge_index, e, e_pending = stash[lo]
                 H = int(v.size(1))
-                buf = torch.empty((int(v_old.size(0)), H + int(v_old.size(1))), dtype=torch.float32, device=v.device)
-                _blocks.knn_interpolate(v, getattr(g, f"y_idx_{hi}{lo}"), getattr(g, f"x_idx_{hi}{lo}"),
-                                        getattr(g, f"weights_{hi}{lo}"), out=buf[:, :H])
-                ops.copy_cols(v_old, buf, H)
+                if ops.grad_mode() and (v.requires_grad or v_old.requires_grad):
+                    up = _blocks.knn_interpolate(v, getattr(g, f"y_idx_{hi}{lo}"), getattr(g, f"x_idx_{hi}{lo}"),
+                                                 getattr(g, f"weights_{hi}{lo}"))
+                    buf = torch.cat((up, v_old), 1)        # (recorded for autograd; inference writes both halves in place)
+                else:
+                    buf = torch.empty((int(v_old.size(0)), H + int(v_old.size(1))), dtype=torch.float32, device=v.device)
+                    _blocks.knn_interpolate(v, getattr(g, f"y_idx_{hi}{lo}"), getattr(g, f"x_idx_{hi}{lo}"),
+                                            getattr(g, f"weights_{hi}{lo}"), out=buf[:, :H])
+                    ops.copy_cols(v_old, buf, H)
                 v, level, products = buf, lo, None
         nf = self.num_fields
         return self.node_decoder.run_coded([Source(v)], n, NONE, resid=field0, resid_col0=int(field0.size(1)) - nf)

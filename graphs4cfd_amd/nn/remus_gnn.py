@@ -67,7 +67,6 @@ class NsRotEquiTreeScaleGNN(GNN):
         self.to(self.device)
 
     def forward(self, graph: Graph, t: Optional[int] = None) -> torch.Tensor:
-        self._require_inference("the training path (autograd.py) covers the MuS-GNN family")
         g = graph
         sfx = {1: "", 2: "2", 3: "3"}
         nfeat = int(g.field.size(1)) // 2
@@ -116,6 +115,8 @@ class NsRotEquiTreeScaleGNN(GNN):
 
 
 def _add_last_fields(field: torch.Tensor, out: torch.Tensor, nf: int) -> torch.Tensor:
+    if ops.grad_mode() and out.requires_grad:
+        return field[:, int(field.size(1)) - nf:] + out
     res = torch.empty_like(out)
     ops.add_cols(field, int(field.size(1)) - nf, out, res)
     return res

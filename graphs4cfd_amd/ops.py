@@ -130,6 +130,12 @@ def activation_(x: Tensor, act: int) -> Tensor:
 
 def weighted_segment_mean(x: Tensor, x_idx32: Tensor, w: Tensor, csr: CsrPlan, out: Optional[Tensor] = None,
                           out_idx32: Optional[Tensor] = None) -> Tensor:
+    if torch.is_grad_enabled() and x.requires_grad:
+        if out is not None:
+            raise NotImplementedError("weighted_segment_mean(out=...) is not differentiable (autograd.weighted_segment_mean "
+                                      "returns the full tensor)")
+        from . import autograd as _ag
+        return _ag.weighted_segment_mean(x, x_idx32, w, csr)
     lib = _lib.load()
     x = _f32_2d(x, "x")
     w = w.reshape(-1).contiguous()
@@ -146,6 +152,9 @@ def weighted_segment_mean(x: Tensor, x_idx32: Tensor, w: Tensor, csr: CsrPlan, o
 
 
 def project_to_edges(v: Tensor, node32: Optional[Tensor], unit: Tensor, n_edges: int, n_feat: int) -> Tensor:
+    if torch.is_grad_enabled() and v.requires_grad:
+        from . import autograd as _ag
+        return _ag.project_to_edges(v, node32, unit, n_edges, n_feat)
     lib = _lib.load()
     v = _f32_2d(v, "v")
     unit = _f32_2d(unit, "edgeUnitVector").contiguous()
@@ -157,6 +166,9 @@ def project_to_edges(v: Tensor, node32: Optional[Tensor], unit: Tensor, n_edges:
 
 
 def edge_scalar_to_node_vector(e: Tensor, unit_inv: Tensor, n_nodes: int, k: int) -> Tensor:
+    if torch.is_grad_enabled() and e.requires_grad:
+        from . import autograd as _ag
+        return _ag.edge_scalar_to_node_vector(e, unit_inv, n_nodes, k)
     lib = _lib.load()
     e = _f32_2d(e, "edge_attr")
     unit_inv = unit_inv.contiguous()

@@ -269,10 +269,42 @@ def test_fit_reduces_the_loss_checkpoints_and_resumes(tmp_path, capsys):
     assert again.history[0]['training_loss'] < h[1]['training_loss']
 
 
-def test_remus_and_mugs_refuse_a_forward_that_autograd_cannot_see():
-    g = S.mugs_graph(1500, levels=2, seed=1).to(DEV)
-    model = gfd.nn.NsTwoGuillardScaleGNN(arch=S.mugs_arch("NsTwoGuillardScaleGNN", 32), device=DEV)
-    with pytest.raises(NotImplementedError):
-        model.forward(g)
-    with torch.no_grad():
-        assert torch.isfinite(model.forward(g)).all()
+def _f64(graph_dict):
+    return {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in graph_dict.items()}
+
+
+def _grad_parity(model, pred, target, ref_fn, tol=2e-3):
+    """Gradients against the oracle evaluated in float64 (torch autograd over the restatement): for these deeper models the
+    fp32 oracle itself sits 2-3e-3 from float64 (measured: REMuS worst 3.4e-3), the HIP path 6e-4."""
+    loss = F.mse_loss(pred, target)
+    loss.backward()
+    got = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
+    w = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    pred_ref = ref_fn(w)
+    close(pred.detach().cpu().double(), pred_ref.detach(), 5e-4, "forward")
+    F.mse_loss(pred_ref, target.cpu().double()).backward()
+    assert set(got) == set(w) and all(v.grad is not None for v in w.values())
+    worst = max(float((got[k] - w[k].grad).abs().max()) / max(float(w[k].grad.abs().max()), 1e-12) for k in w)
+    assert worst < tol, worst
+
+
+@pytest.mark.parametrize("cls,levels", [("NsTwoGuillardScaleGNN", 2), ("NsThreeGuillardScaleGNN", 3)])
+def test_gmus_parameter_gradients_match_oracle_autograd(cls, levels):
+    """gMuS-GNN (nn/mugs_gnn.py): restriction = row gather, knn_interpolate, 2H-wide node latents after each up-sampling."""
+    g = S.mugs_graph(2500 if levels == 2 else 3000, levels=levels, seed=11)
+    torch.manual_seed(12)
+    model = getattr(gfd.nn, cls)(arch=S.mugs_arch(cls, 64), device=DEV)
+    target = torch.randn(g.num_nodes, 3, device=DEV)
+    pred = model.forward(g.clone().to(DEV))
+    _grad_parity(model, pred, target, lambda w: O.mugs_forward(cls, _f64(g.to_dict()), w, 3))
+
+
+def test_remus_parameter_gradients_match_oracle_autograd():
+    """REMuS-GNN (nn/remus_gnn.py:119-199): EdgeMP / DownEdgeMP / UpEdgeMP (edge scalars -> node vectors, interpolation with a
+    masked write, projection on the edges), decoder through edgeScalarToNodeVector, residual on the last two fields."""
+    g = S.remus_graph(1500, k=5, seed=4)
+    torch.manual_seed(13)
+    model = gfd.nn.NsRotEquiTreeScaleGNN(arch=S.remus_arch(64), device=DEV)
+    target = torch.randn(g.num_nodes, 2, device=DEV)
+    pred = model.forward(g.clone().to(DEV))
+    _grad_parity(model, pred, target, lambda w: O.remus_forward(_f64(g.to_dict()), w))
