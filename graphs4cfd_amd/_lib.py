@@ -94,7 +94,7 @@ _SIGNATURES = {
                                 C.c_int32, C.c_int64, C.c_void_p]),
     # training path (train_ops.hip)
     "g4c_train_gather": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
-                                   C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+                                   C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "g4c_act_grad": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                C.c_int32, C.c_int64, C.c_void_p]),
     "g4c_layernorm_grad_partials": (C.c_int32, [C.c_int64]),

@@ -60,11 +60,11 @@ def _buf(rows: int, cols: int, dev) -> Tensor:
 
 
 def train_gather(src: Tensor, dst: Tensor, dcol0: int, scol0: int, width: int, idx32: Optional[Tensor], pre_act: int,
-                 negate: bool, n_rows: int) -> None:
+                 negate: bool, n_rows: int, accumulate: bool = False) -> None:
     lib = _lib.load()
     dev = _lib.require_hip(src, dst, idx32)
     _lib.check(lib.g4c_train_gather(_lib.ptr(src), _ld(src), scol0, _lib.ptr(idx32), pre_act, 1 if negate else 0, _lib.ptr(dst),
-                                    _ld(dst), dcol0, width, n_rows, _lib.stream_handle(dev)))
+                                    _ld(dst), dcol0, width, n_rows, 1 if accumulate else 0, _lib.stream_handle(dev)))
 
 
 def act_grad(dy: Tensor, ref: Tensor, act: int, from_input: bool, out: Optional[Tensor] = None) -> Tensor:
@@ -180,25 +180,56 @@ class _FusedMLP(torch.autograd.Function):
         dy = _dense(dy)
         needs = ctx.needs_input_grad          # index 0 is `spec`
 
-        # ---- recompute: concatenated input, hidden activations, last pre-norm rows
-        k0 = sum(m["width"] for m in spec.meta)
-        X = _buf(M, k0, dev)
-        c0 = 0
+        # ---- input blocks: dense ones are concatenated (X_d); a block gathered through an index from a tensor with fewer rows
+        # than the launch is HOISTED — W1_j t[idx] = (t W1_j^T)[idx], so its share of the first layer, of dW1 and of the input
+        # gradient is computed on the tensor's rows (the adjoint of the inference path's first-layer hoisting):
+        #   z1 += (tt_j W1_j^T)[idx_j],   dW1_j = segsum_idx(g)^T tt_j,   d tt_j = segsum_idx(g) W1_j
+        cols, c0 = [], 0
+        for m in spec.meta:
+            cols.append(c0)
+            c0 += m["width"]
+        hoisted = [j for j, (t, m) in enumerate(zip(src_t, spec.meta)) if m["index"] is not None and int(t.size(0)) < M]
+        dense = [j for j in range(n_src) if j not in hoisted]
+        kd = sum(spec.meta[j]["width"] for j in dense)
+        W1 = W[0]
+        N1 = int(W1.size(0))
+        X = _buf(M, kd, dev) if kd else None
         with _phase("recompute: gather"):
-            for t, m in zip(src_t, spec.meta):
-                if m["segments"] is not None:         # aggregation on load: the block is the segment mean of the source's rows
+            d0 = 0
+            for j in dense:
+                t, m = src_t[j], spec.meta[j]
+                if m["segments"] is not None:     # aggregation on load: the block is the segment mean of the source's rows
                     blk = ops.segment_reduce(t, m["segments"], m["seg_mean"], src_act=m["pre_act"])
-                    train_gather(blk, X, c0, 0, m["width"], None, _lib.ACT_NONE, m["negate"], M)
+                    train_gather(blk, X, d0, 0, m["width"], None, _lib.ACT_NONE, m["negate"], M)
                 else:
-                    train_gather(t, X, c0, m["col0"], m["width"], m["index"], m["pre_act"], m["negate"], M)
-                c0 += m["width"]
-        acts = [X]
-        for l in range(L - 1):
-            with _phase("recompute: GEMM (rocBLAS)"):
-                a = torch.addmm(b[l], acts[-1], W[l].t())
+                    train_gather(t, X, d0, m["col0"], m["width"], m["index"], m["pre_act"], m["negate"], M)
+                d0 += m["width"]
+            tt = {}
+            for j in hoisted:
+                t, m = src_t[j], spec.meta[j]
+                tt[j] = _buf(int(t.size(0)), m["width"], dev)
+                train_gather(t, tt[j], 0, m["col0"], m["width"], None, m["pre_act"], m["negate"], int(t.size(0)))
+        if not hoisted:
+            W_d = W1
+        elif kd:
+            W_d = torch.cat([W1[:, cols[j]:cols[j] + spec.meta[j]["width"]] for j in dense], 1)
+        with _phase("recompute: GEMM (rocBLAS)"):
+            z1 = torch.addmm(b[0], X, W_d.t()) if kd else b[0].expand(M, N1).contiguous()
+            prods = {j: torch.mm(tt[j], W1[:, cols[j]:cols[j] + spec.meta[j]["width"]].t()) for j in hoisted}
+        with _phase("recompute: gather"):
+            for j in hoisted:
+                train_gather(prods[j], z1, 0, 0, N1, spec.meta[j]["index"], _lib.ACT_NONE, False, M, accumulate=True)
+        del prods
+        # acts[l] = input rows of layer l+1 (acts[0] stands for the virtual concatenation and is never formed)
+        acts: List[Optional[Tensor]] = [None]
+        z_last = z1
+        for l in range(1, L):
             with _phase("recompute: SELU"):
-                ops.activation_(a, _lib.ACT_SELU)
-            acts.append(a)
+                ops.activation_(z_last, _lib.ACT_SELU)
+            acts.append(z_last)
+            if l < L - 1 or spec.has_ln:
+                with _phase("recompute: GEMM (rocBLAS)"):
+                    z_last = torch.addmm(b[l], acts[-1], W[l].t())
         # ---- output side: activation, residual, LayerNorm
         g = dy
         d_resid = None
@@ -211,53 +242,83 @@ class _FusedMLP(torch.autograd.Function):
                 g = act_grad(g, _dense(out_act), spec.act, False)
         d_gamma = d_beta = None
         if spec.has_ln:
-            with _phase("recompute: GEMM (rocBLAS)"):
-                z_last = torch.addmm(b[L - 1], acts[-1], W[L - 1].t())
             with _phase("LayerNorm adjoint"):
                 g, d_gamma, d_beta = layernorm_grad(z_last, gamma, g, spec.eps)
-        # ---- layers, last to first
+        # ---- layers, last to second
         dW: List[Optional[Tensor]] = [None] * L
         db: List[Optional[Tensor]] = [None] * L
-        need_dx = any(needs[1 + j] for j in range(n_src))
-        for l in range(L - 1, -1, -1):
+        for l in range(L - 1, 0, -1):
             with _phase("dW GEMM (rocBLAS)"):
                 dW[l] = weight_grad(g, acts[l])
             with _phase("bias column sums"):
                 db[l] = colsum(g)
-            if l > 0:
-                with _phase("dX GEMM (rocBLAS)"):
-                    g = torch.mm(g, W[l])
-                with _phase("activation adjoint"):
-                    g = act_grad(g, acts[l], _lib.ACT_SELU, False, out=g)
-            elif need_dx:
-                with _phase("dX GEMM (rocBLAS)"):
-                    g = torch.mm(g, W[0])
-        # ---- back through the column blocks of the input
+            with _phase("dX GEMM (rocBLAS)"):
+                g = torch.mm(g, W[l])
+            with _phase("activation adjoint"):
+                g = act_grad(g, acts[l], _lib.ACT_SELU, False, out=g)
+        # ---- first layer
+        with _phase("bias column sums"):
+            db[0] = colsum(g)
+        dW1 = torch.empty_like(W1)
         d_src: List[Optional[Tensor]] = [None] * n_src
-        c0 = 0
-        for j, (t, m) in enumerate(zip(src_t, spec.meta)):
+
+        def finish(j: int, gt: Tensor) -> Tensor:
+            """Gradient rows of block j's tensor -> sign, activation-on-load slope, column window."""
+            t, m = src_t[j], spec.meta[j]
             w = m["width"]
-            if needs[1 + j]:
-                gx = g[:, c0:c0 + w]
-                if m["negate"]:
-                    gx = -gx
-                n_t = int(t.size(0))
-                with _phase("input adjoint: gather / aggregation"):
-                    if m["segments"] is not None:
-                        gt = segment_broadcast(gx, m["segments"], m["seg_mean"], n_t)
-                    elif m["index"] is not None:
-                        gt = ops.segment_reduce(gx, plan.gather_csr(m["index"], n_t), False)
-                    else:
-                        gt = gx
-                    if m["pre_act"] != _lib.ACT_NONE:
-                        gt = act_grad(_dense(gt), t[:, m["col0"]:m["col0"] + w], m["pre_act"], True)
-                if m["col0"] == 0 and w == int(t.size(1)):
-                    d_src[j] = gt
+            if m["negate"]:
+                gt = -gt
+            if m["pre_act"] != _lib.ACT_NONE:
+                gt = act_grad(_dense(gt), t[:, m["col0"]:m["col0"] + w], m["pre_act"], True)
+            if m["col0"] == 0 and w == int(t.size(1)):
+                return gt
+            full = torch.zeros_like(t)
+            full[:, m["col0"]:m["col0"] + w] = gt
+            return full
+
+        if kd:
+            with _phase("dW GEMM (rocBLAS)"):
+                dWd = weight_grad(g, X)
+                if hoisted:
+                    d0 = 0
+                    for j in dense:
+                        w = spec.meta[j]["width"]
+                        dW1[:, cols[j]:cols[j] + w] = dWd[:, d0:d0 + w]
+                        d0 += w
                 else:
-                    full = torch.zeros_like(t)
-                    full[:, m["col0"]:m["col0"] + w] = gt
-                    d_src[j] = full
-            c0 += w
+                    dW1 = dWd
+            if any(needs[1 + j] for j in dense):
+                with _phase("dX GEMM (rocBLAS)"):
+                    gX = torch.mm(g, W_d)
+                with _phase("input adjoint: gather / aggregation"):
+                    d0 = 0
+                    for j in dense:
+                        t, m = src_t[j], spec.meta[j]
+                        w = m["width"]
+                        if needs[1 + j]:
+                            gx = gX[:, d0:d0 + w]
+                            if m["segments"] is not None:
+                                gt = segment_broadcast(gx, m["segments"], m["seg_mean"], int(t.size(0)))
+                            elif m["index"] is not None:        # (an index into a tensor with at least as many rows: not hoisted)
+                                gt = ops.segment_reduce(gx, plan.gather_csr(m["index"], int(t.size(0))), False)
+                            else:
+                                gt = gx
+                            d_src[j] = finish(j, gt)
+                        d0 += w
+        for j in hoisted:
+            t, m = src_t[j], spec.meta[j]
+            w = m["width"]
+            with _phase("input adjoint: gather / aggregation"):
+                G = ops.segment_reduce(g, plan.gather_csr(m["index"], int(t.size(0))), False)       # [rows(t), N1]
+            with _phase("dW GEMM (rocBLAS)"):
+                dW1[:, cols[j]:cols[j] + w] = weight_grad(G, tt[j])
+            if needs[1 + j]:
+                with _phase("dX GEMM (rocBLAS)"):
+                    gt = torch.mm(G, W1[:, cols[j]:cols[j] + w])
+                with _phase("input adjoint: gather / aggregation"):
+                    # (sign and slope were applied when tt was formed from t: chain rule through them)
+                    d_src[j] = finish(j, gt)
+        dW[0] = dW1
         grads = [None] + d_src + ([d_resid] if spec.has_resid else []) + dW + db
         if spec.has_ln:
             grads += [d_gamma, d_beta]

@@ -26,27 +26,57 @@ __device__ __forceinline__ float act_slope(float ref, int act, int from_input) {
     return 1.f;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// V = 4: four consecutive columns per thread (16-byte loads / stores; the launcher checks alignment), V = 1: any shape.
+// ACC: dst += (the recomputed first layer adds the pre-multiplied node-side terms, gathered through their index).
+template <int V, bool ACC>
 __global__ __launch_bounds__(256) void train_gather_kernel(const float *__restrict__ src, int src_ld, int scol0,
                                                            const int *__restrict__ idx, int pre_act, float sign,
                                                            float *__restrict__ dst, int dst_ld, int dcol0, int width,
                                                            long long n_rows) {
+    const int wv = width / V;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long r = t / width;
-    const int c = (int)(t - r * width);
+    const long long r = t / wv;
+    const int c = (int)(t - r * wv) * V;
     if (r >= n_rows) return;
     const long long sr = idx ? (long long)idx[r] : r;
-    dst[r * dst_ld + dcol0 + c] = sign * apply_act(src[sr * src_ld + scol0 + c], pre_act);
+    const float *sp = src + sr * src_ld + scol0 + c;
+    float *dp = dst + r * dst_ld + dcol0 + c;
+    if (V == 4) {
+        f32x4 x = *reinterpret_cast<const f32x4 *>(sp);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = sign * apply_act(x[e], pre_act);
+        if (ACC) x += *reinterpret_cast<const f32x4 *>(dp);
+        *reinterpret_cast<f32x4 *>(dp) = x;
+    } else {
+        const float x = sign * apply_act(*sp, pre_act);
+        *dp = ACC ? *dp + x : x;
+    }
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void act_grad_kernel(const float *__restrict__ dy, int dy_ld, const float *__restrict__ ref,
                                                        int ref_ld, int from_input, int act, float *__restrict__ dz, int dz_ld,
                                                        int width, long long n_rows) {
+    const int wv = width / V;
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long r = t / width;
-    const int c = (int)(t - r * width);
+    const long long r = t / wv;
+    const int c = (int)(t - r * wv) * V;
     if (r >= n_rows) return;
-    dz[r * dz_ld + c] = dy[r * dy_ld + c] * act_slope(ref[r * ref_ld + c], act, from_input);
+    if (V == 4) {
+        const f32x4 g = *reinterpret_cast<const f32x4 *>(dy + r * dy_ld + c);
+        const f32x4 x = *reinterpret_cast<const f32x4 *>(ref + r * ref_ld + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = g[e] * act_slope(x[e], act, from_input);
+        *reinterpret_cast<f32x4 *>(dz + r * dz_ld + c) = o;
+    } else {
+        dz[r * dz_ld + c] = dy[r * dy_ld + c] * act_slope(ref[r * ref_ld + c], act, from_input);
+    }
 }
+
+inline bool vec4_ok(const void *p, int ld, int col0) { return ((uintptr_t)p % 16 == 0) && ld % 4 == 0 && col0 % 4 == 0; }
 
 // LayerNorm backward, one wave per row (width <= 256: up to 4 columns per lane), 4 rows per workgroup iteration.
 //   xhat = (z - mean) * rstd;  g = dy * gamma;  dz = rstd * (g - mean(g) - xhat * mean(g * xhat))
@@ -174,15 +204,21 @@ __global__ __launch_bounds__(256) void segment_broadcast_kernel(const float *__r
 
 extern "C" int g4c_train_gather(const float *src, int32_t src_ld, int32_t scol0, const int32_t *idx, int32_t pre_act,
                                 int32_t negate, float *dst, int32_t dst_ld, int32_t dcol0, int32_t width, int64_t n_rows,
-                                void *stream) {
+                                int32_t accumulate, void *stream) {
     G4C_REQUIRE(src && dst, G4C_EINVAL, "g4c_train_gather: null pointer");
     G4C_REQUIRE(width > 0 && n_rows >= 0 && scol0 >= 0 && dcol0 >= 0 && src_ld >= scol0 + width && dst_ld >= dcol0 + width &&
                     pre_act >= 0 && pre_act <= 2,
                 G4C_EINVAL, "g4c_train_gather: bad arguments width=%d src_ld=%d dst_ld=%d pre_act=%d", width, src_ld, dst_ld, pre_act);
     if (n_rows == 0) return G4C_OK;
-    const long long total = n_rows * width;
-    train_gather_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-        src, src_ld, scol0, idx, pre_act, negate ? -1.f : 1.f, dst, dst_ld, dcol0, width, n_rows);
+    const bool v4 = width % 4 == 0 && vec4_ok(src, src_ld, scol0) && vec4_ok(dst, dst_ld, dcol0);
+    const long long total = n_rows * (width / (v4 ? 4 : 1));
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    const float sign = negate ? -1.f : 1.f;
+    hipStream_t st = (hipStream_t)stream;
+#define G4C_TG(V, ACC) train_gather_kernel<V, ACC><<<grid, blk, 0, st>>>(src, src_ld, scol0, idx, pre_act, sign, dst, dst_ld, dcol0, width, n_rows)
+    if (v4) { if (accumulate) G4C_TG(4, true); else G4C_TG(4, false); }
+    else { if (accumulate) G4C_TG(1, true); else G4C_TG(1, false); }
+#undef G4C_TG
     return g4c::check_launch("g4c_train_gather");
 }
 
@@ -192,9 +228,11 @@ extern "C" int g4c_act_grad(const float *dy, int32_t dy_ld, const float *ref, in
     G4C_REQUIRE(width > 0 && n_rows >= 0 && dy_ld >= width && ref_ld >= width && dz_ld >= width && act >= 0 && act <= 2, G4C_EINVAL,
                 "g4c_act_grad: bad arguments width=%d lds=%d,%d,%d act=%d", width, dy_ld, ref_ld, dz_ld, act);
     if (n_rows == 0) return G4C_OK;
-    const long long total = n_rows * width;
-    act_grad_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-        dy, dy_ld, ref, ref_ld, from_input, act, dz, dz_ld, width, n_rows);
+    const bool v4 = width % 4 == 0 && vec4_ok(dy, dy_ld, 0) && vec4_ok(ref, ref_ld, 0) && vec4_ok(dz, dz_ld, 0);
+    const long long total = n_rows * (width / (v4 ? 4 : 1));
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    if (v4) act_grad_kernel<4><<<grid, blk, 0, (hipStream_t)stream>>>(dy, dy_ld, ref, ref_ld, from_input, act, dz, dz_ld, width, n_rows);
+    else act_grad_kernel<1><<<grid, blk, 0, (hipStream_t)stream>>>(dy, dy_ld, ref, ref_ld, from_input, act, dz, dz_ld, width, n_rows);
     return g4c::check_launch("g4c_act_grad");
 }
 

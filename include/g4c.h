@@ -246,10 +246,11 @@ int g4c_copy_cols(const float *src, int32_t src_ld, int32_t scol0, const int32_t
  * in a fixed order: gradients are bit-reproducible.
  * ------------------------------------------------------------------------------------------------------------------ */
 
-/* dst[r, dcol0 : dcol0+width] = (negate ? -1 : 1) * pre_act(src[idx ? idx[r] : r, scol0 : scol0+width]): one column block
- * of the concatenated MLP input (nn/blocks.py:181,185,229,285), recomputed for the backward pass. */
+/* dst[r, dcol0 : dcol0+width] (+)= (negate ? -1 : 1) * pre_act(src[idx ? idx[r] : r, scol0 : scol0+width]): one column block
+ * of the concatenated MLP input (nn/blocks.py:181,185,229,285), recomputed for the backward pass; `accumulate` != 0 adds
+ * into dst (the recomputed first layer: pre-multiplied node-side terms gathered through their index). */
 int g4c_train_gather(const float *src, int32_t src_ld, int32_t scol0, const int32_t *idx, int32_t pre_act, int32_t negate,
-                     float *dst, int32_t dst_ld, int32_t dcol0, int32_t width, int64_t n_rows, void *stream);
+                     float *dst, int32_t dst_ld, int32_t dcol0, int32_t width, int64_t n_rows, int32_t accumulate, void *stream);
 
 /* dz = dy * act'(.)  — `ref` holds the activation's OUTPUT (from_input = 0) or its INPUT (from_input = 1).  dz may alias dy. */
 int g4c_act_grad(const float *dy, int32_t dy_ld, const float *ref, int32_t ref_ld, int32_t from_input, int32_t act,
