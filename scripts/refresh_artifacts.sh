@@ -22,4 +22,11 @@ hipcc -w --offload-arch=gfx950 -O3 -o /tmp/mfma_peak scripts/micro/mfma_peak.hip
   timeout 300 python scripts/bench_mugs.py 2>&1 | tail -2
   timeout 300 python bench.py --precision fp32 --steps 20 --no-cpu-baseline | tail -1
 } > $A/${TAG}_side_configs.log 2>&1
-rm -rf $A/prof; ls -la $A
+# training path: step time + per-phase HIP-event times + the CPU leg; then the per-kernel view of the same step
+timeout -k 10 900 python scripts/bench_train.py --steps 10 --cpu-steps 1 --phases 2> $A/train_stderr.log | tail -1 > $A/${TAG}_train_bench_100k.json
+timeout -k 10 300 python scripts/bench_train.py --nodes 10000 --model NsTwoScaleGNN --steps 30 --cpu-steps 1 2>/dev/null | tail -1 > $A/${TAG}_train_bench_10k.json
+rm -rf $A/prof
+( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $A/prof_train -o t -- \
+    python scripts/bench_train.py --steps 3 --cpu-steps 0 > $A/prof_train_stdout.log 2> $A/prof_train_stderr.log )
+cp $(find $A/prof_train -name '*kernel_stats.csv' | head -1) $A/${TAG}_train_rocprofv3_kernel_stats.csv 2>/dev/null
+rm -rf $A/prof_train; ls -la $A
