@@ -114,6 +114,28 @@ def segment_broadcast(dout: Tensor, csr, mean: bool, n_src_rows: int) -> Tensor:
     return dsrc
 
 
+FUSED_LINEAR = __import__("os").environ.get("G4C_TRAIN_FUSED_LINEAR", "1") != "0"
+HOIST_MIN_ROWS = 32768             # below: the step is host-bound, and hoisting a block costs five more launches than it saves
+FUSED_LINEAR_MIN_ROWS = 65536      # below: packing the weights for one launch costs more host time than the fusion saves
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int = _lib.ACT_NONE) -> Tensor:
+    """act(x weight^T + bias) for the [M, 128 k] x [<= 128, 128 k] products of the backward pass (recomputed hidden layers,
+    input gradients): ONE layer of the fused-MLP kernel — the forward's arithmetic (exact operand split on the bf16 matrix pipe,
+    fp32-accurate) with bias and activation in the epilogue — instead of an fp32 library GEMM plus separate bias / activation
+    passes.  Other shapes go to rocBLAS."""
+    n_out, k = int(weight.size(0)), int(weight.size(1))
+    if not (FUSED_LINEAR and int(x.size(0)) >= FUSED_LINEAR_MIN_ROWS and n_out <= 128 and k % 128 == 0
+            and 128 <= k <= 128 * _lib.MAX_SRC and x.stride(1) == 1):
+        y = torch.mm(x, weight.t()) if bias is None else torch.addmm(bias, x, weight.t())
+        return y if act == _lib.ACT_NONE else ops.activation_(y, act)
+    blocks = k // 128
+    pk = ops.PackedMLP([weight.detach()], [None if bias is None else bias.detach()], None, [128] * blocks, [False] * blocks,
+                       precision=ops.effective_precision([128] * blocks))
+    pk.params = None                                        # (never differentiated through)
+    return ops.mlp_forward(pk, [Source(x, col0=128 * j, width=128) for j in range(blocks)], int(x.size(0)), act)
+
+
 WGRAD_CHUNK = 4096      # rows per split of a weight-gradient GEMM
 
 
@@ -188,7 +210,8 @@ class _FusedMLP(torch.autograd.Function):
         for m in spec.meta:
             cols.append(c0)
             c0 += m["width"]
-        hoisted = [j for j, (t, m) in enumerate(zip(src_t, spec.meta)) if m["index"] is not None and int(t.size(0)) < M]
+        hoisted = [j for j, (t, m) in enumerate(zip(src_t, spec.meta))
+                   if m["index"] is not None and int(t.size(0)) < M and M >= HOIST_MIN_ROWS]
         dense = [j for j in range(n_src) if j not in hoisted]
         kd = sum(spec.meta[j]["width"] for j in dense)
         W1 = W[0]
@@ -213,23 +236,28 @@ class _FusedMLP(torch.autograd.Function):
             W_d = W1
         elif kd:
             W_d = torch.cat([W1[:, cols[j]:cols[j] + spec.meta[j]["width"]] for j in dense], 1)
-        with _phase("recompute: GEMM (rocBLAS)"):
-            z1 = torch.addmm(b[0], X, W_d.t()) if kd else b[0].expand(M, N1).contiguous()
-            prods = {j: torch.mm(tt[j], W1[:, cols[j]:cols[j] + spec.meta[j]["width"]].t()) for j in hoisted}
+        with _phase("recompute: GEMM"):
+            z1 = linear(X, W_d, b[0]) if kd else b[0].expand(M, N1).contiguous()
+            prods = {j: linear(tt[j], W1[:, cols[j]:cols[j] + spec.meta[j]["width"]].contiguous(), None) for j in hoisted}
         with _phase("recompute: gather"):
             for j in hoisted:
                 train_gather(prods[j], z1, 0, 0, N1, spec.meta[j]["index"], _lib.ACT_NONE, False, M, accumulate=True)
         del prods
         # acts[l] = input rows of layer l+1 (acts[0] stands for the virtual concatenation and is never formed)
         acts: List[Optional[Tensor]] = [None]
-        z_last = z1
+        with _phase("recompute: SELU"):
+            ops.activation_(z1, _lib.ACT_SELU)
+        acts.append(z1)
+        z_last = None
         for l in range(1, L):
-            with _phase("recompute: SELU"):
-                ops.activation_(z_last, _lib.ACT_SELU)
-            acts.append(z_last)
-            if l < L - 1 or spec.has_ln:
-                with _phase("recompute: GEMM (rocBLAS)"):
-                    z_last = torch.addmm(b[l], acts[-1], W[l].t())
+            last = l == L - 1
+            if not last or spec.has_ln:
+                with _phase("recompute: GEMM"):           # hidden layers: bias + SELU in the launch's epilogue
+                    out = linear(acts[-1], W[l], b[l], _lib.ACT_NONE if last else _lib.ACT_SELU)
+                if last:
+                    z_last = out
+                else:
+                    acts.append(out)
         # ---- output side: activation, residual, LayerNorm
         g = dy
         d_resid = None
@@ -252,8 +280,8 @@ class _FusedMLP(torch.autograd.Function):
                 dW[l] = weight_grad(g, acts[l])
             with _phase("bias column sums"):
                 db[l] = colsum(g)
-            with _phase("dX GEMM (rocBLAS)"):
-                g = torch.mm(g, W[l])
+            with _phase("dX GEMM"):
+                g = linear(g, W[l].t().contiguous(), None)
             with _phase("activation adjoint"):
                 g = act_grad(g, acts[l], _lib.ACT_SELU, False, out=g)
         # ---- first layer
@@ -288,8 +316,8 @@ class _FusedMLP(torch.autograd.Function):
                 else:
                     dW1 = dWd
             if any(needs[1 + j] for j in dense):
-                with _phase("dX GEMM (rocBLAS)"):
-                    gX = torch.mm(g, W_d)
+                with _phase("dX GEMM"):
+                    gX = linear(g, W_d.t().contiguous(), None) if kd <= 128 else torch.mm(g, W_d)
                 with _phase("input adjoint: gather / aggregation"):
                     d0 = 0
                     for j in dense:
@@ -313,7 +341,7 @@ class _FusedMLP(torch.autograd.Function):
             with _phase("dW GEMM (rocBLAS)"):
                 dW1[:, cols[j]:cols[j] + w] = weight_grad(G, tt[j])
             if needs[1 + j]:
-                with _phase("dX GEMM (rocBLAS)"):
+                with _phase("dX GEMM"):
                     gt = torch.mm(G, W1[:, cols[j]:cols[j] + w])
                 with _phase("input adjoint: gather / aggregation"):
                     # (sign and slope were applied when tt was formed from t: chain rule through them)

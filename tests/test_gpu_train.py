@@ -82,7 +82,11 @@ def test_segment_reduce_autograd_with_permutation_and_activations():
 
 
 # ------------------------------------------------------------------ one fused MLP with every kind of input block
-def test_fused_mlp_gradients_all_source_kinds():
+@pytest.mark.parametrize("hoist_min_rows", [0, 1 << 30])
+def test_fused_mlp_gradients_all_source_kinds(hoist_min_rows, monkeypatch):
+    """hoist_min_rows 0: the gathered block is differentiated on its tensor's rows (autograd.py), 1 << 30: as a dense block."""
+    from graphs4cfd_amd import autograd as A
+    monkeypatch.setattr(A, "HOIST_MIN_ROWS", hoist_min_rows)
     torch.manual_seed(3)
     M, n_a, n_b, H = 3000, 500, 3000, 128
     mlp = B.MLP(2 + H + H + 3, (H, H, H), True).to(DEV)
@@ -113,9 +117,12 @@ def test_fused_mlp_gradients_all_source_kinds():
 
 
 @pytest.mark.parametrize("activation", [None, "selu", torch.tanh])
-def test_gnblock_public_forward_gradients(activation):
+def test_gnblock_public_forward_gradients(activation, monkeypatch):
     """GNBlock.forward(v, e, edge_index) (nn/blocks.py:175-186) under autograd: gradients of both outputs with respect to
-    v, e and every parameter."""
+    v, e and every parameter (first layer differentiated on the node rows: hoisting forced on at this small size)."""
+    from graphs4cfd_amd import autograd as A
+    monkeypatch.setattr(A, "HOIST_MIN_ROWS", 0)
+    monkeypatch.setattr(A, "FUSED_LINEAR_MIN_ROWS", 0)
     torch.manual_seed(5)
     n, H = 1500, 128
     g = S.mus_graph(n, levels=1, seed=9)
