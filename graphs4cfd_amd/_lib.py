@@ -102,6 +102,10 @@ _SIGNATURES = {
                                      C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_void_p]),
     "g4c_colsum_partials": (C.c_int32, [C.c_int64]),
     "g4c_colsum": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "g4c_weight_grad_partials": (C.c_int32, [C.c_int64]),
+    "g4c_weight_grad_scratch_floats": (C.c_int64, [C.c_int64]),
+    "g4c_weight_grad": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                  C.c_void_p]),
     "g4c_segment_broadcast": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_int32, C.c_void_p]),
 }

@@ -136,6 +136,38 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int = _lib.AC
     return ops.mlp_forward(pk, [Source(x, col0=128 * j, width=128) for j in range(blocks)], int(x.size(0)), act)
 
 
+WGRAD_KERNEL_MIN_ROWS = 4096
+
+
+def weight_bias_grad(g: Tensor, a: Tensor, want_bias: bool = True):
+    """(dW [N, K], db [N] or None) = (g^T a, column sums of g).  128-wide g and 128-column blocks of a: g4c_weight_grad (one
+    pass over both operands, MFMA, deterministic partial-tile sum; the bias gradient rides on the first block's pass);
+    any other shape: the split-row rocBLAS GEMM below + g4c_colsum."""
+    M, N, K = int(g.size(0)), int(g.size(1)), int(a.size(1))
+    ok = (N == 128 and K % 128 == 0 and M >= WGRAD_KERNEL_MIN_ROWS and g.stride(1) == 1 and a.stride(1) == 1
+          and _ld(g) % 4 == 0 and _ld(a) % 4 == 0 and g.data_ptr() % 16 == 0 and a.data_ptr() % 16 == 0)
+    if not ok:
+        return weight_grad(g, a), (colsum(g) if want_bias else None)
+    lib = _lib.load()
+    dev = _lib.require_hip(g, a)
+    scratch = torch.empty(int(lib.g4c_weight_grad_scratch_floats(M)), dtype=torch.float32, device=dev)
+    dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = None
+    for j in range(K // 128):
+        out = torch.empty(128 * 128 + 128, dtype=torch.float32, device=dev)
+        blk = a[:, 128 * j:128 * (j + 1)]
+        with_bias = want_bias and j == 0
+        _lib.check(lib.g4c_weight_grad(_lib.ptr(g), _ld(g), _lib.ptr(blk), _ld(a), M, _lib.ptr(scratch), _lib.ptr(out),
+                                       1 if with_bias else 0, _lib.stream_handle(dev)))
+        if K == 128:
+            dW = out[:128 * 128].view(128, 128)
+        else:
+            dW[:, 128 * j:128 * (j + 1)] = out[:128 * 128].view(128, 128)
+        if with_bias:
+            db = out[128 * 128:]
+    return dW, db
+
+
 WGRAD_CHUNK = 4096      # rows per split of a weight-gradient GEMM
 
 
@@ -276,17 +308,13 @@ class _FusedMLP(torch.autograd.Function):
         dW: List[Optional[Tensor]] = [None] * L
         db: List[Optional[Tensor]] = [None] * L
         for l in range(L - 1, 0, -1):
-            with _phase("dW GEMM (rocBLAS)"):
-                dW[l] = weight_grad(g, acts[l])
-            with _phase("bias column sums"):
-                db[l] = colsum(g)
+            with _phase("dW + db"):
+                dW[l], db[l] = weight_bias_grad(g, acts[l])
             with _phase("dX GEMM"):
                 g = linear(g, W[l].t().contiguous(), None)
             with _phase("activation adjoint"):
                 g = act_grad(g, acts[l], _lib.ACT_SELU, False, out=g)
         # ---- first layer
-        with _phase("bias column sums"):
-            db[0] = colsum(g)
         dW1 = torch.empty_like(W1)
         d_src: List[Optional[Tensor]] = [None] * n_src
 
@@ -305,8 +333,8 @@ class _FusedMLP(torch.autograd.Function):
             return full
 
         if kd:
-            with _phase("dW GEMM (rocBLAS)"):
-                dWd = weight_grad(g, X)
+            with _phase("dW + db"):
+                dWd, db[0] = weight_bias_grad(g, X)
                 if hoisted:
                     d0 = 0
                     for j in dense:
@@ -333,13 +361,16 @@ class _FusedMLP(torch.autograd.Function):
                                 gt = gx
                             d_src[j] = finish(j, gt)
                         d0 += w
+        if db[0] is None:
+            with _phase("dW + db"):
+                db[0] = colsum(g)
         for j in hoisted:
             t, m = src_t[j], spec.meta[j]
             w = m["width"]
             with _phase("input adjoint: gather / aggregation"):
                 G = ops.segment_reduce(g, plan.gather_csr(m["index"], int(t.size(0))), False)       # [rows(t), N1]
-            with _phase("dW GEMM (rocBLAS)"):
-                dW1[:, cols[j]:cols[j] + w] = weight_grad(G, tt[j])
+            with _phase("dW + db"):
+                dW1[:, cols[j]:cols[j] + w] = weight_bias_grad(G, tt[j], False)[0]
             if needs[1 + j]:
                 with _phase("dX GEMM"):
                     gt = torch.mm(G, W1[:, cols[j]:cols[j] + w])

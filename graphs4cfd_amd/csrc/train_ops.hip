@@ -181,6 +181,95 @@ __global__ __launch_bounds__(256) void colsum_stage_kernel(const float *__restri
     }
 }
 
+// Weight gradient dW[n, k] = sum_m g[m, n] a[m, k] (and db[n] = sum_m g[m, n]) for n, k = 128: a contraction over up to
+// millions of rows into ONE 128 x 128 tile.  HBM-bound: g and a are each read exactly once (600k rows: 614 MB; fp32 MFMA time
+// for the same rows 125 us = 4.9 TB/s, so the two rooflines meet).  Workgroup w owns a contiguous chunk of rows; per 32-row slab
+// it stages g and a in LDS (16-byte coalesced loads, prefetched into registers one slab ahead) and runs
+// v_mfma_f32_32x32x2_f32 with A = g^T (wave = one 32-row block of n), B = a (four 32-column blocks of k): the row index m is the
+// MFMA's contraction index, two rows per instruction.  Every workgroup writes its partial tile [128*128 | 128 column sums of
+// g]; g4c_colsum adds the partial tiles in a fixed order (deterministic, no atomics).
+constexpr int WG_N = 128, WG_SLAB = 32;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256, 2) void weight_grad_kernel(const float *__restrict__ g, int g_ld, const float *__restrict__ a,
+                                                             int a_ld, long long n_rows, long long chunk,
+                                                             float *__restrict__ partial, int with_bias) {
+    __shared__ __attribute__((aligned(16))) float sG[WG_SLAB * WG_N];
+    __shared__ __attribute__((aligned(16))) float sA[WG_SLAB * WG_N];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const long long r0 = (long long)blockIdx.x * chunk;
+    const long long r1 = r0 + chunk < n_rows ? r0 + chunk : n_rows;
+    const int c4 = (tid & 31) * 4, rr = tid >> 5;               // this thread's 4 columns / first row inside a slab (rows rr + 8 it)
+    f32x16 acc[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[kb][j] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pg[4], pa[4];
+    auto fetch = [&](long long m0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const long long r = m0 + rr + 8 * it;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            pg[it] = r < r1 ? *reinterpret_cast<const f32x4 *>(g + r * g_ld + c4) : z;
+            pa[it] = r < r1 ? *reinterpret_cast<const f32x4 *>(a + r * a_ld + c4) : z;
+        }
+    };
+    if (r0 < r1) fetch(r0);
+    for (long long m0 = r0; m0 < r1; m0 += WG_SLAB) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            *reinterpret_cast<f32x4 *>(sG + (rr + 8 * it) * WG_N + c4) = pg[it];
+            *reinterpret_cast<f32x4 *>(sA + (rr + 8 * it) * WG_N + c4) = pa[it];
+            bsum += pg[it];
+        }
+        __syncthreads();
+        if (m0 + WG_SLAB < r1) fetch(m0 + WG_SLAB);           // in flight during this slab's MFMAs
+        // operands of step s+1 are read from LDS before the MFMAs of step s are issued (LDS latency under the matrix pipe)
+        const float *pG = sG + h * WG_N + wave * 32 + i, *pA = sA + h * WG_N + i;
+        float av = pG[0], bv[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) bv[kb] = pA[kb * 32];
+#pragma unroll
+        for (int s = 0; s < WG_SLAB / 2; ++s) {
+            float av_n = 0.f, bv_n[4] = {0.f, 0.f, 0.f, 0.f};
+            if (s + 1 < WG_SLAB / 2) {
+                av_n = pG[(2 * s + 2) * WG_N];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) bv_n[kb] = pA[(2 * s + 2) * WG_N + kb * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);        // (the scheduler otherwise sinks these reads to just before their use)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[kb], acc[kb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            av = av_n;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) bv[kb] = bv_n[kb];
+        }
+        __syncthreads();
+    }
+    float *out = partial + (long long)blockIdx.x * (WG_N * WG_N + WG_N);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int n = wave * 32 + 4 * h + 8 * (j >> 2) + (j & 3);
+            out[n * WG_N + kb * 32 + i] = acc[kb][j];
+        }
+    if (with_bias) {                                            // column sums of g: the eight threads sharing c4, in order
+        *reinterpret_cast<f32x4 *>(sG + rr * WG_N + c4) = bsum;
+        __syncthreads();
+        if (tid < WG_N) {
+            float t = sG[tid];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) t += sG[q * WG_N + tid];
+            out[WG_N * WG_N + tid] = t;
+        }
+    }
+}
+
 // adjoint of the segmented sum / mean: every row of a segment receives the segment's gradient (/ max(count, 1))
 __global__ __launch_bounds__(256) void segment_broadcast_kernel(const float *__restrict__ dout, int dout_ld,
                                                                 const int *__restrict__ off, const int *__restrict__ perm,
@@ -278,4 +367,39 @@ extern "C" int g4c_segment_broadcast(const float *dout, int32_t dout_ld, const i
     segment_broadcast_kernel<<<dim3((unsigned)((n_seg + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(
         dout, dout_ld, off, perm, n_seg, width, mean, dsrc, dsrc_ld);
     return g4c::check_launch("g4c_segment_broadcast");
+}
+
+extern "C" int32_t g4c_weight_grad_partials(int64_t n_rows) {
+    const long long slabs = (n_rows + WG_SLAB - 1) / WG_SLAB;
+    const long long want = slabs / 6;
+    // at most one resident round: 256 CUs x 3 workgroups (156 registers per lane) — a second, partly filled round would idle CUs
+    return (int32_t)(want < 1 ? 1 : (want > 768 ? 768 : want));
+}
+
+extern "C" int g4c_weight_grad(const float *g, int32_t g_ld, const float *a, int32_t a_ld, int64_t n_rows, float *scratch,
+                               float *out, int32_t with_bias, void *stream) {
+    G4C_REQUIRE(g && a && scratch && out, G4C_EINVAL, "g4c_weight_grad: null pointer");
+    G4C_REQUIRE(n_rows >= 0 && g_ld >= WG_N && a_ld >= WG_N && g_ld % 4 == 0 && a_ld % 4 == 0 && (uintptr_t)g % 16 == 0 &&
+                    (uintptr_t)a % 16 == 0,
+                G4C_EINVAL, "g4c_weight_grad: 128-wide, 16-byte aligned operands expected (g_ld=%d a_ld=%d)", g_ld, a_ld);
+    const int G = g4c_weight_grad_partials(n_rows);
+    const long long slabs = (n_rows + WG_SLAB - 1) / WG_SLAB;
+    const long long chunk = ((slabs + G - 1) / G) * WG_SLAB;
+    hipStream_t st = (hipStream_t)stream;
+    weight_grad_kernel<<<dim3(G), dim3(256), 0, st>>>(g, g_ld, a, a_ld, n_rows, chunk > 0 ? chunk : WG_SLAB, scratch, with_bias);
+    // fixed-order sum of the partial tiles ([dW | db] is contiguous in every partial row)
+    const int width = WG_N * WG_N + (with_bias ? WG_N : 0), ld = WG_N * WG_N + WG_N;
+    float *scratch2 = scratch + (long long)G * ld;
+    const int g2 = g4c_colsum_partials(G);
+    const long long chunk2 = (G + g2 - 1) / g2;
+    const unsigned cb = (unsigned)((width + 255) / 256);
+    colsum_stage_kernel<<<dim3(g2, cb), dim3(256), 0, st>>>(scratch, ld, width, G, chunk2 > 0 ? chunk2 : 1, scratch2, ld);
+    colsum_stage_kernel<<<dim3(1, cb), dim3(256), 0, st>>>(scratch2, ld, width, g2, g2, out, ld);
+    return g4c::check_launch("g4c_weight_grad");
+}
+
+extern "C" int64_t g4c_weight_grad_scratch_floats(int64_t n_rows) {
+    const long long ld = WG_N * WG_N + WG_N;
+    const long long G = g4c_weight_grad_partials(n_rows);
+    return (G + g4c_colsum_partials(G)) * ld;
 }

@@ -266,6 +266,16 @@ int g4c_layernorm_grad(const float *z, int32_t z_ld, const float *gamma, const f
 int32_t g4c_colsum_partials(int64_t n_rows);
 int g4c_colsum(const float *x, int32_t ld, int32_t width, int64_t n_rows, float *scratch, float *out, void *stream);
 
+/* Weight / bias gradient of one nn.Linear with 128 inputs and 128 outputs (every hidden layer of every published arch):
+ * out[0 : 128*128] = dW[n, k] = sum_r g[r, n] a[r, k] (row-major [128, 128]), and, if with_bias, out[128*128 : +128] =
+ * db[n] = sum_r g[r, n].  g = dL/d(layer output) [n_rows, 128], a = the layer's input rows [n_rows, 128] (a 128-column window
+ * of a wider tensor is fine: a_ld).  One pass over g and a (HBM-bound), fp32 MFMA, partial tiles per workgroup added in a
+ * fixed order.  `scratch`: g4c_weight_grad_scratch_floats(n_rows) floats; `out`: 128*128 + 128 floats. */
+int32_t g4c_weight_grad_partials(int64_t n_rows);
+int64_t g4c_weight_grad_scratch_floats(int64_t n_rows);
+int g4c_weight_grad(const float *g, int32_t g_ld, const float *a, int32_t a_ld, int64_t n_rows, float *scratch, float *out,
+                    int32_t with_bias, void *stream);
+
 /* Adjoint of g4c_segment_reduce: dsrc[perm ? perm[p] : p] = dout[s] (/ max(count_s, 1) if mean) for p in segment s.
  * Rows of dsrc that belong to no segment are left untouched (zero them first when perm is not a full permutation). */
 int g4c_segment_broadcast(const float *dout, int32_t dout_ld, const int32_t *off, const int32_t *perm, int32_t n_seg,

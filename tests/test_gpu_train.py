@@ -319,3 +319,19 @@ def test_remus_parameter_gradients_match_oracle_autograd():
     target = torch.randn(g.num_nodes, 2, device=DEV)
     pred = model.forward(g.clone().to(DEV))
     _grad_parity(model, pred, target, lambda w: O.remus_forward(_f64(g.to_dict()), w))
+
+
+@pytest.mark.parametrize("rows,k", [(4096, 128), (33333, 128), (70001, 256), (600000, 128)])
+def test_weight_grad_kernel(rows, k):
+    """g4c_weight_grad: dW = g^T a and db = column sums of g in one pass, against float64; bit-reproducible."""
+    from graphs4cfd_amd import autograd as A
+    torch.manual_seed(rows)
+    g = torch.randn(rows, 128, device=DEV)
+    wide = torch.randn(rows, k + 4, device=DEV)
+    a = wide[:, 4:]                                       # a 16-byte aligned column window of a wider tensor
+    dW, db = A.weight_bias_grad(g, a)
+    ref = (g.double().t() @ a.double())
+    close(dW.double(), ref, 2e-6, "dW")
+    close(db.double(), g.double().sum(0), 2e-6, "db")
+    dW2, db2 = A.weight_bias_grad(g, a)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
