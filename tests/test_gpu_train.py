@@ -156,10 +156,12 @@ def test_gnblock_public_forward_gradients(activation, monkeypatch):
 
 
 def _model_and_oracle_grads(model_name, levels, nodes, hidden, seed):
-    g = S.mus_graph(nodes, levels=levels, seed=seed)
+    adv = model_name.startswith("Adv")            # advection models: one field, `loc` among the node inputs
+    nf = 1 if adv else 3
+    g = S.mus_graph(nodes, levels=levels, seed=seed, nf=nf, loc=adv)
     torch.manual_seed(seed + 1)
-    model = getattr(gfd.nn, model_name)(arch=S.mus_arch(model_name, hidden), device=DEV)
-    target = torch.randn(nodes, 3, device=DEV)
+    model = getattr(gfd.nn, model_name)(arch=S.mus_arch(model_name, hidden, nf=nf, node_in=nf + 2 + (2 if adv else 0)), device=DEV)
+    target = torch.randn(nodes, nf, device=DEV)
     gd = g.clone().to(DEV)
     model.train()
     pred = model.forward(gd)
@@ -167,13 +169,14 @@ def _model_and_oracle_grads(model_name, levels, nodes, hidden, seed):
     loss.backward()
     got = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
     w = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    pred_ref = O.mus_forward(model_name, g.to_dict(), w, 3)
+    pred_ref = O.mus_forward(model_name, g.to_dict(), w, nf)
     loss_ref = F.mse_loss(pred_ref, target.cpu())
     loss_ref.backward()
     return model, float(loss), float(loss_ref), got, {k: v.grad for k, v in w.items()}
 
 
-@pytest.mark.parametrize("model_name,levels,hidden", [("NsOneScaleGNN", 1, 128), ("NsThreeScaleGNN", 3, 128), ("NsTwoScaleGNN", 2, 32)])
+@pytest.mark.parametrize("model_name,levels,hidden", [("NsOneScaleGNN", 1, 128), ("NsThreeScaleGNN", 3, 128), ("NsTwoScaleGNN", 2, 32),
+                                                      ("NsFourScaleGNN", 4, 64), ("AdvThreeScaleGNN", 3, 128)])
 def test_model_parameter_gradients_match_oracle_autograd(model_name, levels, hidden):
     model, loss, loss_ref, got, ref = _model_and_oracle_grads(model_name, levels, 2500, hidden, 7)
     assert abs(loss - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref))
