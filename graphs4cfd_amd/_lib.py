@@ -53,6 +53,8 @@ _SIGNATURES = {
     "g4c_plan_csr": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "g4c_plan_pool_edge": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    "g4c_plan_pool_edge_ordered": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p]),
     "g4c_segment_reduce": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "g4c_weighted_segment_mean": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,

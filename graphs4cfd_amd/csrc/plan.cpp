@@ -54,41 +54,62 @@ extern "C" int64_t g4c_plan_tiles(const int32_t *off, int32_t n_seg, int32_t max
     return nt;
 }
 
-extern "C" int64_t g4c_plan_pool_edge(const int64_t *idx_hr_to_lr, int64_t n_hr, const int64_t *edge_index,
-                                      int64_t n_edges, int64_t *coarse_edge_index, int32_t *perm, int32_t *off,
-                                      int64_t *n_kept) {
+extern "C" int64_t g4c_plan_pool_edge_ordered(const int64_t *idx_hr_to_lr, int64_t n_hr, const int64_t *edge_index,
+                                              int64_t n_edges, int32_t target_major, int64_t *coarse_edge_index, int32_t *perm,
+                                              int32_t *off, int64_t *n_kept) {
     G4C_REQUIRE(n_hr >= 0 && n_edges >= 0 && n_edges < (1LL << 31), G4C_EINVAL, "g4c_plan_pool_edge: bad sizes");
     G4C_REQUIRE((idx_hr_to_lr || n_hr == 0) && (edge_index || n_edges == 0) && off && n_kept, G4C_EINVAL,
                 "g4c_plan_pool_edge: null pointer");
     int64_t n_lr = 0;
     for (int64_t i = 0; i < n_hr; ++i) n_lr = std::max(n_lr, idx_hr_to_lr[i] + 1);
-    struct Item { int64_t key; int32_t e; };
-    std::vector<Item> items;
-    items.reserve((size_t)n_edges);
+    // surviving fine edges with their coarse endpoints (remove_self_loops), in fine-edge order
+    std::vector<int32_t> cr, cc, id;
+    cr.reserve((size_t)n_edges); cc.reserve((size_t)n_edges); id.reserve((size_t)n_edges);
     const int64_t *row = edge_index, *col = edge_index + n_edges;
     for (int64_t e = 0; e < n_edges; ++e) {
         G4C_REQUIRE(row[e] >= 0 && row[e] < n_hr && col[e] >= 0 && col[e] < n_hr, G4C_EINVAL,
                     "g4c_plan_pool_edge: edge %lld endpoint outside [0, %lld)", (long long)e, (long long)n_hr);
         const int64_t r = idx_hr_to_lr[row[e]], c = idx_hr_to_lr[col[e]];
-        if (r != c) items.push_back({r * n_lr + c, (int32_t)e});   // remove_self_loops
+        if (r != c) { cr.push_back((int32_t)r); cc.push_back((int32_t)c); id.push_back((int32_t)e); }
     }
-    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.key < b.key; });
-    const int64_t kept = (int64_t)items.size();
+    const int64_t kept = (int64_t)id.size();
     *n_kept = kept;
-    // first pass: count coarse edges so the two rows of coarse_edge_index can be written contiguously
+    // stable two-pass counting sort (minor key, then major key): coalesce order = (row, col), target-major = (col, row);
+    // ties keep fine-edge order, as the stable comparison sort on row * n_lr + col did
+    const std::vector<int32_t> &major = target_major ? cc : cr, &minor = target_major ? cr : cc;
+    std::vector<int32_t> order((size_t)kept), tmp((size_t)kept);
+    std::vector<int64_t> cnt((size_t)n_lr + 1);
+    auto pass = [&](const std::vector<int32_t> &key, const int32_t *in, int32_t *out) {
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (int64_t p = 0; p < kept; ++p) ++cnt[(size_t)key[(size_t)in[p]] + 1];
+        for (int64_t b = 0; b < n_lr; ++b) cnt[(size_t)b + 1] += cnt[(size_t)b];
+        for (int64_t p = 0; p < kept; ++p) out[cnt[(size_t)key[(size_t)in[p]]]++] = in[p];
+    };
+    for (int64_t p = 0; p < kept; ++p) tmp[(size_t)p] = (int32_t)p;
+    pass(minor, tmp.data(), order.data());
+    pass(major, order.data(), tmp.data());          // tmp: positions (into cr / cc / id) in final order
     int64_t n_coarse = 0;
-    for (int64_t p = 0; p < kept; ++p)
-        if (p == 0 || items[p].key != items[p - 1].key) ++n_coarse;
+    for (int64_t p = 0; p < kept; ++p) {
+        const int32_t q = tmp[(size_t)p];
+        if (p == 0 || cr[(size_t)q] != cr[(size_t)tmp[(size_t)p - 1]] || cc[(size_t)q] != cc[(size_t)tmp[(size_t)p - 1]]) ++n_coarse;
+    }
     int64_t s = -1;
     for (int64_t p = 0; p < kept; ++p) {
-        if (p == 0 || items[p].key != items[p - 1].key) {
+        const int32_t q = tmp[(size_t)p];
+        if (p == 0 || cr[(size_t)q] != cr[(size_t)tmp[(size_t)p - 1]] || cc[(size_t)q] != cc[(size_t)tmp[(size_t)p - 1]]) {
             ++s;
             off[s] = (int32_t)p;
-            coarse_edge_index[s] = items[p].key / n_lr;
-            coarse_edge_index[n_coarse + s] = items[p].key % n_lr;
+            coarse_edge_index[s] = cr[(size_t)q];
+            coarse_edge_index[n_coarse + s] = cc[(size_t)q];
         }
-        perm[p] = items[p].e;
+        perm[p] = id[(size_t)q];
     }
     off[n_coarse] = (int32_t)kept;
     return n_coarse;
+}
+
+extern "C" int64_t g4c_plan_pool_edge(const int64_t *idx_hr_to_lr, int64_t n_hr, const int64_t *edge_index,
+                                      int64_t n_edges, int64_t *coarse_edge_index, int32_t *perm, int32_t *off,
+                                      int64_t *n_kept) {
+    return g4c_plan_pool_edge_ordered(idx_hr_to_lr, n_hr, edge_index, n_edges, 0, coarse_edge_index, perm, off, n_kept);
 }

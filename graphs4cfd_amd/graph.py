@@ -59,9 +59,15 @@ class Graph:
 
     def to(self, device, non_blocking: bool = False) -> "Graph":
         """Moves every tensor attribute in place (like `Data.to`) and returns self."""
+        from . import plan as _plan
         for k, v in list(self.__dict__.items()):
             if torch.is_tensor(v):
-                self.__dict__[k] = v.to(device, non_blocking=non_blocking)
+                moved = v.to(device, non_blocking=non_blocking)
+                if v.device.type == "cpu" and moved.device.type != "cpu" and not v.dtype.is_floating_point:
+                    # the static-plan builders run on the host: keep the host image of index tensors so they never
+                    # have to read them back (a read-back waits for the whole launch queue)
+                    _plan.remember_host(moved, v)
+                self.__dict__[k] = moved
         return self
 
     def clone(self) -> "Graph":

@@ -42,13 +42,13 @@ class CsrPlan:
             self._tiles = None
             if self.perm is None and self.n > 0 and 0 < self.max_deg <= max_rows:
                 lib = _lib.load()
-                off = np.ascontiguousarray(self.off.detach().cpu().numpy().astype(np.int32))
+                off = np.ascontiguousarray(_host_i64(self.off).astype(np.int32))
                 cap = self.n_seg + 2
                 rows, seg = np.empty(cap, np.int32), np.empty(cap, np.int32)
                 nt = int(lib.g4c_plan_tiles(off.ctypes.data, self.n_seg, max_rows, rows.ctypes.data, seg.ctypes.data, cap))
                 if nt > 0:
                     dev = self.off.device
-                    self._tiles = (torch.from_numpy(rows[: nt + 1].copy()).to(dev), torch.from_numpy(seg[: nt + 1].copy()).to(dev), nt)
+                    self._tiles = (_upload(rows[: nt + 1].copy(), dev), _upload(seg[: nt + 1].copy(), dev), nt)
         return self._tiles
 
 
@@ -69,7 +69,28 @@ class PoolEdgePlan:
 
 
 def _host_i64(t: torch.Tensor) -> np.ndarray:
+    """Host int64 copy of an index tensor.  A device tensor whose host image is known (`remember_host`: the graph was moved
+    with `Graph.to`, or the tensor was produced by a host-side plan builder) is NOT read back: a device->host copy waits for
+    every launch queued so far, which in a training loop over fresh batches serialises the host and the GPU once per plan."""
+    if t.device.type != "cpu":
+        hit = _host_copies.get(_Cache.key(t))
+        if hit is not None:
+            return np.ascontiguousarray(hit, dtype=np.int64)
     return np.ascontiguousarray(t.detach().to("cpu", torch.int64).numpy())
+
+
+def _upload(arr: np.ndarray, device) -> torch.Tensor:
+    """Host array -> device tensor.  (Through pageable memory: staging through `pin_memory()` was measured 2.5x slower per
+    training iteration over fresh batches — every new array size costs a pinned allocation of several ms.)"""
+    return torch.from_numpy(arr).to(device)
+
+
+def remember_host(dev_tensor: torch.Tensor, host) -> None:
+    """Register the host image (numpy array or CPU tensor, not to be modified afterwards) of a device index tensor."""
+    if dev_tensor.device.type == "cpu" or dev_tensor.dtype.is_floating_point or not _REMEMBER_HOST:
+        return
+    arr = host.detach().numpy() if torch.is_tensor(host) else np.asarray(host)
+    _host_copies.put(_Cache.key(dev_tensor), (dev_tensor,), arr)
 
 
 def build_csr(keys: torch.Tensor, n_seg: int, device: torch.device, drop_last_segment: bool = False) -> CsrPlan:
@@ -87,10 +108,13 @@ def build_csr(keys: torch.Tensor, n_seg: int, device: torch.device, drop_last_se
     n_kept = int(perm.shape[0])
     identity = n_kept == n and bool(np.array_equal(perm, np.arange(n, dtype=np.int32)))
     deg = np.diff(off)
-    return CsrPlan(
-        perm=None if identity else torch.from_numpy(perm.copy()).to(device),
-        off=torch.from_numpy(off.copy()).to(device),
+    off_h = off.copy()
+    out = CsrPlan(
+        perm=None if identity else _upload(perm.copy(), device),
+        off=_upload(off_h, device),
         n=n_kept, n_seg=n_seg, max_deg=int(deg.max()) if deg.size else 0)
+    remember_host(out.off, off_h)
+    return out
 
 
 class _Cache:
@@ -118,13 +142,15 @@ class _Cache:
 
 
 _edge_plans = _Cache()
+_host_copies = _Cache(capacity=256)
+_REMEMBER_HOST = __import__("os").environ.get("G4C_HOST_COPIES", "1") != "0"      # (0: always read index tensors back; A/B only)
 _pool_plans = _Cache()
 _index_plans = _Cache()
 _cluster_plans = _Cache()
 
 
 def clear_caches() -> None:
-    for c in (_edge_plans, _pool_plans, _index_plans, _cluster_plans):
+    for c in (_edge_plans, _pool_plans, _index_plans, _cluster_plans, _host_copies):
         c.data.clear()
 
 
@@ -137,6 +163,10 @@ def edge_plan(edge_index: torch.Tensor) -> EdgePlan:
         dev = _lib.require_hip(edge_index)
         plan = EdgePlan(row=edge_index[0].to(torch.int32).contiguous(), col=edge_index[1].to(torch.int32).contiguous(),
                         n_edges=int(edge_index.size(1)), csr={})
+        host = _host_copies.get(_Cache.key(edge_index))
+        if host is not None:
+            remember_host(plan.row, host[0])
+            remember_host(plan.col, host[1])
         _edge_plans.put(key, (edge_index,), plan)
     return plan
 
@@ -145,7 +175,7 @@ def edge_csr(edge_index: torch.Tensor, n_targets: int) -> Tuple[EdgePlan, CsrPla
     plan = edge_plan(edge_index)
     csr = plan.csr.get(n_targets)
     if csr is None:
-        csr = build_csr(edge_index[1], n_targets, edge_index.device)
+        csr = build_csr(plan.col, n_targets, edge_index.device)
         plan.csr[n_targets] = csr
     return plan, csr
 
@@ -159,6 +189,9 @@ def index32(index: torch.Tensor) -> torch.Tensor:
     if out is None:
         _lib.require_hip(index)
         out = _index_plans.put(key, (index,), index.to(torch.int32).contiguous())
+        host = _host_copies.get(key)
+        if host is not None:
+            remember_host(out, host)
     return out
 
 
@@ -245,20 +278,6 @@ def pool_edge_plan(idx_hr_to_lr: torch.Tensor, edge_index: torch.Tensor, target_
     (SURVEY.md appendix A.2), and in this order the coarse MP layers need no permutation and can aggregate on load."""
     key = _Cache.key(idx_hr_to_lr, edge_index) + (bool(target_major),)
     plan = _pool_plans.get(key)
-    if plan is None and target_major:
-        base = pool_edge_plan(idx_hr_to_lr, edge_index, False)
-        dev = base.edge_index.device
-        ei = base.edge_index.cpu().numpy()
-        off = base.csr.off.cpu().numpy().astype(np.int64)
-        perm = base.csr.perm.cpu().numpy()
-        order = np.argsort(ei[1], kind="stable")
-        deg = np.diff(off)[order]
-        off_new = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
-        perm_new = (np.concatenate([perm[off[c]:off[c + 1]] for c in order]) if order.size else perm[:0]).astype(np.int32)
-        csr = CsrPlan(perm=torch.from_numpy(perm_new).to(dev), off=torch.from_numpy(off_new).to(dev), n=base.csr.n,
-                      n_seg=base.n_coarse, max_deg=base.csr.max_deg)
-        plan = PoolEdgePlan(edge_index=torch.from_numpy(np.ascontiguousarray(ei[:, order])).to(dev), csr=csr, n_coarse=base.n_coarse)
-        _pool_plans.put(key, (idx_hr_to_lr, edge_index), plan)
     if plan is None:
         lib = _lib.load()
         dev = _lib.require_hip(idx_hr_to_lr, edge_index)
@@ -268,8 +287,8 @@ def pool_edge_plan(idx_hr_to_lr: torch.Tensor, edge_index: torch.Tensor, target_
         perm = np.empty(max(n_edges, 1), dtype=np.int32)
         off = np.empty(n_edges + 1, dtype=np.int32)
         kept = C.c_int64(0)
-        n_coarse = lib.g4c_plan_pool_edge(idx.ctypes.data, n_hr, ei.ctypes.data, n_edges, coarse.ctypes.data,
-                                          perm.ctypes.data, off.ctypes.data, C.byref(kept))
+        n_coarse = lib.g4c_plan_pool_edge_ordered(idx.ctypes.data, n_hr, ei.ctypes.data, n_edges, 1 if target_major else 0,
+                                                  coarse.ctypes.data, perm.ctypes.data, off.ctypes.data, C.byref(kept))
         if n_coarse < 0:
             _lib.check(int(n_coarse))
         n_coarse, n_kept = int(n_coarse), int(kept.value)
@@ -277,8 +296,11 @@ def pool_edge_plan(idx_hr_to_lr: torch.Tensor, edge_index: torch.Tensor, target_
         flat = coarse.reshape(-1)[: 2 * n_coarse].reshape(2, n_coarse) if n_coarse else np.empty((2, 0), dtype=np.int64)
         off = off[: n_coarse + 1].copy()
         deg = np.diff(off)
-        csr = CsrPlan(perm=torch.from_numpy(perm[:n_kept].copy()).to(dev), off=torch.from_numpy(off).to(dev),
+        csr = CsrPlan(perm=_upload(perm[:n_kept].copy(), dev), off=_upload(off, dev),
                       n=n_kept, n_seg=n_coarse, max_deg=int(deg.max()) if deg.size else 0)
-        plan = PoolEdgePlan(edge_index=torch.from_numpy(flat.copy()).to(dev), csr=csr, n_coarse=n_coarse)
+        flat_h = flat.copy()
+        plan = PoolEdgePlan(edge_index=_upload(flat_h, dev), csr=csr, n_coarse=n_coarse)
+        remember_host(plan.edge_index, flat_h)
+        remember_host(csr.off, off)
         _pool_plans.put(key, (idx_hr_to_lr, edge_index), plan)
     return plan

@@ -62,6 +62,13 @@ int64_t g4c_plan_pool_edge(const int64_t *idx_hr_to_lr /*host, n_hr*/, int64_t n
                            int32_t *perm /*host, n_edges capacity*/,
                            int32_t *off /*host, n_edges+1 capacity*/,
                            int64_t *n_kept /*host, 1*/);
+/* Same, with the order of the coarse edges selectable: target_major = 0 is the function above; target_major = 1 groups the
+ * coarse edges by TARGET (sorted by (col, row)) — the order the models use internally: the reference never exposes the
+ * coarse edge order and in this order the coarse MP layers need no permutation.  O(n) (two stable
+ * counting-sort passes). */
+int64_t g4c_plan_pool_edge_ordered(const int64_t *idx_hr_to_lr, int64_t n_hr, const int64_t *edge_index, int64_t n_edges,
+                                   int32_t target_major, int64_t *coarse_edge_index, int32_t *perm, int32_t *off,
+                                   int64_t *n_kept);
 
 /* ---------------------------------------------------------------- aggregation (HBM-bound)
  * out[s, :] = act( reduce_{p in [off[s], off[s+1])} src_act( src[perm ? perm[p] : p, :] ) )
