@@ -73,10 +73,21 @@ def _host_i64(t: torch.Tensor) -> np.ndarray:
     with `Graph.to`, or the tensor was produced by a host-side plan builder) is NOT read back: a device->host copy waits for
     every launch queued so far, which in a training loop over fresh batches serialises the host and the GPU once per plan."""
     if t.device.type != "cpu":
-        hit = _host_copies.get(_Cache.key(t))
+        hit = _host_image(t)
         if hit is not None:
             return np.ascontiguousarray(hit, dtype=np.int64)
     return np.ascontiguousarray(t.detach().to("cpu", torch.int64).numpy())
+
+
+def _host_image(t: torch.Tensor) -> Optional[np.ndarray]:
+    """The registered host image of a device tensor, unless its source CPU tensor was modified in place since."""
+    hit = _host_copies.get(_Cache.key(t))
+    if hit is None:
+        return None
+    arr, src, version = hit
+    if src is not None and src._version != version:
+        return None
+    return arr
 
 
 def _upload(arr: np.ndarray, device) -> torch.Tensor:
@@ -89,8 +100,9 @@ def remember_host(dev_tensor: torch.Tensor, host) -> None:
     """Register the host image (numpy array or CPU tensor, not to be modified afterwards) of a device index tensor."""
     if dev_tensor.device.type == "cpu" or dev_tensor.dtype.is_floating_point or not _REMEMBER_HOST:
         return
-    arr = host.detach().numpy() if torch.is_tensor(host) else np.asarray(host)
-    _host_copies.put(_Cache.key(dev_tensor), (dev_tensor,), arr)
+    src = host if torch.is_tensor(host) else None
+    arr = host.detach().numpy() if src is not None else np.asarray(host)
+    _host_copies.put(_Cache.key(dev_tensor), (dev_tensor,), (arr, src, src._version if src is not None else 0))
 
 
 def build_csr(keys: torch.Tensor, n_seg: int, device: torch.device, drop_last_segment: bool = False) -> CsrPlan:
@@ -163,10 +175,10 @@ def edge_plan(edge_index: torch.Tensor) -> EdgePlan:
         dev = _lib.require_hip(edge_index)
         plan = EdgePlan(row=edge_index[0].to(torch.int32).contiguous(), col=edge_index[1].to(torch.int32).contiguous(),
                         n_edges=int(edge_index.size(1)), csr={})
-        host = _host_copies.get(_Cache.key(edge_index))
+        host = _host_image(edge_index)
         if host is not None:
-            remember_host(plan.row, host[0])
-            remember_host(plan.col, host[1])
+            remember_host(plan.row, np.ascontiguousarray(host[0]))
+            remember_host(plan.col, np.ascontiguousarray(host[1]))
         _edge_plans.put(key, (edge_index,), plan)
     return plan
 
@@ -189,9 +201,9 @@ def index32(index: torch.Tensor) -> torch.Tensor:
     if out is None:
         _lib.require_hip(index)
         out = _index_plans.put(key, (index,), index.to(torch.int32).contiguous())
-        host = _host_copies.get(key)
+        host = _host_image(index)
         if host is not None:
-            remember_host(out, host)
+            remember_host(out, host.copy())
     return out
 
 

@@ -338,3 +338,21 @@ def test_weight_grad_kernel(rows, k):
     close(db.double(), g.double().sum(0), 2e-6, "db")
     dW2, db2 = A.weight_bias_grad(g, a)
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
+
+
+def test_plans_use_registered_host_images_and_drop_stale_ones():
+    """Graph.to(device) registers the host image of index tensors (plan.remember_host): plan builders then never read them
+    back; an image whose source CPU tensor was modified in place afterwards is ignored (the device tensor is read back)."""
+    g = S.mus_graph(900, levels=2, seed=31)
+    ei_cpu = g.edge_index
+    gd = g.to(DEV)
+    assert plan._host_image(gd.edge_index) is not None
+    ep, csr = plan.edge_csr(gd.edge_index, 900)
+    assert plan._host_image(ep.row) is not None and plan._host_image(csr.off) is not None
+    ref = plan.build_csr(gd.edge_index[1].cpu(), 900, DEV)
+    assert torch.equal(csr.off, ref.off)
+    ei_cpu += 1                                            # in-place change of the source tensor: image is stale now
+    assert plan._host_image(gd.edge_index) is None
+    plan.clear_caches()
+    ep2, csr2 = plan.edge_csr(gd.edge_index, 900)          # falls back to reading the device tensor
+    assert torch.equal(csr2.off, ref.off)
