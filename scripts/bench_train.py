@@ -78,7 +78,8 @@ if a.cpu_steps > 0:
     w = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     copt = torch.optim.Adam(list(w.values()), lr=1e-4)
     gd = g_cpu.to_dict()
-    torch.set_num_threads(os.cpu_count())
+    threads = min(16, os.cpu_count())          # (more threads are slower and erratic on the 2-socket host: profiles/r01_cpu_thread_sweep.log)
+    torch.set_num_threads(threads)
     t0 = time.perf_counter()
     for _ in range(a.cpu_steps):
         closs = O.graph_loss(gd, O.mus_forward(a.model, gd, w, 3), gd["target"], 0.25)
@@ -86,6 +87,6 @@ if a.cpu_steps > 0:
         copt.step()
         copt.zero_grad()
     cdt = (time.perf_counter() - t0) / a.cpu_steps
-    out.update({"cpu_ms_per_training_step": 1e3 * cdt, "cpu_cores": os.cpu_count(), "cpu_kind": "port (oracle + torch autograd)",
+    out.update({"cpu_ms_per_training_step": 1e3 * cdt, "cpu_cores": threads, "cpu_kind": "port (oracle + torch autograd)",
                 "cpu_sample": f"{a.cpu_steps} training step(s) of the same mesh and weights", "gpu_over_cpu": cdt / dt})
 print(json.dumps(out))
