@@ -114,6 +114,10 @@ def segment_broadcast(dout: Tensor, csr, mean: bool, n_src_rows: int) -> Tensor:
     return dsrc
 
 
+# keep the hidden activations of every fused MLP from the forward launch (g4c_mlp_forward_bx6_save) instead of recomputing them
+# in the backward pass: ~3 x [rows, 128] fp32 more per MLP between the passes (100k nodes, 3-scale: 7 -> 17 GB), no recompute
+# GEMMs.  G4C_TRAIN_SAVE=0: the memory-light recompute path.
+SAVE_ACTIVATIONS = __import__("os").environ.get("G4C_TRAIN_SAVE", "1") != "0"
 FUSED_LINEAR = __import__("os").environ.get("G4C_TRAIN_FUSED_LINEAR", "1") != "0"
 HOIST_MIN_ROWS = 32768             # below: the step is host-bound, and hoisting a block costs five more launches than it saves
 FUSED_LINEAR_MIN_ROWS = 65536      # below: packing the weights for one launch costs more host time than the fusion saves
@@ -210,8 +214,13 @@ class _FusedMLP(torch.autograd.Function):
             srcs.append(Source(t, index=m["index"], col0=m["col0"], width=m["width"], negate=m["negate"], pre_act=m["pre_act"],
                                segments=m["segments"], seg_mean=m["seg_mean"]))
         resid = tensors[n_src] if spec.has_resid else None
-        y = ops.mlp_forward(spec.packed, srcs, spec.n_rows, spec.act, resid=resid, resid_col0=spec.resid_col0)
-        ctx.spec = spec
+        saves = None
+        if SAVE_ACTIVATIONS and spec.packed.precision == "bf16x6" and spec.n_rows > 0:
+            dev = tensors[0].device
+            saves = [_buf(spec.n_rows, 128, dev) for _ in range(spec.n_layers - 1)] + \
+                    [_buf(spec.n_rows, 128, dev) if spec.has_ln else None]
+        y = ops.mlp_forward(spec.packed, srcs, spec.n_rows, spec.act, resid=resid, resid_col0=spec.resid_col0, save=saves)
+        ctx.spec, ctx.saves = spec, saves
         ctx.save_for_backward(y, *tensors)
         return y
 
@@ -268,28 +277,35 @@ class _FusedMLP(torch.autograd.Function):
             W_d = W1
         elif kd:
             W_d = torch.cat([W1[:, cols[j]:cols[j] + spec.meta[j]["width"]] for j in dense], 1)
-        with _phase("recompute: GEMM"):
-            z1 = linear(X, W_d, b[0]) if kd else b[0].expand(M, N1).contiguous()
-            prods = {j: linear(tt[j], W1[:, cols[j]:cols[j] + spec.meta[j]["width"]].contiguous(), None) for j in hoisted}
-        with _phase("recompute: gather"):
-            for j in hoisted:
-                train_gather(prods[j], z1, 0, 0, N1, spec.meta[j]["index"], _lib.ACT_NONE, False, M, accumulate=True)
-        del prods
+        saves, ctx.saves = ctx.saves, None            # (released with this call, not with the whole graph)
         # acts[l] = input rows of layer l+1 (acts[0] stands for the virtual concatenation and is never formed)
         acts: List[Optional[Tensor]] = [None]
-        with _phase("recompute: SELU"):
-            ops.activation_(z1, _lib.ACT_SELU)
-        acts.append(z1)
         z_last = None
-        for l in range(1, L):
-            last = l == L - 1
-            if not last or spec.has_ln:
-                with _phase("recompute: GEMM"):           # hidden layers: bias + SELU in the launch's epilogue
-                    out = linear(acts[-1], W[l], b[l], _lib.ACT_NONE if last else _lib.ACT_SELU)
-                if last:
-                    z_last = out
-                else:
-                    acts.append(out)
+        if saves is not None:         # kept by the forward launch
+            for l in range(L - 1):
+                acts.append(saves[l][:, :int(W[l].size(0))])
+            if spec.has_ln:
+                z_last = saves[L - 1][:, :int(W[L - 1].size(0))]
+        else:
+            with _phase("recompute: GEMM"):
+                z1 = linear(X, W_d, b[0]) if kd else b[0].expand(M, N1).contiguous()
+                prods = {j: linear(tt[j], W1[:, cols[j]:cols[j] + spec.meta[j]["width"]].contiguous(), None) for j in hoisted}
+            with _phase("recompute: gather"):
+                for j in hoisted:
+                    train_gather(prods[j], z1, 0, 0, N1, spec.meta[j]["index"], _lib.ACT_NONE, False, M, accumulate=True)
+            del prods
+            with _phase("recompute: SELU"):
+                ops.activation_(z1, _lib.ACT_SELU)
+            acts.append(z1)
+            for l in range(1, L):
+                last = l == L - 1
+                if not last or spec.has_ln:
+                    with _phase("recompute: GEMM"):           # hidden layers: bias + SELU in the launch's epilogue
+                        out = linear(acts[-1], W[l], b[l], _lib.ACT_NONE if last else _lib.ACT_SELU)
+                    if last:
+                        z_last = out
+                    else:
+                        acts.append(out)
         # ---- output side: activation, residual, LayerNorm
         g = dy
         d_resid = None

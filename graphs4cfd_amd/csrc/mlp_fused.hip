@@ -114,6 +114,10 @@ struct Params {
     // narrow input blocks of the first layer, multiplied in fp32 on the vector ALUs (bf16x6 kernel)
     NarSrc nar[G4C_MAX_SRC];
     int n_nar;
+    // training forward (g4c_mlp_forward_bx6_save): save[l] (or null) receives layer l's output rows, [M, 128] fp32 — the SELU
+    // activations of a hidden layer, the pre-LayerNorm rows of the last one — so the backward pass recomputes nothing
+    float *save[G4C_MAX_LAYERS];
+    int save_ld;
 };
 
 template <int RT> struct Acc { f32x16 t[RT][4]; };
@@ -1641,7 +1645,7 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
 // twice the rows.
 // FULL: every weighted input block and every additive block is exactly 128 wide and 16-byte aligned (the MP layers):
 // no column masks anywhere.
-template <int RT, bool VEC, bool FULL, int SP>
+template <int RT, bool VEC, bool FULL, int SP, bool SAVE = false>
 __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kernel(const Params p) {
     constexpr int ROWS = 32 * RT, NW = 4;
     constexpr int PLN = ROWS * HB;              // one bf16 operand plane [ROWS][136]
@@ -1940,6 +1944,10 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x[e] = acc[t][4 * gq + e] + b4[e];
                     *reinterpret_cast<f32x4 *>(sH + (i + 32 * t) * HS + fbase + 8 * gq) = x;
+                    if (SAVE) {
+                        const long long gr = row0 + i + 32 * t;
+                        if (p.save[l] && gr < mlim) *reinterpret_cast<f32x4 *>(p.save[l] + gr * p.save_ld + fbase + 8 * gq) = x;
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             __syncthreads();
@@ -1955,7 +1963,12 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = acc[t][4 * gq + e];
                 bf16x4 vh, vm, vl;
-                split3x4<SP>(selu4(x + b4), vh, vm, vl);
+                const f32x4 y = selu4(x + b4);
+                if (SAVE) {
+                    const long long gr = row0 + i + 32 * t;
+                    if (p.save[l] && gr < mlim) *reinterpret_cast<f32x4 *>(p.save[l] + gr * p.save_ld + fbase + 8 * gq) = y;
+                }
+                split3x4<SP>(y, vh, vm, vl);
                 __bf16 *d = sB + (i + 32 * t) * HB + fbase + 8 * gq;
                 *reinterpret_cast<bf16x4 *>(d) = vh;
                 if (SP == 3) {
@@ -2189,6 +2202,11 @@ extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int3
     return rc;
 }
 
+struct SaveArgs {          // training forward (g4c_mlp_forward_bx6_save)
+    float *const *ptr;     // n_layers entries, each may be null
+    int32_t ld;
+};
+
 struct AggArgs {           // fused aggregation (g4c_mlp_forward_bx6_agg); all null / 0 otherwise
     const int32_t *tile_rows, *tile_seg, *seg_off;
     int32_t n_tiles;
@@ -2201,7 +2219,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
                       float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                       const float *resid, int32_t resid_ld, int32_t resid_col0,
                       const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream,
-                      const AggArgs *agg = nullptr);
+                      const AggArgs *agg = nullptr, const SaveArgs *save = nullptr);
 
 extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                     int64_t row_begin, int64_t row_count, int32_t tile_rows,
@@ -2246,6 +2264,15 @@ extern "C" int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp, const g4c_src_t *sr
                       nullptr, 0, nullptr, 0, stream, &a);
 }
 
+extern "C" int g4c_mlp_forward_bx6_save(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                                        float *out, int32_t out_ld, int32_t act, const float *resid, int32_t resid_ld,
+                                        int32_t resid_col0, float *const *save, int32_t save_ld, void *stream) {
+    G4C_REQUIRE(save, G4C_EINVAL, "g4c_mlp_forward_bx6_save: null save list");
+    const SaveArgs sv{save, save_ld};
+    return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3248, out, out_ld, nullptr, act, resid, resid_ld, resid_col0,
+                      nullptr, 0, nullptr, 0, stream, nullptr, &sv);
+}
+
 extern "C" int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                    float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                                    const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream) {
@@ -2258,7 +2285,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
                       float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                       const float *resid, int32_t resid_ld, int32_t resid_col0,
                       const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream,
-                      const AggArgs *agg) {
+                      const AggArgs *agg, const SaveArgs *save) {
     const bool round1 = (tile_rows == 3216);     // operands rounded to bf16: only the leading plane of the stream is used
     const bool bx6 = (tile_rows == 3248) || round1;   // weights: the three-plane stream of g4c_mlp_pack_layer_bx6
     const bool bf16 = bx6;                       // input blocks padded to 128 k
@@ -2350,6 +2377,17 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         p.tile_rows = agg->tile_rows; p.tile_seg = agg->tile_seg; p.seg_off = agg->seg_off;
         p.agg = agg->out; p.agg_ld = agg->out_ld; p.agg_mean = agg->mean;
     }
+    for (int l = 0; l < G4C_MAX_LAYERS; ++l) p.save[l] = nullptr;
+    p.save_ld = 0;
+    if (save) {
+        G4C_REQUIRE(bx6 && !round1 && !agg && !n_heads && !out_idx && save->ptr && save->ld >= NP && (save->ld & 3) == 0, G4C_EUNSUPPORTED,
+                    "g4c_mlp_forward_bx6_save: needs the bf16x6 kernel without heads / aggregation / output index, save_ld >= 128 and a multiple of 4");
+        for (int l = 0; l < mlp->n_layers; ++l) {
+            G4C_REQUIRE(((uintptr_t)save->ptr[l] & 15) == 0, G4C_EINVAL, "g4c_mlp_forward_bx6_save: save[%d] is not 16-byte aligned", l);
+            p.save[l] = save->ptr[l];
+        }
+        p.save_ld = save->ld;
+    }
     p.n_heads = n_heads; p.head_ld = head_ld;
     for (int hd = 0; hd < G4C_MAX_HEADS; ++hd) p.head_out[hd] = hd < n_heads ? head_out[hd] : nullptr;
     if (n_heads) {
@@ -2386,7 +2424,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         for (int a = 0; a < p.n_add; ++a)
             full = full && p.add[a].width == NP && (p.add[a].ld & 3) == 0 && ((uintptr_t)p.add[a].ptr & 15) == 0;
         const dim3 blk(256);
-        const bool rt2 = !agg && row_count >= rt2_rows && p.n_src <= 2 && p.n_add <= 2;      // 64-row tiles (tuning only)
+        const bool rt2 = !agg && !save && row_count >= rt2_rows && p.n_src <= 2 && p.n_add <= 2;      // 64-row tiles (tuning only)
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + (rt2 ? 63 : 31)) / (rt2 ? 64 : 32));
         if (p.n_tiles == 0) return G4C_OK;
         const dim3 grid(p.n_tiles);
@@ -2396,7 +2434,12 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
             else if (all_vec) mlp_bx6_kernel<RT, true, false, SP><<<grid, blk, 0, st>>>(p);            \
             else mlp_bx6_kernel<RT, false, false, SP><<<grid, blk, 0, st>>>(p);                        \
         } while (0)
-        if (round1) { if (rt2) G4C_BX6_LAUNCH(2, 1); else G4C_BX6_LAUNCH(1, 1); }
+        if (save) {
+            if (full) mlp_bx6_kernel<1, true, true, 3, true><<<grid, blk, 0, st>>>(p);
+            else if (all_vec) mlp_bx6_kernel<1, true, false, 3, true><<<grid, blk, 0, st>>>(p);
+            else mlp_bx6_kernel<1, false, false, 3, true><<<grid, blk, 0, st>>>(p);
+        }
+        else if (round1) { if (rt2) G4C_BX6_LAUNCH(2, 1); else G4C_BX6_LAUNCH(1, 1); }
         else { if (rt2) G4C_BX6_LAUNCH(2, 3); else G4C_BX6_LAUNCH(1, 3); }
 #undef G4C_BX6_LAUNCH
     } else if (tile_rows == 644) {

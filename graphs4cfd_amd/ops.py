@@ -400,17 +400,20 @@ def mlp_mode(sources: Sequence[Source], n_rows: int) -> int:
 def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: int = _lib.ACT_NONE,
                 out: Optional[Tensor] = None, out_idx32: Optional[Tensor] = None,
                 resid: Optional[Tensor] = None, resid_col0: int = 0, tile_mode: Optional[int] = None,
-                head_outs: Optional[Sequence[Tensor]] = None, agg: Optional[Tuple[CsrPlan, Tensor, bool]] = None) -> Tensor:
+                head_outs: Optional[Sequence[Tensor]] = None, agg: Optional[Tuple[CsrPlan, Tensor, bool]] = None,
+                save: Optional[Sequence[Optional[Tensor]]] = None) -> Tensor:
     """One fused MLP launch (g4c_mlp_forward).  `tile_mode` (tests / tuning) runs every row through
     g4c_mlp_forward_rows with that kernel variant instead of the library's own choice.
     `head_outs` ([n_rows, 128] tensors, one per head of `packed`): g4c_mlp_forward_heads.
     `agg` = (csr, out [n_seg, 128], mean): also aggregate the output rows over the segments of `csr` (rows must be in segment
     order) — inside the launch when the kernel can (g4c_mlp_forward_bx6_agg), otherwise with a g4c_segment_reduce afterwards.
+    `save` (training forward, bf16x6 only): one [n_rows, 128] fp32 tensor (or None) per layer, receiving that layer's output rows
+    (g4c_mlp_forward_bx6_save).
     With gradients enabled and a differentiable input / parameter, the call is recorded for autograd (autograd.py)."""
     if torch.is_grad_enabled():
         from . import autograd as _ag
         if _ag.wants_grad(packed, sources, resid):
-            if out is not None or out_idx32 is not None or head_outs is not None or agg is not None or tile_mode is not None:
+            if out is not None or out_idx32 is not None or head_outs is not None or agg is not None or tile_mode is not None or save is not None:
                 raise NotImplementedError("out= / heads / fused aggregation are inference-only forms of mlp_forward; "
                                           "call under torch.no_grad() or use the plain form")
             return _ag.mlp(packed, sources, n_rows, act, resid, resid_col0)
@@ -453,6 +456,23 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
         else:
             _timed("mlp_bx6_kernel", packed.flops_per_row * n_rows,
                    4.0 * ((sum(packed.seg_widths) + packed.n_out) * n_rows + packed.n_out * csr.n_seg), call)
+    elif save is not None:
+        if packed.precision != "bf16x6" or head_outs is not None or out_idx32 is not None or tile_mode is not None:
+            raise NotImplementedError("save= needs the bf16x6 kernel without heads / output index / forced tile mode")
+        if len(save) != packed.desc.n_layers:
+            raise ValueError(f"{len(save)} save tensors for {packed.desc.n_layers} layers")
+        live = [t for t in save if t is not None]
+        _lib.require_hip(*live)
+        if any(t.dim() != 2 or t.size(0) < n_rows or t.size(1) < 128 or t.stride(1) != 1 or _ld(t) != _ld(live[0]) for t in live):
+            raise ValueError("save tensors must be [n_rows, >= 128] fp32 with one common leading dimension")
+        sv = (C.c_void_p * len(save))(*[None if t is None else t.data_ptr() for t in save])
+        call = lambda: _lib.check(lib.g4c_mlp_forward_bx6_save(
+            C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out), _ld(out), act, _lib.ptr(resid),
+            _ld(resid) if resid is not None else 0, resid_col0, sv, _ld(live[0]) if live else 128, _lib.stream_handle(dev)))
+        if KernelTimer.active is None:
+            call()
+        else:
+            _timed("mlp_bx6_kernel", packed.flops_per_row * n_rows, 4.0 * (sum(packed.seg_widths) + packed.n_out + 128 * len(live)) * n_rows, call)
     elif packed.precision != "fp32":
         if tile_mode is not None or (head_outs is not None and packed.precision == "bf16"):
             raise NotImplementedError("bf16 MLP with a forced tile mode / plain bf16 with heads")

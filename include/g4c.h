@@ -245,6 +245,14 @@ int g4c_activation_inplace(float *x, int64_t n, int32_t act, void *stream);
 int g4c_copy_cols(const float *src, int32_t src_ld, int32_t scol0, const int32_t *idx,
                   float *dst, int32_t dst_ld, int32_t dcol0, int32_t width, int64_t n_rows, void *stream);
 
+/* g4c_mlp_forward_bx6 for the training forward: in addition to the output, save[l] (l < n_layers; an entry may be NULL) receives
+ * the rows layer l produces — SELU(hidden) for l < n_layers-1, the pre-LayerNorm rows for the last layer — as fp32
+ * [n_rows, 128] (leading dimension save_ld >= 128, multiple of 4; columns past the layer's width are padding).  With them
+ * the backward pass of the block recomputes nothing (autograd.py).  No output index / heads / fused aggregation. */
+int g4c_mlp_forward_bx6_save(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                             float *out, int32_t out_ld, int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0,
+                             float *const *save, int32_t save_ld, void *stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Training path: the backward pass of the fused blocks.  The reference differentiates
  * cat / index / nn.Linear / SELU / LayerNorm / scatter with torch autograd (GNN.fit, nn/model.py:152-301); here the forward

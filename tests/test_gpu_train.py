@@ -82,11 +82,14 @@ def test_segment_reduce_autograd_with_permutation_and_activations():
 
 
 # ------------------------------------------------------------------ one fused MLP with every kind of input block
+@pytest.mark.parametrize("save", [True, False])
 @pytest.mark.parametrize("hoist_min_rows", [0, 1 << 30])
-def test_fused_mlp_gradients_all_source_kinds(hoist_min_rows, monkeypatch):
-    """hoist_min_rows 0: the gathered block is differentiated on its tensor's rows (autograd.py), 1 << 30: as a dense block."""
+def test_fused_mlp_gradients_all_source_kinds(hoist_min_rows, save, monkeypatch):
+    """hoist_min_rows 0: the gathered block is differentiated on its tensor's rows (autograd.py), 1 << 30: as a dense block.
+    save: hidden activations kept by the forward launch (g4c_mlp_forward_bx6_save) / recomputed in the backward pass."""
     from graphs4cfd_amd import autograd as A
     monkeypatch.setattr(A, "HOIST_MIN_ROWS", hoist_min_rows)
+    monkeypatch.setattr(A, "SAVE_ACTIVATIONS", save)
     torch.manual_seed(3)
     M, n_a, n_b, H = 3000, 500, 3000, 128
     mlp = B.MLP(2 + H + H + 3, (H, H, H), True).to(DEV)
@@ -175,9 +178,12 @@ def _model_and_oracle_grads(model_name, levels, nodes, hidden, seed):
     return model, float(loss), float(loss_ref), got, {k: v.grad for k, v in w.items()}
 
 
+@pytest.mark.parametrize("save", [True, False])
 @pytest.mark.parametrize("model_name,levels,hidden", [("NsOneScaleGNN", 1, 128), ("NsThreeScaleGNN", 3, 128), ("NsTwoScaleGNN", 2, 32),
                                                       ("NsFourScaleGNN", 4, 64), ("AdvThreeScaleGNN", 3, 128)])
-def test_model_parameter_gradients_match_oracle_autograd(model_name, levels, hidden):
+def test_model_parameter_gradients_match_oracle_autograd(model_name, levels, hidden, save, monkeypatch):
+    from graphs4cfd_amd import autograd as A
+    monkeypatch.setattr(A, "SAVE_ACTIVATIONS", save)
     model, loss, loss_ref, got, ref = _model_and_oracle_grads(model_name, levels, 2500, hidden, 7)
     assert abs(loss - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref))
     assert set(got) == set(ref)
