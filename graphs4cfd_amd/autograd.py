@@ -140,6 +140,28 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int = _lib.AC
     return ops.mlp_forward(pk, [Source(x, col0=128 * j, width=128) for j in range(blocks)], int(x.size(0)), act)
 
 
+FUSED_CHAIN = __import__("os").environ.get("G4C_TRAIN_FUSED_CHAIN", "1") != "0"
+
+
+def backward_chain(g: Tensor, weights: Sequence[Tensor], acts: Sequence[Tensor], w_dense: Tensor):
+    """Hidden layers of an MLP backward in ONE launch of the fused kernel (g4c_mlp_forward_bx6_save with `mul`):
+        D[l] = (D[l+1] W[l]) * selu'(acts[l])   for l = L-1 .. 1,      gX = D[1] W_dense
+    with g = D[L] [M, 128], W[l] [128, 128], acts[l] the SELU outputs [M, 128], W_dense [128, 128] the first layer's columns of
+    the dense input block.  Returns ({l: D[l]}, gX).  The transposed weights are packed last layer first; every D[l] leaves
+    the launch through `save`, the tile itself goes from layer to layer through LDS — instead of a product launch and an
+    elementwise pass (read, read, write) per layer."""
+    L = len(weights)                                  # weights[l] for l = 0 .. L-1 (weights[0] unused: W_dense replaces it)
+    M, dev = int(g.size(0)), g.device
+    ws = [weights[l].t() for l in range(L - 1, 0, -1)] + [w_dense.t()]
+    pk = ops.PackedMLP(ws, [None] * len(ws), None, [128], [False], precision="bf16x6")
+    pk.params = None
+    D = {l: _buf(M, 128, dev) for l in range(L - 1, 0, -1)}
+    save = [D[l] for l in range(L - 1, 0, -1)] + [None]
+    mul = [acts[l] for l in range(L - 1, 0, -1)] + [None]
+    gx = ops.mlp_forward(pk, [Source(g)], M, _lib.ACT_NONE, save=save, mul=mul)
+    return D, gx
+
+
 WGRAD_KERNEL_MIN_ROWS = 4096
 
 
@@ -323,13 +345,27 @@ class _FusedMLP(torch.autograd.Function):
         # ---- layers, last to second
         dW: List[Optional[Tensor]] = [None] * L
         db: List[Optional[Tensor]] = [None] * L
-        for l in range(L - 1, 0, -1):
+        need_dx_dense = any(needs[1 + j] for j in dense)
+        gX = None
+        chain = (FUSED_CHAIN and ops.mlp_precision() == "bf16x6" and M >= FUSED_LINEAR_MIN_ROWS and kd == 128 and need_dx_dense
+                 and int(g.size(1)) == 128 and all(tuple(W[l].shape) == (128, 128) for l in range(1, L)) and N1 == 128
+                 and all(a is not None and a.stride(1) == 1 for a in acts[1:]))
+        if chain:
+            with _phase("dX chain (one launch)"):
+                D, gX = backward_chain(g if g.is_contiguous() else g.contiguous(), W, acts, W_d)
+            D[L] = g
             with _phase("dW + db"):
-                dW[l], db[l] = weight_bias_grad(g, acts[l])
-            with _phase("dX GEMM"):
-                g = linear(g, W[l].t().contiguous(), None)
-            with _phase("activation adjoint"):
-                g = act_grad(g, acts[l], _lib.ACT_SELU, False, out=g)
+                for l in range(L - 1, 0, -1):
+                    dW[l], db[l] = weight_bias_grad(D[l + 1], acts[l])
+            g = D[1]
+        else:
+            for l in range(L - 1, 0, -1):
+                with _phase("dW + db"):
+                    dW[l], db[l] = weight_bias_grad(g, acts[l])
+                with _phase("dX GEMM"):
+                    g = linear(g, W[l].t().contiguous(), None)
+                with _phase("activation adjoint"):
+                    g = act_grad(g, acts[l], _lib.ACT_SELU, False, out=g)
         # ---- first layer
         dW1 = torch.empty_like(W1)
         d_src: List[Optional[Tensor]] = [None] * n_src
@@ -359,9 +395,10 @@ class _FusedMLP(torch.autograd.Function):
                         d0 += w
                 else:
                     dW1 = dWd
-            if any(needs[1 + j] for j in dense):
-                with _phase("dX GEMM"):
-                    gX = linear(g, W_d.t().contiguous(), None) if kd <= 128 else torch.mm(g, W_d)
+            if need_dx_dense:
+                if gX is None:
+                    with _phase("dX GEMM"):
+                        gX = linear(g, W_d.t().contiguous(), None) if kd <= 128 else torch.mm(g, W_d)
                 with _phase("input adjoint: gather / aggregation"):
                     d0 = 0
                     for j in dense:

@@ -118,6 +118,11 @@ struct Params {
     // activations of a hidden layer, the pre-LayerNorm rows of the last one — so the backward pass recomputes nothing
     float *save[G4C_MAX_LAYERS];
     int save_ld;
+    // backward chain (same entry point): mul[l] (or null) = the SELU OUTPUT rows a hidden layer l's result is multiplied by the
+    // slope of, instead of bias + SELU:  y = x * selu'(.)  — the launch then computes  g_{k-1} = (g_k W_k) * selu'(a_{k-1})  layer
+    // after layer, writing every g through save[]
+    const float *mul[G4C_MAX_LAYERS];
+    int mul_ld;
 };
 
 template <int RT> struct Acc { f32x16 t[RT][4]; };
@@ -1963,7 +1968,16 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = acc[t][4 * gq + e];
                 bf16x4 vh, vm, vl;
-                const f32x4 y = selu4(x + b4);
+                f32x4 y;
+                if (SAVE && p.mul[l]) {
+                    const long long gr = row0 + i + 32 * t;
+                    const f32x4 r = *reinterpret_cast<const f32x4 *>(p.mul[l] + (gr < mlim ? gr : mlim - 1) * p.mul_ld + fbase + 8 * gq);
+                    const float sc = 1.0507009873554804934193349852946f, sa = 1.7580993408473768599402175208123f;   // scale, scale * alpha
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = (x[e] + b4[e]) * (r[e] > 0.f ? sc : r[e] + sa);
+                } else {
+                    y = selu4(x + b4);
+                }
                 if (SAVE) {
                     const long long gr = row0 + i + 32 * t;
                     if (p.save[l] && gr < mlim) *reinterpret_cast<f32x4 *>(p.save[l] + gr * p.save_ld + fbase + 8 * gq) = y;
@@ -2202,9 +2216,11 @@ extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int3
     return rc;
 }
 
-struct SaveArgs {          // training forward (g4c_mlp_forward_bx6_save)
+struct SaveArgs {          // training forward / backward chain (g4c_mlp_forward_bx6_save)
     float *const *ptr;     // n_layers entries, each may be null
     int32_t ld;
+    const float *const *mul;   // null, or n_layers entries, each may be null
+    int32_t mul_ld;
 };
 
 struct AggArgs {           // fused aggregation (g4c_mlp_forward_bx6_agg); all null / 0 otherwise
@@ -2266,9 +2282,10 @@ extern "C" int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp, const g4c_src_t *sr
 
 extern "C" int g4c_mlp_forward_bx6_save(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                         float *out, int32_t out_ld, int32_t act, const float *resid, int32_t resid_ld,
-                                        int32_t resid_col0, float *const *save, int32_t save_ld, void *stream) {
+                                        int32_t resid_col0, float *const *save, int32_t save_ld, const float *const *mul,
+                                        int32_t mul_ld, void *stream) {
     G4C_REQUIRE(save, G4C_EINVAL, "g4c_mlp_forward_bx6_save: null save list");
-    const SaveArgs sv{save, save_ld};
+    const SaveArgs sv{save, save_ld, mul, mul_ld};
     return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3248, out, out_ld, nullptr, act, resid, resid_ld, resid_col0,
                       nullptr, 0, nullptr, 0, stream, nullptr, &sv);
 }
@@ -2377,8 +2394,8 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         p.tile_rows = agg->tile_rows; p.tile_seg = agg->tile_seg; p.seg_off = agg->seg_off;
         p.agg = agg->out; p.agg_ld = agg->out_ld; p.agg_mean = agg->mean;
     }
-    for (int l = 0; l < G4C_MAX_LAYERS; ++l) p.save[l] = nullptr;
-    p.save_ld = 0;
+    for (int l = 0; l < G4C_MAX_LAYERS; ++l) { p.save[l] = nullptr; p.mul[l] = nullptr; }
+    p.save_ld = 0; p.mul_ld = 0;
     if (save) {
         G4C_REQUIRE(bx6 && !round1 && !agg && !n_heads && !out_idx && save->ptr && save->ld >= NP && (save->ld & 3) == 0, G4C_EUNSUPPORTED,
                     "g4c_mlp_forward_bx6_save: needs the bf16x6 kernel without heads / aggregation / output index, save_ld >= 128 and a multiple of 4");
@@ -2387,6 +2404,14 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
             p.save[l] = save->ptr[l];
         }
         p.save_ld = save->ld;
+        if (save->mul) {
+            G4C_REQUIRE(save->mul_ld >= NP && (save->mul_ld & 3) == 0, G4C_EINVAL, "g4c_mlp_forward_bx6_save: mul_ld=%d", save->mul_ld);
+            for (int l = 0; l + 1 < mlp->n_layers; ++l) {
+                G4C_REQUIRE(((uintptr_t)save->mul[l] & 15) == 0, G4C_EINVAL, "g4c_mlp_forward_bx6_save: mul[%d] is not 16-byte aligned", l);
+                p.mul[l] = save->mul[l];
+            }
+            p.mul_ld = save->mul_ld;
+        }
     }
     p.n_heads = n_heads; p.head_ld = head_ld;
     for (int hd = 0; hd < G4C_MAX_HEADS; ++hd) p.head_out[hd] = hd < n_heads ? head_out[hd] : nullptr;

@@ -401,14 +401,15 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                 out: Optional[Tensor] = None, out_idx32: Optional[Tensor] = None,
                 resid: Optional[Tensor] = None, resid_col0: int = 0, tile_mode: Optional[int] = None,
                 head_outs: Optional[Sequence[Tensor]] = None, agg: Optional[Tuple[CsrPlan, Tensor, bool]] = None,
-                save: Optional[Sequence[Optional[Tensor]]] = None) -> Tensor:
+                save: Optional[Sequence[Optional[Tensor]]] = None, mul: Optional[Sequence[Optional[Tensor]]] = None) -> Tensor:
     """One fused MLP launch (g4c_mlp_forward).  `tile_mode` (tests / tuning) runs every row through
     g4c_mlp_forward_rows with that kernel variant instead of the library's own choice.
     `head_outs` ([n_rows, 128] tensors, one per head of `packed`): g4c_mlp_forward_heads.
     `agg` = (csr, out [n_seg, 128], mean): also aggregate the output rows over the segments of `csr` (rows must be in segment
     order) — inside the launch when the kernel can (g4c_mlp_forward_bx6_agg), otherwise with a g4c_segment_reduce afterwards.
     `save` (training forward, bf16x6 only): one [n_rows, 128] fp32 tensor (or None) per layer, receiving that layer's output rows
-    (g4c_mlp_forward_bx6_save).
+    (g4c_mlp_forward_bx6_save); `mul` (with `save`): per hidden layer the SELU-output rows whose slope multiplies that layer's
+    result instead of bias + SELU (the backward chain of a block, see include/g4c.h).
     With gradients enabled and a differentiable input / parameter, the call is recorded for autograd (autograd.py)."""
     if torch.is_grad_enabled():
         from . import autograd as _ag
@@ -466,9 +467,17 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
         if any(t.dim() != 2 or t.size(0) < n_rows or t.size(1) < 128 or t.stride(1) != 1 or _ld(t) != _ld(live[0]) for t in live):
             raise ValueError("save tensors must be [n_rows, >= 128] fp32 with one common leading dimension")
         sv = (C.c_void_p * len(save))(*[None if t is None else t.data_ptr() for t in save])
+        ml, ml_ld = None, 0
+        if mul is not None:
+            lm = [t for t in mul if t is not None]
+            _lib.require_hip(*lm)
+            if len(mul) != len(save) or any(t.size(0) < n_rows or t.size(1) < 128 or t.stride(1) != 1 or _ld(t) != _ld(lm[0]) for t in lm):
+                raise ValueError("mul tensors must be [n_rows, >= 128] fp32 with one common leading dimension, one entry per layer")
+            ml = (C.c_void_p * len(mul))(*[None if t is None else t.data_ptr() for t in mul])
+            ml_ld = _ld(lm[0]) if lm else 128
         call = lambda: _lib.check(lib.g4c_mlp_forward_bx6_save(
             C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out), _ld(out), act, _lib.ptr(resid),
-            _ld(resid) if resid is not None else 0, resid_col0, sv, _ld(live[0]) if live else 128, _lib.stream_handle(dev)))
+            _ld(resid) if resid is not None else 0, resid_col0, sv, _ld(live[0]) if live else 128, ml, ml_ld, _lib.stream_handle(dev)))
         if KernelTimer.active is None:
             call()
         else:

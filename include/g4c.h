@@ -248,10 +248,15 @@ int g4c_copy_cols(const float *src, int32_t src_ld, int32_t scol0, const int32_t
 /* g4c_mlp_forward_bx6 for the training forward: in addition to the output, save[l] (l < n_layers; an entry may be NULL) receives
  * the rows layer l produces — SELU(hidden) for l < n_layers-1, the pre-LayerNorm rows for the last layer — as fp32
  * [n_rows, 128] (leading dimension save_ld >= 128, multiple of 4; columns past the layer's width are padding).  With them
- * the backward pass of the block recomputes nothing (autograd.py).  No output index / heads / fused aggregation. */
+ * the backward pass of the block recomputes nothing (autograd.py).  No output index / heads / fused aggregation.
+ * `mul` (NULL for the forward): the same launch as the BACKWARD chain of a block.  With mul[l] != NULL, hidden layer l's result
+ * is multiplied by the SELU slope of the rows mul[l] holds (SELU outputs, [n_rows, 128], leading dimension mul_ld) instead of
+ * bias + SELU.  Packing the transposed weights last layer first (zero biases) and passing the kept activations as `mul` gives
+ *   g_{k-1} = (g_k W_k) * selu'(a_{k-1})   for every hidden layer, each g written through save[], and the input gradient as
+ * the launch's output — one launch instead of a product + an elementwise pass per layer. */
 int g4c_mlp_forward_bx6_save(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                              float *out, int32_t out_ld, int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0,
-                             float *const *save, int32_t save_ld, void *stream);
+                             float *const *save, int32_t save_ld, const float *const *mul, int32_t mul_ld, void *stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Training path: the backward pass of the fused blocks.  The reference differentiates

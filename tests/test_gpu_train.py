@@ -184,6 +184,9 @@ def _model_and_oracle_grads(model_name, levels, nodes, hidden, seed):
 def test_model_parameter_gradients_match_oracle_autograd(model_name, levels, hidden, save, monkeypatch):
     from graphs4cfd_amd import autograd as A
     monkeypatch.setattr(A, "SAVE_ACTIVATIONS", save)
+    if save:       # also the large-launch forms at this small size: single-layer products and the one-launch backward chain
+        monkeypatch.setattr(A, "FUSED_LINEAR_MIN_ROWS", 0)
+        monkeypatch.setattr(A, "HOIST_MIN_ROWS", 0)
     model, loss, loss_ref, got, ref = _model_and_oracle_grads(model_name, levels, 2500, hidden, 7)
     assert abs(loss - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref))
     assert set(got) == set(ref)
