@@ -250,6 +250,7 @@ class _FusedMLP(torch.autograd.Function):
     def backward(ctx, dy: Tensor):
         spec: _Spec = ctx.spec
         y, *tensors = ctx.saved_tensors
+        ops.bump_weights_epoch()          # a training step is under way: packed weight images are stale after it
         n_src, L = len(spec.meta), spec.n_layers
         src_t = tensors[:n_src]
         pos = n_src

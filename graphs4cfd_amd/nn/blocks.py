@@ -79,7 +79,7 @@ class MLP(nn.Module):
         return [m for m in self.MLP if isinstance(m, nn.Linear)]
 
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (ops.weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def packed(self, seg_widths: Sequence[int], seg_negate: Sequence[bool], narrow: Optional[Sequence[bool]] = None) -> ops.PackedMLP:
         prec = ops.effective_precision(seg_widths)

@@ -227,6 +227,22 @@ FUSE_AGG = os.environ.get("G4C_FUSE_AGG", "0") == "1"
 AGG_ON_LOAD = os.environ.get("G4C_AGG_ON_LOAD", "1") == "1"
 
 
+_weights_epoch = 0
+
+
+def weights_epoch() -> int:
+    """Counter folded into the validity key of every packed-weight image (nn/blocks.py MLP._signature).  The key otherwise
+    relies on the parameters' version counters, which in-place updates that bypass autograd's bookkeeping do not advance —
+    torch's own `fused=True` optimizers among them (measured: `Adam(fused=True).step()` leaves `p._version` unchanged).  Every
+    backward pass through a fused MLP advances the epoch, so the forward after a training step always repacks."""
+    return _weights_epoch
+
+
+def bump_weights_epoch() -> None:
+    global _weights_epoch
+    _weights_epoch += 1
+
+
 def grad_mode() -> bool:
     """True when calls are being recorded for autograd: the block / model code then keeps to the plain forms of the
     launches (no heads, no pre-multiplied products, no in-place epilogues), which are the differentiable ones."""

@@ -23,7 +23,7 @@ torch.manual_seed(0)
 model = getattr(gfd.nn, a.model)(arch=S.mus_arch(a.model, 128), device=dev)
 g = g_cpu.clone().to(dev)
 crit = gfd.nn.GraphLoss(lambda_d=0.25)
-opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)        # (as GNN.fit does on the GPU)
 model.train()
 
 

@@ -365,3 +365,24 @@ def test_plans_use_registered_host_images_and_drop_stale_ones():
     plan.clear_caches()
     ep2, csr2 = plan.edge_csr(gd.edge_index, 900)          # falls back to reading the device tensor
     assert torch.equal(csr2.off, ref.off)
+
+
+def test_packed_weights_follow_an_optimizer_that_does_not_bump_versions():
+    """torch's fused optimizers update parameters without advancing their version counters; the packed-weight cache must not
+    serve the old image afterwards (ops.weights_epoch)."""
+    g = S.mus_graph(1200, levels=1, seed=41).to(DEV)
+    torch.manual_seed(42)
+    model = gfd.nn.NsOneScaleGNN(arch=S.mus_arch("NsOneScaleGNN", 32), device=DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=True)
+    target = torch.randn(1200, 3, device=DEV)
+    for _ in range(2):
+        F.mse_loss(model.forward(g), target).backward()
+        v0 = next(model.parameters())._version
+        opt.step(); opt.zero_grad()
+    with torch.no_grad():
+        got = model.forward(g)
+    w = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    gc = S.mus_graph(1200, levels=1, seed=41)
+    with torch.no_grad():
+        ref = O.mus_forward("NsOneScaleGNN", gc.to_dict(), w, 3)
+    torch.testing.assert_close(got.cpu(), ref, rtol=5e-4, atol=5e-4)
