@@ -1,19 +1,23 @@
-"""Training path: autograd for the fused blocks.
+"""Training path: autograd for the fused blocks (design and measurements in DESIGN.md §7).
 
 The reference trains through torch autograd over `cat` / index / `nn.Linear` / SELU / LayerNorm / `scatter`
 (GNN.fit, nn/model.py:152-301; blocks nn/blocks.py:117-290), keeping every intermediate of every block alive between
 the passes (per MP layer at 100k nodes: the [E, 3H] concatenation, three [E, H] hidden tensors, ...).
 
-Here the forward of a block stays ONE fused launch (g4c_mlp_forward / g4c_segment_reduce) and only the block's inputs
-and output are kept.  The backward of a block
+Here the forward of a block stays ONE fused launch, recorded by a `torch.autograd.Function`:
 
-  * rebuilds its concatenated input with g4c_train_gather and its hidden activations with rocBLAS GEMMs (plain library
-    GEMMs) + g4c_activation_inplace,
-  * runs LayerNorm / activation adjoints in train_ops.hip (g4c_layernorm_grad, g4c_act_grad), bias gradients with
-    g4c_colsum, weight / input gradients with rocBLAS,
-  * sends the input gradient back through the gathers as deterministic segmented sums on the CSR plan of the gather index
-    (g4c_segment_reduce — the adjoint of an index gather is the scatter the reference's autograd does with atomics), and
-    through aggregations with g4c_segment_broadcast.
+  * forward: g4c_mlp_forward_bx6_save — the fused kernel also writes each layer's output rows (SELU(hidden), pre-LayerNorm
+    rows), so the backward recomputes no product (SAVE_ACTIVATIONS; `G4C_TRAIN_SAVE=0` keeps only block inputs / outputs and
+    re-forms the hidden layers in the backward with single-layer launches of the same kernel);
+  * weight + bias gradients of the 128-wide layers: g4c_weight_grad (one pass over dZ and A, fp32 MFMA, partial tiles added in a
+    fixed order); other widths: a split-row strided-batched rocBLAS GEMM + g4c_colsum;
+  * hidden layers of an edge MLP's backward: one launch of the fused kernel with a multiplicative SELU-slope epilogue
+    (`backward_chain`); other input-gradient products: single-layer launches (`linear`), rocBLAS below 64k rows;
+  * the first layer of a block gathered through an index is differentiated on the gathered tensor's rows (the adjoint of the
+    inference path's hoisting): segmented sums of dZ by the index, then node-sized products;
+  * LayerNorm / activation adjoints, input columns, bias sums: train_ops.hip (g4c_layernorm_grad, g4c_act_grad,
+    g4c_train_gather, g4c_colsum); the adjoint of an index gather is g4c_segment_reduce on the CSR plan of the index (the
+    reference's autograd does this scatter with atomics), of an aggregation g4c_segment_broadcast.
 
 No atomics anywhere: two runs of a training step produce bit-identical gradients.
 """
@@ -115,7 +119,7 @@ def segment_broadcast(dout: Tensor, csr, mean: bool, n_src_rows: int) -> Tensor:
 
 
 # keep the hidden activations of every fused MLP from the forward launch (g4c_mlp_forward_bx6_save) instead of recomputing them
-# in the backward pass: ~3 x [rows, 128] fp32 more per MLP between the passes (100k nodes, 3-scale: 7 -> 17 GB), no recompute
+# in the backward pass: ~3 x [rows, 128] fp32 more per MLP between the passes (100k nodes, 3-scale: 7.3 -> 27.5 GB peak), no recompute
 # GEMMs.  G4C_TRAIN_SAVE=0: the memory-light recompute path.
 SAVE_ACTIVATIONS = __import__("os").environ.get("G4C_TRAIN_SAVE", "1") != "0"
 FUSED_LINEAR = __import__("os").environ.get("G4C_TRAIN_FUSED_LINEAR", "1") != "0"

@@ -1,7 +1,8 @@
 // Backward-pass kernels of the training path (gfx950).  All HBM-bound: one pass over their operands, coalesced rows,
 // deterministic reductions (no atomics), so two runs of a training step give bit-identical gradients.
-// The dense contractions of the backward pass (dW = dZ^T A, dA = dZ W) are plain GEMMs and go to rocBLAS from the host
-// side (graphs4cfd_amd/autograd.py); everything around them is here.
+// The weight / bias gradients of the 128-wide layers are weight_grad_kernel below (MFMA, one pass over both operands); the
+// input-gradient products run as launches of the fused-MLP kernel (mlp_fused.hip), rocBLAS only for shapes outside that
+// envelope (graphs4cfd_amd/autograd.py); everything around them is here.
 //
 // Reference being differentiated: graphs4cfd/nn/blocks.py:117-144 (MLP), :175-186 (GNBlock), :219-237 (DownMP),
 // :265-290 (UpMP); the reference relies on torch autograd over cat / index / Linear / SELU / LayerNorm / scatter.
