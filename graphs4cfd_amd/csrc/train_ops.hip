@@ -192,80 +192,90 @@ __global__ __launch_bounds__(256) void colsum_stage_kernel(const float *__restri
 constexpr int WG_N = 128, WG_SLAB = 32;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256, 2) void weight_grad_kernel(const float *__restrict__ g, int g_ld, const float *__restrict__ a,
-                                                             int a_ld, long long n_rows, long long chunk,
-                                                             float *__restrict__ partial, int with_bias) {
+// Eight waves per workgroup: wave = (32-row block of n, half of k), so a wave holds 2 x 16 accumulators and the 512 threads
+// stage a slab with two 16-byte loads per operand each — few enough registers to keep TWO slabs in flight (the global loads
+// of slab s+2 are issued before the MFMAs of slab s), which one slab of look-ahead (1.7 us of MFMA work) did not cover.
+constexpr int WG_THREADS = 512;
+__global__ __launch_bounds__(WG_THREADS, 2) void weight_grad_kernel(const float *__restrict__ g, int g_ld, const float *__restrict__ a,
+                                                                    int a_ld, long long n_rows, long long chunk,
+                                                                    float *__restrict__ partial, int with_bias) {
     __shared__ __attribute__((aligned(16))) float sG[WG_SLAB * WG_N];
     __shared__ __attribute__((aligned(16))) float sA[WG_SLAB * WG_N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = wave & 3, kh = wave >> 2;
     const int i = lane & 31, h = lane >> 5;
     const long long r0 = (long long)blockIdx.x * chunk;
     const long long r1 = r0 + chunk < n_rows ? r0 + chunk : n_rows;
-    const int c4 = (tid & 31) * 4, rr = tid >> 5;               // this thread's 4 columns / first row inside a slab (rows rr + 8 it)
-    f32x16 acc[4];
+    const int c4 = (tid & 31) * 4, rr = tid >> 5;               // this thread's 4 columns / first row inside a slab (rows rr, rr + 16)
+    f32x16 acc[2];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[kb][j] = 0.f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    f32x4 pg[4], pa[4];
-    auto fetch = [&](long long m0) __attribute__((always_inline)) {
+    f32x4 pg[2][2], pa[2][2];                                   // [slab parity][row of the pair]
+    auto fetch = [&](int q, long long m0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const long long r = m0 + rr + 8 * it;
+        for (int it = 0; it < 2; ++it) {
+            const long long r = m0 + rr + 16 * it;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            pg[it] = r < r1 ? *reinterpret_cast<const f32x4 *>(g + r * g_ld + c4) : z;
-            pa[it] = r < r1 ? *reinterpret_cast<const f32x4 *>(a + r * a_ld + c4) : z;
+            pg[q][it] = r < r1 ? *reinterpret_cast<const f32x4 *>(g + r * g_ld + c4) : z;
+            pa[q][it] = r < r1 ? *reinterpret_cast<const f32x4 *>(a + r * a_ld + c4) : z;
         }
     };
-    if (r0 < r1) fetch(r0);
-    for (long long m0 = r0; m0 < r1; m0 += WG_SLAB) {
+    auto slab = [&](int q, long long m0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            *reinterpret_cast<f32x4 *>(sG + (rr + 8 * it) * WG_N + c4) = pg[it];
-            *reinterpret_cast<f32x4 *>(sA + (rr + 8 * it) * WG_N + c4) = pa[it];
-            bsum += pg[it];
+        for (int it = 0; it < 2; ++it) {
+            *reinterpret_cast<f32x4 *>(sG + (rr + 16 * it) * WG_N + c4) = pg[q][it];
+            *reinterpret_cast<f32x4 *>(sA + (rr + 16 * it) * WG_N + c4) = pa[q][it];
+            bsum += pg[q][it];
         }
         __syncthreads();
-        if (m0 + WG_SLAB < r1) fetch(m0 + WG_SLAB);           // in flight during this slab's MFMAs
+        if (m0 + 2 * WG_SLAB < r1) fetch(q, m0 + 2 * WG_SLAB);   // two slabs ahead
         // operands of step s+1 are read from LDS before the MFMAs of step s are issued (LDS latency under the matrix pipe)
-        const float *pG = sG + h * WG_N + wave * 32 + i, *pA = sA + h * WG_N + i;
-        float av = pG[0], bv[4];
+        const float *pG = sG + h * WG_N + nb * 32 + i, *pA = sA + h * WG_N + kh * 64 + i;
+        float av = pG[0], bv[2];
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) bv[kb] = pA[kb * 32];
+        for (int kb = 0; kb < 2; ++kb) bv[kb] = pA[kb * 32];
 #pragma unroll
         for (int s = 0; s < WG_SLAB / 2; ++s) {
-            float av_n = 0.f, bv_n[4] = {0.f, 0.f, 0.f, 0.f};
+            float av_n = 0.f, bv_n[2] = {0.f, 0.f};
             if (s + 1 < WG_SLAB / 2) {
                 av_n = pG[(2 * s + 2) * WG_N];
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) bv_n[kb] = pA[(2 * s + 2) * WG_N + kb * 32];
+                for (int kb = 0; kb < 2; ++kb) bv_n[kb] = pA[(2 * s + 2) * WG_N + kb * 32];
             }
             __builtin_amdgcn_sched_barrier(0);        // (the scheduler otherwise sinks these reads to just before their use)
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[kb], acc[kb], 0, 0, 0);
+            for (int kb = 0; kb < 2; ++kb) acc[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[kb], acc[kb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             av = av_n;
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) bv[kb] = bv_n[kb];
+            for (int kb = 0; kb < 2; ++kb) bv[kb] = bv_n[kb];
         }
         __syncthreads();
+    };
+    if (r0 < r1) fetch(0, r0);
+    if (r0 + WG_SLAB < r1) fetch(1, r0 + WG_SLAB);
+    for (long long m0 = r0; m0 < r1; m0 += 2 * WG_SLAB) {
+        slab(0, m0);
+        if (m0 + WG_SLAB < r1) slab(1, m0 + WG_SLAB);
     }
     float *out = partial + (long long)blockIdx.x * (WG_N * WG_N + WG_N);
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int n = wave * 32 + 4 * h + 8 * (j >> 2) + (j & 3);
-            out[n * WG_N + kb * 32 + i] = acc[kb][j];
+            const int n = nb * 32 + 4 * h + 8 * (j >> 2) + (j & 3);
+            out[n * WG_N + kh * 64 + kb * 32 + i] = acc[kb][j];
         }
-    if (with_bias) {                                            // column sums of g: the eight threads sharing c4, in order
+    if (with_bias) {                                            // column sums of g: the sixteen threads sharing c4, in order
         *reinterpret_cast<f32x4 *>(sG + rr * WG_N + c4) = bsum;
         __syncthreads();
         if (tid < WG_N) {
             float t = sG[tid];
 #pragma unroll
-            for (int q = 1; q < 8; ++q) t += sG[q * WG_N + tid];
+            for (int q = 1; q < 16; ++q) t += sG[q * WG_N + tid];
             out[WG_N * WG_N + tid] = t;
         }
     }
@@ -370,11 +380,14 @@ extern "C" int g4c_segment_broadcast(const float *dout, int32_t dout_ld, const i
     return g4c::check_launch("g4c_segment_broadcast");
 }
 
+static inline int wg_stage2_rows(int G) { return (G + 15) / 16; }
+
 extern "C" int32_t g4c_weight_grad_partials(int64_t n_rows) {
     const long long slabs = (n_rows + WG_SLAB - 1) / WG_SLAB;
     const long long want = slabs / 6;
-    // at most one resident round: 256 CUs x 3 workgroups (156 registers per lane) — a second, partly filled round would idle CUs
-    return (int32_t)(want < 1 ? 1 : (want > 768 ? 768 : want));
+    // at most one resident round: 256 CUs x 2 workgroups of 8 waves (127 registers per lane) — a second, partly filled round
+    // would idle CUs
+    return (int32_t)(want < 1 ? 1 : (want > 512 ? 512 : want));
 }
 
 extern "C" int g4c_weight_grad(const float *g, int32_t g_ld, const float *a, int32_t a_ld, int64_t n_rows, float *scratch,
@@ -387,11 +400,11 @@ extern "C" int g4c_weight_grad(const float *g, int32_t g_ld, const float *a, int
     const long long slabs = (n_rows + WG_SLAB - 1) / WG_SLAB;
     const long long chunk = ((slabs + G - 1) / G) * WG_SLAB;
     hipStream_t st = (hipStream_t)stream;
-    weight_grad_kernel<<<dim3(G), dim3(256), 0, st>>>(g, g_ld, a, a_ld, n_rows, chunk > 0 ? chunk : WG_SLAB, scratch, with_bias);
+    weight_grad_kernel<<<dim3(G), dim3(WG_THREADS), 0, st>>>(g, g_ld, a, a_ld, n_rows, chunk > 0 ? chunk : WG_SLAB, scratch, with_bias);
     // fixed-order sum of the partial tiles ([dW | db] is contiguous in every partial row)
     const int width = WG_N * WG_N + (with_bias ? WG_N : 0), ld = WG_N * WG_N + WG_N;
     float *scratch2 = scratch + (long long)G * ld;
-    const int g2 = g4c_colsum_partials(G);
+    const int g2 = wg_stage2_rows(G);          // 16 partial tiles per first-stage workgroup: both stages are short
     const long long chunk2 = (G + g2 - 1) / g2;
     const unsigned cb = (unsigned)((width + 255) / 256);
     colsum_stage_kernel<<<dim3(g2, cb), dim3(256), 0, st>>>(scratch, ld, width, G, chunk2 > 0 ? chunk2 : 1, scratch2, ld);
@@ -402,5 +415,5 @@ extern "C" int g4c_weight_grad(const float *g, int32_t g_ld, const float *a, int
 extern "C" int64_t g4c_weight_grad_scratch_floats(int64_t n_rows) {
     const long long ld = WG_N * WG_N + WG_N;
     const long long G = g4c_weight_grad_partials(n_rows);
-    return (G + g4c_colsum_partials(G)) * ld;
+    return (G + wg_stage2_rows((int)G)) * ld;
 }
