@@ -10,17 +10,23 @@ from graphs4cfd_amd import synthetic as S
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--nodes", type=int, default=100_000)
-ap.add_argument("--model", default="NsThreeScaleGNN")
+ap.add_argument("--model", default="NsThreeScaleGNN", help="a MuS-GNN class, NsThreeGuillardScaleGNN (gMuS) or NsRotEquiTreeScaleGNN (REMuS)")
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--cpu-steps", type=int, default=1)
 ap.add_argument("--phases", action="store_true", help="HIP-event time per phase of the backward pass (one extra step)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
-levels = {"NsOneScaleGNN": 1, "NsTwoScaleGNN": 2, "NsThreeScaleGNN": 3, "NsFourScaleGNN": 4}[a.model]
-g_cpu = S.mus_graph(a.nodes, levels=levels, seed=0)
-g_cpu.target = torch.randn(a.nodes, 3)
+nf = 3
+if a.model == "NsRotEquiTreeScaleGNN":
+    g_cpu, arch, nf = S.remus_graph(a.nodes, k=5, seed=0), S.remus_arch(128), 2
+elif "Guillard" in a.model:
+    g_cpu, arch = S.mugs_graph(a.nodes, levels={"Two": 2, "Three": 3, "Four": 4}[a.model[2:].split("Guillard")[0]], seed=0), S.mugs_arch(a.model, 128)
+else:
+    levels = {"NsOneScaleGNN": 1, "NsTwoScaleGNN": 2, "NsThreeScaleGNN": 3, "NsFourScaleGNN": 4}[a.model]
+    g_cpu, arch = S.mus_graph(a.nodes, levels=levels, seed=0), S.mus_arch(a.model, 128)
+g_cpu.target = torch.randn(a.nodes, nf)
 torch.manual_seed(0)
-model = getattr(gfd.nn, a.model)(arch=S.mus_arch(a.model, 128), device=dev)
+model = getattr(gfd.nn, a.model)(arch=arch, device=dev)
 g = g_cpu.clone().to(dev)
 crit = gfd.nn.GraphLoss(lambda_d=0.25)
 opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)        # (as GNN.fit does on the GPU)
@@ -48,9 +54,11 @@ dt = (time.perf_counter() - t0) / a.steps
 # forward only (same launches, recorded for autograd) and inference forward for scale
 t0 = time.perf_counter()
 for _ in range(a.steps):
+    pred = None                      # (release the previous graph and the activations it keeps before building the next)
     pred = model.forward(g, 0)
 torch.cuda.synchronize()
 fwd = (time.perf_counter() - t0) / a.steps
+pred = None
 with torch.no_grad():
     model.forward(g, 0)
     torch.cuda.synchronize()
@@ -81,8 +89,10 @@ if a.cpu_steps > 0:
     threads = min(16, os.cpu_count())          # (more threads are slower and erratic on the 2-socket host: profiles/r01_cpu_thread_sweep.log)
     torch.set_num_threads(threads)
     t0 = time.perf_counter()
+    fwd = (lambda: O.remus_forward(gd, w)) if a.model == "NsRotEquiTreeScaleGNN" else \
+          (lambda: O.mugs_forward(a.model, gd, w, 3)) if "Guillard" in a.model else (lambda: O.mus_forward(a.model, gd, w, 3))
     for _ in range(a.cpu_steps):
-        closs = O.graph_loss(gd, O.mus_forward(a.model, gd, w, 3), gd["target"], 0.25)
+        closs = O.graph_loss(gd, fwd(), gd["target"], 0.25)
         closs.backward()
         copt.step()
         copt.zero_grad()
