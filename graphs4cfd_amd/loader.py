@@ -31,13 +31,20 @@ class Collater(object):
                 setattr(graph, f"angle_index{s}", getattr(graph, f"angle_index{s}") + shift)
                 nxt, prv = f"angle_index{lvl}{lvl + 1}", f"angle_index{lvl - 1}{lvl}"
                 if hasattr(elem, nxt):
-                    getattr(graph, nxt)[0] += shift
+                    t = getattr(graph, nxt).clone()
+                    t[0] += shift
+                    setattr(graph, nxt, t)
                 if lvl > 1 and hasattr(elem, prv):
-                    getattr(graph, prv)[1] += shift
+                    t = getattr(graph, prv).clone()
+                    t[1] += shift
+                    setattr(graph, prv, t)
                 num_nodes += graph.num_nodes
                 num_edges += int(getattr(graph, f"edge_index{s}").size(1))
 
     def collate(self, batch: List[Graph]):
+        # (shallow copies: the reference shifts the angle indices of the dataset's own graphs in place, loader.py:23-55, which
+        # compounds from epoch to epoch when the dataset holds its graphs in memory)
+        batch = [Graph(**{k: v for k, v in g.__dict__.items()}) for g in batch]
         self._fix_angle_indices(batch)
         out = collate(list(batch))
         return out if self.transform is None else self.transform(out)

@@ -129,15 +129,29 @@ class BuildKnnInterpWeights:
         self.k = k
 
     def __call__(self, graph: Graph) -> Graph:
-        if getattr(graph, "batch", None) is not None and int(graph.batch.max()) > 0:
-            raise NotImplementedError("batched graphs (solve() takes one fixed mesh)")
+        """On a collated batch (the reference applies this transform to the batch, examples/training/NsREMuSGNN/*.py:39-41, with
+        `knn(..., batch_x, batch_y)`): neighbours are searched inside each graph; the indices address the batch's compact
+        level-l / level-(l-1) node lists."""
+        batch = getattr(graph, "batch", None)
+        n_graphs = int(batch.max()) + 1 if batch is not None and batch.numel() else 1
         prev = None
         for l in (2, 3, 4):
             if not hasattr(graph, f"coarse_mask{l}"):
                 break
             cm = getattr(graph, f"coarse_mask{l}")
-            pos_f = graph.pos if prev is None else graph.pos[prev]
-            y, x, w = S.knn_interp_weights(graph.pos[cm], pos_f, self.k)
+            pos_c, pos_f = graph.pos[cm], (graph.pos if prev is None else graph.pos[prev])
+            if n_graphs == 1:
+                y, x, w = S.knn_interp_weights(pos_c, pos_f, self.k)
+            else:
+                b_c, b_f = batch[cm], (batch if prev is None else batch[prev])
+                ys, xs, ws = [], [], []
+                for b in range(n_graphs):
+                    ic, jf = (b_c == b).nonzero().reshape(-1), (b_f == b).nonzero().reshape(-1)
+                    if not (int(ic[-1]) - int(ic[0]) + 1 == ic.numel() and int(jf[-1]) - int(jf[0]) + 1 == jf.numel()):
+                        raise ValueError("the nodes of every graph must be contiguous in the batch (Collater output)")
+                    yb, xb, wb = S.knn_interp_weights(pos_c[ic], pos_f[jf], self.k)
+                    ys.append(yb + int(jf[0])); xs.append(xb + int(ic[0])); ws.append(wb)
+                y, x, w = torch.cat(ys), torch.cat(xs), torch.cat(ws)
             setattr(graph, f"y_idx_{l}{l - 1}", y); setattr(graph, f"x_idx_{l}{l - 1}", x); setattr(graph, f"weights_{l}{l - 1}", w)
             prev = cm
         return graph

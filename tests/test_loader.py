@@ -1,0 +1,69 @@
+"""gfd.DataLoader / Collater (reference: graphs4cfd/loader.py:7-75): batches of Graphs, REMuS angle-index correction."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import graphs4cfd_amd as gfd                       # noqa: E402
+from graphs4cfd_amd import synthetic as S          # noqa: E402
+
+
+def test_collater_offsets_node_and_edge_indexed_attributes():
+    """loader.py:17-55: `edge_index*` address nodes (offset by the running node count); `angle_index{l}` address the edges of level l
+    and `angle_index{l}{l+1}` the edges of level l (row) / l+1 (col): offset by the running EDGE counts of those levels."""
+    graphs = [S.remus_graph(220 + 30 * i, k=5, seed=70 + i) for i in range(3)]
+    keep = [g.clone() for g in graphs]
+    batch = gfd.Collater()(graphs)
+    for g, k in zip(graphs, keep):                      # the inputs are left alone (a dataset held in memory is collated every epoch)
+        assert all(torch.equal(getattr(g, a), getattr(k, a)) for a in ("angle_index", "angle_index2", "angle_index12", "angle_index23"))
+    assert torch.equal(gfd.Collater()(graphs).angle_index12, batch.angle_index12)
+    n_off = e1 = e2 = e3 = 0
+    pieces = {k: [] for k in ("edge_index", "edge_index2", "angle_index", "angle_index2", "angle_index3", "angle_index12", "angle_index23")}
+    for g in keep:
+        pieces["edge_index"].append(g.edge_index + n_off)
+        pieces["edge_index2"].append(g.edge_index2 + n_off)
+        pieces["angle_index"].append(g.angle_index + e1)
+        pieces["angle_index2"].append(g.angle_index2 + e2)
+        pieces["angle_index3"].append(g.angle_index3 + e3)
+        pieces["angle_index12"].append(g.angle_index12 + torch.tensor([[e1], [e2]]))
+        pieces["angle_index23"].append(g.angle_index23 + torch.tensor([[e2], [e3]]))
+        n_off += g.num_nodes
+        e1 += g.edge_index.size(1); e2 += g.edge_index2.size(1); e3 += g.edge_index3.size(1)
+    for k, v in pieces.items():
+        assert torch.equal(getattr(batch, k), torch.cat(v, 1)), k
+    assert batch.num_nodes == n_off and torch.equal(batch.batch, torch.repeat_interleave(torch.arange(3), torch.tensor([g.num_nodes for g in keep])))
+    assert torch.equal(batch.field, torch.cat([g.field for g in keep]))
+
+
+def test_dataloader_applies_batch_transform_and_keeps_targets():
+    data = []
+    for i in range(5):
+        g = S.mus_graph(150, levels=1, seed=i)
+        g.target = torch.randn(150, 6)
+        data.append(g)
+    seen = []
+    loader = gfd.DataLoader(data, batch_size=2, shuffle=False, transform=lambda b: (seen.append(b.num_nodes), b)[1])
+    sizes = [b.num_nodes for b in loader]
+    assert sizes == [300, 300, 150] and seen == sizes
+    b = next(iter(loader))
+    assert b.target.shape == (300, 6) and int(b.edge_index.max()) == 299 and int(b.edge_index[:, :900].max()) == 149
+
+
+def test_knn_interp_weights_as_a_batch_transform():
+    """BuildKnnInterpWeights on a collated batch (examples/training/NsREMuSGNN/NsRotEquiTreeScaleGNN.py:39-41): neighbours are
+    searched per graph; indices address the batch's compact level lists, i.e. each graph's own indices shifted by the number
+    of level-l / level-(l-1) nodes before it."""
+    graphs = [S.remus_graph(200 + 40 * i, k=5, seed=90 + i) for i in range(3)]
+    batch = gfd.Collater(gfd.transforms.BuildKnnInterpWeights(5))(graphs)
+    for hi, lo in ((2, 1), (3, 2)):
+        off_c = off_f = 0
+        ys, xs, ws = [], [], []
+        for g in graphs:
+            ys.append(getattr(g, f"y_idx_{hi}{lo}") + off_f); xs.append(getattr(g, f"x_idx_{hi}{lo}") + off_c); ws.append(getattr(g, f"weights_{hi}{lo}"))
+            off_c += int(getattr(g, f"coarse_mask{hi}").sum())
+            off_f += g.num_nodes if lo == 1 else int(getattr(g, f"coarse_mask{lo}").sum())
+        assert torch.equal(getattr(batch, f"y_idx_{hi}{lo}"), torch.cat(ys))
+        assert torch.equal(getattr(batch, f"x_idx_{hi}{lo}"), torch.cat(xs))
+        torch.testing.assert_close(getattr(batch, f"weights_{hi}{lo}"), torch.cat(ws))
