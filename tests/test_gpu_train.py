@@ -403,3 +403,14 @@ def test_remus_batch_through_collater_equals_individual_graphs_and_fit_runs(tmp_
     cfg = gfd.nn.TrainConfig(name="r", folder=str(tmp_path), epochs=5, num_steps=[1], training_loss=gfd.nn.GraphLoss(), lr=2e-3, device=DEV)
     model.fit(cfg, gfd.DataLoader(graphs, batch_size=2, transform=gfd.transforms.BuildKnnInterpWeights(5)))
     assert model.history[-1]['training_loss'] < model.history[0]['training_loss']
+
+
+def test_gmus_batch_through_collater_equals_individual_graphs():
+    """gMuS-GNN batches as in examples/training/NsMuGSGNN/*.py:42-48 (BuildKnnInterpWeights as the batch transform)."""
+    graphs = [S.mugs_graph(1500 + 200 * i, levels=3, seed=85 + i) for i in range(2)]
+    torch.manual_seed(86)
+    model = gfd.nn.NsThreeGuillardScaleGNN(arch=S.mugs_arch("NsThreeGuillardScaleGNN", 32), device=DEV)
+    with torch.no_grad():
+        alone = [model.forward(g.clone().to(DEV)) for g in graphs]
+        both = model.forward(gfd.Collater(gfd.transforms.BuildKnnInterpWeights(6))(graphs).to(DEV))
+    torch.testing.assert_close(both, torch.cat(alone), rtol=1e-4, atol=1e-4)
