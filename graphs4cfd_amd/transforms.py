@@ -4,8 +4,9 @@ interpolate}.py) on top of the vectorised builders of `synthetic.py` — no torc
 the reference's O(E^2) Python loops (transforms/remus.py:36,159-161).  Outputs are checked against the reference's own
 transforms in tests/test_synthetic.py (tests/golden/transforms.pt, models_mugs.pt).
 
-Host-side, once per mesh.  Periodic domains (`period`) and the data-scaling / augmentation transforms are not part of
-the hot path's contract and are not provided.
+Host-side, once per mesh.  Periodic domains (`period`) are not provided.  The data-scaling / augmentation transforms of the
+training pipelines (ScaleNs, AddUniformNoise, NodeSubset, RandomNodeSubset, GraphRotation, RandomGraphRotation, RandomGraphFlip)
+live in `augment.py` and are re-exported here.
 """
 from __future__ import annotations
 
@@ -14,6 +15,8 @@ from typing import List, Optional, Sequence, Tuple, Union
 import torch
 
 from . import synthetic as S
+from .augment import (AddUniformNoise, GraphRotation, NodeSubset, RandomGraphFlip, RandomGraphRotation, RandomNodeSubset,      # noqa: F401
+                      ScaleNs, flip_graph_dim, rotate_graph)
 from .graph import Graph
 
 

@@ -449,7 +449,42 @@ def gen_training():
                              lambda_d=0.5, steps=steps))
 
 
+def gen_augment():
+    # scale.py:33-80, geometric.py:33-252, subset.py:7-30: the deterministic data transforms of the training pipelines
+    out = {}
+    g = mus_graph(120, 6, [0.2], seed=70, n_in=2)
+    g.target = torch.randn(120, 9)
+    stages = [("input", None),
+              ("ScaleNs", gfd.transforms.ScaleNs({'u': (-2.1, 2.6), 'v': (-2.25, 2.1), 'p': (-3.7, 2.35), 'Re': (500, 1000)}, format='uvp')),
+              ("GraphRotation", gfd.transforms.GraphRotation(37.0, eq='ns', format='uvp')),
+              ("flip_y", lambda gr: gfd.transforms.geometric.flip_graph_dim(gr, 1, eq='ns', format='uvp')),
+              ("NodeSubset", gfd.transforms.NodeSubset(list(range(0, 120, 3))))]
+    seq = []
+    for name, t in stages:
+        if t is not None:
+            g = t(g)
+        seq.append((name, graph_dict(g)))
+    out["mus_uvp"] = dict(ref="transforms/scale.py:33-80, geometric.py:33-114,170-216, subset.py:7-30", stages=seq)
+    ga = mus_graph(90, 6, None, seed=71, nf=1, loc=True)
+    gi = graph_dict(ga)
+    out["adv"] = dict(ref="geometric.py:33-114 (eq='adv')", input=gi, theta=201.5,
+                      output=graph_dict(gfd.transforms.GraphRotation(201.5, eq='adv')(ga)))
+    gr = remus_graph(150, 5, seed=72)
+    gr.target = torch.randn(150, 4)
+    gi = graph_dict(gr)
+    out["remus_uv"] = dict(ref="geometric.py:69-86 (angle_index: unit vectors + pseudo-inverses)", input=gi, theta=123.0,
+                           output=graph_dict(gfd.transforms.GraphRotation(123.0, eq='ns', format='uv')(gr)))
+    g3 = mus_graph(60, 6, None, seed=73, dim=3)
+    gi = graph_dict(g3)
+    out["rot3d"] = dict(ref="geometric.py:63-66 (Tait-Bryan)", input=gi, theta=[30.0, 75.0, 210.0],
+                        output=graph_dict(gfd.transforms.GraphRotation([30.0, 75.0, 210.0])(g3)))
+    save("augment.pt", out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "augment":
+        gen_augment()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "training":      # (adds one fixture without rewriting the others)
         gen_training()
         sys.exit(0)
@@ -461,3 +496,4 @@ if __name__ == "__main__":
     gen_checkpoint()
     gen_transforms()
     gen_training()
+    gen_augment()

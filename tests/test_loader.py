@@ -67,3 +67,58 @@ def test_knn_interp_weights_as_a_batch_transform():
         assert torch.equal(getattr(batch, f"y_idx_{hi}{lo}"), torch.cat(ys))
         assert torch.equal(getattr(batch, f"x_idx_{hi}{lo}"), torch.cat(xs))
         torch.testing.assert_close(getattr(batch, f"weights_{hi}{lo}"), torch.cat(ws))
+
+
+# ------------------------------------------------------------------ scaling / augmentation transforms against the reference's
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "augment.pt")
+
+
+def _same(got: gfd.Graph, ref: dict, what: str):
+    for k, v in ref.items():
+        if torch.is_tensor(v):
+            g = getattr(got, k)
+            assert g.shape == v.shape, (what, k)
+            if v.is_floating_point():
+                torch.testing.assert_close(g, v, rtol=1e-5, atol=1e-6, msg=lambda m: f"{what}: {k}: {m}")
+            else:
+                assert torch.equal(g, v), (what, k)
+
+
+def test_scale_rotate_flip_subset_match_the_reference():
+    """tests/golden/augment.pt (make_golden.py gen_augment): the reference's ScaleNs -> GraphRotation -> flip_graph_dim ->
+    NodeSubset chain on a MuS graph with a two-step history and a three-step target; rotation of an advection graph (`loc`),
+    of a REMuS graph (edge unit vectors and their pseudo-inverses, `edge_attr` untouched) and a 3-D Tait-Bryan rotation."""
+    c = torch.load(GOLD, weights_only=False)
+    T = gfd.transforms
+    stages = c["mus_uvp"]["stages"]
+    g = gfd.Graph(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in stages[0][1].items()})
+    ops = {"ScaleNs": T.ScaleNs({'u': (-2.1, 2.6), 'v': (-2.25, 2.1), 'p': (-3.7, 2.35), 'Re': (500, 1000)}, format='uvp'),
+           "GraphRotation": T.GraphRotation(37.0, eq='ns', format='uvp'),
+           "flip_y": lambda gr: T.flip_graph_dim(gr, 1, eq='ns', format='uvp'),
+           "NodeSubset": T.NodeSubset(list(range(0, 120, 3)))}
+    for name, ref in stages[1:]:
+        g = ops[name](g)
+        keys = ("pos", "field", "target", "glob", "omega") if name == "NodeSubset" else ref.keys()    # (NodeSubset: node attributes only)
+        _same(g, {k: ref[k] for k in keys}, name)
+    for case, kw in (("adv", dict(eq='adv')), ("remus_uv", dict(eq='ns', format='uv')), ("rot3d", {})):
+        e = c[case]
+        g = gfd.Graph(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in e["input"].items()})
+        _same(T.GraphRotation(e["theta"], **kw)(g), e["output"], case)
+    with pytest.raises(ValueError):
+        T.flip_graph_dim(gfd.Graph(**c["remus_uv"]["input"]), 0, eq='ns', format='uv')
+
+
+def test_random_transforms_keep_shapes_and_ranges():
+    torch.manual_seed(0)
+    g = S.mus_graph(200, levels=1, seed=1)
+    g.target = torch.randn(200, 3)
+    f0 = g.field.clone()
+    g = gfd.transforms.AddUniformNoise(0.01)(g)
+    assert float((g.field - f0).abs().max()) <= 0.01 and float((g.field - f0).abs().max()) > 0
+    speed = g.field[:, :2].norm(dim=1).clone()
+    g = gfd.transforms.RandomGraphRotation(eq='ns', format='uvp')(g)
+    g = gfd.transforms.RandomGraphFlip(eq='ns', format='uvp')(g)
+    torch.testing.assert_close(g.field[:, :2].norm(dim=1), speed, rtol=1e-5, atol=1e-6)      # rotations / mirrors keep |u|
+    g2 = gfd.Graph(pos=torch.rand(100, 2), field=torch.randn(100, 3), glob=torch.rand(100, 1))
+    assert gfd.transforms.RandomNodeSubset(0.8)(g2).num_nodes == 80
+    assert gfd.transforms.RandomNodeSubset(30)(g2).pos.shape == (30, 2)
