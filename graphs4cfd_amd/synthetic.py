@@ -30,10 +30,29 @@ def knn_neighbours(points: np.ndarray, queries: np.ndarray, k: int) -> np.ndarra
     return np.asarray(nbr).reshape(len(queries), k)
 
 
-def connect_knn(pos: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Non-periodic `connect_knn` (transforms/connect.py:58-60): edges neighbour -> centre, grouped by
-    centre, k per centre, nearest first; edge_attr = pos[col] - pos[row]."""
-    p = pos.detach().cpu().double().numpy()
+def connect_knn(pos: torch.Tensor, k: int, period=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`connect_knn` (transforms/connect.py:9-72): edges neighbour -> centre, grouped by centre, k per centre, nearest
+    first; edge_attr = pos[col] - pos[row].  `period`: one entry per axis — None (not periodic), a length, or "auto" (the
+    extent of the point cloud along that axis).  A periodic axis enters the neighbour search as a point on a circle,
+    (cos, sin)(2 pi x / period) (:38-56), and its edge components are wrapped into [-period/2, period/2] (:62-71)."""
+    dim = int(pos.size(1))
+    if dim not in (2, 3):
+        raise ValueError(f"Invalid dimension: {dim}, must be 2 or 3.")
+    per = [None] * dim if period is None else list(period)
+    if len(per) != dim:
+        raise ValueError(f"period needs {dim} entries")
+    lengths, cols = [], []
+    for ax in range(dim):
+        x = pos[:, ax].detach().cpu().double()
+        d = per[ax]
+        if d is None:
+            lengths.append(None)
+            cols.append(x.unsqueeze(1))
+        else:
+            d = float(x.max() - x.min()) if isinstance(d, str) and d == "auto" else float(d)
+            lengths.append(d)
+            cols.append(torch.stack((torch.cos(2 * np.pi / d * x), torch.sin(2 * np.pi / d * x)), 1))
+    p = torch.cat(cols, 1).numpy()
     n = p.shape[0]
     nbr = knn_neighbours(p, p, k + 1)
     centre = np.repeat(np.arange(n), k + 1)
@@ -42,7 +61,12 @@ def connect_knn(pos: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     row = torch.from_numpy(flat[keep].astype(np.int64))
     col = torch.from_numpy(centre[keep].astype(np.int64))
     edge_index = torch.stack([row, col], 0)
-    return edge_index, pos[col] - pos[row]
+    edge_attr = pos[col] - pos[row]
+    for ax, d in enumerate(lengths):
+        if d is not None:
+            c = edge_attr[:, ax]
+            edge_attr[:, ax] = torch.where(c < -d / 2, c + d, torch.where(c > d / 2, c - d, c))
+    return edge_index, edge_attr
 
 
 def grid_clustering(pos_1: torch.Tensor, cell_size_2: float):

@@ -4,7 +4,7 @@ interpolate}.py) on top of the vectorised builders of `synthetic.py` — no torc
 the reference's O(E^2) Python loops (transforms/remus.py:36,159-161).  Outputs are checked against the reference's own
 transforms in tests/test_synthetic.py (tests/golden/transforms.pt, models_mugs.pt).
 
-Host-side, once per mesh.  Periodic domains (`period`) are not provided.  The data-scaling / augmentation transforms of the
+Host-side, once per mesh.  The data-scaling / augmentation transforms of the
 training pipelines (ScaleNs, AddUniformNoise, NodeSubset, RandomNodeSubset, GraphRotation, RandomGraphRotation, RandomGraphFlip)
 live in `augment.py` and are re-exported here.
 """
@@ -38,14 +38,14 @@ class Compose:
 
 
 class ConnectKNN:
-    """kNN edges grouped by target, `edge_attr = pos[col] - pos[row]` (reference: transforms/connect.py:74-92)."""
+    """kNN edges grouped by target, `edge_attr = pos[col] - pos[row]`, optionally on a periodic domain
+    (reference: transforms/connect.py:9-92)."""
 
     def __init__(self, k: int, period: Optional[Union[Tuple, None]] = (None, None)):
-        _no_period(period)
         self.k, self.period = k, period
 
     def __call__(self, graph: Graph) -> Graph:
-        graph.edge_index, graph.edge_attr = S.connect_knn(graph.pos, self.k)
+        graph.edge_index, graph.edge_attr = S.connect_knn(graph.pos, self.k, period=self.period)
         return graph
 
 
@@ -81,20 +81,19 @@ class GuillardCoarseningAndConnectKNN:
 
     def __init__(self, k: Sequence[int], period=None, scale_edge_attr: Optional[Sequence] = None):
         assert 1 < len(k) < 5, "The number of levels in gMuS-GNN must be between 2 and 4."
-        _no_period(period)
         self.k, self.period = list(k), period
         self.scale_edge_attr = list(scale_edge_attr) if scale_edge_attr is not None else [None] * len(k)
 
     def __call__(self, graph: Graph) -> Graph:
         pos, n = graph.pos, int(graph.pos.size(0))
-        graph.edge_index, ea = S.connect_knn(pos, self.k[0])
+        graph.edge_index, ea = S.connect_knn(pos, self.k[0], period=self.period)
         graph.edge_attr = ea if self.scale_edge_attr[0] is None else ea / (2 * self.scale_edge_attr[0])
         prev, ei_local = torch.ones(n, dtype=torch.bool), graph.edge_index
         for l in range(2, len(self.k) + 1):
             cm = torch.zeros(n, dtype=torch.bool)
             cm[prev] = S.guillard_coarsening(ei_local, int(prev.sum()))
             idx = cm.nonzero().reshape(-1)
-            ei_local, ea = S.connect_knn(pos[idx], self.k[l - 1])
+            ei_local, ea = S.connect_knn(pos[idx], self.k[l - 1], period=self.period)      # ("auto": the extent of this level's nodes, as the reference)
             sc = self.scale_edge_attr[l - 1]
             setattr(graph, f"coarse_mask{l}", cm)
             setattr(graph, f"edge_index{l}", idx[ei_local])

@@ -478,6 +478,14 @@ def gen_augment():
     gi = graph_dict(g3)
     out["rot3d"] = dict(ref="geometric.py:63-66 (Tait-Bryan)", input=gi, theta=[30.0, 75.0, 210.0],
                         output=graph_dict(gfd.transforms.GraphRotation([30.0, 75.0, 210.0])(g3)))
+    # periodic kNN connect (transforms/connect.py:36-71) and the Guillard transform on a periodic domain (mugs.py:57-88)
+    torch.manual_seed(74)
+    pos = torch.rand(300, 2) * torch.tensor([4.0, 1.0])
+    for name, period in (("per_y_auto", (None, "auto")), ("per_xy", (4.0, 1.0))):
+        gp = gfd.transforms.ConnectKNN(6, period=period)(gfd.Graph(pos=pos.clone()))
+        out[name] = dict(ref="transforms/connect.py:9-72", pos=pos.clone(), period=period, edge_index=gp.edge_index.clone(), edge_attr=gp.edge_attr.clone())
+    gg = gfd.transforms.GuillardCoarseningAndConnectKNN(k=(6, 6, 6), period=(None, "auto"), scale_edge_attr=(0.1, 0.25, 0.5))(gfd.Graph(pos=pos.clone()))
+    out["guillard_periodic"] = dict(ref="transforms/mugs.py:32-89", pos=pos.clone(), graph=graph_dict(gg))
     save("augment.pt", out)
 
 

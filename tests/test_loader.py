@@ -122,3 +122,17 @@ def test_random_transforms_keep_shapes_and_ranges():
     g2 = gfd.Graph(pos=torch.rand(100, 2), field=torch.randn(100, 3), glob=torch.rand(100, 1))
     assert gfd.transforms.RandomNodeSubset(0.8)(g2).num_nodes == 80
     assert gfd.transforms.RandomNodeSubset(30)(g2).pos.shape == (30, 2)
+
+
+def test_periodic_knn_connect_matches_the_reference():
+    """ConnectKNN on periodic domains (a given period per axis, or "auto") and the Guillard transform with a periodic axis,
+    against the reference's outputs (neighbour search on the (cos, sin) embedding, wrapped edge vectors)."""
+    c = torch.load(GOLD, weights_only=False)
+    for name in ("per_y_auto", "per_xy"):
+        e = c[name]
+        g = gfd.transforms.ConnectKNN(6, period=e["period"])(gfd.Graph(pos=e["pos"].clone()))
+        assert torch.equal(g.edge_index, e["edge_index"]), name
+        torch.testing.assert_close(g.edge_attr, e["edge_attr"], rtol=1e-5, atol=1e-6)
+    e = c["guillard_periodic"]
+    g = gfd.transforms.GuillardCoarseningAndConnectKNN(k=(6, 6, 6), period=(None, "auto"), scale_edge_attr=(0.1, 0.25, 0.5))(gfd.Graph(pos=e["pos"].clone()))
+    _same(g, e["graph"], "guillard_periodic")
