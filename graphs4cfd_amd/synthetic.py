@@ -38,7 +38,7 @@ def connect_knn(pos: torch.Tensor, k: int, period=None) -> Tuple[torch.Tensor, t
     dim = int(pos.size(1))
     if dim not in (2, 3):
         raise ValueError(f"Invalid dimension: {dim}, must be 2 or 3.")
-    per = [None] * dim if period is None else list(period)
+    per = [None] * dim if (period is None or all(d is None for d in period)) else list(period)
     if len(per) != dim:
         raise ValueError(f"period needs {dim} entries")
     lengths, cols = [], []
