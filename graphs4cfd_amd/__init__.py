@@ -11,7 +11,7 @@ eager-torch fallback.  Training (`model.fit`, `gfd.nn.TrainConfig`, `gfd.nn.Grap
 forward recorded for autograd (autograd.py).  Out of scope: datasets, plotting, augmentation.
 """
 from .graph import Graph
-from . import nn, plan, ops, synthetic, transforms
+from . import nn, plan, ops, synthetic, transforms, metrics
 from .loader import DataLoader, Collater
 from .ops import mlp_precision, set_mlp_precision      # "fp32" (default) | "bf16" (opt-in bf16-MFMA MLPs)
 

@@ -136,3 +136,14 @@ def test_periodic_knn_connect_matches_the_reference():
     e = c["guillard_periodic"]
     g = gfd.transforms.GuillardCoarseningAndConnectKNN(k=(6, 6, 6), period=(None, "auto"), scale_edge_attr=(0.1, 0.25, 0.5))(gfd.Graph(pos=e["pos"].clone()))
     _same(g, e["graph"], "guillard_periodic")
+
+
+def test_r2_metric():
+    torch.manual_seed(3)
+    t = torch.randn(50, 6)
+    assert gfd.metrics.r2(t, t) == 1.0
+    p = t + 0.1 * torch.randn_like(t)
+    ref = 1 - float(((t - p) ** 2).sum() / ((t - t.mean()) ** 2).sum())
+    assert abs(gfd.metrics.r2(p, t) - ref) < 1e-6
+    with pytest.raises(RuntimeError):
+        gfd.metrics.r2(t[None], t[None])
