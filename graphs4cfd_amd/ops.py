@@ -225,6 +225,10 @@ FUSE_AGG = os.environ.get("G4C_FUSE_AGG", "0") == "1"
 # Aggregation on load (g4c_src_t.seg_off): the node-MLP launch averages each target's messages while it gathers its input,
 # instead of a separate g4c_segment_reduce pass (bit-identical values; no tile-alignment constraint, unlike FUSE_AGG).
 AGG_ON_LOAD = os.environ.get("G4C_AGG_ON_LOAD", "1") == "1"
+# below this many rows to aggregate, the launch that gathers them is latency-bound and a separate g4c_segment_reduce is quicker
+# (same-box sweep: 12.5k-node 3-scale mesh 789 -> 822 steps/s, 2-scale 10k nodes 1079 -> 1110, 25k nodes 503 -> 516 with the
+# threshold at 50k rows; neutral at 100k nodes)
+AGG_ON_LOAD_MIN_ROWS = int(os.environ.get("G4C_AGG_ON_LOAD_MIN_ROWS", "50000"))
 
 
 _weights_epoch = 0
@@ -253,7 +257,8 @@ def can_aggregate_on_load(csr: CsrPlan, width: int, consumer_widths: Sequence[in
     """`consumer_widths`: input blocks of the MLP that would aggregate while loading (it must run on the bf16x6 kernels)."""
     # (rows in segment order only: through a permutation the kernel supports it too — Source(segments=csr with perm) — but the
     # extra dependent index round trip in the consumer's prologue gives back what the separate reduction costs; measured neutral)
-    return AGG_ON_LOAD and effective_precision(consumer_widths) != "fp32" and csr.perm is None and width == 128 and csr.n > 0
+    return (AGG_ON_LOAD and effective_precision(consumer_widths) != "fp32" and csr.perm is None and width == 128
+            and csr.n > 0 and csr.n >= AGG_ON_LOAD_MIN_ROWS)
 
 
 def mlp_precision() -> str:

@@ -554,7 +554,11 @@ def test_reference_checkpoint_loads_and_runs(golden):
 
 
 # ------------------------------------------------------------------ production width vs oracle
-def test_three_scale_h128_vs_oracle():
+@pytest.mark.parametrize("agg_on_load_min_rows", [0, 1 << 30])
+def test_three_scale_h128_vs_oracle(agg_on_load_min_rows, monkeypatch):
+    """(0: every level aggregates inside the node launch's gather; 1 << 30: separate g4c_segment_reduce launches — the default
+    switches between the two at ops.AGG_ON_LOAD_MIN_ROWS aggregated rows)"""
+    monkeypatch.setattr(ops, "AGG_ON_LOAD_MIN_ROWS", agg_on_load_min_rows)
     g = S.mus_graph(6000, levels=3, seed=3)
     arch = S.mus_arch("NsThreeScaleGNN", 128)
     torch.manual_seed(5)
