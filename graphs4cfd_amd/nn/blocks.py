@@ -13,7 +13,7 @@ blocks fuses the `F.selu` the model applies right after the block, nn/mus_gnn.py
 from __future__ import annotations
 
 from collections import OrderedDict
-from typing import Callable, List, Optional, Sequence, Tuple, Union
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 from torch import nn

@@ -13,7 +13,6 @@ host synchronisation and can be captured once in a hipGraph and replayed (`captu
 from __future__ import annotations
 
 import os
-import contextlib
 from typing import Callable, List, Optional, Union
 
 import torch

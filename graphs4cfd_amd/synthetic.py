@@ -253,7 +253,7 @@ def mugs_graph(n: int, levels: int = 2, k: int = 6, seed: int = 0, nf: int = 3) 
 
 
 def remus_graph(n: int, k: int = 5, seed: int = 0, scale: Optional[Sequence[float]] = None,
-                pos: Optional[torch.Tensor] = None) -> Graph:
+                pos: Optional[torch.Tensor] = None, period=None) -> Graph:
     """Synthetic 3-level REMuS-GNN input: `BuildRemusGraph(num_levels=3, k, scale_edge_length)` +
     `BuildKnnInterpWeights(k)` (transforms/remus.py:84-148, interpolate.py:134-155)."""
     gen = torch.Generator().manual_seed(seed)
@@ -264,17 +264,17 @@ def remus_graph(n: int, k: int = 5, seed: int = 0, scale: Optional[Sequence[floa
         h = 2.0 * float(n) ** -0.5
         scale = (h, 2 * h, 4 * h)
     g = Graph(pos=pos)
-    g.edge_index, g.edge_attr = connect_knn(pos, k)
+    g.edge_index, g.edge_attr = connect_knn(pos, k, period=period)
     g.edge_attr = g.edge_attr / (2 * scale[0])
     g.coarse_mask2 = guillard_coarsening(g.edge_index, n)
     ci2 = g.coarse_mask2.nonzero().reshape(-1)
-    ei2, ea2 = connect_knn(pos[ci2], k)
+    ei2, ea2 = connect_knn(pos[ci2], k, period=period)
     ea2 = ea2 / (2 * scale[1])
     m3 = torch.zeros(n, dtype=torch.bool)
     m3[g.coarse_mask2] = guillard_coarsening(ei2, ci2.numel())
     g.coarse_mask3 = m3
     ci3 = m3.nonzero().reshape(-1)
-    ei3, ea3 = connect_knn(pos[ci3], k)
+    ei3, ea3 = connect_knn(pos[ci3], k, period=period)
     ea3 = ea3 / (2 * scale[2])
     g.edge_index2, g.edge_attr2 = ci2[ei2], ea2
     g.edge_index3, g.edge_attr3 = ci3[ei3], ea3

@@ -20,11 +20,6 @@ from .augment import (AddUniformNoise, GraphRotation, NodeSubset, RandomGraphFli
 from .graph import Graph
 
 
-def _no_period(period) -> None:
-    if period is not None and any(p is not None for p in (period if isinstance(period, (tuple, list)) else (period,))):
-        raise NotImplementedError("periodic domains are not supported by this build's kNN connect")
-
-
 class Compose:
     """`torchvision.transforms.Compose` as the reference's examples use it: apply the transforms in order."""
 
@@ -109,13 +104,12 @@ class BuildRemusGraph:
     def __init__(self, num_levels: int, k: int, period=None, scale_edge_length: Optional[Sequence] = None):
         if num_levels != 3:
             raise NotImplementedError("REMuS-GNN (nn/remus_gnn.py) has exactly 3 levels")
-        _no_period(period)
         if scale_edge_length is None or any(s is None or s == "auto" for s in scale_edge_length):
             raise NotImplementedError("scale_edge_length must give one number per level")
         self.num_levels, self.k, self.period, self.scale_edge_length = num_levels, k, period, tuple(scale_edge_length)
 
     def __call__(self, graph: Graph) -> Graph:
-        built = S.remus_graph(int(graph.pos.size(0)), k=self.k, scale=self.scale_edge_length, pos=graph.pos)
+        built = S.remus_graph(int(graph.pos.size(0)), k=self.k, scale=self.scale_edge_length, pos=graph.pos, period=self.period)
         skip = ("field", "glob", "omega", "pos", "y_idx_21", "x_idx_21", "weights_21", "y_idx_32", "x_idx_32", "weights_32")
         for key, val in built.to_dict().items():
             if key not in skip:

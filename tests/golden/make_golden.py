@@ -485,6 +485,8 @@ def gen_augment():
         gp = gfd.transforms.ConnectKNN(6, period=period)(gfd.Graph(pos=pos.clone()))
         out[name] = dict(ref="transforms/connect.py:9-72", pos=pos.clone(), period=period, edge_index=gp.edge_index.clone(), edge_attr=gp.edge_attr.clone())
     gg = gfd.transforms.GuillardCoarseningAndConnectKNN(k=(6, 6, 6), period=(None, "auto"), scale_edge_attr=(0.1, 0.25, 0.5))(gfd.Graph(pos=pos.clone()))
+    gb = gfd.transforms.BuildRemusGraph(num_levels=3, k=5, period=(None, "auto"), scale_edge_length=(0.1, 0.2, 0.4))(gfd.Graph(pos=pos[:200].clone()))
+    out["remus_periodic"] = dict(ref="transforms/remus.py:63-148 with period", pos=pos[:200].clone(), graph=graph_dict(gb))
     out["guillard_periodic"] = dict(ref="transforms/mugs.py:32-89", pos=pos.clone(), graph=graph_dict(gg))
     save("augment.pt", out)
 

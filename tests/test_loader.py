@@ -136,6 +136,9 @@ def test_periodic_knn_connect_matches_the_reference():
     e = c["guillard_periodic"]
     g = gfd.transforms.GuillardCoarseningAndConnectKNN(k=(6, 6, 6), period=(None, "auto"), scale_edge_attr=(0.1, 0.25, 0.5))(gfd.Graph(pos=e["pos"].clone()))
     _same(g, e["graph"], "guillard_periodic")
+    e = c["remus_periodic"]
+    g = gfd.transforms.BuildRemusGraph(num_levels=3, k=5, period=(None, "auto"), scale_edge_length=(0.1, 0.2, 0.4))(gfd.Graph(pos=e["pos"].clone()))
+    _same(g, e["graph"], "remus_periodic")
 
 
 def test_r2_metric():
