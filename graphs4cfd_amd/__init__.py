@@ -8,10 +8,10 @@ Drop-in for the hot-path slice of `import graphs4cfd as gfd`:
 
 Compute runs in hand-written HIP kernels (libg4c.so, C-ABI in include/g4c.h); there is no CPU or
 eager-torch fallback.  Training (`model.fit`, `gfd.nn.TrainConfig`, `gfd.nn.GraphLoss`, `gfd.DataLoader`) runs the same fused
-forward recorded for autograd (autograd.py).  Out of scope: datasets, plotting, augmentation.
+forward recorded for autograd (autograd.py).  Out of scope: plotting.
 """
 from .graph import Graph
-from . import nn, plan, ops, synthetic, transforms, metrics
+from . import nn, plan, ops, synthetic, transforms, metrics, datasets
 from .loader import DataLoader, Collater
 from .ops import mlp_precision, set_mlp_precision      # "fp32" (default) | "bf16" (opt-in bf16-MFMA MLPs)
 

@@ -488,6 +488,21 @@ def gen_augment():
     gb = gfd.transforms.BuildRemusGraph(num_levels=3, k=5, period=(None, "auto"), scale_edge_length=(0.1, 0.2, 0.4))(gfd.Graph(pos=pos[:200].clone()))
     out["remus_periodic"] = dict(ref="transforms/remus.py:63-148 with period", pos=pos[:200].clone(), graph=graph_dict(gb))
     out["guillard_periodic"] = dict(ref="transforms/mugs.py:32-89", pos=pos.clone(), graph=graph_dict(gg))
+    # datasets.py:120-337: record layout -> Graph (data2graph) of the three dataset classes, on synthetic NaN-padded records
+    from graphs4cfd import datasets as rds
+    torch.manual_seed(75)
+    T, n_real, n_pad = 12, 40, 7
+    cases = {}
+    for name, cls, kw, cols in (("Adv", rds.Adv, {}, 5 + T), ("NsCircle_uvp", rds.NsCircle, {"format": "uvp"}, 4 + 3 * T),
+                                ("NsCircle_uv", rds.NsCircle, {"format": "uv"}, 4 + 3 * T), ("NsEllipse_uv", rds.NsEllipse, {"format": "uv"}, 4 + 6 * T),
+                                ("NsEllipse_uvp", rds.NsEllipse, {"format": "uvp"}, 4 + 6 * T)):
+        rec = torch.randn(n_real + n_pad, cols)
+        rec[:, 4 if name == "Adv" else 3] = torch.randint(0, 5 if name != "Adv" else 4, (n_real + n_pad,)).float()
+        rec[n_real:] = float("nan")
+        ds = cls(path="unused.h5", training_info={"n_in": 2, "n_out": 3, "step": 2, "T": T}, **kw)
+        g = ds.data2graph(rec, 1, 1 + 2 * 2, 1 + (2 + 3) * 2 - 1, 2)
+        cases[name] = dict(record=rec.clone(), args=(1, 5, 10, 2), graph=graph_dict(g), length=ds.training_sequences_length)
+    out["datasets"] = dict(ref="datasets.py:26-44 (window length), :158-197, :222-266, :291-337", cases=cases)
     save("augment.pt", out)
 
 

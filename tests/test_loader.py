@@ -150,3 +150,45 @@ def test_r2_metric():
     assert abs(gfd.metrics.r2(p, t) - ref) < 1e-6
     with pytest.raises(RuntimeError):
         gfd.metrics.r2(t[None], t[None])
+
+
+# ------------------------------------------------------------------ datasets
+def test_dataset_record_layouts_match_the_reference(tmp_path):
+    """Adv / NsCircle / NsEllipse `data2graph` (datasets.py:158-337) on NaN-padded records, against the reference's own output;
+    then the storage side: the same records through a .npy file (memory-mapped and preloaded), `get_sequence`, `__getitem__`,
+    `idx=`, the transform hook and the loud failure for HDF5 without h5py."""
+    import numpy as np
+    c = torch.load(GOLD, weights_only=False)["datasets"]["cases"]
+    D = gfd.datasets
+    classes = {"Adv": (D.Adv, {}), "NsCircle_uvp": (D.NsCircle, {"format": "uvp"}), "NsCircle_uv": (D.NsCircle, {"format": "uv"}),
+               "NsEllipse_uv": (D.NsEllipse, {"format": "uv"}), "NsEllipse_uvp": (D.NsEllipse, {"format": "uvp"})}
+    info = {"n_in": 2, "n_out": 3, "step": 2, "T": 12}
+    for name, e in c.items():
+        cls, kw = classes[name]
+        stack = torch.stack([e["record"], e["record"].flip(1)])                  # two "simulations"
+        ds = cls(data=stack, training_info=info, **kw)
+        assert len(ds) == 2 and ds.training_sequences_length == e["length"]
+        g = ds.data2graph(e["record"], *e["args"])
+        _same(g, e["graph"], name)
+        _same(ds.get_sequence(0, 1, n_in=2, n_out=3, step=2), e["graph"], name + " get_sequence")
+    # storage: .npy file, lazily and preloaded; one simulation only; transforms
+    e = c["NsCircle_uvp"]
+    path = os.path.join(tmp_path, "ns.npy")
+    np.save(path, torch.stack([e["record"], e["record"]]).numpy())
+    seen = []
+    for preload in (False, True):
+        ds = D.NsCircle("uvp", path=path, training_info=info, preload=preload, transform=lambda g: seen.append(g.num_nodes))
+        assert len(ds) == 2
+        _same(ds.get_sequence(1, 1, n_in=2, n_out=3, step=2), e["graph"], f"npy preload={preload}")
+        s = ds[0]
+        assert s.field.shape == (40, 6) and s.target.shape == (40, 9) and s.omega.shape == (40, 1)
+    assert seen == [40] * 4
+    one = D.NsCircle("uvp", path=path, training_info=info, idx=1, preload=True)
+    assert len(one) == 1
+    with pytest.raises(ValueError):
+        D.NsCircle("uvp", path=path, training_info=info, idx=1)
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            len(D.NsCircle("uvp", path=os.path.join(tmp_path, "x.h5"), training_info=info))
