@@ -202,3 +202,62 @@ class RandomGraphFlip:
             if flag and np.random.randint(2):
                 graph = flip_graph_dim(graph, axis, eq=self.eq, format=self.format)
         return graph
+
+
+# ------------------------------------------------------------------------------------- interpolation to another node set
+def interpolate_nodes(graph: Graph, pos: torch.Tensor, method: Optional[str] = None) -> Graph:
+    """Interpolate the fields of a point cloud (no edges yet) to the nodes `pos` with `scipy.interpolate.griddata`
+    (transforms/interpolate.py:13-49): `loc`, `glob`, `field`, `target` with `method` (default 'cubic' in 2-D, 'linear' in 3-D),
+    `omega` and `bound` linearly — omega thresholded at 0.9, bound rounded."""
+    from scipy.interpolate import griddata
+    if getattr(graph, "edge_index", None) is not None:
+        raise ValueError("Graphs cannot be interpolated, only sets of nodes.")
+    if method is None:
+        method = "cubic" if pos.size(1) == 2 else "linear"
+    src = graph.pos.numpy()
+    resample = lambda t, m: griddata(src, t.numpy(), pos.numpy(), method=m)
+    for name in ("loc", "glob"):
+        if hasattr(graph, name):
+            setattr(graph, name, torch.tensor(resample(getattr(graph, name), method).astype(np.float32)))
+    graph.field = torch.tensor(resample(graph.field, method).astype(np.float32))
+    graph.target = torch.tensor(resample(graph.target, method).astype(np.float32))
+    omega = torch.tensor(resample(graph.omega, "linear").astype(np.float32))
+    graph.bound = torch.tensor(np.round(resample(graph.bound, "linear")), dtype=torch.uint8)
+    graph.omega = (omega >= 0.9).float()
+    graph.pos = pos
+    return graph
+
+
+class InterpolateNodes:
+    """`interpolate_nodes` to a fixed node set (transforms/interpolate.py:52-68)."""
+
+    def __init__(self, pos: torch.Tensor) -> None:
+        self.pos = pos
+
+    def __call__(self, graph: Graph) -> Graph:
+        return interpolate_nodes(graph, self.pos)
+
+
+class InterpolateNodesToXml:
+    """`interpolate_nodes` to the vertices of a NekMesh-generated xml file (`GEOMETRY/VERTEX/V`), or of one drawn at random
+    from a directory whose name ends in `_xml` (`num_meshes` of its files, chosen with replacement, or 'all')
+    (transforms/interpolate.py:71-107)."""
+
+    def __init__(self, xml_file: str, num_meshes: Union[int, str] = "all"):
+        import os
+        if isinstance(num_meshes, str):
+            assert num_meshes == "all", "num_meshes must be an integer or 'all'"
+        if xml_file[-4:] == ".xml":
+            self.xml_files = [xml_file]
+        elif xml_file[-4:] == "_xml":
+            files = [os.path.join(xml_file, f) for f in sorted(os.listdir(xml_file))]
+            self.xml_files = random.choices(files, k=len(files) if num_meshes == "all" else num_meshes)
+        else:
+            raise ValueError(f"{xml_file}: expected an .xml file or a directory named *_xml")
+
+    def __call__(self, graph: Graph) -> Graph:
+        from xml.etree import ElementTree
+        dim = int(graph.pos.size(1))
+        vertices = ElementTree.parse(random.choice(self.xml_files)).findall("GEOMETRY/VERTEX/V")
+        pos = torch.tensor([list(map(float, v.text.split()[:dim])) for v in vertices], dtype=torch.float32)
+        return interpolate_nodes(graph, pos)

@@ -15,7 +15,7 @@ from typing import List, Optional, Sequence, Tuple, Union
 import torch
 
 from . import synthetic as S
-from .augment import (AddUniformNoise, GraphRotation, NodeSubset, RandomGraphFlip, RandomGraphRotation, RandomNodeSubset,      # noqa: F401
+from .augment import (AddUniformNoise, GraphRotation, InterpolateNodes, InterpolateNodesToXml, NodeSubset, interpolate_nodes, RandomGraphFlip, RandomGraphRotation, RandomNodeSubset,      # noqa: F401
                       ScaleNs, flip_graph_dim, rotate_graph)
 from .graph import Graph
 

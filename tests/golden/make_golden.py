@@ -488,6 +488,17 @@ def gen_augment():
     gb = gfd.transforms.BuildRemusGraph(num_levels=3, k=5, period=(None, "auto"), scale_edge_length=(0.1, 0.2, 0.4))(gfd.Graph(pos=pos[:200].clone()))
     out["remus_periodic"] = dict(ref="transforms/remus.py:63-148 with period", pos=pos[:200].clone(), graph=graph_dict(gb))
     out["guillard_periodic"] = dict(ref="transforms/mugs.py:32-89", pos=pos.clone(), graph=graph_dict(gg))
+    # interpolate.py:13-49: griddata interpolation of a point cloud to new nodes
+    torch.manual_seed(76)
+    gp = gfd.Graph(pos=torch.rand(400, 2))
+    gp.edge_index = None
+    gp.loc, gp.field, gp.target = torch.randn(400, 2), torch.sin(3 * gp.pos[:, :1]) * torch.ones(1, 2), torch.cos(2 * gp.pos[:, 1:]) * torch.ones(1, 3)
+    gp.omega = (gp.pos[:, :1] < 0.1).float()
+    gp.bound = (2 * (gp.pos[:, 0] < 0.1)).type(torch.uint8)
+    new_pos = 0.2 + 0.6 * torch.rand(150, 2)
+    gi = graph_dict(gp)
+    out["interpolate_nodes"] = dict(ref="transforms/interpolate.py:13-49", input=gi, new_pos=new_pos.clone(),
+                                    output=graph_dict(gfd.transforms.InterpolateNodes(new_pos)(gp)))
     # datasets.py:120-337: record layout -> Graph (data2graph) of the three dataset classes, on synthetic NaN-padded records
     from graphs4cfd import datasets as rds
     torch.manual_seed(75)

@@ -192,3 +192,20 @@ def test_dataset_record_layouts_match_the_reference(tmp_path):
     except ImportError:
         with pytest.raises(ImportError):
             len(D.NsCircle("uvp", path=os.path.join(tmp_path, "x.h5"), training_info=info))
+
+
+def test_interpolate_nodes_matches_the_reference(tmp_path):
+    """InterpolateNodes (scipy griddata: cubic for the fields, linear + threshold / rounding for omega / bound) against the
+    reference's output, and InterpolateNodesToXml reading the vertices of a NekMesh-style xml file."""
+    e = torch.load(GOLD, weights_only=False)["interpolate_nodes"]
+    mk = lambda: gfd.Graph(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in e["input"].items()})
+    _same(gfd.transforms.InterpolateNodes(e["new_pos"])(mk()), e["output"], "interpolate_nodes")
+    xml = os.path.join(tmp_path, "mesh.xml")
+    with open(xml, "w") as f:
+        f.write("<NEKTAR><GEOMETRY><VERTEX>" + "".join(f'<V ID="{i}">{float(p[0])!r} {float(p[1])!r} 0.0</V>' for i, p in enumerate(e["new_pos"]))
+                + "</VERTEX></GEOMETRY></NEKTAR>")
+    _same(gfd.transforms.InterpolateNodesToXml(xml)(mk()), e["output"], "interpolate_nodes via xml")
+    g = mk()
+    g.edge_index = torch.zeros(2, 1, dtype=torch.long)
+    with pytest.raises(ValueError):
+        gfd.transforms.InterpolateNodes(e["new_pos"])(g)
