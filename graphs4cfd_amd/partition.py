@@ -260,8 +260,10 @@ class HaloExchanger:
 
     def exchange(self, v: torch.Tensor, level: int) -> None:
         m = self.mesh
-        if m.world == 1 or (sum(m.send_counts[level - 1]) == 0 and sum(m.recv_counts[level - 1]) == 0):
+        if m.world == 1:
             return
+        # (no per-rank shortcut for an empty halo: the exchange is a collective, every rank of the group has to enter it, with
+        # zero-length splits if it has nothing to send or receive at this level)
         import torch.distributed as dist
         width = int(v.size(1))
         n_send = sum(m.send_counts[level - 1])

@@ -2,6 +2,7 @@
 partition, and the partitioned V-cycle run on 2 gloo ranks with the ORACLE as the arithmetic back-end,
 compared with the single-process oracle forward (the HIP back-end is covered by the -m gpu tests)."""
 import os
+import types
 
 import numpy as np
 import pytest
@@ -168,3 +169,31 @@ def test_partitioned_forward_matches_global_on_two_gloo_ranks(tmp_path, model_na
     r = torch.load(os.path.join(str(tmp_path), "result.pt"))
     assert all(h > 0 for h in r["halo"][0]), "the test mesh must actually have halos on every level"
     torch.testing.assert_close(r["full"], r["ref"], rtol=1e-4, atol=1e-4)
+
+
+def _lonely_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # ranks 0 and 1 exchange two rows each way; rank 2 neither sends nor receives at this level
+        counts = {0: ([0, 2, 0], [0, 2, 0]), 1: ([2, 0, 0], [2, 0, 0]), 2: ([0, 0, 0], [0, 0, 0])}[rank]
+        send_idx = [torch.tensor([1, 3], dtype=torch.int32) if c else torch.zeros(0, dtype=torch.int32) for c in counts[0]]
+        mesh = types.SimpleNamespace(world=world, rank=rank, n_own=[4], send_counts=[counts[0]], recv_counts=[counts[1]], send_idx32=[send_idx])
+        v = torch.zeros(4 + sum(counts[1]), 3)
+        v[:4] = torch.arange(12.).reshape(4, 3) + 100 * rank
+        P.HaloExchanger(mesh).exchange(v, 1)
+        torch.save(v, os.path.join(out_dir, f"v{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_halo_exchange_is_entered_by_ranks_with_an_empty_halo(tmp_path):
+    """The exchange is a collective: a rank with nothing to send or receive at a level still has to enter it (zero-length
+    splits), or the ranks that do exchange wait for it forever."""
+    import torch.multiprocessing as mp
+    port = 29900 + os.getpid() % 90
+    mp.spawn(_lonely_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    v0, v1, v2 = (torch.load(os.path.join(tmp_path, f"v{r}.pt")) for r in range(3))
+    own = lambda r: torch.arange(12.).reshape(4, 3) + 100 * r
+    assert torch.equal(v0[4:], own(1)[[1, 3]]) and torch.equal(v1[4:], own(0)[[1, 3]]) and torch.equal(v2, own(2))
