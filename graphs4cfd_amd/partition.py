@@ -99,6 +99,14 @@ def assign_owners(graph: Graph, levels: int, world: int) -> List[np.ndarray]:
     return owners
 
 
+def uniform_edge_counts(parts: List[List[LevelPart]]) -> List[int]:
+    """Per level, the smallest number of owned edges over the ranks.  Whether an MP layer hoists its first layer — and with it
+    WHAT the halo exchange before it carries (the latents, or the first-layer products of the same size) — is decided on the
+    edge count; every rank must decide alike or one rank's products land in another rank's latents.  Every rank builds the
+    same partition table, so the minimum over the table is the same number everywhere."""
+    return [min(int(p[l].edge_index.shape[1]) for p in parts) for l in range(len(parts[0]))]
+
+
 def build_partition(graph: Graph, levels: int, world: int) -> List[List[LevelPart]]:
     """parts[rank][level-1] for every rank (the whole table is cheap and lets tests check consistency)."""
     edges = coarse_topology(graph, levels)
@@ -163,6 +171,9 @@ class LocalMesh:
             ei = parts[l].edge_index
             self._edge_index_np[l] = np.ascontiguousarray(ei[:, np.argsort(ei[1], kind="stable")])
         self.edge_index = [t(a) for a in self._edge_index_np]
+        # edge count per level that rank-uniform decisions are taken on (see `uniform_edge_counts`); the local counts unless the
+        # caller knows the whole partition table
+        self.decision_edges = [int(a.shape[1]) for a in self._edge_index_np]
         # owned edges split by where their SENDER lives: interior (owned sender: computable before the halo exchange has
         # landed) / boundary (halo sender).  int32 row lists + the matching sender / target lists, for the overlapped MP layer.
         self.sub = []
@@ -403,7 +414,7 @@ class MusPartitionedForward:
 
         def wants(k: int, lvl: int) -> bool:      # program entry k is an MP layer that will hoist its first layer
             return (k < len(self.program) and self.program[k].startswith("mp")
-                    and impl.hoists(int(m.edge_index[lvl - 1].size(1))))
+                    and impl.hoists(m.decision_edges[lvl - 1]))
 
         # (W1r v [own + halo rows], W1c v [own rows]) of the next MP layer, when the launch producing v already made them
         w0 = wants(0, 1)
@@ -441,8 +452,7 @@ class MusPartitionedForward:
                     self.xch.exchange(v, level)
                 v_new = self._buf(level)
                 nxt = self.program[k + 1] if k + 1 < len(self.program) else ""
-                n_edges = int(m.edge_index[level - 1].size(1))
-                want_next = nxt.startswith("mp") and impl.hoists(n_edges)
+                want_next = nxt.startswith("mp") and impl.hoists(m.decision_edges[level - 1])
                 kw = {"overlap": overlap} if overlap is not None else {}
                 e, prod = impl.mp(name, v, e, e_pending, m.edge_index[level - 1], n_own, v_new[:n_own], products=prod,
                                   next_name=nxt if want_next else None, pr_out=self._buf(level) if want_next else None, **kw)
@@ -464,6 +474,7 @@ class DistributedRollout:
         parts = build_partition(graph_cpu, levels, world)
         self.n_global = int(graph_cpu.pos.size(0))
         self.mesh = LocalMesh(graph_cpu, levels, parts[rank], device, rank, world)
+        self.mesh.decision_edges = uniform_edge_counts(parts)
         self.nf = int(model.num_fields)
         width = int(model.node_encoder.output_size)
         self.fwd = MusPartitionedForward(program, self.mesh, HipImpl(model), HaloExchanger(self.mesh, group), width, self.nf)

@@ -20,6 +20,10 @@ def test_partition_invariants():
         edges = P.coarse_topology(g, 3)
         owners = P.assign_owners(g, 3, world)
         sizes = [int(g.pos.size(0)), int(g.pos_2.size(0)), int(g.pos_3.size(0))]
+        # the count rank-uniform decisions are taken on (what a halo exchange carries): the smallest rank's, the same for all
+        uni = P.uniform_edge_counts(parts)
+        assert uni == [min(parts[r][l].edge_index.shape[1] for r in range(world)) for l in range(3)]
+        assert all(uni[l] <= parts[r][l].edge_index.shape[1] for r in range(world) for l in range(3))
         for l in range(3):
             own_all = np.concatenate([parts[r][l].owned for r in range(world)])
             assert np.array_equal(np.sort(own_all), np.arange(sizes[l])), "every node owned exactly once"
