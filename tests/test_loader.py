@@ -47,6 +47,9 @@ def test_dataloader_applies_batch_transform_and_keeps_targets():
     loader = gfd.DataLoader(data, batch_size=2, shuffle=False, transform=lambda b: (seen.append(b.num_nodes), b)[1])
     sizes = [b.num_nodes for b in loader]
     assert sizes == [300, 300, 150] and seen == sizes
+    # worker processes (the reference's scripts use num_workers=4): graphs and batch transforms cross the process boundary
+    workers = gfd.DataLoader(data, batch_size=2, shuffle=False, transform=gfd.transforms.GridClustering([0.3]), num_workers=2)
+    assert [(b.num_nodes, hasattr(b, "cluster_2")) for b in workers] == [(300, True), (300, True), (150, True)]
     b = next(iter(loader))
     assert b.target.shape == (300, 6) and int(b.edge_index.max()) == 299 and int(b.edge_index[:, :900].max()) == 149
 
