@@ -414,3 +414,17 @@ def test_gmus_batch_through_collater_equals_individual_graphs():
         alone = [model.forward(g.clone().to(DEV)) for g in graphs]
         both = model.forward(gfd.Collater(gfd.transforms.BuildKnnInterpWeights(6))(graphs).to(DEV))
     torch.testing.assert_close(both, torch.cat(alone), rtol=1e-4, atol=1e-4)
+
+
+def test_training_in_fp32_mfma_mode(monkeypatch):
+    """`gfd.set_mlp_precision("fp32")`: the forward runs the fp32-MFMA kernels (no activation saving there: the backward
+    recomputes), gradients still match the oracle."""
+    old = ops.mlp_precision()
+    ops.set_mlp_precision("fp32")
+    try:
+        model, loss, loss_ref, got, ref = _model_and_oracle_grads("NsTwoScaleGNN", 2, 2500, 128, 17)
+    finally:
+        ops.set_mlp_precision(old)
+    assert abs(loss - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref))
+    worst = max(float((got[k].cpu() - ref[k]).abs().max()) / max(float(ref[k].abs().max()), 1e-7) for k in ref)
+    assert worst < 2e-3, worst
