@@ -1,0 +1,168 @@
+// Shared declarations of the fused-MLP kernels (mlp_fused.hip: tile kernels, mlp_px6.hip: persistent ping-pong kernel):
+// launch parameter block, LDS / stream constants, operand split and activation helpers.
+#pragma once
+#include "g4c_common.h"
+#include <type_traits>
+
+#ifndef G4C_ABLATE
+#define G4C_ABLATE 0
+#endif
+
+namespace g4cm {
+
+constexpr int KC = 32;        // K chunk = one revolution of the weight ring (8 steps of 4 k)
+constexpr int XS = KC + 2;    // LDS row stride of an input chunk (conflict-free ds_read_b64)
+constexpr int HS = 128 + 4;   // LDS row stride of the hidden activations (16-byte aligned rows)
+constexpr int NP = 128;       // every layer is computed 128 wide
+constexpr int CHUNK_FLOATS = KC * NP;   // packed weights per chunk: [16 kpairs][32 lanes][4 tiles][2]
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Src {
+    const float *ptr;
+    const int *idx;
+    int width, wpad, ld, col0, vec, pre_act;
+    const int *seg_off;      // bf16x6 kernel: row r = sum / mean of rows [seg_off[r], seg_off[r+1]) (aggregation on load)
+    int seg_mean;
+    const int *seg_perm;     // optional row indirection of those positions
+};
+
+struct NarSrc {          // narrow input block multiplied on the VALUs (g4c_src_t.additive == 2): rows = the tile's own rows
+    const float *ptr;    // first used column of row 0
+    const float *w;      // fp32 [width][128]
+    int width, ld;
+};
+
+struct AddSrc {          // pre-multiplied first-layer term, gathered per row and added to the layer-0 output
+    const float *ptr;
+    const int *idx;
+    int width, ld;
+};
+
+struct Params {
+    Src src[G4C_MAX_SRC];
+    int n_src;
+    AddSrc add[G4C_MAX_SRC];
+    int n_add;
+    int n_layers;
+    int chunks0;              // number of 32-k chunks of layer 0 (sum of source widths padded to 32)
+    const float *w;           // all layers packed back to back, chunk after chunk (+ one chunk of slack)
+    const float *b;           // [n_layers][128] biases, zero padded
+    const float *gamma, *beta;
+    float eps;
+    int n_out;
+    long long M;
+    float *out;
+    int out_ld;
+    const int *out_idx;
+    int act;
+    const float *resid;
+    int resid_ld, resid_col0;
+    int n_tiles;
+    long long row_base;       // first row of this launch (a call may be split into a 64-row and a 32-row launch)
+    // "heads": extra bias-free 128x128 products of the FINAL output tile (after LayerNorm / activation), their
+    // weights continuing the packed stream after the last layer.  Used to emit the next MP layer's pre-multiplied
+    // node-side terms (W1_row v', W1_col v') from the node-MLP launch that produces v' (column-split kernels only).
+    int n_heads;
+    float *head_out[G4C_MAX_HEADS];
+    int head_ld;
+    // fused aggregation (bf16x6 kernel): tiles of whole CSR segments (g4c_plan_tiles) instead of fixed 32-row tiles; after
+    // the store, the tile's segments are summed / averaged from the LDS copy of the output rows into agg[segment, :]
+    const int *tile_rows, *tile_seg, *seg_off;
+    float *agg;
+    int agg_ld, agg_mean;
+    // narrow input blocks of the first layer, multiplied in fp32 on the vector ALUs (bf16x6 kernel)
+    NarSrc nar[G4C_MAX_SRC];
+    int n_nar;
+    // training forward (g4c_mlp_forward_bx6_save): save[l] (or null) receives layer l's output rows, [M, 128] fp32 — the SELU
+    // activations of a hidden layer, the pre-LayerNorm rows of the last one — so the backward pass recomputes nothing
+    float *save[G4C_MAX_LAYERS];
+    int save_ld;
+    // backward chain (same entry point): mul[l] (or null) = the SELU OUTPUT rows a hidden layer l's result is multiplied by the
+    // slope of, instead of bias + SELU:  y = x * selu'(.)  — the launch then computes  g_{k-1} = (g_k W_k) * selu'(a_{k-1})  layer
+    // after layer, writing every g through save[]
+    const float *mul[G4C_MAX_LAYERS];
+    int mul_ld;
+};
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int HB = 128 + 8;                 // LDS row stride of a bf16 operand plane (272 B: conflict-free ds_read_b128)
+constexpr int STEP6 = 3 * 512;                  // bf16 elements of one 16-k step of one column tile (3 planes)
+constexpr int BLOCK6 = 4 * 8 * STEP6;           // one 128-k block of the bf16x6 stream
+
+// 16-byte weight-fragment load through a buffer descriptor: 32-bit lane offset (one VGPR for the whole kernel) + wave-uniform
+// byte offset in an SGPR + immediate, instead of a 64-bit VALU address computation (and two address VGPRs) per load.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 ldw(__amdgpu_buffer_rsrc_t rs, unsigned voff_bytes, unsigned soff_bytes) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff_bytes, soff_bytes, 0);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// SELU of four values with the multiplies / fused multiply-adds written as vector math (v_pk_mul_f32 / v_pk_fma_f32):
+// scale*max(x,0) + scale*alpha*(exp(min(x,0)) - 1); the second term is exactly 0 for x >= 0.
+__device__ __forceinline__ f32x4 selu4(f32x4 x) {
+    const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f;
+    const float scale = 1.0507009873554804934193349852946f;
+    f32x4 t, m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { t[e] = fminf(x[e], 0.f); m[e] = fmaxf(x[e], 0.f); }
+    t = t * 1.4426950408889634f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_exp2f(t[e]);
+    return m * scale + (t * sa - sa);
+}
+
+// exact three-way bf16 split of four fp32 values.  Two values at a time: ONE v_cvt_pk_bf16_f32 gives both bf16 terms, and
+// their fp32 values come back with a shift / a mask of that packed word (instead of one extra conversion per element);
+// the remainders are vector subtractions (v_pk_add_f32).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(f32x2 x, f32x2 &back) {
+    bf16x2 b;
+    b[0] = (__bf16)x[0]; b[1] = (__bf16)x[1];
+    const unsigned u = __builtin_bit_cast(unsigned, b);
+    back[0] = __builtin_bit_cast(float, u << 16);
+    back[1] = __builtin_bit_cast(float, u & 0xffff0000u);
+    return u;
+}
+template <int SP = 3>
+__device__ __forceinline__ void split3x4(f32x4 x, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
+    if (SP == 1 || (G4C_ABLATE & 512)) {          // SP == 1: round to bf16 (only h is stored)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = (__bf16)x[e]; m[e] = h[e]; l[e] = h[e]; }
+        return;
+    }
+    unsigned hu[2], mu[2], lu[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        f32x2 v, hf, mf, lf;
+        v[0] = x[2 * j]; v[1] = x[2 * j + 1];
+        hu[j] = pack_bf16(v, hf);
+        const f32x2 r1 = v - hf;
+        mu[j] = pack_bf16(r1, mf);
+        const f32x2 r2 = r1 - mf;
+        lu[j] = pack_bf16(r2, lf);
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 hh, mm, ll;
+    hh[0] = hu[0]; hh[1] = hu[1]; mm[0] = mu[0]; mm[1] = mu[1]; ll[0] = lu[0]; ll[1] = lu[1];
+    h = __builtin_bit_cast(bf16x4, hh); m = __builtin_bit_cast(bf16x4, mm); l = __builtin_bit_cast(bf16x4, ll);
+}
+
+// exact three-way bf16 split of an fp32 value
+__device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+// persistent ping-pong kernel (mlp_px6.hip)
+int px6_enable(int on);
+bool px6_eligible(const Params &p, bool agg, bool save, bool all_vec);
+int px6_launch(const Params &p, bool round1, bool agg, hipStream_t st);
+
+}  // namespace g4cm

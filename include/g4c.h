@@ -188,6 +188,12 @@ int g4c_mlp_pack_layer_bx6(const float *W, int32_t n_out, int32_t k_in, const in
 int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
                         int64_t n_rows, float *out, int32_t out_ld, const int32_t *out_idx,
                         int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
+/* The bf16x6 / bf16 entry points run on one of two kernels with identical arithmetic per 128 x 128 block: the persistent
+ * ping-pong kernel (mlp_px6.hip: one 8-wave workgroup per CU, every weight block held in registers for a whole stage,
+ * matrix phases of one wave group overlapped with the vector / memory phases of the other) for the launches inside its
+ * envelope, the 32-row-tile kernel otherwise (training saves, aggregation on load, unaligned inputs).
+ * g4c_mlp_px6_enable(1 | 0) switches the former on / off, (-1) only queries; returns the previous setting. */
+int g4c_mlp_px6_enable(int on);
 /* Rounded-bf16 variant (opt-in only; BASELINE config 3 "bf16 edge-MLP MFMA"): the same stream and kernel structure, but
  * only the LEADING bf16 term of every operand is used (one product per multiply-add): weights and the activations
  * entering each Linear are rounded to bf16, accumulation / bias / SELU / LayerNorm / additive sources / residual stay
