@@ -62,7 +62,8 @@ constexpr int RTB = 32 * ROWB;         // one row-tile region
 constexpr int NARW_MAX = 16;           // narrow input columns whose W1^T rows are staged in LDS
 constexpr int HOB = 64 * 16 * 16;         // one accumulator hand-over buffer: [ct][gq][lane] x 16 bytes
 constexpr int IXB = 2 * 2 * 4 * 32 * 4;   // gather rows of the additive terms: [tile parity][source][rt][32 rows] int
-constexpr int PX_LDS = 4 * RTB + 2 * HOB + ((G4C_MAX_LAYERS + 1) * NP + 2 * NP + NARW_MAX * NP) * 4 + 16 + IXB;
+constexpr int STB = 2 * 2 * 128 * 4;      // LayerNorm partial statistics: [unit parity][pass][column tile][32 rows] float
+constexpr int PX_LDS = 4 * RTB + 2 * HOB + ((G4C_MAX_LAYERS + 1) * NP + 2 * NP + NARW_MAX * NP) * 4 + 16 + IXB + STB;
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
     float *sNarW = sGB + 2 * NP;
     unsigned *sCnt = reinterpret_cast<unsigned *>(sNarW + NARW_MAX * NP);      // arrival counter of group_sync
     int *sIx = reinterpret_cast<int *>(sCnt + 4);
+    float *sStat = reinterpret_cast<float *>(sIx + IXB / 4);
 
     // the parameter block is read through a pointer to the kernarg segment
     typedef const __attribute__((address_space(4))) Params *ParamsPtr;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
                 // one interval; the row tile is a compile-time constant (accumulators and prefetch registers are indexed by it)
                 auto interval = [&](auto rc) __attribute__((always_inline)) {
                     constexpr int r = decltype(rc)::value;
-                    if (j == iters && r >= 2) return;        // (the drain has two intervals)
+                    if (j == iters && r >= 1) return;        // (the drain has one interval)
                     PX_STAMP();
                     remat();
                     constexpr int pr = (r + 3) & 3;
@@ -418,25 +420,33 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
     // Everything that is not a matrix product or a hidden-layer epilogue: input rows (fetched a tile ahead, parked into the
     // planes), gathered additive rows / narrow input blocks (summed into the matrix waves' start values), the last layer's
     // LayerNorm / stores / aggregation, head stores.  Per-row-tile state is derived from the loop position.
-    // xp[r] = this lane's 16 values of row `prow` of the rows row tile r is parked with next; bit r of xp_have: requested.
-    f32x4 xp[4][4];
-    unsigned xp_have = 0;
-    auto fetch = [&](int j, int s, int r) __attribute__((always_inline)) {
+    //
+    // Prefetch loads are issued UNCONDITIONALLY, once per interval and register set (the address is selected, not the load:
+    // rows that are not needed are requested again or replaced by a dummy row).  A load under a wave-uniform condition
+    // merges with the register's previous value at the join, hipcc copies it there, and the copy waits for the data — every
+    // prefetch then costs its full memory latency (measured: 3000 cycles per row fetch).
+    f32x4 xp[4][4];                      // xp[r] = this lane's 16 values of row `prow` of the rows row tile r is parked with next
+    f32x4 ad[2][2][4];                   // ad[unit parity][source][gq]: gathered additive rows, in flight for two intervals
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { xp[r][q] = f32x4{0.f, 0.f, 0.f, 0.f}; ad[r & 1][r >> 1][q] = xp[r][q]; }
+    auto ld16 = [&](f32x4 &dst, const float *ptr) __attribute__((always_inline)) { dst = *reinterpret_cast<const f32x4 *>(ptr); };
+    auto fetch = [&](auto rc, int j, int s) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
         int row0, n;
         rt_info(j, r, row0, n);
-        xp_have |= 1u << r;
         const int rr = prow < n ? prow : n - 1;
         long long gr = row0 + rr;
         if (P.src[s].idx) gr = P.src[s].idx[gr];
         const float *rp = P.src[s].ptr + gr * P.src[s].ld + P.src[s].col0 + c4;
         const int width = P.src[s].width;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xp[r][q] = *reinterpret_cast<const f32x4 *>(rp + ((q * KC + c4 < width) ? q * KC : -c4));
+        for (int q = 0; q < 4; ++q) ld16(xp[r][q], rp + ((q * KC + c4 < width) ? q * KC : -c4));
     };
     // park source s of tile j into row tile r (rows >= n are clamped copies of the last row: never stored)
-    auto park = [&](int j, int s, int r) __attribute__((always_inline)) {
-        if (!(xp_have & (1u << r))) fetch(j, s, r);
-        xp_have &= ~(1u << r);
+    auto park = [&](auto rc, int j, int s) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
         const int width = P.src[s].width;
         const bool act = P.src[s].pre_act != 0;
         unsigned char *d = lds + r * RTB + prow * ROWB + 2 * c4;
@@ -449,13 +459,28 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
             put_split<SP>(d + 2 * q * KC, v);
         }
     };
-    // the rows row tile r needs after the park of (tile j, source s): next source of the tile, or source 0 of the next tile
-    auto fetch_after = [&](int j, int s, int r) __attribute__((always_inline)) {
-        int nj = j, ns = s + 1;
-        if (ns >= n_src) { ns = 0; ++nj; }
+    // same, for the loop: always issued; (j, s) clamped to rows that exist (requesting rows again is harmless)
+    auto fetch_always = [&](auto rc, int j, int s) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
         int row0, n;
-        rt_info(nj, r, row0, n);
-        if (n > 0) fetch(nj, ns, r);
+        rt_info(j, r, row0, n);
+        if (n <= 0) { rt_info(0, 0, row0, n); s = 0; }         // (the first row tile always exists)
+        const int rr = prow < n ? prow : n - 1;
+        long long gr = row0 + rr;
+        const int *ix = P.src[s].idx;
+        if (ix) gr = ix[gr];
+        const float *rp = P.src[s].ptr + gr * P.src[s].ld + P.src[s].col0 + c4;
+        const int width = P.src[s].width;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ld16(xp[r][q], rp + ((q * KC + c4 < width) ? q * KC : -c4));
+    };
+    // the park that follows the latest one of a row tile whose most recent unit is (tile qj, stage qs)
+    auto next_park = [&](int qj, int qs, int &nj2, int &ns2) __attribute__((always_inline)) {
+        if (qs < st_l0) {
+            if (qs + 2 <= st_l0) { nj2 = qj; ns2 = qs + 2; } else { nj2 = qj + 1; ns2 = 0; }
+        } else if (qs < NS - 1) { nj2 = qj + 1; ns2 = 0; }
+        else if (n_src > 1) { nj2 = qj + 1; ns2 = 1; }
+        else { nj2 = qj + 2; ns2 = 0; }
     };
 
     // gather rows of the additive terms, staged in LDS a tile ahead: helper wave ct loads those of row tile ct
@@ -468,32 +493,31 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
             sIx[(((j & 1) * 2 + h) * 4 + ct) * 32 + i] = P.add[h].idx ? P.add[h].idx[gr] : gr;
         }
     };
-    // gathered additive rows, in flight for two intervals: ad[unit parity][source][gq]
-    f32x4 ad[2][2][4];
-    auto issue_adds = [&](int j, int r) __attribute__((always_inline)) {
+    // gathers of unit (j, st_l0, r) (need) or of a dummy row (the load itself is unconditional, see above)
+    auto issue_adds = [&](auto rc, int j, bool need) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             if (a < n_add) {
-                const int row = sIx[(((j & 1) * 2 + a) * 4 + r) * 32 + i];
+                const int row = need ? sIx[(((j & 1) * 2 + a) * 4 + r) * 32 + i] : 0;
                 const float *pr = P.add[a].ptr + (long long)row * P.add[a].ld + fbase;
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) ad[r & 1][a][gq] = *reinterpret_cast<const f32x4 *>(pr + 8 * gq);
+                for (int gq = 0; gq < 4; ++gq) ld16(ad[r & 1][a][gq], pr + 8 * gq);
             }
         }
     };
     // start values of unit (j, st_l0, r) beyond the bias: gathered rows + narrow input blocks, into the hand-over buffer
-    auto presum = [&](int j, int r) __attribute__((always_inline)) {
+    auto presum = [&](auto rc, int j) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
         int row0, n;
         rt_info(j, r, row0, n);
         f32x4 x[4];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) x[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n_add > 0) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-            if (a < n_add) {
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) x[gq] += ad[r & 1][a][gq];
-            }
+            for (int gq = 0; gq < 4; ++gq) { x[gq] = ad[r & 1][0][gq]; if (n_add > 1) x[gq] += ad[r & 1][1][gq]; }
+        }
         // narrow input blocks: x[row, k] * W1^T[k, :] in fp32 on the vector ALUs
         int base = 0;
         const int gr = row0 + (i < n ? i : n - 1);
@@ -516,167 +540,153 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
         for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4 *>(d + gq * 1024) = x[gq];
     };
 
-    // ---- LayerNorm / activation / residual / store (/ aggregation) of the finished row tile r of tile fj, then what
-    // refills its planes
-    auto finish = [&](int fj, int r) __attribute__((always_inline)) {
+    // ---- last layer of row tile r of tile fj: LayerNorm / activation / residual / store (/ aggregation) in the accumulator
+    // layout (this lane: row i, features fbase + 8 gq + e; row statistics exchanged between the four helper waves through
+    // LDS), then what refills the row tile's planes: the heads' operand planes, or the next tile's input rows
+    auto finish = [&](auto rc, int fj) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
         unsigned char *reg = lds + r * RTB;
         int row0, n;
         rt_info(fj, r, row0, n);
         const int n_out = P.n_out;
-        const float inv_n = 1.0f / (float)n_out;
-        const int rl = lane_v & 7, part = lane_v >> 3, cb = part * 16;
-        auto norm_rows = [&](int rb, int re) __attribute__((always_inline)) {       // rows [rb, re) of the row tile, 8 per pass
-            for (int r8 = rb; r8 < re; r8 += 8) {
-                const int row = r8 + rl;
-                const bool on = row < re;
-                float *rowp = reinterpret_cast<float *>(reg + (on ? row : rb) * ROWB) + cb;
-                float x[16];
+        unsigned char *hs = sHO + (r & 1) * HOB + (ct * 4 * 64 + lane_v) * 16;
+        f32x4 x[4];
 #pragma unroll
-                for (int c = 0; c < 16; c += 4) {
-                    const f32x4 t = *reinterpret_cast<const f32x4 *>(rowp + c);
-                    x[c] = t[0]; x[c + 1] = t[1]; x[c + 2] = t[2]; x[c + 3] = t[3];
-                }
-                if (P.gamma) {
-                    float sum = 0.f;
+        for (int gq = 0; gq < 4; ++gq) x[gq] = *reinterpret_cast<const f32x4 *>(hs + gq * 1024);
+        if (P.gamma) {
+            const float inv_n = 1.0f / (float)n_out;
+            float *st0 = sStat + ((r & 1) * 2 + 0) * 128, *st1 = sStat + ((r & 1) * 2 + 1) * 128;
+            float sum = 0.f;
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) sum += (cb + c < n_out) ? x[c] : 0.f;
+            for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-                    for (int o = 8; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
-                    const float mean = sum * inv_n;
-                    float var = 0.f;
+                for (int e = 0; e < 4; ++e) sum += (fbase + 8 * gq + e < n_out) ? x[gq][e] : 0.f;
+            sum += __shfl_xor(sum, 32);
+            if (h == 0) st0[ct * 32 + i] = sum;
+            group_sync(sCnt, sync_epoch, lane_v);
+            const float mean = (st0[i] + st0[32 + i] + st0[64 + i] + st0[96 + i]) * inv_n;
+            float var = 0.f;
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) { const float dlt = x[c] - mean; var += (cb + c < n_out) ? dlt * dlt : 0.f; }
+            for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-                    for (int o = 8; o < 64; o <<= 1) var += __shfl_xor(var, o);
-                    const float rstd = rsqrtf(var * inv_n + P.eps);
+                for (int e = 0; e < 4; ++e) { const float dl = x[gq][e] - mean; var += (fbase + 8 * gq + e < n_out) ? dl * dl : 0.f; }
+            var += __shfl_xor(var, 32);
+            if (h == 0) st1[ct * 32 + i] = var;
+            group_sync(sCnt, sync_epoch, lane_v);
+            const float rstd = rsqrtf((st1[i] + st1[32 + i] + st1[64 + i] + st1[96 + i]) * inv_n + P.eps);
 #pragma unroll
-                    for (int c = 0; c < 16; c += 4) {
-                        const f32x4 g4 = *reinterpret_cast<const f32x4 *>(sGB + cb + c);
-                        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sGB + NP + cb + c);
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4 *>(sGB + fbase + 8 * gq);
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sGB + NP + fbase + 8 * gq);
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) x[c + u] = fmaf((x[c + u] - mean) * rstd, g4[u], b4[u]);
-                    }
-                }
-                if (P.act == G4C_ACT_SELU) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) x[c] = g4c::selu_f(x[c]);
-                } else if (P.act == G4C_ACT_TANH) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) x[c] = g4c::tanh_f(x[c]);
-                }
-                if (on) {
-#pragma unroll
-                    for (int c = 0; c < 16; c += 4) {
-                        f32x4 t;
-                        t[0] = x[c]; t[1] = x[c + 1]; t[2] = x[c + 2]; t[3] = x[c + 3];
-                        *reinterpret_cast<f32x4 *>(rowp + c) = t;
-                    }
-                }
+                for (int e = 0; e < 4; ++e) x[gq][e] = fmaf((x[gq][e] - mean) * rstd, g4[e], b4[e]);
             }
-        };
-        const bool fast = (n_out == NP) && ((P.out_ld & 3) == 0) && (((uintptr_t)P.out & 15) == 0) && (P.resid == nullptr);
-        auto store_rows = [&](int rb, int re) __attribute__((always_inline)) {      // whole rows, one per half wave
-            if (!P.out) return;
+        }
+        if (P.act == G4C_ACT_SELU) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) x[gq] = selu4(x[gq]);
+        } else if (P.act == G4C_ACT_TANH) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[gq][e] = g4c::tanh_f(x[gq][e]);
+        }
+        // ---- rows to global memory: 16-byte pieces (this lane's four runs of four features)
+        if (P.out && i < n) {
+            const long long grow = row0 + i;
+            const long long orow = P.out_idx ? P.out_idx[grow] : grow;
+            const bool fast = (n_out == NP) && ((P.out_ld & 3) == 0) && (((uintptr_t)P.out & 15) == 0) && (P.resid == nullptr);
+            float *op = P.out + orow * P.out_ld + fbase;
             if (fast) {
-                for (int row = rb + h; row < re; row += 2) {
-                    const long long grow = row0 + row;
-                    const long long orow = P.out_idx ? P.out_idx[grow] : grow;
-                    const f32x4 t = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(reg + row * ROWB) + 4 * i);
-                    *reinterpret_cast<f32x4 *>(P.out + orow * P.out_ld + 4 * i) = t;
-                }
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4 *>(op + 8 * gq) = x[gq];
             } else {
-                for (int e = lane_v; e < (re - rb) * n_out; e += 64) {
-                    const int rr = e / n_out, c = e - rr * n_out;
-                    const int row = rb + rr;
-                    const long long grow = row0 + row;
-                    const long long orow = P.out_idx ? P.out_idx[grow] : grow;
-                    float y = reinterpret_cast<const float *>(reg + row * ROWB)[c];
-                    if (P.resid) y += P.resid[grow * P.resid_ld + P.resid_col0 + c];
-                    P.out[orow * P.out_ld + c] = y;
-                }
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c = fbase + 8 * gq + e;
+                        if (c < n_out) {
+                            float y = x[gq][e];
+                            if (P.resid) y += P.resid[grow * P.resid_ld + P.resid_col0 + c];
+                            op[8 * gq + e] = y;
+                        }
+                    }
             }
-        };
-        const bool post = P.gamma || P.act;
+        }
         if (AGG) {
-            // this wave's segments: normalise their rows, store them, then add them up in row order (= g4c_segment_reduce)
+            // the finished rows back into the hand-over buffer, then every wave adds up its 32 columns of the row tile's
+            // segments in row order (= g4c_segment_reduce): lane -> (feature quad lane & 7, one of 8 segments at a time)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4 *>(hs + gq * 1024) = x[gq];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (only this wave's own columns are read back)
             const int fu = u_begin + 4 * fj + r;
             const int s0 = P.tile_seg[fu], s1 = P.tile_seg[fu + 1];
-            for (int sg = s0 + ct; sg < s1; sg += 4) {
+            const int fq = lane_v & 7, gqa = fq >> 1, ha = fq & 1;
+            const unsigned char *hb = sHO + (r & 1) * HOB + ((ct * 4 + gqa) * 64 + ha * 32) * 16;
+            for (int sg = s0 + (lane_v >> 3); sg < s1; sg += 8) {
                 const int b = P.seg_off[sg] - row0, e = P.seg_off[sg + 1] - row0;
-                if (post) norm_rows(b, e);
-                store_rows(b, e);
-                f32x2 a = {0.f, 0.f};
-                for (int row = b; row < e; ++row) a += *reinterpret_cast<const f32x2 *>(reinterpret_cast<const float *>(reg + row * ROWB) + 2 * lane_v);
-                if (P.agg_mean) { const float cnt = (float)((e - b) > 1 ? (e - b) : 1); a[0] /= cnt; a[1] /= cnt; }
-                *reinterpret_cast<f32x2 *>(P.agg + (long long)sg * P.agg_ld + 2 * lane_v) = a;
-            }
-        } else {
-            const int rb = 8 * ct, re = (rb + 8 < n) ? rb + 8 : n;
-            if (rb < re) {
-                if (post) norm_rows(rb, re);
-                PX_SUB(5);
-                store_rows(rb, re);
-                PX_SUB(6);
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                for (int row = b; row < e; ++row) a += *reinterpret_cast<const f32x4 *>(hb + row * 16);
+                if (P.agg_mean) {
+                    const float cnt = (float)((e - b) > 1 ? (e - b) : 1);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] /= cnt;
+                }
+                *reinterpret_cast<f32x4 *>(P.agg + (long long)sg * P.agg_ld + ct * 32 + 4 * ha + 8 * gqa) = a;
             }
         }
         if (n_heads) {
-            // heads: the finished fp32 rows -> operand planes, re-read in the park layout by the wave that normalised them
-            // (with AGG the owners differ -> heads and AGG are not combined: the launcher refuses)
-            const float *src = reinterpret_cast<const float *>(reg + prow * ROWB) + c4;
-            f32x4 v[4];
+            // heads: the finished rows are the operand of the head blocks
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4 *>(src + q * KC);
-            unsigned char *d = reg + prow * ROWB + 2 * c4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) put_split<SP>(d + 2 * q * KC, v[q]);
+            for (int gq = 0; gq < 4; ++gq) put_split<SP>(reg + i * ROWB + 2 * (fbase + 8 * gq), x[gq]);
         } else {
             int row0n, nn;
             rt_info(fj + 1, r, row0n, nn);
-            if (nn > 0) {
-                // (AGG: rows were read by the waves that own their segments, the park writes them by row block)
-                if (AGG) group_sync(sCnt, sync_epoch, lane_v);
-                park(fj + 1, 0, r);
-                if (n_add == 0) fetch_after(fj + 1, 0, r);
-            }
+            if (nn > 0) park(rc, fj + 1, 0);
         }
     };
 
-    // ---- prologue: first tile's source 0 rows, fetched and parked just in time; the next rows and indices in flight
+    // ---- prologue: first tile's source 0 rows, fetched and parked just in time; the next rows, indices and gathers in flight
     __builtin_amdgcn_sched_barrier(0);
     if (n_add > 0) { load_ix(0); load_ix(1); }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    auto pro_fetch = [&](auto rc, int s) __attribute__((always_inline)) {
         int row0, n;
-        rt_info(0, r, row0, n);
-        if (n > 0) fetch(0, 0, r);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
+        rt_info(0, decltype(rc)::value, row0, n);
+        if (n > 0) fetch(rc, 0, s);
+    };
+    auto pro_park = [&](auto rc) __attribute__((always_inline)) {
         int row0, n;
-        rt_info(0, r, row0, n);
-        if (n > 0) { park(0, 0, r); if (n_add == 0) fetch_after(0, 0, r); }
+        rt_info(0, decltype(rc)::value, row0, n);
+        if (n > 0) park(rc, 0, 0);
+    };
+    pro_fetch(std::integral_constant<int, 0>{}, 0); pro_fetch(std::integral_constant<int, 1>{}, 0);
+    pro_fetch(std::integral_constant<int, 2>{}, 0); pro_fetch(std::integral_constant<int, 3>{}, 0);
+    pro_park(std::integral_constant<int, 0>{}); pro_park(std::integral_constant<int, 1>{});
+    pro_park(std::integral_constant<int, 2>{}); pro_park(std::integral_constant<int, 3>{});
+    // the rows of the first park inside the loop: the second input block of the first tile, or the next tile's rows
+    {
+        const int fj0 = n_src > 1 ? 0 : 1, fs0 = n_src > 1 ? 1 : 0;
+        fetch_always(std::integral_constant<int, 0>{}, fj0, fs0); fetch_always(std::integral_constant<int, 1>{}, fj0, fs0);
+        fetch_always(std::integral_constant<int, 2>{}, fj0, fs0); fetch_always(std::integral_constant<int, 3>{}, fj0, fs0);
     }
     if (n_add > 0) group_sync(sCnt, sync_epoch, lane_v);          // (the index rows are visible to the other helper waves)
     if (pre_on && st_l0 == 0) {
-        // start values of the first unit, gathers of the next two (every later unit: issued three intervals before its
-        // matrix phase, summed one interval before it)
+        // gathers of the first three units (every later unit: issued three intervals before its matrix phase), start values
+        // of the first (every later unit: summed one interval before its matrix phase)
+        auto pro_adds = [&](auto rc) __attribute__((always_inline)) {
+            int row0, n;
+            rt_info(0, decltype(rc)::value, row0, n);
+            if (n_add > 0) issue_adds(rc, 0, n > 0);
+        };
+        pro_adds(std::integral_constant<int, 0>{}); pro_adds(std::integral_constant<int, 1>{});
         int row0, n;
         rt_info(0, 0, row0, n);
-        if (n > 0) { if (n_add > 0) issue_adds(0, 0); presum(0, 0); }
-        if (n_add > 0) {
-            rt_info(0, 1, row0, n);
-            if (n > 0) issue_adds(0, 1);
-        }
+        if (n > 0) presum(std::integral_constant<int, 0>{}, 0);
+        pro_adds(std::integral_constant<int, 2>{});            // (into the registers unit 0's gathers have just left)
     }
     wg_barrier();
-    if (pre_on && st_l0 == 0 && n_add > 0) {
-        int row0, n;
-        rt_info(0, 2, row0, n);
-        // (unit 2's gathers go where unit 0's were: those have been summed)
-        if (n > 0) issue_adds(0, 2);
-    }
 
-    const int st_fetch = (st_l0 + 1 < NS) ? st_l0 + 1 : NS - 1;       // stage at whose transition delayed row fetches are issued
     for (int j = 0; j <= iters; ++j) {
         // (indices of tile j + 1 go where tile j - 1's were: its last gathers were issued long ago)
         if (j > 0 && n_add > 0) load_ix(j + 1);
@@ -689,54 +699,36 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
             if (nst == NS) { nst = 0; nj = j + 1; }
             auto interval = [&](auto rc) __attribute__((always_inline)) {
                 constexpr int r = decltype(rc)::value;
-                if (j == iters && r >= 2) return;
+                if (j == iters && r >= 1) return;
                 PX_STAMP();
                 remat();
                 PX_SUB(0);
                 // ---------------------------------------------------------------- the previous unit
                 {
                     constexpr int ur = (r + 3) & 3;
+                    const std::integral_constant<int, ur> urc{};
                     const int uj = (r == 0) ? pj : j, ust = (r == 0) ? pst : st;
                     int urow0, un;
                     rt_info(uj, ur, urow0, un);
                     if (un > 0) {
-                        unsigned char *reg = lds + ur * RTB;
                         if (ust < st_l0) {
-                            park(uj, ust + 1, ur);                    // next input block of layer 0; the accumulator carries on
-                            if (n_add == 0) fetch_after(uj, ust + 1, ur);
-                        } else if (ust >= st_fin) {
-                            // last layer / head: the matrix waves' accumulators (this lane's row i, features fbase + 8 gq + e)
+                            park(urc, uj, ust + 1);                   // next input block of layer 0; the accumulator carries on
+                        } else if (ust == st_fin) {
+                            finish(urc, uj);
+                        } else if (ust > st_fin) {
+                            // head: plain product of the finished rows, stored as it is
                             const unsigned char *hs = sHO + (ur & 1) * HOB + (ct * 4 * 64 + lane_v) * 16;
-                            f32x4 x[4];
+                            float *ho = P.head_out[ust - st_fin - 1];
+                            if (i < un) {
+                                float *orow = ho + (long long)(urow0 + i) * P.head_ld + fbase;
 #pragma unroll
-                            for (int gq = 0; gq < 4; ++gq) x[gq] = *reinterpret_cast<const f32x4 *>(hs + gq * 1024);
-                            if (ust == st_fin) {
-#pragma unroll
-                                for (int gq = 0; gq < 4; ++gq)
-                                    *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(reg + i * ROWB) + fbase + 8 * gq) = x[gq];
-                            } else {
-                                float *ho = P.head_out[ust - st_fin - 1];
-                                if (i < un) {
-                                    float *orow = ho + (long long)(urow0 + i) * P.head_ld + fbase;
-#pragma unroll
-                                    for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4 *>(orow + 8 * gq) = x[gq];
-                                }
-                                if (ust + 1 == NS) {
-                                    int row0n, nn;
-                                    rt_info(uj + 1, ur, row0n, nn);
-                                    if (nn > 0) { park(uj + 1, 0, ur); if (n_add == 0) fetch_after(uj + 1, 0, ur); }
-                                }
+                                for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4 *>(orow + 8 * gq) = *reinterpret_cast<const f32x4 *>(hs + gq * 1024);
                             }
-                        }
-                        // with gathered additive terms in flight, the next rows of this row tile are requested in a quiet
-                        // interval (loads return in order: a wait for a younger gather would wait for them too)
-                        if (n_add > 0 && ust == st_fetch && !(xp_have & (1u << ur))) {
-                            int fj2 = uj, fs = 0;
-                            if (st_fetch < st_l0) fs = st_fetch + 2; else ++fj2;       // (next source of this tile, or the next tile)
-                            if (fs >= n_src) { fs = 0; fj2 = uj + 1; }
-                            int row0n, nn;
-                            rt_info(fj2, ur, row0n, nn);
-                            if (nn > 0) fetch(fj2, fs, ur);
+                            if (ust + 1 == NS) {
+                                int row0n, nn;
+                                rt_info(uj + 1, ur, row0n, nn);
+                                if (nn > 0) park(urc, uj + 1, 0);
+                            }
                         }
                     }
                 }
@@ -749,31 +741,27 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
                     if (ast == st_l0) {
                         int row0a, na;
                         rt_info(aj, ar, row0a, na);
-                        if (na > 0) presum(aj, ar);
+                        if (na > 0) presum(std::integral_constant<int, ar>{}, aj);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 PX_SUB(2);
-                // ---------------------------------------------------------------- LayerNorm / stores of the unit before the previous one
-                {
-                    constexpr int fr = (r + 2) & 3;
-                    const int fj = (r < 2) ? pj : j, fst = (r < 2) ? pst : st;
-                    if (fst == st_fin && fj >= 0) {
-                        int row0f, nf;
-                        rt_info(fj, fr, row0f, nf);
-                        if (nf > 0) finish(fj, fr);
-                    }
-                }
-                PX_SUB(7);
                 // ---------------------------------------------------------------- gathers for the unit three ahead
                 if (n_add > 0) {
                     constexpr int gr = (r + 3) & 3;
                     const int gj = (r == 0) ? j : nj, gst = (r == 0) ? st : nst;
-                    if (gst == st_l0) {
-                        int row0g, ng;
-                        rt_info(gj, gr, row0g, ng);
-                        if (ng > 0) issue_adds(gj, gr);
-                    }
+                    int row0g, ng;
+                    rt_info(gj, gr, row0g, ng);
+                    issue_adds(std::integral_constant<int, gr>{}, gj, gst == st_l0 && ng > 0);
+                }
+                PX_SUB(3);
+                // ---------------------------------------------------------------- next input rows of the row tile two units back
+                {
+                    constexpr int qr = (r + 2) & 3;
+                    const int qj = (r < 2) ? pj : j, qs = (r < 2) ? pst : st;
+                    int fj2 = n_src > 1 ? 0 : 1, fs = n_src > 1 ? 1 : 0;        // (before its first unit: what the prologue requested)
+                    if (qj >= 0) next_park(qj, qs, fj2, fs);
+                    fetch_always(std::integral_constant<int, qr>{}, fj2, fs);
                 }
                 PX_SUB(4);
                 PX_STAMP();

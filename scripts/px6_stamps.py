@@ -10,6 +10,7 @@ from graphs4cfd_amd.nn import blocks as B
 torch.set_grad_enabled(False)
 if len(sys.argv) > 2: ops.set_mlp_precision(sys.argv[2])
 lib = _lib.load()
+lib.g4c_mlp_px6_enable(1)
 lib.g4c_px_read_stamps.restype = C.c_int; lib.g4c_px_read_stamps.argtypes = [C.c_void_p, C.c_int]
 dev = torch.device("cuda", 0); H = 128
 torch.manual_seed(0)
@@ -42,14 +43,11 @@ sub = np.zeros(256 * 8, dtype=np.uint64)
 lib.g4c_px_read_sub.restype = C.c_int; lib.g4c_px_read_sub.argtypes = [C.c_void_p, C.c_int]
 lib.g4c_px_read_sub(sub.ctypes.data, 256 * 8)
 sub = sub.reshape(256, 8).astype(np.int64)
-print("helper sub-stamps per interval (cycles from interval begin): 0 start | 1 previous unit done | 2 presum done | 5 LayerNorm done | 6 rows stored | 7 finish (park) done | 4 gathers issued | end")
+print("helper sub-stamps per interval (cycles from interval begin): 0 start | 1 previous unit done (park / finish / head) | 2 presum done | 3 gathers issued | 4 rows requested | end")
 for k in range(1, 40):
     b, e = st[1, 2 * k], st[1, 2 * k + 1]
     s_ = sub[k]
     def d(q):
         v = int(s_[q] - b)
         return f"{v:6d}" if 0 <= v < 100000 else "     -"
-    print(f"  interval {k:3d}: " + "  ".join(d(q) for q in (0, 1, 2, 5, 6, 7, 4)) + f"   end {int(e - b):6d}")
-print("raw sub-stamps of intervals 10..13 minus interval begin:")
-for k in range(10, 14):
-    print(k, [int(x - st[1, 2 * k]) for x in sub[k]])
+    print(f"  interval {k:3d}: " + "  ".join(d(q) for q in (0, 1, 2, 3, 4)) + f"   end {int(e - b):6d}")
