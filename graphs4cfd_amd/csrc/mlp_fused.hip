@@ -669,6 +669,7 @@ __device__ __forceinline__ void split_finish(const Params &p, float *sH, const f
     // (each wave reads back only the rows it normalised itself: no barrier needed)
 
     // ---------------------------------------------------------------- store this wave's rows
+    if (p.out == nullptr) return;          // (only the aggregate of the rows is wanted: g4c_mlp_forward_bx6_agg with out == NULL)
     const bool fast = (n_out == NP) && ((p.out_ld & 3) == 0) && (((uintptr_t)p.out & 15) == 0) && (p.resid == nullptr);
     if (fast) {
 #pragma unroll
@@ -2182,7 +2183,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     G4C_REQUIRE(n_rows >= 0 && n_rows < (1LL << 31), G4C_EINVAL, "g4c_mlp_forward: n_rows %lld out of range", (long long)n_rows);
     G4C_REQUIRE(act >= 0 && act <= 2, G4C_EINVAL, "g4c_mlp_forward: bad activation %d", act);
     if (n_rows == 0) return G4C_OK;
-    G4C_REQUIRE(out, G4C_EINVAL, "g4c_mlp_forward: null output");
+    G4C_REQUIRE(out || agg, G4C_EINVAL, "g4c_mlp_forward: null output");
     Params p;
     int kp = 0;
     bool all_vec = true, deep_ok = true;

@@ -1,11 +1,11 @@
 """`gfd.nn.blocks` on MI355X: same classes, constructor arguments, `forward` signatures, submodule
 names and `state_dict` keys as the reference's graphs4cfd/nn/blocks.py, with every forward routed
-to the hand-written HIP kernels of libg4c.so (fused gather+MLP+LayerNorm+activation on fp32 MFMA,
-CSR segmented reductions, static-plan pooling).  There is no torch / CPU fallback: tensors must live
+to the hand-written HIP kernels of libg4c.so (fused gather+MLP+LayerNorm+activation with fp32-accurate products on the
+bf16 matrix pipe, CSR segmented reductions, static-plan pooling).  There is no torch / CPU fallback: tensors must live
 on a HIP device and the library must be built.
 
-Inference only (the training loop and backward kernels are out of scope):
-outputs carry no autograd graph.
+With gradients enabled every block is recorded for autograd (autograd.py: HIP forward and backward); under
+torch.no_grad() the inference-only forms of the launches (heads, pre-multiplied products, fused aggregation) are used.
 
 Extensions over the reference signatures are keyword-only and optional (`activation=` on the MP
 blocks fuses the `F.selu` the model applies right after the block, nn/mus_gnn.py:182).
@@ -282,12 +282,14 @@ def edgeScalarToNodeVector(edge_attr: Tensor, edge_index: Tensor, edgeUnitVector
 # ------------------------------------------------------------------------------------- MP
 def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, aggr: str, act_code: int,
              e_pre_act: int = _lib.ACT_NONE, v_src: Optional[Tensor] = None,
-             products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None):
+             products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None, keep_e: bool = True):
     """Shared body of GNBlock / EdgeMP / DownEdgeMP (nn/blocks.py:175-186,322-333,360-381):
         e' = msg_mlp([e | s[row] | v[col]]);  agg = reduce(e' -> col);  v' = act(upd_mlp([agg | v])).
     Returns (v', e') where e' is stored WITHOUT the activation: the aggregation consumes the raw
     messages, and the consumer of e' applies the activation while loading (`e_pre_act` here is that
     pending activation of the incoming `e`).  `v_src` (DownEdgeMP) gathers sender rows from another tensor.
+    `keep_e=False`: the caller discards e' (the last MP layer of a level, nn/mus_gnn.py:199-200,211-212): when the edge launch
+    can reduce its own rows they are then not stored and None is returned for e'.
     `products` = (W1[:, H:2H] v, W1[:, 2H:3H] v) of msg_mlp's first layer when the launch that produced `v` already
     multiplied them; `next_msg` = the message MLP of the MP layer that will consume v' on the SAME graph: the node
     launch then emits its products as well and a third value (those products, or None) is returned."""
@@ -297,7 +299,15 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
     senders = v if v_src is None else v_src
     mean = aggr == "mean"
     e_src = e if isinstance(e, Source) else Source(e, pre_act=e_pre_act)      # (a Source: DownMP.pool(lazy_edges=True))
-    if ops.can_aggregate_on_load(csr, msg_mlp.output_size, [msg_mlp.output_size, int(v.size(1))]) and not ops.FUSE_AGG:
+    if ops.can_fuse_aggregation(csr, msg_mlp.output_size):
+        # the edge launch reduces the rows it has just computed (whole CSR segments per row tile, g4c_mlp_forward_bx6_agg):
+        # no second pass over the messages; with keep_e=False (the model discards e', nn/mus_gnn.py:199-200) they are not
+        # even written
+        agg = torch.empty((csr.n_seg, msg_mlp.output_size), dtype=torch.float32, device=v.device)
+        e_new = msg_mlp.run_hoisted([e_src], [(senders, ep.row), (v, ep.col)], ep.n_edges,
+                                    products=products, agg=(csr, agg, mean), store_rows=keep_e)
+        agg_src = Source(agg)
+    elif ops.can_aggregate_on_load(csr, msg_mlp.output_size, [msg_mlp.output_size, int(v.size(1))]):
         # the node launch averages each target's messages while it gathers its input (g4c_src_t.seg_off): no separate
         # aggregation pass, no aggregate written to / re-read from HBM
         e_new = msg_mlp.run_hoisted([e_src], [(senders, ep.row), (v, ep.col)], ep.n_edges, products=products)
@@ -306,8 +316,6 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
         e_new = msg_mlp.run_hoisted([e_src], [(senders, ep.row), (v, ep.col)], ep.n_edges)
         agg_src = Source(ops.segment_reduce(e_new, csr, mean))
     else:
-        # (G4C_FUSE_AGG: the aggregation rides on the EDGE launch when the kernel can reduce the tile it has just computed,
-        # ops.mlp_forward(agg=...); otherwise that call runs g4c_segment_reduce right after the launch)
         agg = torch.empty((csr.n_seg, msg_mlp.output_size), dtype=torch.float32, device=v.device)
         e_new = msg_mlp.run_hoisted([e_src], [(senders, ep.row), (v, ep.col)], ep.n_edges,
                                     products=products, agg=(csr, agg, mean))
@@ -359,11 +367,11 @@ class GNBlock(nn.Module):
                 m.reset_parameters()
 
     def step(self, v: Tensor, e: Tensor, edge_index: Tensor, act_code: int, e_pre_act: int = _lib.ACT_NONE,
-             products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None):
+             products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None, keep_e: bool = True):
         """Internal form used by the model programs: returns (act(v'), raw e') — and, when `next_msg` (the edge MLP of
         the next MP layer on the same graph) is given, a third value: that layer's `products` or None (see _mp_step)."""
         return _mp_step(self.edge_mlp, self.node_mlp, v, e, edge_index, self.aggr, act_code, e_pre_act,
-                        products=products, next_msg=next_msg)
+                        products=products, next_msg=next_msg, keep_e=keep_e)
 
     def forward(self, v: Tensor, e: Tensor, edge_index: Tensor, *, activation=None) -> Tuple[Tensor, Tensor]:
         return _public_mp(self.edge_mlp, self.node_mlp, v, e, edge_index, self.aggr, activation)
@@ -474,10 +482,10 @@ class EdgeMP(nn.Module):
                 item.reset_parameters()
 
     def step(self, e: Tensor, a: Tensor, angle_index: Tensor, act_code: int, a_pre_act: int = _lib.ACT_NONE,
-             products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None):
+             products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None, keep_e: bool = True):
         """Internal form: returns (act(e'), raw a') (+ the next EdgeMP's `products` when `next_msg` is given, see GNBlock.step)."""
         return _mp_step(self.angle_mlp, self.edge_mlp, e, a, angle_index, self.aggr, act_code, a_pre_act,
-                        products=products, next_msg=next_msg)
+                        products=products, next_msg=next_msg, keep_e=keep_e)
 
     def forward(self, e: Tensor, a: Tensor, angle_index: Tensor, *, activation=None) -> Tuple[Tensor, Tensor]:
         return _public_mp(self.angle_mlp, self.edge_mlp, e, a, angle_index, self.aggr, activation)

@@ -96,7 +96,10 @@ class _MuSGNN(GNN):
                     v, e, products = block.step(v, e, edge_index, SELU, e_pre_act=e_pending, products=products,
                                                 next_msg=getattr(self, nxt).edge_mlp)
                 else:
-                    v, e = block.step(v, e, edge_index, SELU, e_pre_act=e_pending, products=products)
+                    # the level's edge latents are dropped after this layer when an UpMP or the decoder follows (the up leg
+                    # restores the latents stashed before the DownMP): they then need not be stored
+                    drop_e = nxt.startswith("up_mp") or nxt == ""
+                    v, e = block.step(v, e, edge_index, SELU, e_pre_act=e_pending, products=products, keep_e=not drop_e)
                     products = None
                 e_pending = SELU
         nf = self.num_fields

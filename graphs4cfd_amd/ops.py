@@ -217,11 +217,13 @@ def rollout_advance(field: Tensor, pred: Tensor, outputs: Tensor, step: Tensor, 
 _PRECISION = os.environ.get("G4C_MLP_PRECISION", "bf16x6")
 
 
-# Fused aggregation in the edge-MLP launch (g4c_mlp_forward_bx6_agg).  Bit-identical to the separate g4c_segment_reduce, but
-# the launch then runs on tiles of WHOLE segments: with in-degree 6 (or 5) a 32-row tile holds 30 rows, i.e. 6.7 % more tiles,
-# which eats what the saved HBM pass gains (measured +0.8 % on the 100k-node rollout).  Off by default; worth it when the
-# degree divides 32.
-FUSE_AGG = os.environ.get("G4C_FUSE_AGG", "0") == "1"
+# Fused aggregation in the edge-MLP launch (g4c_mlp_forward_bx6_agg): bit-identical to the separate g4c_segment_reduce, and the
+# node launch no longer re-reads the 307 MB of messages (the largest single stream of a level-1 MP layer after the messages'
+# own write).  The launch then runs on tiles of WHOLE segments: with in-degree 6 (or 5) a 32-row tile holds 30 rows, i.e.
+# 6.7 % more tiles — speed-neutral on the 100k rollout (+0.8 %), 2.5 GB less traffic per step.  On from FUSE_AGG_MIN_ROWS
+# rows (below, launches are latency-bound and the row tiles of whole segments only cost); G4C_FUSE_AGG=0 switches it off.
+FUSE_AGG = os.environ.get("G4C_FUSE_AGG", "1") == "1"
+FUSE_AGG_MIN_ROWS = int(os.environ.get("G4C_FUSE_AGG_MIN_ROWS", "50000"))
 # Aggregation on load (g4c_src_t.seg_off): the node-MLP launch averages each target's messages while it gathers its input,
 # instead of a separate g4c_segment_reduce pass (bit-identical values; no tile-alignment constraint, unlike FUSE_AGG).
 AGG_ON_LOAD = os.environ.get("G4C_AGG_ON_LOAD", "1") == "1"
@@ -251,6 +253,13 @@ def grad_mode() -> bool:
     """True when calls are being recorded for autograd: the block / model code then keeps to the plain forms of the
     launches (no heads, no pre-multiplied products, no in-place epilogues), which are the differentiable ones."""
     return torch.is_grad_enabled()
+
+
+def can_fuse_aggregation(csr: CsrPlan, width: int) -> bool:
+    """The edge launch itself can reduce its rows per target (g4c_mlp_forward_bx6_agg): rows in segment order, segments of
+    at most 32 rows, the exact-split kernels, a 128-wide output, enough rows to be throughput-bound."""
+    return (FUSE_AGG and _PRECISION == "bf16x6" and width == 128 and csr.perm is None and csr.n >= FUSE_AGG_MIN_ROWS
+            and not grad_mode() and csr.tiles() is not None)
 
 
 def can_aggregate_on_load(csr: CsrPlan, width: int, consumer_widths: Sequence[int]) -> bool:
@@ -422,7 +431,8 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                 out: Optional[Tensor] = None, out_idx32: Optional[Tensor] = None,
                 resid: Optional[Tensor] = None, resid_col0: int = 0, tile_mode: Optional[int] = None,
                 head_outs: Optional[Sequence[Tensor]] = None, agg: Optional[Tuple[CsrPlan, Tensor, bool]] = None,
-                save: Optional[Sequence[Optional[Tensor]]] = None, mul: Optional[Sequence[Optional[Tensor]]] = None) -> Tensor:
+                save: Optional[Sequence[Optional[Tensor]]] = None, mul: Optional[Sequence[Optional[Tensor]]] = None,
+                store_rows: bool = True) -> Optional[Tensor]:
     """One fused MLP launch (g4c_mlp_forward).  `tile_mode` (tests / tuning) runs every row through
     g4c_mlp_forward_rows with that kernel variant instead of the library's own choice.
     `head_outs` ([n_rows, 128] tensors, one per head of `packed`): g4c_mlp_forward_heads.
@@ -456,28 +466,34 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                     raise ValueError("a narrow input block cannot be gathered through an index or activated on load")
                 a.additive, a.w = 2, packed.narrow_w[j].data_ptr()
             j += 1
-    if out is None:
+    # store_rows=False (with a fused aggregation only): the output rows are not written, only their aggregate
+    fusable = (agg is not None and FUSE_AGG and packed.precision == "bf16x6" and packed.n_out == 128 and head_outs is None
+               and tile_mode is None and out_idx32 is None and resid is None and n_rows == agg[0].n and agg[0].tiles() is not None)
+    if not store_rows and not fusable:
+        raise ValueError("store_rows=False needs an aggregation the launch can fuse (ops.can_fuse_aggregation)")
+    if out is None and store_rows:
         out = torch.empty((n_rows, packed.n_out), dtype=torch.float32, device=dev)
-    args = (_lib.ptr(out), _ld(out), _lib.ptr(out_idx32), act, _lib.ptr(resid), _ld(resid) if resid is not None else 0,
-            resid_col0, _lib.stream_handle(dev))
+    if store_rows:
+        args = (_lib.ptr(out), _ld(out), _lib.ptr(out_idx32), act, _lib.ptr(resid), _ld(resid) if resid is not None else 0,
+                resid_col0, _lib.stream_handle(dev))
     if agg is not None:
         csr, agg_out, agg_mean = agg
-        tiles = csr.tiles() if (FUSE_AGG and packed.precision == "bf16x6" and packed.n_out == 128 and head_outs is None and tile_mode is None
-                                and out_idx32 is None and resid is None and n_rows == csr.n) else None
+        tiles = csr.tiles() if fusable else None
         if tiles is None:        # not fusable here: the plain launch, then the separate reduction
             y = mlp_forward(packed, sources, n_rows, act, out, out_idx32, resid, resid_col0, tile_mode, head_outs)
             segment_reduce(y, csr, agg_mean, out=agg_out)
             return y
         _lib.require_hip(agg_out)
         t_rows, t_seg, nt = tiles
-        call = lambda: _lib.check(lib.g4c_mlp_forward_bx6_agg(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out), _ld(out), act,
+        call = lambda: _lib.check(lib.g4c_mlp_forward_bx6_agg(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out),
+                                                              _ld(out) if out is not None else 128, act,
                                                               _lib.ptr(t_rows), _lib.ptr(t_seg), _lib.ptr(csr.off), nt, _lib.ptr(agg_out),
                                                               _ld(agg_out), 1 if agg_mean else 0, _lib.stream_handle(dev)))
         if KernelTimer.active is None:
             call()
         else:
             _timed("mlp_bx6_kernel", packed.flops_per_row * n_rows,
-                   4.0 * ((sum(packed.seg_widths) + packed.n_out) * n_rows + packed.n_out * csr.n_seg), call)
+                   4.0 * ((sum(packed.seg_widths) + (packed.n_out if store_rows else 0)) * n_rows + packed.n_out * csr.n_seg), call)
     elif save is not None:
         if packed.precision != "bf16x6" or head_outs is not None or out_idx32 is not None or tile_mode is not None:
             raise NotImplementedError("save= needs the bf16x6 kernel without heads / output index / forced tile mode")

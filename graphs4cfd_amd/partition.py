@@ -364,10 +364,12 @@ class HipImpl:
             else:
                 agg_src = Source(ops.segment_reduce(e_new, csr, mean))
             return e_new, self._node_launch(blk.node_mlp, [agg_src, Source(v[:n_own])], n_own, SELU, v_out, next_name, pr_out)
-        if ops.can_aggregate_on_load(csr, blk.edge_mlp.output_size, [blk.edge_mlp.output_size, int(v.size(1))]) and not ops.FUSE_AGG:
+        if (not ops.can_fuse_aggregation(csr, blk.edge_mlp.output_size)
+                and ops.can_aggregate_on_load(csr, blk.edge_mlp.output_size, [blk.edge_mlp.output_size, int(v.size(1))])):
             e_new = blk.edge_mlp.run_hoisted([Source(e, pre_act=e_pending)], [(v, ep.row), (v, ep.col)], ep.n_edges, products=products)
             agg_src = Source(e_new, segments=csr, seg_mean=mean)
         else:
+            # (the edge launch reduces its own rows where it can, ops.can_fuse_aggregation; otherwise a separate reduction)
             agg = torch.empty((csr.n_seg, blk.edge_mlp.output_size), dtype=torch.float32, device=e.device)
             e_new = blk.edge_mlp.run_hoisted([Source(e, pre_act=e_pending)], [(v, ep.row), (v, ep.col)], ep.n_edges,
                                              products=products, agg=(csr, agg, mean))

@@ -206,7 +206,9 @@ int g4c_mlp_forward_bf16(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*
  * [tile_rows[t], tile_rows[t+1]).  g4c_mlp_forward_bx6_agg runs the MLP on those tiles (max_rows must be 32) and, from
  * the on-chip copy of each tile's output rows, writes agg[s, :] = sum or mean (agg_mean) of the rows of segment s —
  * same order and formula as g4c_segment_reduce, i.e. the `scatter(e', col, reduce)` of nn/blocks.py:183 without
- * re-reading e' from HBM.  tile_rows / tile_seg / seg_off are device int32 arrays. */
+ * re-reading e' from HBM.  tile_rows / tile_seg / seg_off are device int32 arrays.  out == NULL: the rows themselves are
+ * not stored, only their aggregate — the last MP layer of a level, whose edge output the reference discards
+ * (nn/mus_gnn.py:199-200,211-212). */
 int64_t g4c_plan_tiles(const int32_t *off /*host*/, int32_t n_seg, int32_t max_rows, int32_t *tile_rows /*host, out*/,
                        int32_t *tile_seg /*host, out*/, int64_t capacity);
 int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
