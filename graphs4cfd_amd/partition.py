@@ -244,6 +244,13 @@ class HaloExchanger:
         self._send_buf: Dict[tuple, torch.Tensor] = {}
         self._send_cat: Dict[int, Optional[torch.Tensor]] = {}
         self._side = None
+        # bookkeeping for bench.py: exchanges entered and bytes moved since reset_stats(); with `timing` on, an event pair
+        # around every collective (on the stream it is enqueued on; eager steps only)
+        self.n_exchanges, self.bytes_sent, self.bytes_recv = 0, 0, 0
+        self.timing, self.events = False, []
+
+    def reset_stats(self) -> None:
+        self.n_exchanges, self.bytes_sent, self.bytes_recv, self.events = 0, 0, 0, []
 
     def exchange_async(self, v: torch.Tensor, level: int):
         """`exchange` on a side stream (ordered after everything enqueued so far on the current stream); returns a handle for
@@ -293,8 +300,18 @@ class HaloExchanger:
             else:   # CPU tests (gloo): host logic only
                 buf[:n_send] = v[cat.long()]
         recv = v[m.n_own[level - 1]:]
+        self.n_exchanges += 1
+        self.bytes_sent += n_send * width * v.element_size()
+        self.bytes_recv += int(sum(m.recv_counts[level - 1])) * width * v.element_size()
+        ev = None
+        if self.timing and v.is_cuda and not torch.cuda.is_current_stream_capturing():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         dist.all_to_all_single(recv, buf[:n_send], output_split_sizes=m.recv_counts[level - 1],
                                input_split_sizes=m.send_counts[level - 1], group=self.group)
+        if ev is not None:
+            ev[1].record()
+            self.events.append(ev)
 
 
 # ------------------------------------------------------------------------------------- compute back-ends
@@ -486,6 +503,7 @@ class DistributedRollout:
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=device)
         self.steps_done = 0
         self.capture = capture and device.type == "cuda"
+        self.capture_error = None if self.capture else "capture not requested"
         self._hipgraph = None
 
     def _one(self) -> None:
@@ -502,16 +520,31 @@ class DistributedRollout:
                 self._one()
             elif self._hipgraph is None:
                 torch.cuda.synchronize(self.device)
+                hg, err = None, None
                 try:
                     hg = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(hg):
                         self._one()
+                except Exception as exc:   # keep the rollout alive on stacks where the collective cannot be captured
+                    hg, err = None, f"{type(exc).__name__}: {exc}"
+                # every rank takes the same path: one rank replaying while another launches eagerly would pair a captured
+                # collective with an eager one
+                ok = hg is not None
+                if self.world > 1:
+                    import torch.distributed as dist
+                    torch.cuda.synchronize(self.device)
+                    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    if ok and int(flag.item()) == 0:
+                        ok, err = False, "capture failed on another rank"
+                if ok:
                     self._hipgraph = hg
                     self._hipgraph.replay()
-                except Exception as exc:   # keep the rollout alive on stacks where the collective cannot be captured
+                else:
                     import sys
+                    self.capture_error = err
                     print(f"[graphs4cfd_amd] rank {self.rank}: hipGraph capture of the partitioned step failed "
-                          f"({type(exc).__name__}: {exc}); continuing with eager launches", file=sys.stderr)
+                          f"({err}); continuing with eager launches", file=sys.stderr)
                     self.capture, self._hipgraph = False, None
                     torch.cuda.synchronize(self.device)
                     self._one()

@@ -290,6 +290,26 @@ def gen_mus_models():
     save("models_mus.pt", out)
 
 
+def gen_mus_3d():
+    # BASELINE config 5's data path: the reference's NsFourScaleGNN (and, smaller, NsTwoScaleGNN) on a 3-D mesh —
+    # edge_encoder in = 3, down in = 3 + H, up in = 3 + 2H (nn/mus_gnn.py:485-562 on transforms/connect.py, mus.py with dim 3)
+    out = {}
+    H = 32
+    for i, (cls, cells, n) in enumerate((("NsFourScaleGNN", [0.20, 0.40, 0.80], 700), ("NsTwoScaleGNN", [0.25], 300))):
+        g = mus_graph(n, 6, cells, seed=90 + i, nf=3, dim=3)
+        arch = mus_arch(cls, H, 3, 5, d=3)
+        torch.manual_seed(290 + i)
+        model = getattr(gfd.nn, cls)(arch=arch)
+        gi = graph_dict(g)
+        with torch.no_grad():
+            model.eval()
+            y = model.forward(g)
+        y3 = model.solve(g, 3)
+        out[cls] = dict(ref="nn/mus_gnn.py forward + nn/model.py:303-327 solve, 3-D mesh", arch=arch, weights=sd(model),
+                        graph=gi, forward=y, solve3=y3, num_params=model.num_params)
+    save("models_mus_3d.pt", out)
+
+
 MUGS_LAYERS = {
     "NsTwoGuillardScaleGNN": (["mp111", "mp112", "mp113", "mp114", "mp21", "mp22", "mp23", "mp24", "mp121", "mp122", "mp123", "mp124"],
                               ["mp121"]),
@@ -521,11 +541,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "augment":
         gen_augment()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mus3d":
+        gen_mus_3d()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "training":      # (adds one fixture without rewriting the others)
         gen_training()
         sys.exit(0)
     gen_blocks()
     gen_mus_models()
+    gen_mus_3d()
     gen_mugs_models()
     gen_rollout()
     gen_remus_model()
