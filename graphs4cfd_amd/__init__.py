@@ -8,11 +8,12 @@ Drop-in for the hot-path slice of `import graphs4cfd as gfd`:
 
 Compute runs in hand-written HIP kernels (libg4c.so, C-ABI in include/g4c.h); there is no CPU or
 eager-torch fallback.  Training (`model.fit`, `gfd.nn.TrainConfig`, `gfd.nn.GraphLoss`, `gfd.DataLoader`) runs the same fused
-forward recorded for autograd (autograd.py).  Out of scope: plotting.
+forward recorded for autograd (autograd.py).  Out of scope: plotting.  The package is also importable under
+the reference's name (`import graphs4cfd as gfd`, the alias package at the repository root).
 """
 from .graph import Graph
 from . import nn, plan, ops, synthetic, transforms, metrics, datasets
 from .loader import DataLoader, Collater
-from .ops import mlp_precision, set_mlp_precision      # "fp32" (default) | "bf16" (opt-in bf16-MFMA MLPs)
+from .ops import mlp_precision, set_mlp_precision      # "bf16x6" (default: fp32-accurate bf16-split MFMA) | "fp32" | "bf16" (opt-in)
 
 __version__ = "0.1.0"

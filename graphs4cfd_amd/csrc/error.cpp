@@ -9,6 +9,15 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+int visible_devices() {
+    static const int n = [] {
+        int c = 0;
+        if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); c = 0; }
+        return c;
+    }();
+    return n;
+}
 }  // namespace g4c
 
 extern "C" int g4c_version(void) { return 1; }

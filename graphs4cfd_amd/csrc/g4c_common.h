@@ -20,6 +20,29 @@ inline int check_launch(const char *what) {
     return G4C_OK;
 }
 
+// Every launching entry point runs on the device that owns its buffers, whatever the caller's current device is (the reference
+// API takes `device=cuda:N`; the stream argument alone cannot say which device — torch's default stream of any device is the
+// null handle).  With one visible device (one process per GPU, the normal deployment) the guard costs nothing.
+int visible_devices();
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(const void *device_ptr) {
+        if (visible_devices() <= 1 || !device_ptr) return;
+        hipPointerAttribute_t attr;
+        int cur = 0;
+        if (hipPointerGetAttributes(&attr, device_ptr) != hipSuccess || hipGetDevice(&cur) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        if (attr.device != cur && hipSetDevice(attr.device) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 #define G4C_REQUIRE(cond, code, ...)      \
     do {                                  \
         if (!(cond)) {                    \

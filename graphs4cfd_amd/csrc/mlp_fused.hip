@@ -1972,6 +1972,7 @@ extern "C" int g4c_mlp_pack_layer(const float *W, int32_t n_out, int32_t k_in, c
     G4C_REQUIRE(ksum == k_in, G4C_EINVAL, "g4c_mlp_pack_layer: blocks sum to %d columns, weight has %d", ksum, k_in);
     G4C_REQUIRE(kpsum <= k_pad && k_pad % KC == 0, G4C_EINVAL, "g4c_mlp_pack_layer: k_pad %d too small for %d (or not a multiple of 32)", k_pad, kpsum);
     const int total = k_pad * NP;
+    g4c::DeviceGuard on_device(packed);
     pack_layer_kernel<<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(W, n_out, k_in, segs, packed, k_pad);
     return g4c::check_launch("g4c_mlp_pack_layer");
 }
@@ -2003,6 +2004,7 @@ static int pack_layer_16(bool six, const float *W, int32_t n_out, int32_t k_in, 
     }
     G4C_REQUIRE(ksum == k_in, G4C_EINVAL, "g4c_mlp_pack_layer_bf16: blocks sum to %d columns, weight has %d", ksum, k_in);
     const int total = k_pad * NP;
+    g4c::DeviceGuard on_device(packed);
     pack_layer_bx6_kernel<<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(W, n_out, k_in, segs, (__bf16 *)packed, k_pad);
     return g4c::check_launch("g4c_mlp_pack_layer_bx6");
 }
@@ -2184,6 +2186,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     G4C_REQUIRE(act >= 0 && act <= 2, G4C_EINVAL, "g4c_mlp_forward: bad activation %d", act);
     if (n_rows == 0) return G4C_OK;
     G4C_REQUIRE(out || agg, G4C_EINVAL, "g4c_mlp_forward: null output");
+    g4c::DeviceGuard on_device(mlp->w[0]);
     Params p;
     int kp = 0;
     bool all_vec = true, deep_ok = true;

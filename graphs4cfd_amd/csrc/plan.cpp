@@ -61,7 +61,13 @@ extern "C" int64_t g4c_plan_pool_edge_ordered(const int64_t *idx_hr_to_lr, int64
     G4C_REQUIRE((idx_hr_to_lr || n_hr == 0) && (edge_index || n_edges == 0) && off && n_kept, G4C_EINVAL,
                 "g4c_plan_pool_edge: null pointer");
     int64_t n_lr = 0;
-    for (int64_t i = 0; i < n_hr; ++i) n_lr = std::max(n_lr, idx_hr_to_lr[i] + 1);
+    for (int64_t i = 0; i < n_hr; ++i) {
+        // (-1 is the 'empty' value of the reference's mask2idx tables: a fine node without a coarse node cannot be pooled)
+        G4C_REQUIRE(idx_hr_to_lr[i] >= 0, G4C_EINVAL, "g4c_plan_pool_edge: idx_hr_to_lr[%lld] = %lld is negative", (long long)i,
+                    (long long)idx_hr_to_lr[i]);
+        n_lr = std::max(n_lr, idx_hr_to_lr[i] + 1);
+    }
+    G4C_REQUIRE(n_lr < (1LL << 31), G4C_EINVAL, "g4c_plan_pool_edge: %lld coarse nodes do not fit int32", (long long)n_lr);
     // surviving fine edges with their coarse endpoints (remove_self_loops), in fine-edge order
     std::vector<int32_t> cr, cc, id;
     cr.reserve((size_t)n_edges); cc.reserve((size_t)n_edges); id.reserve((size_t)n_edges);

@@ -96,6 +96,7 @@ __global__ void bump_step_kernel(int *step) { *step += 1; }
 extern "C" int g4c_project_to_edges(const float *v, int32_t v_ld, const int32_t *node, const float *unit,
                                     int64_t n_edges, int32_t n_feat, float *out, int32_t out_ld, void *stream) {
     G4C_REQUIRE(v && unit && out, G4C_EINVAL, "g4c_project_to_edges: null pointer");
+    g4c::DeviceGuard on_device(out);
     G4C_REQUIRE(n_edges >= 0 && n_feat > 0 && v_ld >= 2 * n_feat && out_ld >= n_feat && v_ld % 2 == 0 && ((uintptr_t)v % 8 == 0),
                 G4C_EINVAL, "g4c_project_to_edges: bad sizes n_feat=%d v_ld=%d out_ld=%d", n_feat, v_ld, out_ld);
     if (n_edges == 0) return G4C_OK;
@@ -108,6 +109,7 @@ extern "C" int g4c_project_to_edges(const float *v, int32_t v_ld, const int32_t 
 extern "C" int g4c_edge_scalar_to_node_vector(const float *e, int32_t e_ld, const float *unit_inv, int32_t k,
                                               int64_t n_nodes, int32_t n_feat, float *out, int32_t out_ld, void *stream) {
     G4C_REQUIRE(e && unit_inv && out, G4C_EINVAL, "g4c_edge_scalar_to_node_vector: null pointer");
+    g4c::DeviceGuard on_device(out);
     G4C_REQUIRE(n_nodes >= 0 && k > 0 && n_feat > 0 && e_ld >= n_feat && out_ld >= 2 * n_feat && out_ld % 2 == 0 && ((uintptr_t)out % 8 == 0),
                 G4C_EINVAL, "g4c_edge_scalar_to_node_vector: bad sizes k=%d n_feat=%d e_ld=%d out_ld=%d", k, n_feat, e_ld, out_ld);
     if (n_nodes == 0) return G4C_OK;
@@ -119,6 +121,7 @@ extern "C" int g4c_edge_scalar_to_node_vector(const float *e, int32_t e_ld, cons
 
 extern "C" int g4c_activation_inplace(float *x, int64_t n, int32_t act, void *stream) {
     G4C_REQUIRE(x || n == 0, G4C_EINVAL, "g4c_activation_inplace: null pointer");
+    g4c::DeviceGuard on_device(x);
     G4C_REQUIRE(n >= 0 && act >= 0 && act <= 2 && ((uintptr_t)x % 16 == 0), G4C_EINVAL, "g4c_activation_inplace: bad arguments");
     if (n == 0 || act == G4C_ACT_NONE) return G4C_OK;
     const long long nthreads = (n + 3) / 4;
@@ -129,6 +132,7 @@ extern "C" int g4c_activation_inplace(float *x, int64_t n, int32_t act, void *st
 extern "C" int g4c_add_cols(const float *a, int32_t a_ld, int32_t a_col0, const float *b, int32_t b_ld,
                             float *out, int32_t out_ld, int32_t width, int64_t n_rows, void *stream) {
     G4C_REQUIRE(a && b && out, G4C_EINVAL, "g4c_add_cols: null pointer");
+    g4c::DeviceGuard on_device(out);
     G4C_REQUIRE(width > 0 && n_rows >= 0 && a_col0 >= 0 && a_ld >= a_col0 + width && b_ld >= width && out_ld >= width,
                 G4C_EINVAL, "g4c_add_cols: bad sizes width=%d a_ld=%d b_ld=%d out_ld=%d", width, a_ld, b_ld, out_ld);
     if (n_rows == 0) return G4C_OK;
@@ -141,6 +145,7 @@ extern "C" int g4c_add_cols(const float *a, int32_t a_ld, int32_t a_col0, const 
 extern "C" int g4c_copy_cols(const float *src, int32_t src_ld, int32_t scol0, const int32_t *idx,
                              float *dst, int32_t dst_ld, int32_t dcol0, int32_t width, int64_t n_rows, void *stream) {
     G4C_REQUIRE(src && dst, G4C_EINVAL, "g4c_copy_cols: null pointer");
+    g4c::DeviceGuard on_device(dst);
     G4C_REQUIRE(width > 0 && n_rows >= 0 && src_ld >= scol0 + width && dst_ld >= dcol0 + width && scol0 >= 0 && dcol0 >= 0,
                 G4C_EINVAL, "g4c_copy_cols: bad sizes width=%d src_ld=%d dst_ld=%d", width, src_ld, dst_ld);
     if (n_rows == 0) return G4C_OK;
@@ -153,6 +158,7 @@ extern "C" int g4c_copy_cols(const float *src, int32_t src_ld, int32_t scol0, co
 extern "C" int g4c_rollout_advance(float *field, int32_t field_cols, const float *pred, int32_t nf,
                                    float *outputs, int32_t out_ld, int32_t *step, int64_t n_nodes, void *stream) {
     G4C_REQUIRE(field && pred && outputs && step, G4C_EINVAL, "g4c_rollout_advance: null pointer");
+    g4c::DeviceGuard on_device(field);
     G4C_REQUIRE(nf > 0 && field_cols >= nf && out_ld >= nf && n_nodes >= 0, G4C_EINVAL,
                 "g4c_rollout_advance: bad sizes nf=%d field_cols=%d out_ld=%d", nf, field_cols, out_ld);
     hipStream_t s = (hipStream_t)stream;

@@ -106,6 +106,7 @@ extern "C" int g4c_segment_reduce(const float *src, int32_t src_ld, const int32_
                 "g4c_segment_reduce: bad sizes n_seg=%d width=%d src_ld=%d out_ld=%d", n_seg, width, src_ld, out_ld);
     if (n_seg == 0) return G4C_OK;
     G4C_REQUIRE(off != nullptr && out != nullptr, G4C_EINVAL, "g4c_segment_reduce: null pointer");
+    g4c::DeviceGuard on_device(out);
     G4C_REQUIRE(src != nullptr || perm == nullptr, G4C_EINVAL, "g4c_segment_reduce: null src with a permutation");
     hipStream_t s = (hipStream_t)stream;
     const bool vec = (width % 4 == 0) && (src_ld % 4 == 0) && (out_ld % 4 == 0) &&
@@ -142,6 +143,7 @@ extern "C" int g4c_weighted_segment_mean(const float *x, int32_t x_ld, const int
     G4C_REQUIRE(n_seg >= 0 && width > 0 && x_ld >= width && out_ld >= width, G4C_EINVAL,
                 "g4c_weighted_segment_mean: bad sizes n_seg=%d width=%d", n_seg, width);
     G4C_REQUIRE(x && x_idx && w && off && out, G4C_EINVAL, "g4c_weighted_segment_mean: null pointer");
+    g4c::DeviceGuard on_device(out);
     if (n_seg == 0) return G4C_OK;
     hipStream_t s = (hipStream_t)stream;
     const long long total = (long long)n_seg * 64;

@@ -306,6 +306,7 @@ extern "C" int g4c_train_gather(const float *src, int32_t src_ld, int32_t scol0,
                                 int32_t negate, float *dst, int32_t dst_ld, int32_t dcol0, int32_t width, int64_t n_rows,
                                 int32_t accumulate, void *stream) {
     G4C_REQUIRE(src && dst, G4C_EINVAL, "g4c_train_gather: null pointer");
+    g4c::DeviceGuard on_device(dst);
     G4C_REQUIRE(width > 0 && n_rows >= 0 && scol0 >= 0 && dcol0 >= 0 && src_ld >= scol0 + width && dst_ld >= dcol0 + width &&
                     pre_act >= 0 && pre_act <= 2,
                 G4C_EINVAL, "g4c_train_gather: bad arguments width=%d src_ld=%d dst_ld=%d pre_act=%d", width, src_ld, dst_ld, pre_act);
@@ -325,6 +326,7 @@ extern "C" int g4c_train_gather(const float *src, int32_t src_ld, int32_t scol0,
 extern "C" int g4c_act_grad(const float *dy, int32_t dy_ld, const float *ref, int32_t ref_ld, int32_t from_input, int32_t act,
                             float *dz, int32_t dz_ld, int32_t width, int64_t n_rows, void *stream) {
     G4C_REQUIRE(dy && ref && dz, G4C_EINVAL, "g4c_act_grad: null pointer");
+    g4c::DeviceGuard on_device(dz);
     G4C_REQUIRE(width > 0 && n_rows >= 0 && dy_ld >= width && ref_ld >= width && dz_ld >= width && act >= 0 && act <= 2, G4C_EINVAL,
                 "g4c_act_grad: bad arguments width=%d lds=%d,%d,%d act=%d", width, dy_ld, ref_ld, dz_ld, act);
     if (n_rows == 0) return G4C_OK;
@@ -344,6 +346,7 @@ extern "C" int32_t g4c_layernorm_grad_partials(int64_t n_rows) {
 extern "C" int g4c_layernorm_grad(const float *z, int32_t z_ld, const float *gamma, const float *dy, int32_t dy_ld, float *dz,
                                   int32_t dz_ld, float *partial, int32_t width, int64_t n_rows, float eps, void *stream) {
     G4C_REQUIRE(z && gamma && dy && dz && partial, G4C_EINVAL, "g4c_layernorm_grad: null pointer");
+    g4c::DeviceGuard on_device(dz);
     G4C_REQUIRE(width > 0 && width <= 64 * LN_MAXC && n_rows >= 0 && z_ld >= width && dy_ld >= width && dz_ld >= width,
                 G4C_EUNSUPPORTED, "g4c_layernorm_grad: width %d (max %d) / leading dimensions", width, 64 * LN_MAXC);
     const int n_wg = g4c_layernorm_grad_partials(n_rows);
@@ -359,6 +362,7 @@ extern "C" int32_t g4c_colsum_partials(int64_t n_rows) {
 
 extern "C" int g4c_colsum(const float *x, int32_t ld, int32_t width, int64_t n_rows, float *scratch, float *out, void *stream) {
     G4C_REQUIRE(x && scratch && out, G4C_EINVAL, "g4c_colsum: null pointer");
+    g4c::DeviceGuard on_device(out);
     G4C_REQUIRE(width > 0 && n_rows >= 0 && ld >= width, G4C_EINVAL, "g4c_colsum: bad sizes width=%d ld=%d", width, ld);
     const int g = g4c_colsum_partials(n_rows);
     const long long chunk = (n_rows + g - 1) / g;
@@ -372,6 +376,7 @@ extern "C" int g4c_colsum(const float *x, int32_t ld, int32_t width, int64_t n_r
 extern "C" int g4c_segment_broadcast(const float *dout, int32_t dout_ld, const int32_t *off, const int32_t *perm, int32_t n_seg,
                                      int32_t width, int32_t mean, float *dsrc, int32_t dsrc_ld, void *stream) {
     G4C_REQUIRE(dout && off && dsrc, G4C_EINVAL, "g4c_segment_broadcast: null pointer");
+    g4c::DeviceGuard on_device(dsrc);
     G4C_REQUIRE(width > 0 && n_seg >= 0 && dout_ld >= width && dsrc_ld >= width, G4C_EINVAL,
                 "g4c_segment_broadcast: bad sizes width=%d dout_ld=%d dsrc_ld=%d", width, dout_ld, dsrc_ld);
     if (n_seg == 0) return G4C_OK;
@@ -393,6 +398,7 @@ extern "C" int32_t g4c_weight_grad_partials(int64_t n_rows) {
 extern "C" int g4c_weight_grad(const float *g, int32_t g_ld, const float *a, int32_t a_ld, int64_t n_rows, float *scratch,
                                float *out, int32_t with_bias, void *stream) {
     G4C_REQUIRE(g && a && scratch && out, G4C_EINVAL, "g4c_weight_grad: null pointer");
+    g4c::DeviceGuard on_device(out);
     G4C_REQUIRE(n_rows >= 0 && g_ld >= WG_N && a_ld >= WG_N && g_ld % 4 == 0 && a_ld % 4 == 0 && (uintptr_t)g % 16 == 0 &&
                     (uintptr_t)a % 16 == 0,
                 G4C_EINVAL, "g4c_weight_grad: 128-wide, 16-byte aligned operands expected (g_ld=%d a_ld=%d)", g_ld, a_ld);

@@ -18,7 +18,7 @@ from typing import Callable, List, Optional, Union
 import torch
 from torch import nn
 
-from .. import _lib, ops
+from .. import _lib, ops, plan
 from ..graph import Graph
 
 
@@ -215,6 +215,8 @@ class GNN(nn.Module):
                         nn.utils.clip_grad_norm_(self.parameters(), train_config['grad_clip']["limit"])
                     optimiser.step()
                     optimiser.zero_grad()
+                    self.invalidate_packed()     # the step changed the weights, whatever path the gradients came from
+                plan.clear_caches()              # a fresh batch never reuses the previous one's plans: do not pin them in HBM
             training_loss /= (iteration + 1)
             gradients_norm /= (iteration + 1)
             print(f"Epoch: {epoch:4d}, Training   loss: {training_loss:.4e}, Gradients: {gradients_norm:.4e}")
@@ -292,12 +294,22 @@ class GNN(nn.Module):
                 ro.run(n_out)
                 return ro.outputs
 
-    def _require_inference(self, why: str) -> None:
-        """Model families whose launches are not recorded for autograd call this first: a forward with gradients enabled
-        would silently return a tensor cut off from the parameters."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(f"{type(self).__name__}.forward with gradients enabled: {why}; "
-                                      "wrap inference in torch.no_grad() (solve() does)")
+    def invalidate_packed(self) -> None:
+        """Declare every packed weight image stale (they are rebuilt on the next launch).  The images are keyed on the parameters'
+        version counters, which updates that bypass autograd's bookkeeping do not advance (`p.data.copy_`, EMA / SWA `lerp_`, a manual
+        broadcast, torch's `fused=True` optimisers): call this after any such update.  `fit`, `load_state_dict` and `_apply`
+        (`.to()`, `.float()` ...) do it themselves; a live `Rollout` re-captures its hipGraph on the next step."""
+        ops.bump_weights_epoch()
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_packed()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        ops.bump_weights_epoch()
+        return out
 
     def shift_and_replace(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         """Shift the fields in x by num_fields and replace the last num_fields with y (nn/model.py:323-327).
@@ -350,7 +362,7 @@ class Rollout:
         self.outputs = torch.zeros((graph.num_nodes, self.nf * self.max_steps), dtype=torch.float32, device=dev)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.steps_done = 0
-        self._hipgraph = None
+        self._hipgraph, self._epoch, self._pins = None, -1, None
         graph.field = self.field
 
     def _one(self):
@@ -361,10 +373,14 @@ class Rollout:
         if self.steps_done >= self.max_steps:
             raise RuntimeError(f"rollout buffer holds {self.max_steps} steps")
         with torch.no_grad():
-            if self.steps_done == 0 or not self.capture:
-                self._one()
+            if self._hipgraph is not None and ops.weights_epoch() != self._epoch:
+                self._hipgraph, self._epoch = None, -1    # the weights changed under the captured step: its images are stale
+            if self.steps_done == 0 or not self.capture or self._epoch == -1:
+                self._one()                               # eager: builds the plans and the packed weight images
+                self._epoch = ops.weights_epoch()
             elif self._hipgraph is None:
                 torch.cuda.synchronize(self.field.device)
+                self._pins = plan.snapshot()              # the graph bakes these pointers in: keep them past cache eviction
                 self._hipgraph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._hipgraph):   # records only; nothing executes during capture
                     self._one()

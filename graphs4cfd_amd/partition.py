@@ -521,6 +521,7 @@ class DistributedRollout:
             elif self._hipgraph is None:
                 torch.cuda.synchronize(self.device)
                 hg, err = None, None
+                self._pins = plan.snapshot()       # the graph bakes the plans' pointers in: keep them past cache eviction
                 try:
                     hg = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(hg):
@@ -551,6 +552,10 @@ class DistributedRollout:
             else:
                 self._hipgraph.replay()
         self.steps_done += 1
+
+    @property
+    def captured(self) -> bool:
+        return self._hipgraph is not None
 
     def run(self, n: int) -> None:
         for _ in range(n):

@@ -129,9 +129,32 @@ def build_csr(keys: torch.Tensor, n_seg: int, device: torch.device, drop_last_se
     return out
 
 
+def _nbytes(obj, depth: int = 0) -> int:
+    """Bytes pinned by a cache entry (device index tensors, host images), walked through tuples / dataclasses."""
+    if torch.is_tensor(obj):
+        return obj.numel() * obj.element_size()
+    if isinstance(obj, np.ndarray):
+        return int(obj.nbytes)
+    if depth > 3 or obj is None or isinstance(obj, (int, float, str, bool)):
+        return 0
+    if isinstance(obj, (tuple, list)):
+        return sum(_nbytes(o, depth + 1) for o in obj)
+    if isinstance(obj, dict):
+        return sum(_nbytes(o, depth + 1) for o in obj.values())
+    if hasattr(obj, "__dict__"):
+        return sum(_nbytes(o, depth + 1) for o in vars(obj).values())
+    return 0
+
+
 class _Cache:
-    def __init__(self, capacity: int = 256):
+    """LRU over plans, bounded both by entry count and by the bytes its entries pin (key tensors are kept alive so their
+    data_ptr cannot be recycled under a cached plan; over fresh training batches nothing is ever reused, so an unbounded
+    cache would just retain the last N batches' index data in HBM).  G4C_PLAN_CACHE_MB: per-cache byte bound."""
+
+    def __init__(self, capacity: int = 256, max_bytes: Optional[int] = None):
         self.capacity = capacity
+        self.max_bytes = int(__import__("os").environ.get("G4C_PLAN_CACHE_MB", "1024")) << 20 if max_bytes is None else max_bytes
+        self.bytes = 0
         self.data = collections.OrderedDict()
 
     @staticmethod
@@ -146,11 +169,21 @@ class _Cache:
         return None
 
     def put(self, key, tensors, value):
-        # keep the key tensors alive so their data_ptr cannot be recycled under the cached plan
-        self.data[key] = (tensors, value)
-        if len(self.data) > self.capacity:
-            self.data.popitem(last=False)
+        old = self.data.pop(key, None)
+        if old is not None:
+            self.bytes -= old[2]
+        size = _nbytes(tensors) + _nbytes(value)
+        self.data[key] = (tensors, value, size)
+        self.bytes += size
+        # the newest entry always stays (a single mesh larger than the bound must still be planned once per rollout)
+        while len(self.data) > 1 and (len(self.data) > self.capacity or self.bytes > self.max_bytes):
+            _, (_, _, freed) = self.data.popitem(last=False)
+            self.bytes -= freed
         return value
+
+    def clear(self) -> None:
+        self.data.clear()
+        self.bytes = 0
 
 
 _edge_plans = _Cache()
@@ -161,9 +194,16 @@ _index_plans = _Cache()
 _cluster_plans = _Cache()
 
 
+def snapshot() -> list:
+    """References to everything the caches hold right now.  A captured hipGraph bakes the plans' device pointers in, so its
+    owner (nn.model.Rollout, partition.DistributedRollout) keeps this list for as long as it may replay: eviction from the
+    caches then cannot free memory the graph still reads."""
+    return [entry for c in (_edge_plans, _pool_plans, _index_plans, _cluster_plans) for entry in c.data.values()]
+
+
 def clear_caches() -> None:
     for c in (_edge_plans, _pool_plans, _index_plans, _cluster_plans, _host_copies):
-        c.data.clear()
+        c.clear()
 
 
 def edge_plan(edge_index: torch.Tensor) -> EdgePlan:

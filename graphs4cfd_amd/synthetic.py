@@ -55,10 +55,14 @@ def connect_knn(pos: torch.Tensor, k: int, period=None) -> Tuple[torch.Tensor, t
     p = torch.cat(cols, 1).numpy()
     n = p.shape[0]
     nbr = knn_neighbours(p, p, k + 1)
-    centre = np.repeat(np.arange(n), k + 1)
-    flat = nbr.reshape(-1)
-    keep = flat != centre
-    row = torch.from_numpy(flat[keep].astype(np.int64))
+    # exactly one of the k + 1 hits is dropped per centre — the centre itself, or, when coincident points pushed it out of the
+    # hit list, the farthest — so that the in-degree is k everywhere (REMuS's edgeScalarToNodeVector relies on it)
+    is_self = nbr == np.arange(n)[:, None]
+    drop = np.where(is_self.any(1), is_self.argmax(1), k)
+    keep = np.ones((n, k + 1), dtype=bool)
+    keep[np.arange(n), drop] = False
+    centre = np.repeat(np.arange(n), k + 1).reshape(n, k + 1)
+    row = torch.from_numpy(nbr[keep].astype(np.int64))
     col = torch.from_numpy(centre[keep].astype(np.int64))
     edge_index = torch.stack([row, col], 0)
     edge_attr = pos[col] - pos[row]

@@ -8,21 +8,26 @@ import graphs4cfd_amd as gfd
 from graphs4cfd_amd import partition as P, synthetic as S
 ap = argparse.ArgumentParser(); ap.add_argument("--backend", default="nccl"); ap.add_argument("--same-gpu", action="store_true")
 ap.add_argument("--nodes", type=int, default=20000); ap.add_argument("--steps", type=int, default=4)
+ap.add_argument("--model", default="NsThreeScaleGNN"); ap.add_argument("--dim", type=int, default=2); ap.add_argument("--hidden", type=int, default=128)
+ap.add_argument("--capture", type=int, default=-1, help="-1: capture the step in a hipGraph iff the transport is nccl")
 a = ap.parse_args()
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda", 0 if a.same_gpu else int(os.environ["LOCAL_RANK"]))
 torch.cuda.set_device(dev)
 dist.init_process_group(a.backend)
-g = S.mus_graph(a.nodes, levels=3, seed=1)
+levels = {"NsOneScaleGNN": 1, "NsTwoScaleGNN": 2, "NsThreeScaleGNN": 3, "NsFourScaleGNN": 4}[a.model]
+g = S.mus_graph(a.nodes, levels=levels, dim=a.dim, seed=1)
 torch.manual_seed(2)
-model = gfd.nn.NsThreeScaleGNN(arch=S.mus_arch("NsThreeScaleGNN", 128), device=dev)
-dr = P.DistributedRollout(model, g, a.steps, rank, world, dev, capture=(a.backend == "nccl"))
+model = getattr(gfd.nn, a.model)(arch=S.mus_arch(a.model, a.hidden, dim=a.dim), device=dev)
+dr = P.DistributedRollout(model, g, a.steps, rank, world, dev, capture=(a.backend == "nccl") if a.capture < 0 else bool(a.capture))
 dr.run(a.steps)
 full = dr.gather_outputs()
 if rank == 0:
     ref = model.solve(g.clone().to(dev), a.steps, capture=False)
     err = (full - ref).abs().max().item()
-    print(f"world={world} backend={a.backend}: halo rows per level {dr.mesh.n_halo}, max|partitioned - single| = {err:.3e}", flush=True)
+    x = dr.fwd.xch
+    print(f"world={world} backend={a.backend} {a.model} dim={a.dim}: halo rows per level {dr.mesh.n_halo}, "
+          f"{x.n_exchanges} exchanges, {x.bytes_sent} B sent, captured={dr.captured}, max|partitioned - single| = {err:.3e}", flush=True)
     assert err < 2e-3, err
 dist.barrier()
 dist.destroy_process_group()

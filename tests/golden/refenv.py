@@ -24,6 +24,7 @@ Restated semantics (PyG >= 2.3, torch_cluster HEAD):
       grouped by centre, neighbours by ascending distance.
   * `knn(x, y, k)` -> [2, |y|*k]: row0 = query (y) index, row1 = neighbour (x) index.
 """
+import os
 import sys
 import types
 
@@ -224,4 +225,6 @@ def install():
 def import_reference():
     install()
     import graphs4cfd  # noqa: the reference, from /root/reference
+    assert os.path.abspath(graphs4cfd.__file__).startswith(REFERENCE_ROOT), \
+        f"'graphs4cfd' resolved to {graphs4cfd.__file__} (this repository's alias package?), not to the reference"
     return graphs4cfd

@@ -604,6 +604,78 @@ def test_models_bf16_mode_vs_oracle():
         ops.set_mlp_precision(old)
 
 
+# ------------------------------------------------------------------ BASELINE configs at size
+def test_headline_100k_vs_oracle():
+    """The bench workload itself (NsThreeScaleGNN, H = 128, 100k-node 2-D mesh, default bf16x6 kernels with the fused
+    per-target aggregation): forward vs the oracle at the stated fp32 tolerance, then the hipGraph-replayed rollout step
+    vs the eager one, bit for bit."""
+    assert ops.mlp_precision() == "bf16x6"
+    g = S.mus_graph(100_000, levels=3, seed=0)
+    torch.manual_seed(1)
+    model = gfd.nn.NsThreeScaleGNN(arch=S.mus_arch("NsThreeScaleGNN", 128), device=DEV)
+    ref = O.mus_forward("NsThreeScaleGNN", g.to_dict(), {k: v.cpu() for k, v in model.state_dict().items()}, 3)
+    gd = g.clone().to(DEV)
+    with torch.no_grad():
+        y = model.forward(gd)
+    torch.testing.assert_close(y.cpu(), ref, **FWD)
+    cap, eag = model.solve(gd, 4, capture=True), model.solve(gd, 4, capture=False)
+    assert torch.equal(cap, eag) and torch.isfinite(cap).all()
+
+
+@pytest.mark.parametrize("prec", ["bf16x6", "bf16"])
+def test_remus_20k_vs_oracle(prec):
+    """BASELINE config 3's model (REMuS-GNN 3-scale, H = 128) at 20k nodes / 100k level-1 edges, on the fp32-accurate default and on
+    the config's bf16 edge-MLP MFMA variant (tolerance of SURVEY 8(c): ~1e-2 on O(1) outputs)."""
+    old = ops.set_mlp_precision(prec)
+    try:
+        g = S.remus_graph(20_000, k=5, seed=21)
+        torch.manual_seed(22)
+        model = gfd.nn.NsRotEquiTreeScaleGNN(arch=S.remus_arch(128), device=DEV)
+        ref = O.remus_forward(g.to_dict(), {k: v.cpu() for k, v in model.state_dict().items()})
+        with torch.no_grad():
+            y = model.forward(g.clone().to(DEV)).cpu()
+        if prec == "bf16x6":
+            torch.testing.assert_close(y, ref, **FWD)
+        else:
+            d = (y - ref).abs()
+            assert d.max().item() < 6e-2 and d.mean().item() < 1e-2, (d.max().item(), d.mean().item())
+    finally:
+        ops.set_mlp_precision(old)
+
+
+@pytest.mark.parametrize("cls", ["NsFourScaleGNN", "NsTwoScaleGNN"])
+def test_mus_models_3d(golden, cls):
+    """BASELINE config 5's data path at fixture size: the reference's own forward / solve on a 3-D mesh (3-wide edge
+    attributes, 3 + H pooling inputs)."""
+    c = golden("models_mus_3d.pt")[cls]
+    model = getattr(gfd.nn, cls)(arch=c["arch"], device=DEV)
+    model.load_state_dict(c["weights"])
+    assert model.num_params == c["num_params"]
+    g = gfd.Graph(**cu(c["graph"]))
+    with torch.no_grad():
+        torch.testing.assert_close(model.forward(g).cpu(), c["forward"], **FWD)
+    torch.testing.assert_close(model.solve(g, 3).cpu(), c["solve3"], rtol=1e-3, atol=1e-3)
+
+
+def test_four_scale_3d_500_step_captured_rollout():
+    """Config 5 on one GPU, scaled to 30k nodes: NsFourScaleGNN (H = 128) on a 3-D mesh vs the oracle, then the 500-step
+    rollout with the hipGraph-captured step == the eager rollout bit for bit (and stays finite)."""
+    g = S.mus_graph(30_000, levels=4, dim=3, seed=31)
+    torch.manual_seed(32)
+    model = gfd.nn.NsFourScaleGNN(arch=S.mus_arch("NsFourScaleGNN", 128, dim=3), device=DEV)
+    for p in model.decoder.parameters():    # damp the residual update so that 500 steps of a random-weight model stay O(1)
+        p.data.mul_(0.02)
+    model.invalidate_packed()
+    ref = O.mus_forward("NsFourScaleGNN", g.to_dict(), {k: v.cpu() for k, v in model.state_dict().items()}, 3)
+    gd = g.clone().to(DEV)
+    with torch.no_grad():
+        torch.testing.assert_close(model.forward(gd).cpu(), ref, **FWD)
+    cap = model.solve(gd, 500, capture=True)
+    eag = model.solve(gd, 500, capture=False)
+    assert cap.shape == (30_000, 1500) and torch.isfinite(cap).all()
+    assert torch.equal(cap, eag), "hipGraph replay must reproduce the eager rollout bit for bit over 500 steps"
+
+
 # ------------------------------------------------------------------ full-size properties (100k nodes)
 def test_full_size_properties():
     n, k, H = 100_000, 6, 128
@@ -776,3 +848,117 @@ def test_distributed_rollout_two_processes_one_gpu():
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
         assert "max|partitioned - single|" in out.stdout
+
+
+def test_distributed_rollout_four_processes_one_gpu():
+    """BASELINE config 4's split (100k-node mesh, node-partitioned 4-way) with four processes on this box's single GPU over the
+    gloo transport: latent exchange (default) and first-layer-product exchange, plus a 3-D four-scale model
+    (config 5's program) on a smaller mesh; compared inside the script with the single-process rollout."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29300 + os.getpid() % 200
+    base = [sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.join(root, "scripts", "dist_check.py"), "--backend", "gloo", "--same-gpu"]
+    runs = [(base + ["--nodes", "100000", "--steps", "2"], dict(os.environ)),
+            (base + ["--nodes", "30000", "--steps", "2"], dict(os.environ, G4C_HOIST_MIN_ROWS="0")),
+            (base + ["--nodes", "20000", "--steps", "2", "--model", "NsFourScaleGNN", "--dim", "3"], dict(os.environ))]
+    for cmd, env in runs:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        assert "world=4" in out.stdout and "max|partitioned - single|" in out.stdout
+
+
+# ------------------------------------------------------------------ weights that change under cached images / captured steps
+def test_invalidate_packed_and_rollout_recapture():
+    """An update that bypasses autograd's version counters (`p.data` arithmetic, EMA, a broadcast) is picked up after
+    model.invalidate_packed(); a live Rollout drops its captured hipGraph and re-captures on the new images."""
+    from graphs4cfd_amd.nn.model import Rollout
+    g = S.mus_graph(4000, levels=2, seed=41).to(DEV)
+    torch.manual_seed(42)
+    model = gfd.nn.NsTwoScaleGNN(arch=S.mus_arch("NsTwoScaleGNN", 128), device=DEV)
+    g.batch = torch.zeros(g.num_nodes, dtype=torch.long, device=DEV)
+    with torch.no_grad():
+        y0 = model.forward(g).clone()
+        ro = Rollout(model, g, 12, capture=True)
+        ro.run(4)
+        assert ro._hipgraph is not None
+        w_old = {k: v.clone() for k, v in model.state_dict().items()}
+        for p in model.decoder.parameters():
+            p.data.mul_(0.5)                       # does not advance p._version
+        model.invalidate_packed()
+        ro.run(4)                                  # eager on the new weights, re-captured, replayed
+        assert ro._hipgraph is not None
+        got = ro.outputs[:, : 3 * 8].clone()
+        ro.close()
+        y1 = model.forward(g)
+        assert (y1 - y0).abs().max().item() > 1e-3, "the forward must see the new weights"
+        # the same 4 + 4 steps with eager launches only
+        new = {k: v.clone() for k, v in model.state_dict().items()}
+        model.load_state_dict(w_old)
+        ro = Rollout(model, g, 12, capture=False)
+        ro.run(4)
+        model.load_state_dict(new)
+        ro.run(4)
+        assert torch.equal(ro.outputs[:, : 3 * 8], got)
+        ro.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs")
+def test_model_on_a_non_current_device():
+    """`device=cuda:1` while the process's current device stays 0 (the reference API's usage): the C entry points switch to
+    the device that owns their buffers."""
+    assert torch.cuda.current_device() == 0
+    d1 = torch.device("cuda", 1)
+    g = S.mus_graph(3000, levels=2, seed=43)
+    torch.manual_seed(44)
+    m0 = gfd.nn.NsTwoScaleGNN(arch=S.mus_arch("NsTwoScaleGNN", 128), device=DEV)
+    m1 = gfd.nn.NsTwoScaleGNN(arch=S.mus_arch("NsTwoScaleGNN", 128), device=d1)
+    m1.load_state_dict(m0.state_dict())
+    y0 = m0.solve(g.clone().to(DEV), 5)
+    y1 = m1.solve(g.clone().to(d1), 5)
+    assert y1.device == d1 and torch.cuda.current_device() == 0
+    assert torch.equal(y0.cpu(), y1.cpu())
+
+
+# ------------------------------------------------------------------ the opt-in persistent kernel (mlp_px6.hip)
+@pytest.mark.parametrize("rows", [33, 6000, 70000])
+def test_px6_persistent_kernel_equals_tile_kernel(rows):
+    """G4C_PX6 / g4c_mlp_px6_enable(1): the persistent role-specialised bf16x6 kernel against the default 32-row-tile kernel on the
+    hoisted edge form, the node form with heads, and the fused per-target aggregation (bit-exact reduction of equal rows)."""
+    lib = _lib.load()
+    H, n = 128, max(rows // 6, 2)
+    torch.manual_seed(rows)
+    blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
+    v, e = torch.randn(n, H, device=DEV), torch.randn(n * 6, H, device=DEV)
+    col = torch.arange(n).repeat_interleave(6)
+    edge_index = torch.stack([torch.randint(0, n, (n * 6,)), col]).to(DEV)
+    ep, csr = plan.edge_csr(edge_index, n)
+    E = n * 6
+    W1 = blk.edge_mlp.state_dict()["MLP.linear_1.weight"]
+    pr, pc = (v @ W1[:, H:2 * H].T).contiguous(), (v @ W1[:, 2 * H:].T).contiguous()
+    pk_e = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+    src_e = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+    pk_3 = blk.edge_mlp.packed([H, H, H], [False] * 3)
+    src_3 = [ops.Source(e), ops.Source(v, index=ep.row), ops.Source(v, index=ep.col)]
+    pk_v = blk.node_mlp.packed([H, H], [False, False])
+    agg_in = torch.randn(n, H, device=DEV)
+    src_v = [ops.Source(agg_in), ops.Source(v)]
+
+    def run():
+        out = {"edge": ops.mlp_forward(pk_e, src_e, E), "edge3": ops.mlp_forward(pk_3, src_3, E),
+               "node": ops.mlp_forward(pk_v, src_v, n, _lib.ACT_SELU)}
+        if csr.tiles() is not None:
+            a = torch.full((n, H), float("nan"), device=DEV)
+            out["edge_agg_rows"] = ops.mlp_forward(pk_e, src_e, E, agg=(csr, a, True))
+            out["edge_agg"] = a
+        return out
+    ref = run()
+    lib.g4c_mlp_px6_enable(1)
+    try:
+        got = run()
+    finally:
+        lib.g4c_mlp_px6_enable(0)
+    for k in ref:
+        torch.testing.assert_close(got[k], ref[k], rtol=2e-5, atol=2e-5, msg=lambda m: f"{k}: {m}")
+    if "edge_agg" in got:
+        assert torch.equal(got["edge_agg"], ops.segment_reduce(got["edge_agg_rows"], csr, True))

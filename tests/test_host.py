@@ -125,3 +125,67 @@ def test_product_path_has_no_cpu_fallback_and_validates():
         gfd.nn.blocks.MLP(4, (8,))
     src = open(os.path.join(ROOT, "graphs4cfd_amd", "ops.py")).read() + open(os.path.join(ROOT, "graphs4cfd_amd", "nn", "blocks.py")).read()
     assert "oracle" not in src, "the product path must not import the oracle"
+
+
+def test_pool_edge_plan_rejects_unassigned_fine_nodes():
+    """A -1 entry (the 'empty' value of the reference's mask2idx tables) must be an argument error, not a heap overrun."""
+    import ctypes as C
+    lib = _lib.load()
+    idx = np.array([0, 1, -1, 1], dtype=np.int64)
+    ei = np.array([[0, 1, 2], [1, 2, 3]], dtype=np.int64)
+    coarse, perm, off = np.empty((2, 3), dtype=np.int64), np.empty(3, dtype=np.int32), np.empty(4, dtype=np.int32)
+    kept = C.c_int64(0)
+    nc = lib.g4c_plan_pool_edge(idx.ctypes.data, 4, ei.ctypes.data, 3, coarse.ctypes.data, perm.ctypes.data, off.ctypes.data, C.byref(kept))
+    assert nc < 0 and b"negative" in lib.g4c_last_error()
+
+
+def test_plan_caches_are_bounded_by_bytes():
+    c = plan._Cache(capacity=100, max_bytes=10_000)
+    keep = []
+    for i in range(20):
+        k = torch.zeros(250, dtype=torch.int32)      # 1000 bytes pinned by the key + 1000 by the value
+        keep.append(k)
+        c.put(plan._Cache.key(k), (k,), (torch.zeros(250, dtype=torch.int32), 7))
+        assert c.bytes <= 10_000 and c.bytes == sum(e[2] for e in c.data.values())
+    assert len(c.data) == 5 and c.get(plan._Cache.key(keep[-1])) is not None and c.get(plan._Cache.key(keep[0])) is None
+    big = torch.zeros(100_000, dtype=torch.int32)    # larger than the bound: still cached (alone) for the rollout that needs it
+    c.put(plan._Cache.key(big), (big,), None)
+    assert len(c.data) == 1 and c.get(plan._Cache.key(big)) is None and plan._Cache.key(big) in c.data
+    c.clear()
+    assert c.bytes == 0 and not c.data
+    assert isinstance(plan.snapshot(), list)
+
+
+def test_connect_knn_keeps_in_degree_k_with_coincident_points():
+    torch.manual_seed(0)
+    pos = torch.rand(60, 2)
+    pos[10:15] = pos[10]            # five coincident points: a k + 1 query need not return the centre itself
+    ei, ea = S.connect_knn(pos, 3)
+    assert (np.bincount(ei[1].numpy(), minlength=60) == 3).all() and bool((ei[0] != ei[1]).all())
+    torch.testing.assert_close(ea, pos[ei[1]] - pos[ei[0]])
+
+
+def test_reference_package_name_is_an_alias():
+    """`import graphs4cfd as gfd` (the examples' import) binds to the same module objects as graphs4cfd_amd."""
+    import graphs4cfd as ref_name
+    import graphs4cfd.nn.mus_gnn as mus
+    from graphs4cfd.transforms import Compose, ConnectKNN, GridClustering, ScaleEdgeAttr
+    assert ref_name.nn is gfd.nn and ref_name.Graph is gfd.Graph and ref_name.DataLoader is gfd.DataLoader
+    assert mus.NsThreeScaleGNN is gfd.nn.NsThreeScaleGNN and ConnectKNN is gfd.transforms.ConnectKNN
+    g = Compose([ConnectKNN(4), ScaleEdgeAttr(0.1), GridClustering([0.2])])(gfd.Graph(pos=torch.rand(200, 2)))
+    assert g.edge_index.shape == (2, 800) and hasattr(g, "cluster_2")
+    with pytest.raises(ImportError, match="plot"):
+        ref_name.plot
+
+
+def test_invalidate_packed_bumps_the_weights_epoch():
+    from graphs4cfd_amd import ops
+    model = gfd.nn.NsOneScaleGNN(arch=S.mus_arch("NsOneScaleGNN", 32))
+    e0 = ops.weights_epoch()
+    model.invalidate_packed()
+    e1 = ops.weights_epoch()
+    model.load_state_dict(model.state_dict())
+    e2 = ops.weights_epoch()
+    model.float()
+    assert e0 < e1 < e2 < ops.weights_epoch()
+    assert not hasattr(model, "_require_inference")

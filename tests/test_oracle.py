@@ -125,6 +125,15 @@ def test_mus_models(golden, cls):
     torch.testing.assert_close(O.mus_solve(cls, c["graph"], c["weights"], 3, nf), c["solve3"], rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("cls", ["NsFourScaleGNN", "NsTwoScaleGNN"])
+def test_mus_models_3d(golden, cls):
+    """3-D meshes (BASELINE config 5's data path): 3-wide edge attributes through the same programs."""
+    c = golden("models_mus_3d.pt")[cls]
+    assert c["graph"]["pos"].shape[1] == 3 and c["graph"]["edge_attr"].shape[1] == 3
+    torch.testing.assert_close(O.mus_forward(cls, c["graph"], c["weights"], 3), c["forward"], rtol=1e-4, atol=5e-5)
+    torch.testing.assert_close(O.mus_solve(cls, c["graph"], c["weights"], 3, 3), c["solve3"], rtol=1e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize("cls", sorted(O.MUGS_PROGRAMS))
 def test_mugs_models(golden, cls):
     """gMuS-GNN family against the reference's own forward / solve on graphs from its own transforms."""
