@@ -531,11 +531,11 @@ class DistributedRollout:
                 # every rank takes the same path: one rank replaying while another launches eagerly would pair a captured
                 # collective with an eager one
                 ok = hg is not None
-                if self.world > 1:
-                    import torch.distributed as dist
+                import torch.distributed as dist
+                if self.world > 1 and dist.is_available() and dist.is_initialized():     # (in-process test transports have no group)
                     torch.cuda.synchronize(self.device)
                     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=getattr(self.fwd.xch, "group", None))
                     if ok and int(flag.item()) == 0:
                         ok, err = False, "capture failed on another rank"
                 if ok:

@@ -663,7 +663,7 @@ def test_four_scale_3d_500_step_captured_rollout():
     g = S.mus_graph(30_000, levels=4, dim=3, seed=31)
     torch.manual_seed(32)
     model = gfd.nn.NsFourScaleGNN(arch=S.mus_arch("NsFourScaleGNN", 128, dim=3), device=DEV)
-    for p in model.decoder.parameters():    # damp the residual update so that 500 steps of a random-weight model stay O(1)
+    for p in model.node_decoder.parameters():    # damp the residual update so that 500 steps of a random-weight model stay O(1)
         p.data.mul_(0.02)
     model.invalidate_packed()
     ref = O.mus_forward("NsFourScaleGNN", g.to_dict(), {k: v.cpu() for k, v in model.state_dict().items()}, 3)
@@ -883,7 +883,7 @@ def test_invalidate_packed_and_rollout_recapture():
         ro.run(4)
         assert ro._hipgraph is not None
         w_old = {k: v.clone() for k, v in model.state_dict().items()}
-        for p in model.decoder.parameters():
+        for p in model.node_decoder.parameters():
             p.data.mul_(0.5)                       # does not advance p._version
         model.invalidate_packed()
         ro.run(4)                                  # eager on the new weights, re-captured, replayed
