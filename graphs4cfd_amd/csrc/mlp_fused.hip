@@ -50,84 +50,9 @@ extern "C" int g4c_debug_read_stamps(unsigned long long *host, int n) {
 namespace {
 
 
-template <int RT> struct Acc { f32x16 t[RT][4]; };
-
 // offset of 4-k step U inside a chunk of the weight stream: steps are stored in pairs (see pack_layer_kernel)
 __host__ __device__ constexpr int step_off(int U) { return (U >> 1) * 1024 + (U & 1) * 2; }
 
-
-// B operands of one 4-k step for this lane: 4 column tiles x (k, k+1).  Inside a PAIR of steps (1024 floats) the
-// stream is [column tile][lane][step of the pair][e]: the 4-wave column-split kernel, which owns one column tile
-// per wave, fetches both steps of a pair with ONE contiguous 16-byte-per-lane load (1 KiB per wave).
-// `wstep` is wave-uniform (SGPR base), `lane_off` the lane's 32-bit offset in floats: lets hipcc use the
-// scalar-base addressing form instead of per-step 64-bit VALU address arithmetic.
-__device__ __forceinline__ f32x8 load_b(const float *wstep, unsigned lane_off) {
-    const float *p = wstep + lane_off;
-    const float2 c0 = *reinterpret_cast<const float2 *>(p);
-    const float2 c1 = *reinterpret_cast<const float2 *>(p + 256);
-    const float2 c2 = *reinterpret_cast<const float2 *>(p + 512);
-    const float2 c3 = *reinterpret_cast<const float2 *>(p + 768);
-    f32x8 r;
-    r[0] = c0.x; r[1] = c0.y; r[2] = c1.x; r[3] = c1.y;
-    r[4] = c2.x; r[5] = c2.y; r[6] = c3.x; r[7] = c3.y;
-    return r;
-}
-
-// A operands of one 4-k step (lanes<32: k,k+1; lanes>=32: k+2,k+3) for the wave's RT row tiles
-template <int RT> struct AOp { float2 v[RT]; };
-
-template <int RT>
-__device__ __forceinline__ AOp<RT> load_a(const float *pa, int a_tile_stride) {
-    AOp<RT> a;
-#pragma unroll
-    for (int r = 0; r < RT; ++r) a.v[r] = *reinterpret_cast<const float2 *>(pa + r * a_tile_stride);
-    return a;
-}
-
-template <int RT>
-__device__ __forceinline__ void mma_step(const AOp<RT> &a, const f32x8 &b, Acc<RT> &acc) {
-#pragma unroll
-    for (int r = 0; r < RT; ++r) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            acc.t[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[r].x, b[2 * c], acc.t[r][c], 0, 0, 0);
-            acc.t[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[r].y, b[2 * c + 1], acc.t[r][c], 0, 0, 0);
-        }
-    }
-}
-
-struct Ring { f32x8 s0, s1, s2, s3, s4, s5, s6, s7; };
-
-__device__ __forceinline__ void ring_fill(Ring &g, const float *wchunk, unsigned lo) {
-    g.s0 = load_b(wchunk + step_off(0), lo); g.s1 = load_b(wchunk + step_off(1), lo);
-    g.s2 = load_b(wchunk + step_off(2), lo); g.s3 = load_b(wchunk + step_off(3), lo);
-    g.s4 = load_b(wchunk + step_off(4), lo); g.s5 = load_b(wchunk + step_off(5), lo);
-    g.s6 = load_b(wchunk + step_off(6), lo); g.s7 = load_b(wchunk + step_off(7), lo);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// one 32-k chunk: 8 steps.  Per step: (1) issue the NEXT step's A reads from LDS, (2) this step's
-// MFMAs, (3) refill the ring slot just consumed with the same step of the NEXT chunk.  The
-// sched_barriers pin that order: without them hipcc sinks all 16 refill loads to the chunk boundary
-// (a full L2 round trip exposed per chunk) and issues the A reads after the MFMAs (LDS latency
-// exposed per step).
-template <int RT, bool REFILL = true>
-__device__ __forceinline__ void mma_chunk(const float *pa, int a_tile_stride, Ring &g, const float *wnext, unsigned lo,
-                                          Acc<RT> &acc) {
-    AOp<RT> a = load_a<RT>(pa, a_tile_stride);
-#define G4C_STEP(U, SLOT)                                                     \
-    {                                                                         \
-        const AOp<RT> an = load_a<RT>(pa + (((U) + 1) & 7) * 4, a_tile_stride); \
-        __builtin_amdgcn_sched_barrier(0);                                    \
-        mma_step<RT>(a, g.SLOT, acc);                                         \
-        if (REFILL) g.SLOT = load_b(wnext + step_off(U), lo);                   \
-        __builtin_amdgcn_sched_barrier(0);                                    \
-        a = an;                                                               \
-    }
-    G4C_STEP(0, s0) G4C_STEP(1, s1) G4C_STEP(2, s2) G4C_STEP(3, s3)
-    G4C_STEP(4, s4) G4C_STEP(5, s5) G4C_STEP(6, s6) G4C_STEP(7, s7)
-#undef G4C_STEP
-}
 
 // ---- gathered input chunk: lane (r = lane>>3 [+8q], c4 = lane&7) loads 4 consecutive columns.
 // VEC: every source is 16-byte addressable (width, ld, col0 multiples of 4, aligned base) -> one
@@ -153,400 +78,11 @@ __device__ __forceinline__ f32x4 ldx1(const Src &s, int srow, int c) {
     return t;
 }
 
-template <int RT> struct XRegs { f32x16 v[RT]; };   // RT*4 float4 per lane
-
-// Row base pointers of the source being gathered, one per piece (rows (lane>>3) + 8q): computed once per
-// source, so a chunk's gather is one 64-bit add + one load per piece (no kernarg reloads, no LDS reads,
-// no 64-bit multiplies at every chunk).
-template <int RT> struct RowPtrs { const float *p[RT * 4]; };
-
-template <int RT>
-__device__ __forceinline__ void row_ptrs(RowPtrs<RT> &rp, const float *ptr, int ld, int col0, const int *sRow, int lane) {
-#pragma unroll
-    for (int q = 0; q < RT * 4; ++q) rp.p[q] = ptr + (long long)sRow[(lane >> 3) + 8 * q] * ld + col0;
-}
-
-template <int RT, bool VEC>
-__device__ __forceinline__ void load_x_rp(const RowPtrs<RT> &rp, int width, int k0, int lane, XRegs<RT> &x) {
-    const int c = k0 + (lane & 7) * 4;
-#pragma unroll
-    for (int q = 0; q < RT * 4; ++q) {
-        f32x4 t;
-        if (VEC) {
-            t = *reinterpret_cast<const f32x4 *>(rp.p[q] + (c < width ? c : 0));
-        } else {
-            const int w1 = width - 1;
-            t[0] = rp.p[q][c + 0 < w1 ? c + 0 : w1];
-            t[1] = rp.p[q][c + 1 < w1 ? c + 1 : w1];
-            t[2] = rp.p[q][c + 2 < w1 ? c + 2 : w1];
-            t[3] = rp.p[q][c + 3 < w1 ? c + 3 : w1];
-        }
-        x.v[q >> 2][(q & 3) * 4 + 0] = t[0]; x.v[q >> 2][(q & 3) * 4 + 1] = t[1];
-        x.v[q >> 2][(q & 3) * 4 + 2] = t[2]; x.v[q >> 2][(q & 3) * 4 + 3] = t[3];
-    }
-}
-
-template <int RT, bool VEC>
-__device__ __forceinline__ void load_x(const Src &s, const int *sRow, int k0, int lane, XRegs<RT> &x) {
-    const int c = k0 + (lane & 7) * 4;
-#pragma unroll
-    for (int q = 0; q < RT * 4; ++q) {
-        const f32x4 t = ldx1<VEC>(s, sRow[(lane >> 3) + 8 * q], c);
-        x.v[q >> 2][(q & 3) * 4 + 0] = t[0]; x.v[q >> 2][(q & 3) * 4 + 1] = t[1];
-        x.v[q >> 2][(q & 3) * 4 + 2] = t[2]; x.v[q >> 2][(q & 3) * 4 + 3] = t[3];
-    }
-}
-
-// On the way from registers to LDS (after the MFMAs that hid the gather's latency): zero the
-// columns beyond the source width (padding up to 32) and apply the source's pending activation
-// (its producer stored the raw tensor).
-template <int RT>
-__device__ __forceinline__ void pre_act_x(XRegs<RT> &x, int act, int width, int k0, int lane) {
-    // zero fill by select (always); the pending activation (SELU only) under ONE wave-uniform branch
-    const int c = k0 + (lane & 7) * 4;
-#pragma unroll
-    for (int q = 0; q < RT; ++q)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) x.v[q][e] = (c + (e & 3) < width) ? x.v[q][e] : 0.f;
-    if (act) {
-#pragma unroll
-        for (int q = 0; q < RT; ++q)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) x.v[q][e] = g4c::selu_f(x.v[q][e]);
-    }
-}
-
-template <int RT>
-__device__ __forceinline__ void store_x(float *sX, int lane, const XRegs<RT> &x) {
-    const int c = (lane & 7) * 4;
-#pragma unroll
-    for (int q = 0; q < RT * 4; ++q) {
-        float *d = sX + ((lane >> 3) + 8 * q) * XS + c;   // 8-byte aligned
-        *reinterpret_cast<float2 *>(d) = make_float2(x.v[q >> 2][(q & 3) * 4 + 0], x.v[q >> 2][(q & 3) * 4 + 1]);
-        *reinterpret_cast<float2 *>(d + 2) = make_float2(x.v[q >> 2][(q & 3) * 4 + 2], x.v[q >> 2][(q & 3) * 4 + 3]);
-    }
-}
-
-// bias (+ SELU unless last layer) of the accumulators -> hidden buffer.
-// C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-template <int RT, bool LAST>
-__device__ __forceinline__ void store_hidden(const Acc<RT> &acc, float *sH, const float *sBias, int lane) {
-    const int i = lane & 31, h = lane >> 5;
-    float *base = sH + (4 * h) * HS + i;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float bv = sBias[c * 32 + i];
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int row = r * 32 + (q & 3) + 8 * (q >> 2);
-                float x = acc.t[r][c][q] + bv;
-                if (!LAST) x = g4c::selu_f(x);
-                base[row * HS + c * 32] = x;
-            }
-        }
-    }
-}
-
-// acc (C/D layout) += P[idx[row], col] for this wave's rows: the first-layer terms of the node-side inputs
-// that were multiplied once per NODE instead of once per edge (linearity of the first Linear layer).
-// For a fixed register q and column tile c the 32 lanes of a half-wave read 128 contiguous bytes.
-// one batch = 8 accumulator registers x 4 column tiles = 32 independent 4-byte loads per lane
-struct AddBatch { float t[8][4]; };
-
-template <int RT>
-__device__ __forceinline__ void add_batch_load(AddBatch &b, const AddSrc &a, const int *rows, int r, int q0, int i, int h) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int q = q0 + u;
-        const int row = r * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-        const float *pr = a.ptr + (long long)rows[row] * a.ld;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int col = c * 32 + i;
-            b.t[u][c] = pr[col < a.width ? col : 0];
-        }
-    }
-}
-
-template <int RT, int R, int Q0>
-__device__ __forceinline__ void add_batch_apply(Acc<RT> &acc, const AddBatch &b, int width, int i) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc.t[R][c][Q0 + u] += (c * 32 + i < width) ? b.t[u][c] : 0.f;
-}
-
-// All additive sources together, software-pipelined: while batch k (8 registers x 4 column tiles of every
-// source) is added, the loads of batch k+1 are in flight; runs before the weight ring is filled, so the
-// temporaries live in registers that are idle at that point.
-template <int RT>
-__device__ __forceinline__ void add_gathered_all(Acc<RT> &acc, const AddSrc *a, int n_add, const int *rows, int rows_stride, int lane) {
-    const int i = lane & 31, h = lane >> 5;
-    if (n_add == 2) {
-        AddBatch b0[2], b1[2];
-#define G4C_LD(B, R, Q0) add_batch_load<RT>(B[0], a[0], rows, R, Q0, i, h); add_batch_load<RT>(B[1], a[1], rows + rows_stride, R, Q0, i, h); \
-                         __builtin_amdgcn_sched_barrier(0);
-#define G4C_AP(B, R, Q0) add_batch_apply<RT, R, Q0>(acc, B[0], a[0].width, i); add_batch_apply<RT, R, Q0>(acc, B[1], a[1].width, i);
-        G4C_LD(b0, 0, 0)
-        G4C_LD(b1, 0, 8)
-        G4C_AP(b0, 0, 0)
-        if (RT == 2) { G4C_LD(b0, RT - 1, 0) }
-        G4C_AP(b1, 0, 8)
-        if (RT == 2) {
-            G4C_LD(b1, RT - 1, 8)
-            G4C_AP(b0, RT - 1, 0)
-            G4C_AP(b1, RT - 1, 8)
-        }
-#undef G4C_LD
-#undef G4C_AP
-    } else {
-        for (int s = 0; s < n_add; ++s) {
-            AddBatch b0, b1;
-            add_batch_load<RT>(b0, a[s], rows + s * rows_stride, 0, 0, i, h);
-            __builtin_amdgcn_sched_barrier(0);
-            add_batch_load<RT>(b1, a[s], rows + s * rows_stride, 0, 8, i, h);
-            __builtin_amdgcn_sched_barrier(0);
-            add_batch_apply<RT, 0, 0>(acc, b0, a[s].width, i);
-            if (RT == 2) {
-                add_batch_load<RT>(b0, a[s], rows + s * rows_stride, RT - 1, 0, i, h);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            add_batch_apply<RT, 0, 8>(acc, b1, a[s].width, i);
-            if (RT == 2) {
-                add_batch_load<RT>(b1, a[s], rows + s * rows_stride, RT - 1, 8, i, h);
-                __builtin_amdgcn_sched_barrier(0);
-                add_batch_apply<RT, RT - 1, 0>(acc, b0, a[s].width, i);
-                add_batch_apply<RT, RT - 1, 8>(acc, b1, a[s].width, i);
-            }
-        }
-    }
-}
-
-template <int RT>
-__device__ __forceinline__ void zero_acc(Acc<RT> &acc) {
-#pragma unroll
-    for (int r = 0; r < RT; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc.t[r][c][q] = 0.f;
-}
-
-template <int RT, bool VEC>
-__global__ __launch_bounds__(64, RT == 2 ? 1 : 2) void mlp_fused_kernel(const Params p) {
-    constexpr int ROWS = RT * 32;
-    __shared__ __attribute__((aligned(16))) float lds[ROWS * HS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
-    float *sH = lds;                         // hidden activations (layers >= 1) ...
-    float *sX0 = lds;                        // ... aliasing the two input-chunk buffers of layer 0
-    float *sX1 = lds + ROWS * XS;
-    int *sRow = reinterpret_cast<int *>(lds + ROWS * HS);                 // gather rows of the K sources ...
-    int *sRowAdd = sRow + G4C_MAX_SRC * ROWS;                              // ... and of the additive sources
-    float *sBias = lds + ROWS * HS + 2 * G4C_MAX_SRC * ROWS;   // [n_layers][128]
-    float *sGB = sBias + G4C_MAX_LAYERS * NP;                  // gamma[128], beta[128]
-
-    const int lane = threadIdx.x;
-    const int i = lane & 31, h = lane >> 5;
-
-    // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous range of tiles so
-    // neighbouring tiles (which gather the same node rows) share an L2.  Bijective for any n_tiles.
-    int tile;
-    {
-        const int b = blockIdx.x, nt = p.n_tiles;
-        const int q = nt >> 3, r = nt & 7, x = b & 7, j = b >> 3;
-        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-    }
-    const long long row0 = p.row_base + (long long)tile * ROWS;
-
-    for (int r = lane; r < ROWS; r += 64) {
-        long long gr = row0 + r;
-        if (gr >= p.M) gr = p.M - 1;
-        for (int s = 0; s < p.n_src; ++s) sRow[s * ROWS + r] = p.src[s].idx ? p.src[s].idx[gr] : (int)gr;
-        for (int s = 0; s < p.n_add; ++s) sRowAdd[s * ROWS + r] = p.add[s].idx ? p.add[s].idx[gr] : (int)gr;
-    }
-    for (int e = lane; e < p.n_layers * NP; e += 64) sBias[e] = p.b[e];
-    if (p.gamma) {
-        for (int e = lane; e < NP; e += 64) {
-            const int ee = e < p.n_out ? e : 0;
-            sGB[e] = p.gamma[ee];
-            sGB[NP + e] = p.beta[ee];
-        }
-    }
-    // (single wave: LDS operations complete in order, no barrier needed)
-
-    Acc<RT> acc;
-    Ring ring;
-    XRegs<RT> xr;
-    const float *w = p.w;
-    G4C_STAMP(0);
-
-    // ------------------------------------------------------------------ layer 0 (gathered input)
-    zero_acc<RT>(acc);
-    if (p.n_add) add_gathered_all<RT>(acc, p.add, p.n_add, sRowAdd, ROWS, lane);
-    const unsigned lo = (unsigned)(lane * 4);   // lane's offset inside one column tile's 256 floats of a step pair
-    ring_fill(ring, w, lo);
-    {
-        // descriptor of the source currently being gathered, kept in scalars / registers
-        int s = 0, k0 = 0;
-        int cur_width = p.src[0].width, cur_wpad = p.src[0].wpad, cur_act = p.src[0].pre_act;
-        RowPtrs<RT> rp;
-        row_ptrs<RT>(rp, p.src[0].ptr, p.src[0].ld, p.src[0].col0, sRow, lane);
-        load_x_rp<RT, VEC>(rp, cur_width, 0, lane, xr);
-        pre_act_x<RT>(xr, cur_act, cur_width, 0, lane);
-        store_x<RT>(sX0, lane, xr);
-        G4C_STAMP(1);
-        for (int c = 0; c < p.chunks0; ++c) {
-            // next chunk of layer 0: issue its gather now, park it in LDS after this chunk's MFMAs.
-            // Straight-line on purpose (the last iteration re-loads its own chunk into the idle
-            // buffer): hipcc then waits for the gather with an exact vmcnt(16) and leaves the 16
-            // younger weight-ring loads in flight.  Only a source switch (2-3 per tile) touches the
-            // kernel arguments and the row-index table.
-            int nk0 = k0 + KC;
-            if (nk0 >= cur_wpad) {
-                if (s + 1 < p.n_src) {
-                    ++s;
-                    nk0 = 0;
-                    cur_width = p.src[s].width; cur_wpad = p.src[s].wpad; cur_act = p.src[s].pre_act;
-                    row_ptrs<RT>(rp, p.src[s].ptr, p.src[s].ld, p.src[s].col0, sRow + s * ROWS, lane);
-                } else {
-                    nk0 = k0;
-                }
-            }
-            if (!(G4C_ABLATE & 2)) load_x_rp<RT, VEC>(rp, cur_width, nk0, lane, xr);
-            __builtin_amdgcn_sched_barrier(0);
-            const float *sX = (c & 1) ? sX1 : sX0;
-            w += CHUNK_FLOATS;
-            mma_chunk<RT, !(G4C_ABLATE & 1)>(sX + i * XS + 2 * h, 32 * XS, ring, w, lo, acc);
-            if (!(G4C_ABLATE & 2)) {
-                pre_act_x<RT>(xr, cur_act, cur_width, nk0, lane);
-                store_x<RT>((c & 1) ? sX0 : sX1, lane, xr);
-            }
-            k0 = nk0;
-        }
-    }
-
-    // ------------------------------------------------------------------ layers 1..L-1 (K = 128 from LDS)
-    for (int l = 0;; ++l) {
-        const bool last = (l == p.n_layers - 1);
-        G4C_STAMP(2 + 2 * l);
-        if (!(G4C_ABLATE & 4)) {
-            if (last) store_hidden<RT, true>(acc, sH, sBias + l * NP, lane);
-            else store_hidden<RT, false>(acc, sH, sBias + l * NP, lane);
-        }
-        G4C_STAMP(3 + 2 * l);
-        if (last) break;
-        zero_acc<RT>(acc);
-#pragma unroll 1
-        for (int k0 = 0; k0 < NP; k0 += KC) {
-            w += CHUNK_FLOATS;
-            mma_chunk<RT, !(G4C_ABLATE & 1)>(sH + i * HS + k0 + 2 * h, 32 * HS, ring, w, lo, acc);
-        }
-    }
-
-    // ------------------------------------------------------------------ LayerNorm / activation (in LDS)
-    // lane (row = i [+32 per pass], half h) owns columns [64h, 64h+64) of its row
-    const int n_out = p.n_out;
-    if (G4C_ABLATE & 4) {
-        if (acc.t[0][0][0] == 12345.f) p.out[0] = acc.t[0][1][1] + acc.t[RT - 1][2][2] + acc.t[RT - 1][3][3];   // keep acc live
-        return;
-    }
-    if (p.gamma || p.act) {
-        // RT = 2: lane = row, all 128 columns in registers (no cross-lane traffic at all);
-        // RT = 1: lane (row = i, half h) owns 64 columns, one exchange with its partner lane.
-        constexpr int NC = (RT == 2) ? 128 : 64;
-        const int cb = (RT == 2) ? 0 : 64 * h;
-        float *rowp = sH + ((RT == 2) ? lane : i) * HS + cb;
-        const float inv_n = 1.0f / (float)n_out;
-        float x[NC];
-#pragma unroll
-        for (int c = 0; c < NC; c += 4) {
-            const f32x4 t = *reinterpret_cast<const f32x4 *>(rowp + c);
-            x[c] = t[0]; x[c + 1] = t[1]; x[c + 2] = t[2]; x[c + 3] = t[3];
-        }
-        if (p.gamma) {
-            float sum = 0.f;
-            if (n_out == NP) {
-#pragma unroll
-                for (int c = 0; c < NC; ++c) sum += x[c];
-            } else {
-#pragma unroll
-                for (int c = 0; c < NC; ++c) sum += (cb + c < n_out) ? x[c] : 0.f;
-            }
-            if (RT == 1) sum += __shfl_xor(sum, 32);
-            const float mean = sum * inv_n;
-            float var = 0.f;
-            if (n_out == NP) {
-#pragma unroll
-                for (int c = 0; c < NC; ++c) { const float d = x[c] - mean; var = fmaf(d, d, var); }
-            } else {
-#pragma unroll
-                for (int c = 0; c < NC; ++c) { const float d = x[c] - mean; var += (cb + c < n_out) ? d * d : 0.f; }
-            }
-            if (RT == 1) var += __shfl_xor(var, 32);
-            const float rstd = rsqrtf(var * inv_n + p.eps);
-#pragma unroll
-            for (int c = 0; c < NC; c += 4) {
-                const f32x4 g4 = *reinterpret_cast<const f32x4 *>(sGB + cb + c);        // broadcast reads
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sGB + NP + cb + c);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) x[c + u] = fmaf((x[c + u] - mean) * rstd, g4[u], b4[u]);
-            }
-        }
-        if (p.act == G4C_ACT_SELU) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) x[c] = g4c::selu_f(x[c]);
-        } else if (p.act == G4C_ACT_TANH) {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) x[c] = g4c::tanh_f(x[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < NC; c += 4) {
-            f32x4 t;
-            t[0] = x[c]; t[1] = x[c + 1]; t[2] = x[c + 2]; t[3] = x[c + 3];
-            *reinterpret_cast<f32x4 *>(rowp + c) = t;
-        }
-    }
-
-    G4C_STAMP(12);
-    // ------------------------------------------------------------------ store (+ residual)
-    const bool fast = (n_out == NP) && ((p.out_ld & 3) == 0) && (((uintptr_t)p.out & 15) == 0) && (p.resid == nullptr);
-    if (fast) {
-        // two whole rows (2 x 512 B) per instruction; LDS reads issued 8 at a time ahead of the stores
-#pragma unroll 1
-        for (int r0 = 0; r0 < ROWS; r0 += 16) {
-            f32x4 t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4 *>(sH + (r0 + 2 * u + h) * HS + 4 * i);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const long long grow = row0 + r0 + 2 * u + h;
-                if (grow < p.M) {
-                    const long long orow = p.out_idx ? p.out_idx[grow] : grow;
-                    *reinterpret_cast<f32x4 *>(p.out + orow * p.out_ld + 4 * i) = t[u];
-                }
-            }
-        }
-    } else {
-        for (int e = lane; e < ROWS * n_out; e += 64) {
-            const int r = e / n_out, c = e - r * n_out;
-            const long long grow = row0 + r;
-            if (grow < p.M) {
-                const long long orow = p.out_idx ? p.out_idx[grow] : grow;
-                float y = sH[r * HS + c];
-                if (p.resid) y += p.resid[grow * p.resid_ld + p.resid_col0 + c];
-                p.out[orow * p.out_ld + c] = y;
-            }
-        }
-    }
-    G4C_STAMP(13);
-}
-
 // ======================================================================================================
-// Column-split variant for SMALL launches (coarse levels, remainders, per-rank sub-meshes): NW waves share
-// one 32-row tile, each computing NCT = 4/NW of the four 32-column tiles.  A launch with few tiles is
-// latency-bound on one wave's ~80k MFMA cycles; splitting the columns gives NW x more waves with 1/NW of
-// the MFMA work each, so the tile finishes ~NW x sooner and the launch fills more SIMDs.
+// The fp32-MFMA kernel (precision "fp32", and the launches the bf16x6 kernel cannot take): NW = 4 waves share
+// one 32-row tile, each computing NCT = 4/NW of the four 32-column tiles.  (Round 1 also carried single-wave 64- / 32-row
+// tiles, a 2-wave split, a 64-row split and a small-launch variant; the 4-wave split was the fastest or within 2 % of the
+// fastest at every launch size, and the others were removed.)
 // The waves of a tile share the gathered input chunk and the hidden activations through LDS:
 // one barrier per layer-0 chunk, two per layer.  Weights still stream L2 -> registers (each wave only its
 // own column tiles), accumulators stay in registers.
@@ -959,430 +495,6 @@ __global__ __launch_bounds__(64 * NW, G4C_SPLIT_MINW) void mlp_split_kernel(cons
                     const long long grow = row0 + (q & 3) + 8 * (q >> 2) + 4 * h;
                     if (grow < p.M) ho[grow * p.head_ld + (ct0 + c) * 32 + i] = acc.t[c][q];
                 }
-        }
-    }
-}
-
-// ======================================================================================================
-// 64-row form of the 4-wave column split for LARGE launches: each wave multiplies TWO 32-row tiles by its column
-// tile, so every weight element fetched from L2 feeds 4 MFMAs instead of 2 and the per-row count of barriers,
-// index loads and bias / LayerNorm staging halves.  The weight stream out of L2 (not HBM, not the MFMA pipe) is
-// what the 32-row kernel stalls on when every SIMD is full (scripts/ab_test.py ablations: halving it = -6 %).
-// 38 KiB of LDS per workgroup -> 4 workgroups (16 waves) per CU.
-__device__ __forceinline__ void mma_chunk_64(const float *pa0, const float *pa1, Ring4 &g, const float *wnext, unsigned lo4,
-                                             f32x16 &acc0, f32x16 &acc1) {
-    float2 a0 = *reinterpret_cast<const float2 *>(pa0), a1 = *reinterpret_cast<const float2 *>(pa1);
-#define G4C_HALF(AX, AY, B0, B1)                                                                       \
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AX.x, B0, acc0, 0, 0, 0);                          \
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AY.x, B0, acc1, 0, 0, 0);                          \
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(AX.y, B1, acc0, 0, 0, 0);                          \
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(AY.y, B1, acc1, 0, 0, 0);
-#define G4C_PAIR(V, SLOT)                                                                              \
-    {                                                                                                  \
-        const float2 b0 = *reinterpret_cast<const float2 *>(pa0 + (2 * (V) + 1) * 4);                  \
-        const float2 b1 = *reinterpret_cast<const float2 *>(pa1 + (2 * (V) + 1) * 4);                  \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        G4C_HALF(a0, a1, g.SLOT[0], g.SLOT[1])                                                         \
-        const float2 c0 = *reinterpret_cast<const float2 *>(pa0 + ((2 * (V) + 2) & 7) * 4);            \
-        const float2 c1 = *reinterpret_cast<const float2 *>(pa1 + ((2 * (V) + 2) & 7) * 4);            \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        G4C_HALF(b0, b1, g.SLOT[2], g.SLOT[3])                                                         \
-        g.SLOT = *reinterpret_cast<const f32x4 *>(wnext + (V) * 1024 + lo4);                           \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
-        a0 = c0; a1 = c1;                                                                              \
-    }
-    G4C_PAIR(0, p0) G4C_PAIR(1, p1) G4C_PAIR(2, p2) G4C_PAIR(3, p3)
-#undef G4C_PAIR
-#undef G4C_HALF
-}
-
-template <bool VEC>
-__global__ __launch_bounds__(256, 4) void mlp_split64_kernel(const Params p) {
-    constexpr int ROWS = 64, NW = 4, NPIECE = 2;
-    __shared__ __attribute__((aligned(16))) float lds[ROWS * HS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
-    float *sH = lds;
-    float *sX0 = lds;
-    float *sX1 = lds + ROWS * XS;
-    int *sRow = reinterpret_cast<int *>(lds + ROWS * HS);
-    int *sRowAdd = sRow + G4C_MAX_SRC * ROWS;
-    float *sBias = lds + ROWS * HS + 2 * G4C_MAX_SRC * ROWS;
-    float *sGB = sBias + G4C_MAX_LAYERS * NP;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 31, h = lane >> 5;
-    const int ct0 = wave;
-
-    int tile;
-    {
-        const int b = blockIdx.x, nt = p.n_tiles;
-        const int q = nt >> 3, r = nt & 7, x = b & 7, j = b >> 3;
-        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-    }
-    const long long row0 = p.row_base + (long long)tile * ROWS;
-
-    for (int e = tid; e < 2 * G4C_MAX_SRC * ROWS; e += 64 * NW) {
-        const int slot = e / ROWS, r = e % ROWS;
-        long long gr = row0 + r;
-        if (gr >= p.M) gr = p.M - 1;
-        const int *ix = nullptr;
-        bool used;
-        if (slot < G4C_MAX_SRC) { used = slot < p.n_src; if (used) ix = p.src[slot].idx; }
-        else { used = slot - G4C_MAX_SRC < p.n_add; if (used) ix = p.add[slot - G4C_MAX_SRC].idx; }
-        if (used) sRow[e] = ix ? ix[gr] : (int)gr;
-    }
-    for (int e = tid; e < p.n_layers * NP; e += 64 * NW) sBias[e] = p.b[e];
-    if (p.gamma) {
-        for (int e = tid; e < NP; e += 64 * NW) {
-            const int ee = e < p.n_out ? e : 0;
-            sGB[e] = p.gamma[ee];
-            sGB[NP + e] = p.beta[ee];
-        }
-    }
-    __syncthreads();
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { acc0[q] = 0.f; acc1[q] = 0.f; }
-    // pre-multiplied node-side terms of the first layer: 16 loads in flight at a time (one row tile of one source)
-    {
-        const int col = ct0 * 32 + i;
-        for (int a = 0; a < p.n_add; ++a) {
-            const bool ok = col < p.add[a].width;
-            const float *base = p.add[a].ptr + (ok ? col : 0);
-            const int ld = p.add[a].ld;
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                float t[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    t[q] = base[(long long)sRowAdd[a * ROWS + rt * 32 + (q & 3) + 8 * (q >> 2) + 4 * h] * ld];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float v = ok ? t[q] : 0.f;
-                    if (rt == 0) acc0[q] += v; else acc1[q] += v;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-    const float *w = p.w;
-    const unsigned lo4 = (unsigned)(ct0 * 256 + lane * 4);
-    Ring4 ring;
-    ring4_fill(ring, w, lo4);
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---------------------------------------------------------------- layer 0: shared gather, one barrier per chunk
-    {
-        const int c4 = (lane & 7) * 4;
-        f32x4 xp[NPIECE];
-        const float *rp[NPIECE];
-        int s = 0, k0 = 0;
-        int cur_width = p.src[0].width, cur_wpad = p.src[0].wpad, cur_act = p.src[0].pre_act;
-        auto set_rows = [&](int sidx) {
-#pragma unroll
-            for (int q = 0; q < NPIECE; ++q)
-                rp[q] = p.src[sidx].ptr + (long long)sRow[sidx * ROWS + (lane >> 3) + 8 * (wave + NW * q)] * p.src[sidx].ld + p.src[sidx].col0;
-        };
-        auto gather = [&](int kk) {
-            const int c = kk + c4;
-#pragma unroll
-            for (int q = 0; q < NPIECE; ++q) {
-                if (VEC) {
-                    xp[q] = *reinterpret_cast<const f32x4 *>(rp[q] + (c < cur_width ? c : 0));
-                } else {
-                    const int w1 = cur_width - 1;
-                    xp[q][0] = rp[q][c + 0 < w1 ? c + 0 : w1]; xp[q][1] = rp[q][c + 1 < w1 ? c + 1 : w1];
-                    xp[q][2] = rp[q][c + 2 < w1 ? c + 2 : w1]; xp[q][3] = rp[q][c + 3 < w1 ? c + 3 : w1];
-                }
-            }
-        };
-        auto park = [&](float *dst, int kk) {
-            const int c = kk + c4;
-#pragma unroll
-            for (int q = 0; q < NPIECE; ++q) {
-                float t[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = (c + e < cur_width) ? xp[q][e] : 0.f;
-                if (cur_act) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = g4c::selu_f(t[e]);
-                }
-                float *d = dst + ((lane >> 3) + 8 * (wave + NW * q)) * XS + c4;
-                *reinterpret_cast<float2 *>(d) = make_float2(t[0], t[1]);
-                *reinterpret_cast<float2 *>(d + 2) = make_float2(t[2], t[3]);
-            }
-        };
-        set_rows(0);
-        gather(0);
-        park(sX0, 0);
-        __syncthreads();
-        for (int c = 0; c < p.chunks0; ++c) {
-            int nk0 = k0 + KC;
-            if (nk0 >= cur_wpad) {
-                if (s + 1 < p.n_src) {
-                    ++s; nk0 = 0;
-                    cur_width = p.src[s].width; cur_wpad = p.src[s].wpad; cur_act = p.src[s].pre_act;
-                    set_rows(s);
-                } else {
-                    nk0 = k0;
-                }
-            }
-            gather(nk0);
-            __builtin_amdgcn_sched_barrier(0);
-            w += CHUNK_FLOATS;
-            const float *pa = ((c & 1) ? sX1 : sX0) + i * XS + 2 * h;
-            mma_chunk_64(pa, pa + 32 * XS, ring, w, lo4, acc0, acc1);
-            park((c & 1) ? sX0 : sX1, nk0);
-            k0 = nk0;
-            __syncthreads();
-        }
-    }
-
-    // ---------------------------------------------------------------- layers 1..L-1
-    for (int l = 0;; ++l) {
-        const bool last = (l == p.n_layers - 1);
-        {
-            const float bv = sBias[l * NP + ct0 * 32 + i];
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
-                float *base = sH + (rt * 32 + 4 * h) * HS + ct0 * 32 + i;
-#pragma unroll
-                for (int q0 = 0; q0 < 16; q0 += 4) {
-                    float x[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) x[q] = (rt == 0 ? acc0[q0 + q] : acc1[q0 + q]) + bv;
-                    if (!last) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) x[q] = g4c::selu_f(x[q]);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) base[(q + 2 * q0) * HS] = x[q];
-                }
-            }
-        }
-        __syncthreads();
-        if (last) break;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { acc0[q] = 0.f; acc1[q] = 0.f; }
-#pragma unroll 1
-        for (int k0 = 0; k0 < NP; k0 += KC) {
-            w += CHUNK_FLOATS;
-            const float *pa = sH + i * HS + k0 + 2 * h;
-            mma_chunk_64(pa, pa + 32 * HS, ring, w, lo4, acc0, acc1);
-        }
-        __syncthreads();
-    }
-    split_finish<NW, ROWS>(p, sH, sGB, wave, lane, row0);
-}
-
-// ======================================================================================================
-// Latency-oriented variant of the 4-wave column split for SMALL launches (at most a wave or two per SIMD: coarse
-// levels, per-rank sub-meshes).  There nothing hides a memory round trip, and the regular kernel pays one per
-// 32-column input chunk (gather -> barrier) and one per 8 weight steps (the 8-step ring is only ~0.5 us of MFMA
-// work when the wave has the SIMD to itself, less than an Infinity-Cache / HBM access).  This kernel
-//   * keeps FOUR chunks (one whole 128-k layer) of weights in flight per wave: 32 ring slots, refilled 4 chunks ahead;
-//   * gathers a whole 128-wide input block per barrier (4 x 16-byte loads per lane in flight), next block prefetched
-//     while the current one is multiplied.
-// Envelope: every weighted input block exactly 128 wide and 16-byte aligned; anything else runs mlp_split_kernel.
-struct RingD { float2 r[4][8]; };
-
-#define G4C_DSTEP(J, U)                                                                                  \
-    {                                                                                                    \
-        const float2 an = *reinterpret_cast<const float2 *>(pa + (J) * 32 + (((U) + 1) & 7) * 4 + ((U) == 7 && (J) < 3 ? 32 : 0)); \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, g.r[J][U].x, acc.t[0], 0, 0, 0);            \
-        acc.t[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, g.r[J][U].y, acc.t[0], 0, 0, 0);            \
-        g.r[J][U] = *reinterpret_cast<const float2 *>(wn[J] + step_off(U) + lo);                           \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        a = an;                                                                                          \
-    }
-#define G4C_DCHUNK(J) G4C_DSTEP(J, 0) G4C_DSTEP(J, 1) G4C_DSTEP(J, 2) G4C_DSTEP(J, 3) G4C_DSTEP(J, 4) G4C_DSTEP(J, 5) G4C_DSTEP(J, 6) G4C_DSTEP(J, 7)
-
-// one 128-k block (4 chunks) from the LDS rows at `pa` (row stride HS); ring slot j is refilled from wn[j]
-__device__ __forceinline__ void mma_block_deep(const float *pa, RingD &g, const float *const (&wn)[4], unsigned lo, AccN<1> &acc) {
-    float2 a = *reinterpret_cast<const float2 *>(pa);
-    G4C_DCHUNK(0) G4C_DCHUNK(1) G4C_DCHUNK(2) G4C_DCHUNK(3)
-}
-#undef G4C_DCHUNK
-#undef G4C_DSTEP
-
-__global__ __launch_bounds__(256) void mlp_deep_kernel(const Params p) {
-    constexpr int ROWS = 32, NW = 4;
-    __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * HS + 2 * G4C_MAX_SRC * ROWS + (G4C_MAX_LAYERS + 2) * NP];
-    float *sH = lds;                       // block buffer 0 doubles as the hidden buffer
-    float *sXb = lds + ROWS * HS;          // block buffer 1
-    int *sRow = reinterpret_cast<int *>(lds + 2 * ROWS * HS);
-    int *sRowAdd = sRow + G4C_MAX_SRC * ROWS;
-    float *sBias = lds + 2 * ROWS * HS + 2 * G4C_MAX_SRC * ROWS;
-    float *sGB = sBias + G4C_MAX_LAYERS * NP;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 31, h = lane >> 5;
-    const int ct0 = wave;
-
-    int tile;
-    {
-        const int b = blockIdx.x, nt = p.n_tiles;
-        const int q = nt >> 3, r = nt & 7, x = b & 7, j = b >> 3;
-        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-    }
-    const long long row0 = p.row_base + (long long)tile * ROWS;
-    G4C_STAMPW(0);
-
-    // weights first: they depend on nothing, so their round trip overlaps the index loads below
-    const int total_chunks = p.chunks0 + (p.n_layers - 1 + p.n_heads) * (NP / KC);
-    const unsigned lo = (unsigned)(ct0 * 256 + lane * 4);
-    RingD ring;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float *wc = p.w + (size_t)(j < total_chunks ? j : total_chunks - 1) * CHUNK_FLOATS;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) ring.r[j][u] = *reinterpret_cast<const float2 *>(wc + step_off(u) + lo);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // row indices of every input block: one (block, row) per thread, so all index loads are in flight together
-    for (int e = tid; e < 2 * G4C_MAX_SRC * ROWS; e += 64 * NW) {
-        const int slot = e / ROWS, r = e % ROWS;
-        long long gr = row0 + r;
-        if (gr >= p.M) gr = p.M - 1;
-        const int *ix = nullptr;
-        bool used;
-        if (slot < G4C_MAX_SRC) { used = slot < p.n_src; if (used) ix = p.src[slot].idx; }
-        else { used = slot - G4C_MAX_SRC < p.n_add; if (used) ix = p.add[slot - G4C_MAX_SRC].idx; }
-        if (used) sRow[e] = ix ? ix[gr] : (int)gr;      // sRowAdd == sRow + G4C_MAX_SRC * ROWS
-    }
-    for (int e = tid; e < p.n_layers * NP; e += 64 * NW) sBias[e] = p.b[e];
-    if (p.gamma) {
-        for (int e = tid; e < NP; e += 64 * NW) {
-            const int ee = e < p.n_out ? e : 0;
-            sGB[e] = p.gamma[ee];
-            sGB[NP + e] = p.beta[ee];
-        }
-    }
-    __syncthreads();
-    G4C_STAMPW(1);
-
-    // this wave's 8 rows of an input block: lane -> row (lane>>3) + 8*wave, 16 bytes at column 4*(lane&7) of each chunk
-    const int grow_l = (lane >> 3) + 8 * wave, c4 = (lane & 7) * 4;
-    f32x4 xp[4];
-    auto gather = [&](int sidx) {
-        const float *rp = p.src[sidx].ptr + (long long)sRow[sidx * ROWS + grow_l] * p.src[sidx].ld + p.src[sidx].col0 + c4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xp[q] = *reinterpret_cast<const f32x4 *>(rp + q * KC);
-    };
-    auto park = [&](float *dst, int act) {
-        float *d = dst + grow_l * HS + c4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 t = xp[q];
-            if (act) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = g4c::selu_f(t[e]);
-            }
-            *reinterpret_cast<f32x4 *>(d + q * KC) = t;
-        }
-    };
-    gather(0);
-    __builtin_amdgcn_sched_barrier(0);
-
-    AccN<1> acc;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc.t[0][q] = 0.f;
-    // pre-multiplied node-side terms of the first layer (see mlp_split_kernel)
-    for (int a = 0; a < p.n_add; ++a) {
-        float t[16];
-        const int col = ct0 * 32 + i;
-        const bool ok = col < p.add[a].width;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int row = (q & 3) + 8 * (q >> 2) + 4 * h;
-            t[q] = p.add[a].ptr[(long long)sRowAdd[a * ROWS + row] * p.add[a].ld + (ok ? col : 0)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc.t[0][q] += ok ? t[q] : 0.f;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    G4C_STAMPW(2);
-    park(sH, p.src[0].pre_act);
-    __syncthreads();
-    G4C_STAMPW(3);
-
-    int g = 0;                             // chunk index of ring slot 0's current contents
-    const float *wn[4];
-    auto set_refill = [&]() {              // slot j is refilled with chunk g + 4 + j (clamped: the tail is never used)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = g + 4 + j;
-            wn[j] = p.w + (size_t)(c < total_chunks ? c : total_chunks - 1) * CHUNK_FLOATS;
-        }
-    };
-    // ---------------------------------------------------------------- layer 0: one barrier per 128-wide input block
-    for (int s = 0; s < p.n_src; ++s) {
-        const bool more = s + 1 < p.n_src;
-        if (more) gather(s + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        set_refill();
-        mma_block_deep(((s & 1) ? sXb : sH) + i * HS + 2 * h, ring, wn, lo, acc);
-        g += 4;
-        if (more) park((s & 1) ? sH : sXb, p.src[s + 1].pre_act);
-        __syncthreads();
-    }
-
-    G4C_STAMPW(4);
-    // ---------------------------------------------------------------- layers 1..L-1
-    for (int l = 0;; ++l) {
-        const bool last = (l == p.n_layers - 1);
-        {
-            float *base = sH + (4 * h) * HS + i;
-            const float bv = sBias[l * NP + ct0 * 32 + i];
-#pragma unroll
-            for (int q0 = 0; q0 < 16; q0 += 4) {
-                float x[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) x[q] = acc.t[0][q0 + q] + bv;
-                if (!last) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) x[q] = g4c::selu_f(x[q]);
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) base[(q + 2 * q0) * HS + ct0 * 32] = x[q];
-            }
-        }
-        __syncthreads();
-        G4C_STAMPW(5 + 2 * l);
-        if (last) break;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc.t[0][q] = 0.f;
-        set_refill();
-        mma_block_deep(sH + i * HS + 2 * h, ring, wn, lo, acc);
-        g += 4;
-        __syncthreads();
-        G4C_STAMPW(6 + 2 * l);
-    }
-    G4C_STAMPW(12);
-    split_finish<NW>(p, sH, sGB, wave, lane, row0);
-    G4C_STAMPW(13);
-    if (p.n_heads) {
-        __syncthreads();
-        for (int hd = 0; hd < p.n_heads; ++hd) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc.t[0][q] = 0.f;
-            set_refill();
-            mma_block_deep(sH + i * HS + 2 * h, ring, wn, lo, acc);
-            g += 4;
-            float *ho = p.head_out[hd];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const long long grow = row0 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                if (grow < p.M) ho[grow * p.head_ld + ct0 * 32 + i] = acc.t[0][q];
-            }
         }
     }
 }
@@ -2014,64 +1126,12 @@ extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs,
                                     float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                                     const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
 
-// Launches of at most this many rows (about two waves per SIMD) run mlp_deep_kernel when their input blocks allow it:
-// with so few waves nothing hides a memory round trip, so the kernel keeps a whole layer of weights and a whole
-// input block in flight.  G4C_MLP_DEEP_ROWS overrides (0 disables).
-static int64_t deep_rows() {
-    static const int64_t v = getenv("G4C_MLP_DEEP_ROWS") ? atoll(getenv("G4C_MLP_DEEP_ROWS")) : 16384;
-    return v;
-}
-
-extern "C" int64_t g4c_mlp_bulk_rows(int64_t n_rows) {
-    // Tile scheduling.  A 64-row tile (one wave, 512 registers) keeps a SIMD busy for one "round"; the
-    // chip holds 1024 of them.  Whole rounds go to the 64-row kernel; the remainder (< 64 Ki rows) goes to
-    // 32-row tiles, which finish in about half a round when there are at most 1024 of them, instead of
-    // leaving most of the chip idle for a full last round.
-    static const int force_rt = getenv("G4C_MLP_RT") ? atoi(getenv("G4C_MLP_RT")) : 0;
-    if (force_rt == 2) return n_rows;
-    (void)n_rows;
-    return 0;   // default: everything on the column-split kernel (see g4c_mlp_small_tile_mode)
-}
-
-extern "C" int32_t g4c_mlp_small_tile_mode(int64_t rows) {
-    // remainder / small launches: 32-row tiles on 1, 2 or 4 waves.  The chip holds 2048 single-wave
-    // 32-row tiles (two per SIMD); with fewer tiles than that, splitting the columns over more waves
-    // shortens the critical path of the launch.
-    static const int force = getenv("G4C_MLP_SPLIT") ? atoi(getenv("G4C_MLP_SPLIT")) : 0;
-    if (force == 1) return 32;
-    if (force == 2) return 322;
-    if (force == 4) return 324;
-    // measured (scripts/sweep_tile_modes.py, hoisted edge MLP, 8k .. 1M rows): the 4-wave column split is the fastest
-    // or within 2 % of the fastest mode at every size (four waves per SIMD hide each other's non-MFMA phases)
-    (void)rows;
-    return 324;
-}
-
-extern "C" int32_t g4c_mlp_pick_mode(const g4c_src_t *srcs, int32_t n_src, int64_t rows) {
-    const int32_t mode = g4c_mlp_small_tile_mode(rows);
-    if (mode != 324 || rows > deep_rows() || !srcs) return mode;
-    for (int s = 0; s < n_src; ++s) {
-        const g4c_src_t &g = srcs[s];
-        if (g.additive) continue;
-        if (g.width != NP || g.ld % 4 || g.col0 % 4 || (uintptr_t)g.ptr % 16) return mode;
-    }
-    return 325;
-}
-
 extern "C" int g4c_mlp_forward(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                                const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream) {
-    static const int force_mode = getenv("G4C_MLP_FORCE_MODE") ? atoi(getenv("G4C_MLP_FORCE_MODE")) : 0;   // tuning only
-    if (force_mode)
-        return g4c_mlp_forward_rows(mlp, srcs, n_src, n_rows, 0, n_rows, force_mode, out, out_ld, out_idx, act, resid, resid_ld, resid_col0, stream);
-    const int64_t bulk = g4c_mlp_bulk_rows(n_rows);
-    int rc = G4C_OK;
-    if (bulk > 0)
-        rc = g4c_mlp_forward_rows(mlp, srcs, n_src, n_rows, 0, bulk, 64, out, out_ld, out_idx, act, resid, resid_ld, resid_col0, stream);
-    if (rc == G4C_OK && n_rows > bulk)
-        rc = g4c_mlp_forward_rows(mlp, srcs, n_src, n_rows, bulk, n_rows - bulk, g4c_mlp_pick_mode(srcs, n_src, n_rows - bulk), out, out_ld,
-                                  out_idx, act, resid, resid_ld, resid_col0, stream);
-    return rc;
+    // fp32 MFMA: one kernel family, the 4-wave column split on 32-row tiles (measured the fastest or within 2 % of the fastest of
+    // the variants tried in round 1 at every launch size from 8k to 1M rows)
+    return g4c_mlp_forward_rows(mlp, srcs, n_src, n_rows, 0, n_rows, 324, out, out_ld, out_idx, act, resid, resid_ld, resid_col0, stream);
 }
 
 struct SaveArgs {          // training forward / backward chain (g4c_mlp_forward_bx6_save)
@@ -2107,9 +1167,7 @@ extern "C" int g4c_mlp_forward_heads(const g4c_mlp_t *mlp, const g4c_src_t *srcs
                                      float *out, int32_t out_ld, int32_t act,
                                      const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream) {
     G4C_REQUIRE(n_heads >= 1 && n_heads <= G4C_MAX_HEADS && head_w && head_out, G4C_EINVAL, "g4c_mlp_forward_heads: bad heads (n=%d)", n_heads);
-    const int32_t mode = g4c_mlp_pick_mode(srcs, n_src, n_rows);
-    G4C_REQUIRE(mode == 324 || mode == 325, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads: tile mode %d has no heads (only the 4-wave column split)", mode);
-    return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, mode, out, out_ld, nullptr, act, nullptr, 0, 0,
+    return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 324, out, out_ld, nullptr, act, nullptr, 0, 0,
                       head_w, n_heads, head_out, head_ld, stream);
 }
 
@@ -2174,9 +1232,8 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     const bool bf16 = bx6;                       // input blocks padded to 128 k
     const int wbytes = bx6 ? 6 : 4;
     if (bf16) tile_rows = 324;
-    G4C_REQUIRE(tile_rows == 64 || tile_rows == 32 || tile_rows == 322 || tile_rows == 324 || tile_rows == 325 || tile_rows == 644, G4C_EINVAL,
-                "g4c_mlp_forward_rows: tile_rows must be 64, 32, 322 (32 rows / 2 waves), 324 (32 rows / 4 waves) or 325 (324, small-launch variant)");
-    G4C_REQUIRE(row_begin >= 0 && row_count >= 0 && row_begin + row_count <= n_rows && row_begin % 32 == 0 && (tile_rows != 644 || row_begin % 64 == 0), G4C_EINVAL,
+    G4C_REQUIRE(tile_rows == 324, G4C_EINVAL, "g4c_mlp_forward_rows: tile_rows must be 324 (32-row tiles on 4 waves; the one fp32-MFMA kernel), got %d", tile_rows);
+    G4C_REQUIRE(row_begin >= 0 && row_count >= 0 && row_begin + row_count <= n_rows && row_begin % 32 == 0, G4C_EINVAL,
                 "g4c_mlp_forward_rows: bad row range [%lld, +%lld) of %lld", (long long)row_begin, (long long)row_count, (long long)n_rows);
     G4C_REQUIRE(mlp && srcs, G4C_EINVAL, "g4c_mlp_forward: null pointer");
     G4C_REQUIRE(n_src >= 1 && n_src <= G4C_MAX_SRC, G4C_EUNSUPPORTED, "g4c_mlp_forward: %d sources (max %d)", n_src, G4C_MAX_SRC);
@@ -2189,7 +1246,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     g4c::DeviceGuard on_device(mlp->w[0]);
     Params p;
     int kp = 0;
-    bool all_vec = true, deep_ok = true;
+    bool all_vec = true;
     int nk = 0;
     p.n_add = 0;
     p.n_nar = 0;
@@ -2224,7 +1281,6 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
                         "g4c_mlp_forward: aggregation on load needs the bf16x6 kernels and a 128-wide aligned block without gather index");
         d.vec = (g.width % 4 == 0) && (g.ld % 4 == 0) && (g.col0 % 4 == 0) && ((uintptr_t)g.ptr % 16 == 0);
         all_vec = all_vec && d.vec;
-        deep_ok = deep_ok && d.vec && g.width == NP;
         kp += d.wpad;
     }
     G4C_REQUIRE(nk >= 1 || p.n_nar >= 1, G4C_EINVAL, "g4c_mlp_forward: no input block goes through the weights");
@@ -2285,7 +1341,6 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     if (n_heads) {
         G4C_REQUIRE(!round1, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads: no rounded-bf16 variant");
         G4C_REQUIRE((head_ld & 3) == 0 || !bx6, G4C_EINVAL, "g4c_mlp_forward_heads: head outputs need a leading dimension that is a multiple of 4");
-        G4C_REQUIRE(tile_rows == 324 || tile_rows == 325, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads: tile mode %d has no heads", tile_rows);
         G4C_REQUIRE(p.n_out == NP && !resid && !out_idx && head_ld >= NP, G4C_EINVAL,
                     "g4c_mlp_forward_heads: heads need a 128-wide output without residual / output index (n_out=%d)", p.n_out);
         const int last = mlp->n_layers - 1;
@@ -2297,19 +1352,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     if (row_count == 0) return G4C_OK;
     p.row_base = row_begin;
     p.M = row_begin + row_count;          // rows past the range are neither gathered nor stored
-    if (tile_rows == 64) {
-        p.n_tiles = (int)((row_count + 63) / 64);
-        if (all_vec) mlp_fused_kernel<2, true><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
-        else mlp_fused_kernel<2, false><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
-    } else if (tile_rows == 32) {
-        p.n_tiles = (int)((row_count + 31) / 32);
-        if (all_vec) mlp_fused_kernel<1, true><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
-        else mlp_fused_kernel<1, false><<<dim3(p.n_tiles), dim3(64), 0, st>>>(p);
-    } else if (tile_rows == 322) {
-        p.n_tiles = (int)((row_count + 31) / 32);
-        if (all_vec) mlp_split_kernel<2, true><<<dim3(p.n_tiles), dim3(128), 0, st>>>(p);
-        else mlp_split_kernel<2, false><<<dim3(p.n_tiles), dim3(128), 0, st>>>(p);
-    } else if (bx6 && !force_tiles && px6_eligible(p, agg != nullptr, save != nullptr, all_vec) && row_count >= px6_min_rows()) {
+    if (bx6 && !force_tiles && px6_eligible(p, agg != nullptr, save != nullptr, all_vec) && row_count >= px6_min_rows()) {
         // persistent ping-pong kernel (mlp_px6.hip): 32-row units (whole segments with aggregation), two per group tile
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
         if (p.n_tiles == 0) return G4C_OK;
@@ -2339,14 +1382,6 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         else if (round1) { if (rt2) G4C_BX6_LAUNCH(2, 1); else G4C_BX6_LAUNCH(1, 1); }
         else { if (rt2) G4C_BX6_LAUNCH(2, 3); else G4C_BX6_LAUNCH(1, 3); }
 #undef G4C_BX6_LAUNCH
-    } else if (tile_rows == 644) {
-        p.n_tiles = (int)((row_count + 63) / 64);
-        if (all_vec) mlp_split64_kernel<true><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
-        else mlp_split64_kernel<false><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
-    } else if (tile_rows == 325) {
-        G4C_REQUIRE(deep_ok, G4C_EUNSUPPORTED, "g4c_mlp_forward_rows: the small-launch variant needs 128-wide, 16-byte aligned input blocks");
-        p.n_tiles = (int)((row_count + 31) / 32);
-        mlp_deep_kernel<<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
     } else {
         p.n_tiles = (int)((row_count + 31) / 32);
         if (all_vec) mlp_split_kernel<4, true><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);

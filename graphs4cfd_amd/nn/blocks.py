@@ -148,8 +148,6 @@ class MLP(nn.Module):
             self._packed[key] = (sig, pk)
             hit = self._packed[key]
         pk = hit[1]
-        if prec == "fp32" and ops.mlp_mode(sources, n_rows) not in (324, 325):
-            return None
         dev = sources[0].tensor.device
         y = out if out is not None else torch.empty((n_rows, 128), dtype=torch.float32, device=dev)
         outs = [(head_outs[j] if head_outs is not None and head_outs[j] is not None else

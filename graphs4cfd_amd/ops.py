@@ -419,14 +419,6 @@ def _src_array(sources: Sequence[Source]):
     return arr
 
 
-def mlp_mode(sources: Sequence[Source], n_rows: int) -> int:
-    """Kernel variant g4c_mlp_forward would use for these input blocks (g4c_mlp_pick_mode; 0 when a bulk launch is split off)."""
-    lib = _lib.load()
-    if int(lib.g4c_mlp_bulk_rows(n_rows)) > 0:
-        return 0
-    return int(lib.g4c_mlp_pick_mode(_src_array(sources), len(sources), n_rows))
-
-
 def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: int = _lib.ACT_NONE,
                 out: Optional[Tensor] = None, out_idx32: Optional[Tensor] = None,
                 resid: Optional[Tensor] = None, resid_col0: int = 0, tile_mode: Optional[int] = None,
@@ -552,21 +544,12 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
         if KernelTimer.active is None:
             call()
         else:
-            mode = int(lib.g4c_mlp_pick_mode(arr, len(sources), n_rows))
-            name = {324: "mlp_split_kernel<4>", 325: "mlp_deep_kernel"}.get(mode, "mlp_other")
-            _timed(name, packed.flops_per_row * n_rows, 4.0 * (sum(packed.seg_widths) + packed.n_out * (1 + packed.n_heads)) * n_rows, call)
+            _timed("mlp_split_kernel<4>", packed.flops_per_row * n_rows, 4.0 * (sum(packed.seg_widths) + packed.n_out * (1 + packed.n_heads)) * n_rows, call)
     elif tile_mode is not None:
         _lib.check(lib.g4c_mlp_forward_rows(C.byref(packed.desc), arr, len(sources), n_rows, 0, n_rows, tile_mode, *args))
     elif KernelTimer.active is None:
         _lib.check(lib.g4c_mlp_forward(C.byref(packed.desc), arr, len(sources), n_rows, *args))
     else:
-        # same two launches as g4c_mlp_forward, bracketed separately (kernel names as rocprofv3 reports them)
-        bulk = int(lib.g4c_mlp_bulk_rows(n_rows))
-        bpr = 4.0 * (sum(packed.seg_widths) + packed.n_out)
-        small = int(lib.g4c_mlp_pick_mode(arr, len(sources), n_rows - bulk)) if n_rows > bulk else 32
-        small_name = {32: "mlp_fused_kernel<1>", 322: "mlp_split_kernel<2>", 324: "mlp_split_kernel<4>", 325: "mlp_deep_kernel"}[small]
-        for kind, begin, count, tile in (("mlp_fused_kernel<2>", 0, bulk, 64), (small_name, bulk, n_rows - bulk, small)):
-            if count > 0:
-                _timed(kind, packed.flops_per_row * count, bpr * count, lambda: _lib.check(lib.g4c_mlp_forward_rows(
-                    C.byref(packed.desc), arr, len(sources), n_rows, begin, count, tile, *args)))
+        _timed("mlp_split_kernel<4>", packed.flops_per_row * n_rows, 4.0 * (sum(packed.seg_widths) + packed.n_out) * n_rows,
+               lambda: _lib.check(lib.g4c_mlp_forward(C.byref(packed.desc), arr, len(sources), n_rows, *args)))
     return out

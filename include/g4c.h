@@ -148,18 +148,9 @@ int g4c_mlp_forward(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*
                     int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0,
                     void *stream);
 
-/* The two launches g4c_mlp_forward is made of, exposed so that a profiler can bracket them separately:
- * rows [0, g4c_mlp_bulk_rows(n)) run as 64-row tiles (whole "rounds" of 1024 tiles), the remainder as 32-row
- * tiles.  g4c_mlp_forward_rows processes rows [row_begin, row_begin + row_count) with tile_rows in
- * {64, 32, 322, 324, 325}; row_begin must be a multiple of 32. */
-int64_t g4c_mlp_bulk_rows(int64_t n_rows);
-/* tile mode the policy picks for `rows` remainder rows: 32 (one wave per 32-row tile), 322 / 324 (the tile's
- * 128 output columns split over 2 / 4 waves: small launches are latency-bound on one wave's MFMA chain). */
-int32_t g4c_mlp_small_tile_mode(int64_t rows);
-/* the mode g4c_mlp_forward uses for `rows` remainder rows of these sources: g4c_mlp_small_tile_mode(rows), or 325 =
- * the small-launch variant of 324 (a whole layer of weights and a whole 128-wide input block in flight per wave)
- * when rows <= G4C_MLP_DEEP_ROWS (default 16384) and every weighted block is 128 wide and 16-byte aligned. */
-int32_t g4c_mlp_pick_mode(const g4c_src_t *srcs /*host*/, int32_t n_src, int64_t rows);
+/* g4c_mlp_forward on rows [row_begin, row_begin + row_count) only (row_begin a multiple of 32): lets a caller split one
+ * MLP over several launches (profiling, overlap with a halo exchange).  tile_rows names the kernel: 324 = the fp32-MFMA
+ * kernel (32-row tiles, the 128 output columns split over 4 waves; the only fp32 variant since round 2). */
 int g4c_mlp_forward_rows(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
                          int64_t n_rows, int64_t row_begin, int64_t row_count, int32_t tile_rows,
                          float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
@@ -170,8 +161,7 @@ int g4c_mlp_forward_rows(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*
  * whose packed image continues the MLP's stream: head_w == w[last] + k_pad[last]*128, heads back to back, then the
  * usual chunk of slack.  One launch of the node MLP (nn/blocks.py:185) thereby also emits the two node-side first-layer
  * terms W1[:, H:2H] v', W1[:, 2H:3H] v' of the NEXT GNBlock's edge MLP (nn/blocks.py:181), which that edge MLP
- * gathers as additive sources.  Only the 4-wave column-split kernels implement heads (g4c_mlp_pick_mode in {324, 325});
- * G4C_EUNSUPPORTED otherwise, so the caller launches the products separately. */
+ * gathers as additive sources. */
 int g4c_mlp_forward_heads(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
                           int64_t n_rows, float *out, int32_t out_ld, int32_t act,
                           const float *head_w, int32_t n_heads, float *const *head_out /*host*/, int32_t head_ld,

@@ -26,7 +26,7 @@ for rows in [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "192,3072,75
     aa, vv = torch.randn(rows, H, device=dev), torch.randn(rows, H, device=dev)
     src_e = [ops.Source(e), ops.Source(pr, index=row, additive=True), ops.Source(pc, index=col, additive=True)]
     flush = torch.empty(64 << 20, device=dev)     # 256 MB: push weights / inputs out of L2 and most of the Infinity Cache
-    for mode in ((324, 325) if PREC == "fp32" else (None,)):
+    for mode in ((324,) if PREC == "fp32" else (None,)):
         for case, f in (("edge", lambda: ops.mlp_forward(pk_e, src_e, rows, 0, tile_mode=mode)),
                         ("node", lambda: ops.mlp_forward(pk_v, [ops.Source(aa), ops.Source(vv)], rows, 1, tile_mode=mode))):
             for cold in (False, True):

@@ -100,9 +100,9 @@ def test_mlp_row_tails_and_leading_dims(golden):
 
 @pytest.mark.parametrize("rows", [1, 33, 1000, 20000])
 def test_mlp_kernel_variants_agree(rows, monkeypatch):
-    """Every kernel variant behind g4c_mlp_forward_rows (64 / 32-row single-wave tiles, 2- and 4-wave column split,
-    the small-launch variant 325) computes the same MLP: hoisted edge form (gathered additive terms + SELU-on-load)
-    and the two-block node form, against the oracle MLP on the concatenated input."""
+    """The fp32-MFMA kernel (g4c_mlp_forward / g4c_mlp_forward_rows tile_rows = 324), whole and split over two row-range
+    launches: hoisted edge form (gathered additive terms + SELU-on-load) and the two-block node form, against the oracle MLP
+    on the concatenated input.  Any other tile_rows value is an argument error."""
     H, n = 128, max(rows // 6, 1)
     torch.manual_seed(rows)
     monkeypatch.setattr(ops, "_PRECISION", "fp32")      # the tile variants are the fp32-MFMA kernels
@@ -123,7 +123,9 @@ def test_mlp_kernel_variants_agree(rows, monkeypatch):
     src_v = [ops.Source(agg), ops.Source(v, index=idx)]
     wn = {f"m.{k}": t.cpu() for k, t in blk.node_mlp.state_dict().items()}
     ref_v = O.mlp(torch.cat([agg, v[idx.long()]], 1).cpu(), wn, "m")
-    for mode in (64, 32, 322, 324, 325, 644):
+    with pytest.raises(ValueError, match="tile_rows"):
+        ops.mlp_forward(pk_e, src_e, rows, tile_mode=64)
+    for mode in (None, 324):
         y = ops.mlp_forward(pk_e, src_e, rows, tile_mode=mode)
         torch.testing.assert_close(y.cpu(), ref_e, rtol=2e-4, atol=2e-4, msg=lambda m: f"edge mode {mode}: {m}")
         y = ops.mlp_forward(pk_v, src_v, n, _lib.ACT_SELU, tile_mode=mode)
@@ -190,7 +192,7 @@ def test_mlp_bf16_variant(rows):
 @pytest.mark.parametrize("rows", [33, 5000, 40000])
 def test_mlp_heads(rows, prec, monkeypatch):
     """g4c_mlp_forward_heads: the node MLP launch also emits W1[:, H:2H] y and W1[:, 2H:] y of the next edge MLP
-    (both 4-wave split variants: 325 below 16384 rows, 324 above) == separate products of the stored output."""
+    == separate products of the stored output."""
     H = 128
     torch.manual_seed(rows)
     monkeypatch.setattr(ops, "_PRECISION", prec)
