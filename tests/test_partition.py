@@ -13,9 +13,11 @@ from graphs4cfd_amd import partition as P, synthetic as S
 from oracle import g4c_oracle as O
 
 
-def test_partition_invariants():
+@pytest.mark.parametrize("method", ["rcb", "strips"])
+def test_partition_invariants(method, monkeypatch):
+    monkeypatch.setenv("G4C_PARTITION", method)
     g = S.mus_graph(3000, levels=3, seed=2)
-    for world in (2, 4):
+    for world in (2, 4, 3):
         parts = P.build_partition(g, 3, world)
         edges = P.coarse_topology(g, 3)
         owners = P.assign_owners(g, 3, world)
@@ -43,9 +45,30 @@ def test_partition_invariants():
         # clusters are wholly owned: a fine node and its parent have the same owner
         assert np.array_equal(owners[0], owners[1][g.idx1_to_idx2.numpy()])
         assert np.array_equal(owners[1], owners[2][g.idx2_to_idx3.numpy()])
-        # balance: strips within 25 % of the mean
+        # balance: within 25 % of the mean
         counts = np.bincount(owners[0], minlength=world)
         assert counts.max() < 1.25 * counts.mean()
+
+
+def test_rcb_owners_are_compact_and_deterministic():
+    """Recursive coordinate bisection (the default): same table on every call, every rank used, fewer halo rows than slabs along x
+    once the slabs get thin (8 ranks), in 2-D and 3-D."""
+    for dim, n in ((2, 20000), (3, 20000)):
+        g = S.mus_graph(n, levels=2, dim=dim, seed=4)
+        a = P.assign_owners(g, 2, 8, "rcb")
+        b = P.assign_owners(g, 2, 8, "rcb")
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)) and set(a[0].tolist()) == set(range(8))
+        halo = {}
+        for m in ("rcb", "strips"):
+            os.environ["G4C_PARTITION"] = m
+            try:
+                parts = P.build_partition(g, 2, 8)
+            finally:
+                del os.environ["G4C_PARTITION"]
+            halo[m] = max(p[0].n_halo for p in parts)
+        assert halo["rcb"] < 0.8 * halo["strips"], halo
+    with pytest.raises(ValueError):
+        P.assign_owners(g, 2, 8, "metis")
 
 
 class OracleImpl:
