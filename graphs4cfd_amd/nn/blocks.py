@@ -280,7 +280,8 @@ def edgeScalarToNodeVector(edge_attr: Tensor, edge_index: Tensor, edgeUnitVector
 # ------------------------------------------------------------------------------------- MP
 def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, aggr: str, act_code: int,
              e_pre_act: int = _lib.ACT_NONE, v_src: Optional[Tensor] = None,
-             products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None, keep_e: bool = True):
+             products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None, keep_e: bool = True,
+             n_targets: Optional[int] = None, v_out: Optional[Tensor] = None):
     """Shared body of GNBlock / EdgeMP / DownEdgeMP (nn/blocks.py:175-186,322-333,360-381):
         e' = msg_mlp([e | s[row] | v[col]]);  agg = reduce(e' -> col);  v' = act(upd_mlp([agg | v])).
     Returns (v', e') where e' is stored WITHOUT the activation: the aggregation consumes the raw
@@ -290,10 +291,15 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
     can reduce its own rows they are then not stored and None is returned for e'.
     `products` = (W1[:, H:2H] v, W1[:, 2H:3H] v) of msg_mlp's first layer when the launch that produced `v` already
     multiplied them; `next_msg` = the message MLP of the MP layer that will consume v' on the SAME graph: the node
-    launch then emits its products as well and a third value (those products, or None) is returned."""
+    launch then emits its products as well and a third value (those products, or None) is returned.
+    `n_targets` / `v_out` (partitioned sub-meshes, partition_remus.py): only the first `n_targets` rows of `v` are targets (the
+    rows behind them are halo rows, read as senders only); v' for those rows is written into `v_out`."""
     if aggr not in ("mean", "sum", "add"):
         raise ValueError(f"unsupported aggr {aggr!r}")
-    ep, csr = plan.edge_csr(index, int(v.size(0)))
+    n_t = int(v.size(0)) if n_targets is None else int(n_targets)
+    if n_targets is not None and next_msg is not None:
+        raise NotImplementedError("next_msg with n_targets")
+    ep, csr = plan.edge_csr(index, n_t)
     senders = v if v_src is None else v_src
     mean = aggr == "mean"
     e_src = e if isinstance(e, Source) else Source(e, pre_act=e_pre_act)      # (a Source: DownMP.pool(lazy_edges=True))
@@ -327,7 +333,7 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
         if nxt is None:
             return upd_mlp.run_coded([agg_src, Source(v)], int(v.size(0)), act_code), e_new, None
         return nxt[0], e_new, nxt[1]
-    v_new = upd_mlp.run_coded([agg_src, Source(v)], int(v.size(0)), act_code)
+    v_new = upd_mlp.run_coded([agg_src, Source(v)], n_t, act_code, out=v_out)
     return v_new, e_new
 
 

@@ -165,16 +165,23 @@ def project_to_edges(v: Tensor, node32: Optional[Tensor], unit: Tensor, n_edges:
     return out
 
 
-def edge_scalar_to_node_vector(e: Tensor, unit_inv: Tensor, n_nodes: int, k: int) -> Tensor:
+def edge_scalar_to_node_vector(e: Tensor, unit_inv: Tensor, n_nodes: int, k: int, out: Optional[Tensor] = None) -> Tensor:
     if torch.is_grad_enabled() and e.requires_grad:
+        if out is not None:
+            raise NotImplementedError("edge_scalar_to_node_vector(out=...) is not differentiable")
         from . import autograd as _ag
         return _ag.edge_scalar_to_node_vector(e, unit_inv, n_nodes, k)
     lib = _lib.load()
     e = _f32_2d(e, "edge_attr")
     unit_inv = unit_inv.contiguous()
-    dev = _lib.require_hip(e, unit_inv)
+    dev = _lib.require_hip(e, unit_inv, out)
     n_feat = int(e.size(1))
-    out = torch.empty((n_nodes, 2 * n_feat), dtype=torch.float32, device=dev)
+    if int(e.size(0)) != n_nodes * k:
+        raise ValueError(f"{int(e.size(0))} edges cannot be viewed as {n_nodes} nodes x {k} incoming edges")
+    if out is None:
+        out = torch.empty((n_nodes, 2 * n_feat), dtype=torch.float32, device=dev)
+    elif tuple(out.shape) != (n_nodes, 2 * n_feat) or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise ValueError(f"out must be a float32 [{n_nodes}, {2 * n_feat}] tensor with unit column stride")
     _lib.check(lib.g4c_edge_scalar_to_node_vector(_lib.ptr(e), _ld(e), _lib.ptr(unit_inv), k, n_nodes, n_feat,
                                                   _lib.ptr(out), _ld(out), _lib.stream_handle(dev)))
     return out

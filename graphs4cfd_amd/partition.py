@@ -514,17 +514,23 @@ class DistributedRollout:
         capture = capture and os.environ.get("G4C_DIST_HIPGRAPH", "1") != "0"
         self.model, self.rank, self.world, self.device = model, rank, world, device
         program = model._PROGRAM
-        levels = 1 + sum(1 for n in program if n.startswith("down_mp"))
-        parts = build_partition(graph_cpu, levels, world)
         self.n_global = int(graph_cpu.pos.size(0))
-        self.mesh = LocalMesh(graph_cpu, levels, parts[rank], device, rank, world)
-        self.mesh.decision_edges = uniform_edge_counts(parts)
         self.nf = int(model.num_fields)
-        width = int(model.node_encoder.output_size)
-        self.fwd = MusPartitionedForward(program, self.mesh, HipImpl(model), HaloExchanger(self.mesh, group), width, self.nf)
+        if hasattr(model, "_ENCODERS"):          # REMuS-GNN: latents on edges / angles, edge-latent halo (partition_remus.py)
+            from . import partition_remus as PR
+            parts = PR.build_remus_partition(graph_cpu, world)
+            self.mesh = PR.RemusLocalMesh(graph_cpu, parts[rank], device, rank, world)
+            self.fwd = PR.RemusPartitionedForward(program, self.mesh, PR.RemusHipImpl(model, self.mesh), HaloExchanger(self.mesh, group))
+        else:
+            levels = 1 + sum(1 for n in program if n.startswith("down_mp"))
+            parts = build_partition(graph_cpu, levels, world)
+            self.mesh = LocalMesh(graph_cpu, levels, parts[rank], device, rank, world)
+            self.mesh.decision_edges = uniform_edge_counts(parts)
+            width = int(model.node_encoder.output_size)
+            self.fwd = MusPartitionedForward(program, self.mesh, HipImpl(model), HaloExchanger(self.mesh, group), width, self.nf)
         self.max_steps = max_steps
         self.field = self.mesh.inputs["field"] = self.mesh.inputs["field"].clone()
-        self.outputs = torch.zeros((self.mesh.n_own[0], self.nf * max_steps), dtype=torch.float32, device=device)
+        self.outputs = torch.zeros((int(self.mesh.owned_global[0].numel()), self.nf * max_steps), dtype=torch.float32, device=device)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=device)
         self.steps_done = 0
         self.capture = capture and device.type == "cuda"

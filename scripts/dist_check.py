@@ -15,10 +15,14 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda", 0 if a.same_gpu else int(os.environ["LOCAL_RANK"]))
 torch.cuda.set_device(dev)
 dist.init_process_group(a.backend)
-levels = {"NsOneScaleGNN": 1, "NsTwoScaleGNN": 2, "NsThreeScaleGNN": 3, "NsFourScaleGNN": 4}[a.model]
-g = S.mus_graph(a.nodes, levels=levels, dim=a.dim, seed=1)
 torch.manual_seed(2)
-model = getattr(gfd.nn, a.model)(arch=S.mus_arch(a.model, a.hidden, dim=a.dim), device=dev)
+if a.model == "NsRotEquiTreeScaleGNN":           # REMuS-GNN: edge-latent halo (partition_remus.py)
+    g = S.remus_graph(a.nodes, k=5, seed=1)
+    model = gfd.nn.NsRotEquiTreeScaleGNN(arch=S.remus_arch(a.hidden), device=dev)
+else:
+    levels = {"NsOneScaleGNN": 1, "NsTwoScaleGNN": 2, "NsThreeScaleGNN": 3, "NsFourScaleGNN": 4}[a.model]
+    g = S.mus_graph(a.nodes, levels=levels, dim=a.dim, seed=1)
+    model = getattr(gfd.nn, a.model)(arch=S.mus_arch(a.model, a.hidden, dim=a.dim), device=dev)
 dr = P.DistributedRollout(model, g, a.steps, rank, world, dev, capture=(a.backend == "nccl") if a.capture < 0 else bool(a.capture))
 dr.run(a.steps)
 full = dr.gather_outputs()

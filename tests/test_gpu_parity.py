@@ -835,6 +835,60 @@ def test_distributed_rollout_single_rank_equals_rollout():
     torch.testing.assert_close(dr.gather_outputs(), ref, rtol=1e-4, atol=1e-4)
 
 
+def test_distributed_remus_single_rank_and_two_ranks_in_process():
+    """REMuS-GNN through DistributedRollout: world = 1 == model.solve; and a 2-rank partition run in ONE process (both ranks'
+    forwards interleaved by a fake transport that copies halo rows between the two meshes) == the single-rank forward."""
+    from graphs4cfd_amd import partition as P, partition_remus as PR
+    g = S.remus_graph(6000, k=5, seed=51)
+    torch.manual_seed(52)
+    model = gfd.nn.NsRotEquiTreeScaleGNN(arch=S.remus_arch(128), device=DEV)
+    ref = model.solve(g.clone().to(DEV), 3, capture=False)
+    dr = P.DistributedRollout(model, g, 3, 0, 1, DEV)
+    dr.run(3)
+    torch.testing.assert_close(dr.gather_outputs(), ref, rtol=1e-4, atol=1e-4)
+    assert dr.captured
+    # two ranks, one process: run rank 0 and rank 1 in lock step on two threads, exchanging through host memory
+    import threading
+    parts = PR.build_remus_partition(g, 2)
+    meshes = [PR.RemusLocalMesh(g, parts[r], DEV, r, 2) for r in range(2)]
+    barrier, box = threading.Barrier(2), {}
+
+    class PairExchange:
+        def __init__(self, mesh):
+            self.mesh, self.n_exchanges = mesh, 0
+
+        def exchange(self, v, ch):
+            m, r = self.mesh, self.mesh.rank
+            torch.cuda.synchronize()
+            box[r] = v[m.send_idx32[ch - 1][1 - r].long()].clone()
+            barrier.wait()
+            v[m.n_own[ch - 1]:] = box[1 - r]
+            torch.cuda.synchronize()
+            barrier.wait()
+            self.n_exchanges += 1
+
+    preds, errs = {}, []
+
+    def work(r):
+        try:
+            torch.cuda.set_device(DEV)
+            with torch.no_grad():
+                fwd = PR.RemusPartitionedForward(model._PROGRAM, meshes[r], PR.RemusHipImpl(model, meshes[r]), PairExchange(meshes[r]))
+                preds[r] = fwd.forward()
+        except Exception as exc:      # noqa: BLE001
+            errs.append(exc)
+            barrier.abort()
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errs, errs
+    full = torch.zeros(6000, 2, device=DEV)
+    for r in range(2):
+        full[meshes[r].owned_global[0]] = preds[r]
+    torch.testing.assert_close(full, ref[:, :2], rtol=1e-4, atol=1e-4)
+    assert all(meshes[r].n_halo[c] > 0 for r in range(2) for c in range(5))
+
+
 def test_distributed_rollout_two_processes_one_gpu():
     """Two ranks (two processes) drive the partitioned HIP path end to end on this box's single GPU, with the
     gloo transport for the halo exchange (the RCCL transport needs one GPU per rank; the driver's scaling run
@@ -854,8 +908,8 @@ def test_distributed_rollout_two_processes_one_gpu():
 
 def test_distributed_rollout_four_processes_one_gpu():
     """BASELINE config 4's split (100k-node mesh, node-partitioned 4-way) with four processes on this box's single GPU over the
-    gloo transport: latent exchange (default) and first-layer-product exchange, plus a 3-D four-scale model
-    (config 5's program) on a smaller mesh; compared inside the script with the single-process rollout."""
+    gloo transport: latent exchange (default) and first-layer-product exchange, a 3-D four-scale model (config 5's program)
+    and REMuS-GNN (config 3's model, edge-latent halo) on smaller meshes; compared inside the script with the single-process rollout."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29300 + os.getpid() % 200
@@ -863,7 +917,8 @@ def test_distributed_rollout_four_processes_one_gpu():
             "--master-port", str(port), os.path.join(root, "scripts", "dist_check.py"), "--backend", "gloo", "--same-gpu"]
     runs = [(base + ["--nodes", "100000", "--steps", "2"], dict(os.environ)),
             (base + ["--nodes", "30000", "--steps", "2"], dict(os.environ, G4C_HOIST_MIN_ROWS="0")),
-            (base + ["--nodes", "20000", "--steps", "2", "--model", "NsFourScaleGNN", "--dim", "3"], dict(os.environ))]
+            (base + ["--nodes", "20000", "--steps", "2", "--model", "NsFourScaleGNN", "--dim", "3"], dict(os.environ)),
+            (base + ["--nodes", "20000", "--steps", "2", "--model", "NsRotEquiTreeScaleGNN"], dict(os.environ))]
     for cmd, env in runs:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
