@@ -334,7 +334,7 @@ def partition_check(args, runner, model, graph_cpu, dev, rank, world, Rollout):
     step_ms = s.elapsed_time(e)
     ex_us = [a.elapsed_time(b) * 1e3 for a, b in ex.events]
     mine = torch.tensor([step_ms, sum(ex_us) * 1e-3, float(len(ex_us)), float(ex.bytes_sent), float(ex.bytes_recv),
-                         float(runner.mesh.n_own[0])], dtype=torch.float64, device=dev)
+                         float(runner.mesh.owned_global[0].numel())], dtype=torch.float64, device=dev)
     allr = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
     runner.steps_done += 1
@@ -359,8 +359,6 @@ def main():
     from graphs4cfd_amd.nn.model import Rollout
     ops.set_mlp_precision(args.precision)
     remus = args.model == "NsRotEquiTreeScaleGNN"
-    if world > 1 and remus:
-        raise SystemExit("the REMuS-GNN workload is not partitioned yet: run it with --gpus 1")
 
     # G4C_BENCH_SAME_GPU=1 (functional check on a single-GPU box only): every rank uses cuda:0 and the gloo transport
     same_gpu = os.environ.get("G4C_BENCH_SAME_GPU", "0") == "1"
@@ -424,7 +422,8 @@ def main():
                   "bf16": "bf16 MLP operands (fp32 accumulate, bias, SELU, LayerNorm, aggregation)"}[args.precision], "data": "synthetic",
         "config": {"workload": what, "name": args.workload if not args.custom else "custom", "nodes": args.nodes,
                    "edges": int(graph_cpu.edge_index.size(1)), "mp_layers_per_step": n_mp,
-                   "partition": "none" if world == 1 else f"{world}-way node partition, halo exchange per MP layer (RCCL)"},
+                   "partition": "none" if world == 1 else (f"{world}-way node partition (recursive coordinate bisection), " + (
+                       "edge-latent halo exchange per EdgeMP layer (RCCL)" if remus else "halo exchange per MP layer (RCCL)"))},
         "outputs_finite": finite,
     }
     # BASELINE.json's second figure: average over the step's MP layers of all levels (pool / unpool / encoders included)
