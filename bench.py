@@ -132,12 +132,13 @@ def cpu_baseline(args, S, weights, nf, budget_s):
     return {"value": steps / el * scale, "unit": "rollout timesteps/s", "cores": cores, "kind": "port", "sample": sample}
 
 
-def pmc_traffic():
+def pmc_traffic(workload="headline"):
     """HBM bytes per launch from the committed PMC collection (scripts/collect_pmc_traffic.sh: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same bench, gfx950 FETCH_SIZE correction).
     rocprofv3 cannot run inside the timed process, so the latest committed collection is quoted with its source."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    sfx = "" if workload == "headline" else f"_{workload}"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{sfx}.json")))
     if not files:
         return None, None
     k = json.load(open(files[-1]))["kernels"]
@@ -210,8 +211,8 @@ def roofline_blocks(args, result, model, graph_cpu, dev, ops, Rollout):
                 "flop_per_launch": m["flops"] / m["launches"], "ms_per_step": 1e3 * m["seconds"] / 3,
                 **price(kind, m["flops"], m["seconds"])}
 
-    traffic, traffic_src = pmc_traffic()
-    if args.workload != "headline" or args.custom:
+    traffic, traffic_src = pmc_traffic(args.workload)
+    if args.custom:
         traffic = None
     mlp_kinds = [k for k in summ if k.startswith("mlp_")]
     dom = max(mlp_kinds, key=lambda k: summ[k]["seconds"])      # dominant kernel instantiation by GPU time
