@@ -1196,6 +1196,16 @@ extern "C" int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp, const g4c_src_t *sr
                       nullptr, 0, nullptr, 0, stream, &a);
 }
 
+extern "C" int g4c_mlp_forward_bf16_agg(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                                        float *out, int32_t out_ld, int32_t act,
+                                        const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,
+                                        float *agg, int32_t agg_ld, int32_t agg_mean, void *stream) {
+    G4C_REQUIRE(tile_rows && tile_seg && seg_off && agg && n_tiles >= 0 && agg_ld >= NP, G4C_EINVAL, "g4c_mlp_forward_bf16_agg: bad aggregation plan");
+    const AggArgs a{tile_rows, tile_seg, seg_off, n_tiles, agg, agg_ld, agg_mean};
+    return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3216, out, out_ld, nullptr, act, nullptr, 0, 0,
+                      nullptr, 0, nullptr, 0, stream, &a);
+}
+
 extern "C" int g4c_mlp_forward_bx6_save(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                         float *out, int32_t out_ld, int32_t act, const float *resid, int32_t resid_ld,
                                         int32_t resid_col0, float *const *save, int32_t save_ld, const float *const *mul,

@@ -93,7 +93,12 @@ class NsRotEquiTreeScaleGNN(GNN):
                     e[lvl], a[lvl], products[lvl] = block.step(e[lvl], a[lvl], aidx[lvl], SELU, a_pre_act=a_pending[lvl],
                                                                products=products[lvl], next_msg=getattr(self, nxt[1]).angle_mlp)
                 else:
-                    e[lvl], a[lvl] = block.step(e[lvl], a[lvl], aidx[lvl], SELU, a_pre_act=a_pending[lvl], products=products[lvl])
+                    # the angle latents of a level are read again by its next EdgeMP — on the way up as well (a1 after mp114 feeds
+                    # mp121, nn/remus_gnn.py:150-190); after the level's LAST EdgeMP of the step nothing reads them: not stored
+                    # then, when the launch can reduce its own rows (_mp_step keep_e)
+                    last_use = not any(o == "mp" and l == lvl for o, _, l in prog[k + 1:])
+                    e[lvl], a[lvl] = block.step(e[lvl], a[lvl], aidx[lvl], SELU, a_pre_act=a_pending[lvl], products=products[lvl],
+                                                keep_e=not last_use)
                     products[lvl] = None
                 a_pending[lvl] = SELU
             elif op == "down":

@@ -265,7 +265,7 @@ def grad_mode() -> bool:
 def can_fuse_aggregation(csr: CsrPlan, width: int) -> bool:
     """The edge launch itself can reduce its rows per target (g4c_mlp_forward_bx6_agg): rows in segment order, segments of
     at most 32 rows, the exact-split kernels, a 128-wide output, enough rows to be throughput-bound."""
-    return (FUSE_AGG and _PRECISION == "bf16x6" and width == 128 and csr.perm is None and csr.n >= FUSE_AGG_MIN_ROWS
+    return (FUSE_AGG and _PRECISION in ("bf16x6", "bf16") and width == 128 and csr.perm is None and csr.n >= FUSE_AGG_MIN_ROWS
             and not grad_mode() and csr.tiles() is not None)
 
 
@@ -466,7 +466,7 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                 a.additive, a.w = 2, packed.narrow_w[j].data_ptr()
             j += 1
     # store_rows=False (with a fused aggregation only): the output rows are not written, only their aggregate
-    fusable = (agg is not None and FUSE_AGG and packed.precision == "bf16x6" and packed.n_out == 128 and head_outs is None
+    fusable = (agg is not None and FUSE_AGG and packed.precision in ("bf16x6", "bf16") and packed.n_out == 128 and head_outs is None
                and tile_mode is None and out_idx32 is None and resid is None and n_rows == agg[0].n and agg[0].tiles() is not None)
     if not store_rows and not fusable:
         raise ValueError("store_rows=False needs an aggregation the launch can fuse (ops.can_fuse_aggregation)")
@@ -484,7 +484,8 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
             return y
         _lib.require_hip(agg_out)
         t_rows, t_seg, nt = tiles
-        call = lambda: _lib.check(lib.g4c_mlp_forward_bx6_agg(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out),
+        fused_fn = lib.g4c_mlp_forward_bx6_agg if packed.precision == "bf16x6" else lib.g4c_mlp_forward_bf16_agg
+        call = lambda: _lib.check(fused_fn(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out),
                                                               _ld(out) if out is not None else 128, act,
                                                               _lib.ptr(t_rows), _lib.ptr(t_seg), _lib.ptr(csr.off), nt, _lib.ptr(agg_out),
                                                               _ld(agg_out), 1 if agg_mean else 0, _lib.stream_handle(dev)))

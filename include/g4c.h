@@ -205,6 +205,11 @@ int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs
                             int64_t n_rows, float *out, int32_t out_ld, int32_t act,
                             const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,
                             float *agg, int32_t agg_ld, int32_t agg_mean, void *stream);
+/* the same for the rounded-bf16 mode (g4c_mlp_forward_bf16: leading plane of the stream only) */
+int g4c_mlp_forward_bf16_agg(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
+                             int64_t n_rows, float *out, int32_t out_ld, int32_t act,
+                             const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,
+                             float *agg, int32_t agg_ld, int32_t agg_mean, void *stream);
 /* g4c_mlp_forward_heads for the bf16x6 stream (heads packed with g4c_mlp_pack_layer_bx6 right after the last layer) */
 int g4c_mlp_forward_heads_bx6(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
                               int64_t n_rows, float *out, int32_t out_ld, int32_t act,

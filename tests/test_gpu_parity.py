@@ -212,14 +212,16 @@ def test_mlp_heads(rows, prec, monkeypatch):
     assert blk.node_mlp.run_with_heads([ops.Source(agg), ops.Source(v)], rows, _lib.ACT_SELU, nxt.edge_mlp, H, [H, H, H]) is None
 
 
+@pytest.mark.parametrize("prec", ["bf16x6", "bf16"])
 @pytest.mark.parametrize("case", ["knn6", "ragged", "unsorted", "long_segment"])
-def test_edge_mlp_with_fused_aggregation(case, monkeypatch):
+def test_edge_mlp_with_fused_aggregation(case, prec, monkeypatch):
     """ops.mlp_forward(agg=...): the edge launch also reduces its output rows per target (g4c_mlp_forward_bx6_agg on tiles
     of whole segments) == the plain launch followed by g4c_segment_reduce, bit for bit; inputs the fused kernel cannot
     take (rows not in segment order, a segment longer than a tile) go through the separate reduction transparently."""
     H, n = 128, 700
     torch.manual_seed(21)
     monkeypatch.setattr(ops, "FUSE_AGG", True)
+    monkeypatch.setattr(ops, "_PRECISION", prec)       # ("bf16": g4c_mlp_forward_bf16_agg, the rounded-operand mode of config 3)
     if case == "knn6":
         col = torch.arange(n).repeat_interleave(6)
     elif case == "ragged":                          # degrees 0..9 incl. empty targets at both ends
