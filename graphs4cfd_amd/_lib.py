@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libg4c.so")
+LIB_PATH = os.environ.get("G4C_LIB_PATH") or os.path.join(_HERE, "lib", "libg4c.so")      # (G4C_LIB_PATH: A/B of two builds)
 
 OK, EINVAL, ELAUNCH, EUNSUPPORTED = 0, -1, -2, -3
 ACT_NONE, ACT_SELU, ACT_TANH = 0, 1, 2

@@ -26,6 +26,7 @@ def load(path):
 
 libs = [load(p) for p in a.libs]
 ops.set_mlp_precision(a.precision)
+torch.set_grad_enabled(False)
 dev = torch.device("cuda", 0); H = 128
 torch.manual_seed(0)
 _lib._lib = libs[0]

@@ -12,6 +12,7 @@ _lib._lib = lib
 lib.g4c_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 PREC = os.environ.get("G4C_MLP_PRECISION", "fp32")      # the stamps also exist in the bf16x6 kernel
 dev = torch.device("cuda", 0); H = 128
+torch.set_grad_enabled(False)
 torch.manual_seed(0)
 blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(dev)
 pk_e = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
@@ -42,5 +43,13 @@ for rows in [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "192,3072,75
                 parts = " ".join(f"{int(np.median(d[:, k])):6d}" for k in range(9))
                 fin = int(np.median(st[:, 13] - st[:, 12])); tot = int(np.median(st[:, 13] - st[:, 0]))
                 span = int(st[:, 13].max() - st[:, 0].min())
+                nx = ((rows + 31) // 32) // 8            # tiles of XCD 0 (contiguous tile range per XCD)
+                if 0 < nx <= 4096:
+                    x0 = st[:nx]
+                    t0, t1 = int(x0[:, 0].min()), int(x0[:, 13].max())
+                    conc = [int(((x0[:, 0] <= T) & (x0[:, 13] > T)).sum()) for T in np.linspace(t0 + 0.2 * (t1 - t0), t0 + 0.8 * (t1 - t0), 7)]
+                    gaps = np.sort(x0[:, 0])
+                    print(f"    XCD 0: {nx} tiles in {t1 - t0} ticks; tiles in flight at 7 sample times {conc} (32 CUs); "
+                          f"sum of tile lifetimes / span = {float((x0[:, 13] - x0[:, 0]).sum()) / (t1 - t0):.1f}")
                 print(f"rows {rows:6d} mode {mode} {case} {'cold' if cold else 'hot '}: event {s.elapsed_time(t) * 1e3:7.1f} us | phases {parts} | finish {fin:6d} | tile {tot:7d} | launch span {span:8d} ticks")
 print("phases:", "; ".join(names))
