@@ -38,7 +38,7 @@ def act_code(activation) -> Optional[int]:
 class g4c_src_t(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("idx", C.c_void_p), ("width", C.c_int32), ("ld", C.c_int32),
                 ("col0", C.c_int32), ("pre_act", C.c_int32), ("additive", C.c_int32), ("seg_mean", C.c_int32),
-                ("w", C.c_void_p), ("seg_off", C.c_void_p), ("seg_perm", C.c_void_p)]
+                ("w", C.c_void_p), ("seg_off", C.c_void_p), ("seg_perm", C.c_void_p), ("dtype", C.c_int32)]
 
 
 class g4c_mlp_t(C.Structure):
@@ -77,8 +77,8 @@ _SIGNATURES = {
                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                           C.c_void_p]),
     "g4c_mlp_forward_bf16_agg": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
-                                           C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
-                                           C.c_void_p]),
+                                           C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                           C.c_int32, C.c_void_p]),
     "g4c_mlp_forward": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_void_p,
                                   C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "g4c_mlp_px6_enable": (C.c_int, [C.c_int]),

@@ -27,6 +27,7 @@ struct Src {
     const int *seg_off;      // bf16x6 kernel: row r = sum / mean of rows [seg_off[r], seg_off[r+1]) (aggregation on load)
     int seg_mean;
     const int *seg_perm;     // optional row indirection of those positions
+    int bf16;                // rows are stored as bf16 (ptr is a __bf16 pointer in disguise, ld / col0 in elements): rounded-bf16 mode only
 };
 
 struct NarSrc {          // narrow input block multiplied on the VALUs (g4c_src_t.additive == 2): rows = the tile's own rows
@@ -56,6 +57,7 @@ struct Params {
     long long M;
     float *out;
     int out_ld;
+    int out_bf16;            // the output rows are stored as bf16 (out is a __bf16 pointer in disguise, out_ld in elements)
     const int *out_idx;
     int act;
     const float *resid;

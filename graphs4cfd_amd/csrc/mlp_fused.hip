@@ -207,7 +207,22 @@ __device__ __forceinline__ void split_finish(const Params &p, float *sH, const f
     // ---------------------------------------------------------------- store this wave's rows
     if (p.out == nullptr) return;          // (only the aggregate of the rows is wanted: g4c_mlp_forward_bx6_agg with out == NULL)
     const bool fast = (n_out == NP) && ((p.out_ld & 3) == 0) && (((uintptr_t)p.out & 15) == 0) && (p.resid == nullptr);
-    if (fast) {
+    if (p.out_bf16) {
+        // rows kept in bf16 (the rounded-bf16 mode's message tensors: their consumer rounds them to bf16 anyway): 8 bytes per lane
+        __bf16 *o16 = reinterpret_cast<__bf16 *>(p.out);
+#pragma unroll
+        for (int r = h; r < RPW; r += 2) {
+            const int row = wave * RPW + r;
+            const long long grow = row0 + row;
+            if (grow < mlim) {
+                const f32x4 t = *reinterpret_cast<const f32x4 *>(sH + row * HS + 4 * i);
+                bf16x4 b;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) b[u] = (__bf16)t[u];
+                *reinterpret_cast<bf16x4 *>(o16 + grow * p.out_ld + 4 * i) = b;
+            }
+        }
+    } else if (fast) {
 #pragma unroll
         for (int r = h; r < RPW; r += 2) {
             const int row = wave * RPW + r;
@@ -727,6 +742,16 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
             if (direct) { gr = row0 + grow_l + 32 * t; if (gr >= mlim) gr = mlim - 1; }
             else gr = sRow[sidx * ROWS + grow_l + 32 * t];
             const float *rp = p.src[sidx].ptr + gr * p.src[sidx].ld + p.src[sidx].col0;
+            if (SP == 1 && p.src[sidx].bf16) {        // bf16 rows (128 wide, 8-byte aligned: the launcher checks): widen by a shift / a mask
+                const __bf16 *rp16 = reinterpret_cast<const __bf16 *>(p.src[sidx].ptr) + gr * p.src[sidx].ld + p.src[sidx].col0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 w = *reinterpret_cast<const u32x2 *>(rp16 + q * KC + c4);
+                    xp[t][q][0] = __builtin_bit_cast(float, w[0] << 16); xp[t][q][1] = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+                    xp[t][q][2] = __builtin_bit_cast(float, w[1] << 16); xp[t][q][3] = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c = q * KC + c4;
@@ -1146,6 +1171,7 @@ struct AggArgs {           // fused aggregation (g4c_mlp_forward_bx6_agg); all n
     int32_t n_tiles;
     float *out;
     int32_t out_ld, mean;
+    int32_t rows_bf16;       // the MLP's output rows are stored as bf16 (g4c_mlp_forward_bf16_agg, out_dtype)
 };
 
 static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
@@ -1191,18 +1217,19 @@ extern "C" int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp, const g4c_src_t *sr
                                        const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,
                                        float *agg, int32_t agg_ld, int32_t agg_mean, void *stream) {
     G4C_REQUIRE(tile_rows && tile_seg && seg_off && agg && n_tiles >= 0 && agg_ld >= NP, G4C_EINVAL, "g4c_mlp_forward_bx6_agg: bad aggregation plan");
-    const AggArgs a{tile_rows, tile_seg, seg_off, n_tiles, agg, agg_ld, agg_mean};
+    const AggArgs a{tile_rows, tile_seg, seg_off, n_tiles, agg, agg_ld, agg_mean, 0};
     return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3248, out, out_ld, nullptr, act, nullptr, 0, 0,
                       nullptr, 0, nullptr, 0, stream, &a);
 }
 
 extern "C" int g4c_mlp_forward_bf16_agg(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
-                                        float *out, int32_t out_ld, int32_t act,
+                                        void *out, int32_t out_ld, int32_t out_dtype, int32_t act,
                                         const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,
                                         float *agg, int32_t agg_ld, int32_t agg_mean, void *stream) {
     G4C_REQUIRE(tile_rows && tile_seg && seg_off && agg && n_tiles >= 0 && agg_ld >= NP, G4C_EINVAL, "g4c_mlp_forward_bf16_agg: bad aggregation plan");
-    const AggArgs a{tile_rows, tile_seg, seg_off, n_tiles, agg, agg_ld, agg_mean};
-    return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3216, out, out_ld, nullptr, act, nullptr, 0, 0,
+    G4C_REQUIRE(out_dtype == G4C_DTYPE_F32 || out_dtype == G4C_DTYPE_BF16, G4C_EINVAL, "g4c_mlp_forward_bf16_agg: unknown out_dtype %d", out_dtype);
+    const AggArgs a{tile_rows, tile_seg, seg_off, n_tiles, agg, agg_ld, agg_mean, out_dtype == G4C_DTYPE_BF16};
+    return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3216, (float *)out, out_ld, nullptr, act, nullptr, 0, 0,
                       nullptr, 0, nullptr, 0, stream, &a);
 }
 
@@ -1274,7 +1301,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
             continue;
         }
         if (g.additive) {
-            G4C_REQUIRE(g.pre_act == G4C_ACT_NONE && g.width <= NP, G4C_EINVAL, "g4c_mlp_forward: bad additive source %d", s);
+            G4C_REQUIRE(g.pre_act == G4C_ACT_NONE && g.width <= NP && g.dtype == G4C_DTYPE_F32, G4C_EINVAL, "g4c_mlp_forward: bad additive source %d", s);
             AddSrc &a = p.add[p.n_add++];
             a.ptr = g.ptr + g.col0; a.idx = g.idx; a.width = g.width; a.ld = g.ld;
             continue;
@@ -1285,17 +1312,23 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         if (bf16) G4C_REQUIRE(g.width <= NP, G4C_EUNSUPPORTED, "g4c_mlp_forward_bf16: input block %d is %d wide (max 128)", s, g.width);
         d.ptr = g.ptr; d.idx = g.idx; d.width = g.width; d.wpad = bf16 ? NP : (g.width + KC - 1) / KC * KC; d.ld = g.ld; d.col0 = g.col0;
         d.pre_act = g.pre_act;
+        d.bf16 = g.dtype == G4C_DTYPE_BF16;
+        if (d.bf16)
+            G4C_REQUIRE(round1 && g.width == NP && !g.seg_off && g.ld % 4 == 0 && g.col0 % 4 == 0 && (uintptr_t)g.ptr % 8 == 0, G4C_EUNSUPPORTED,
+                        "g4c_mlp_forward: bf16 rows need the rounded-bf16 mode (g4c_mlp_forward_bf16*) and a 128-wide, 8-byte aligned block");
+        else
+            G4C_REQUIRE(g.dtype == G4C_DTYPE_F32, G4C_EINVAL, "g4c_mlp_forward: source %d has unknown dtype %d", s, g.dtype);
         d.seg_off = g.seg_off; d.seg_mean = g.seg_mean; d.seg_perm = g.seg_off ? g.seg_perm : nullptr;
         if (g.seg_off)
             G4C_REQUIRE(bx6 && !g.idx && g.width == NP && g.ld % 4 == 0 && g.col0 % 4 == 0 && (uintptr_t)g.ptr % 16 == 0, G4C_EUNSUPPORTED,
                         "g4c_mlp_forward: aggregation on load needs the bf16x6 kernels and a 128-wide aligned block without gather index");
-        d.vec = (g.width % 4 == 0) && (g.ld % 4 == 0) && (g.col0 % 4 == 0) && ((uintptr_t)g.ptr % 16 == 0);
+        d.vec = (g.width % 4 == 0) && (g.ld % 4 == 0) && (g.col0 % 4 == 0) && ((uintptr_t)g.ptr % (d.bf16 ? 8 : 16) == 0);
         all_vec = all_vec && d.vec;
         kp += d.wpad;
     }
     G4C_REQUIRE(nk >= 1 || p.n_nar >= 1, G4C_EINVAL, "g4c_mlp_forward: no input block goes through the weights");
     p.n_src = nk;
-    if (nk == 0) p.src[0] = Src{nullptr, nullptr, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr};
+    if (nk == 0) p.src[0] = Src{nullptr, nullptr, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 0};
     for (int s = (nk ? nk : 1); s < G4C_MAX_SRC; ++s) p.src[s] = p.src[0];
     for (int s = p.n_nar; s < G4C_MAX_SRC; ++s) p.nar[s] = NarSrc{nullptr, nullptr, 0, 0};
     for (int s = p.n_add; s < G4C_MAX_SRC; ++s) p.add[s] = AddSrc{nullptr, nullptr, 0, 0};
@@ -1320,12 +1353,18 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     G4C_REQUIRE(p.n_out > 0 && p.n_out <= NP && out_ld >= p.n_out, G4C_EINVAL, "g4c_mlp_forward: n_out=%d out_ld=%d", p.n_out, out_ld);
     p.M = n_rows;
     p.out = out; p.out_ld = out_ld; p.out_idx = out_idx; p.act = act;
+    p.out_bf16 = 0;
     p.resid = resid; p.resid_ld = resid_ld; p.resid_col0 = resid_col0;
     p.tile_rows = p.tile_seg = p.seg_off = nullptr; p.agg = nullptr; p.agg_ld = 0; p.agg_mean = 0;
     if (agg) {
         G4C_REQUIRE(bx6 && mlp->n_out == NP && !out_idx && !resid, G4C_EUNSUPPORTED, "g4c_mlp_forward_bx6_agg: needs the bf16x6 kernel and a plain 128-wide output");
         p.tile_rows = agg->tile_rows; p.tile_seg = agg->tile_seg; p.seg_off = agg->seg_off;
         p.agg = agg->out; p.agg_ld = agg->out_ld; p.agg_mean = agg->mean;
+        if (agg->rows_bf16) {
+            G4C_REQUIRE(round1 && (!out || ((out_ld & 3) == 0 && ((uintptr_t)out & 7) == 0)), G4C_EUNSUPPORTED,
+                        "g4c_mlp_forward_bf16_agg: bf16 output rows need the rounded-bf16 mode, out_ld a multiple of 4 and an 8-byte aligned out");
+            p.out_bf16 = 1;
+        }
     }
     for (int l = 0; l < G4C_MAX_LAYERS; ++l) { p.save[l] = nullptr; p.mul[l] = nullptr; }
     p.save_ld = 0; p.mul_ld = 0;

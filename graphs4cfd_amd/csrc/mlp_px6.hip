@@ -792,14 +792,14 @@ int px6_enable(int on) {
 
 bool px6_eligible(const Params &p, bool agg, bool save, bool all_vec) {
     if (!px6_enable(-1) || save || !all_vec) return false;
-    if (p.n_src < 1 || p.n_add > 2) return false;
+    if (p.n_src < 1 || p.n_add > 2 || p.out_bf16) return false;
     if (agg && p.n_heads) return false;
     if (agg && p.n_out != NP) return false;
     int nar = 0;
     for (int a = 0; a < p.n_nar; ++a) nar += p.nar[a].width;
     if (nar > NARW_MAX) return false;
     for (int s = 0; s < p.n_src; ++s)
-        if (p.src[s].seg_off || !p.src[s].vec) return false;
+        if (p.src[s].seg_off || !p.src[s].vec || p.src[s].bf16) return false;
     for (int a = 0; a < p.n_add; ++a)
         if (p.add[a].width != NP || (p.add[a].ld & 3) || ((uintptr_t)p.add[a].ptr & 15)) return false;
     if (p.n_heads && (p.head_ld & 3)) return false;

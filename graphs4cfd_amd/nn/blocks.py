@@ -278,10 +278,13 @@ def edgeScalarToNodeVector(edge_attr: Tensor, edge_index: Tensor, edgeUnitVector
 
 
 # ------------------------------------------------------------------------------------- MP
+COMPACT_MESSAGES = __import__("os").environ.get("G4C_COMPACT_MESSAGES", "1") != "0"     # (0: fp32 message rows in every mode; A/B)
+
+
 def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, aggr: str, act_code: int,
              e_pre_act: int = _lib.ACT_NONE, v_src: Optional[Tensor] = None,
              products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None, keep_e: bool = True,
-             n_targets: Optional[int] = None, v_out: Optional[Tensor] = None):
+             n_targets: Optional[int] = None, v_out: Optional[Tensor] = None, compact_messages: bool = False):
     """Shared body of GNBlock / EdgeMP / DownEdgeMP (nn/blocks.py:175-186,322-333,360-381):
         e' = msg_mlp([e | s[row] | v[col]]);  agg = reduce(e' -> col);  v' = act(upd_mlp([agg | v])).
     Returns (v', e') where e' is stored WITHOUT the activation: the aggregation consumes the raw
@@ -292,6 +295,9 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
     `products` = (W1[:, H:2H] v, W1[:, 2H:3H] v) of msg_mlp's first layer when the launch that produced `v` already
     multiplied them; `next_msg` = the message MLP of the MP layer that will consume v' on the SAME graph: the node
     launch then emits its products as well and a third value (those products, or None) is returned.
+    `compact_messages` (EdgeMP: the returned e' is only ever read by the next EdgeMP's message launch): in the rounded-bf16 mode
+    the launch that fuses the aggregation stores e' as bf16 (ops.mlp_forward rows_dtype) — the consumer rounds it to bf16 anyway, and
+    REMuS-GNN's angle launches are HBM-bound on exactly these rows.
     `n_targets` / `v_out` (partitioned sub-meshes, partition_remus.py): only the first `n_targets` rows of `v` are targets (the
     rows behind them are halo rows, read as senders only); v' for those rows is written into `v_out`."""
     if aggr not in ("mean", "sum", "add"):
@@ -309,7 +315,8 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
         # even written
         agg = torch.empty((csr.n_seg, msg_mlp.output_size), dtype=torch.float32, device=v.device)
         e_new = msg_mlp.run_hoisted([e_src], [(senders, ep.row), (v, ep.col)], ep.n_edges,
-                                    products=products, agg=(csr, agg, mean), store_rows=keep_e)
+                                    products=products, agg=(csr, agg, mean), store_rows=keep_e,
+                                    rows_dtype=torch.bfloat16 if compact_messages and COMPACT_MESSAGES else None)
         agg_src = Source(agg)
     elif ops.can_aggregate_on_load(csr, msg_mlp.output_size, [msg_mlp.output_size, int(v.size(1))]):
         # the node launch averages each target's messages while it gathers its input (g4c_src_t.seg_off): no separate
@@ -487,9 +494,11 @@ class EdgeMP(nn.Module):
 
     def step(self, e: Tensor, a: Tensor, angle_index: Tensor, act_code: int, a_pre_act: int = _lib.ACT_NONE,
              products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None, keep_e: bool = True):
-        """Internal form: returns (act(e'), raw a') (+ the next EdgeMP's `products` when `next_msg` is given, see GNBlock.step)."""
+        """Internal form: returns (act(e'), raw a') (+ the next EdgeMP's `products` when `next_msg` is given, see GNBlock.step).
+        The model feeds a' only to the next EdgeMP.step of the level, so it may come back as bf16 in the rounded-bf16 mode
+        (_mp_step compact_messages); the public forward always returns fp32."""
         return _mp_step(self.angle_mlp, self.edge_mlp, e, a, angle_index, self.aggr, act_code, a_pre_act,
-                        products=products, next_msg=next_msg, keep_e=keep_e)
+                        products=products, next_msg=next_msg, keep_e=keep_e, compact_messages=True)
 
     def forward(self, e: Tensor, a: Tensor, angle_index: Tensor, *, activation=None) -> Tuple[Tensor, Tensor]:
         return _public_mp(self.angle_mlp, self.edge_mlp, e, a, angle_index, self.aggr, activation)

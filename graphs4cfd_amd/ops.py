@@ -68,6 +68,12 @@ def _f32_2d(t: Tensor, name: str) -> Tensor:
     return t
 
 
+def _bf16_2d(t: Tensor) -> Tensor:
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"bf16 source: expected a 2-D tensor with unit column stride, got shape {tuple(t.shape)}")
+    return t
+
+
 def _ld(t: Tensor) -> int:
     return int(t.stride(0)) if t.size(0) > 1 else int(max(t.size(1), t.stride(0)))
 
@@ -80,7 +86,9 @@ class Source:
     def __init__(self, tensor: Tensor, index: Optional[Tensor] = None, col0: int = 0, width: Optional[int] = None,
                  negate: bool = False, pre_act: int = _lib.ACT_NONE, additive: bool = False,
                  segments: Optional[CsrPlan] = None, seg_mean: bool = True):
-        self.tensor = _f32_2d(tensor, "source")
+        # (bf16 rows: the message tensors a fused-aggregation launch stored in the rounded-bf16 mode, mlp_forward(rows_dtype=);
+        # only as a plain 128-wide block of a launch in that mode — the C entry point checks)
+        self.tensor = _bf16_2d(tensor) if tensor.dtype == torch.bfloat16 else _f32_2d(tensor, "source")
         self.index = index          # int32 gather index or None
         self.col0 = col0
         self.width = int(self.tensor.size(1) - col0 if width is None else width)
@@ -421,6 +429,7 @@ def _src_array(sources: Sequence[Source]):
         a.ptr, a.idx, a.width, a.ld, a.col0, a.pre_act = (s.tensor.data_ptr(), _lib.ptr(s.index), s.width, _ld(s.tensor),
                                                           s.col0, s.pre_act)
         a.additive = 1 if s.additive else 0
+        a.dtype = 1 if s.tensor.dtype == torch.bfloat16 else 0
         if s.segments is not None:
             a.seg_off, a.seg_mean, a.seg_perm = _lib.ptr(s.segments.off), 1 if s.seg_mean else 0, _lib.ptr(s.segments.perm)
     return arr
@@ -431,7 +440,7 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                 resid: Optional[Tensor] = None, resid_col0: int = 0, tile_mode: Optional[int] = None,
                 head_outs: Optional[Sequence[Tensor]] = None, agg: Optional[Tuple[CsrPlan, Tensor, bool]] = None,
                 save: Optional[Sequence[Optional[Tensor]]] = None, mul: Optional[Sequence[Optional[Tensor]]] = None,
-                store_rows: bool = True) -> Optional[Tensor]:
+                store_rows: bool = True, rows_dtype: Optional[torch.dtype] = None) -> Optional[Tensor]:
     """One fused MLP launch (g4c_mlp_forward).  `tile_mode` (tests / tuning) runs every row through
     g4c_mlp_forward_rows with that kernel variant instead of the library's own choice.
     `head_outs` ([n_rows, 128] tensors, one per head of `packed`): g4c_mlp_forward_heads.
@@ -440,6 +449,8 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
     `save` (training forward, bf16x6 only): one [n_rows, 128] fp32 tensor (or None) per layer, receiving that layer's output rows
     (g4c_mlp_forward_bx6_save); `mul` (with `save`): per hidden layer the SELU-output rows whose slope multiplies that layer's
     result instead of bias + SELU (the backward chain of a block, see include/g4c.h).
+    `rows_dtype=torch.bfloat16` (rounded-bf16 mode, with an aggregation the launch fuses; ignored otherwise): the output rows are
+    stored as bf16 — their consumer rounds them to bf16 on load anyway, and the launch is HBM-bound on them; the aggregate stays fp32.
     With gradients enabled and a differentiable input / parameter, the call is recorded for autograd (autograd.py)."""
     if torch.is_grad_enabled():
         from . import autograd as _ag
@@ -470,8 +481,11 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                and tile_mode is None and out_idx32 is None and resid is None and n_rows == agg[0].n and agg[0].tiles() is not None)
     if not store_rows and not fusable:
         raise ValueError("store_rows=False needs an aggregation the launch can fuse (ops.can_fuse_aggregation)")
+    rows16 = bool(fusable and store_rows and rows_dtype == torch.bfloat16 and packed.precision == "bf16" and out is None)
     if out is None and store_rows:
-        out = torch.empty((n_rows, packed.n_out), dtype=torch.float32, device=dev)
+        out = torch.empty((n_rows, packed.n_out), dtype=torch.bfloat16 if rows16 else torch.float32, device=dev)
+    # algorithmic bytes per row of the weighted input blocks (bf16 rows count 2 bytes per value)
+    in_bytes = float(sum(s.width * (2 if s.tensor.dtype == torch.bfloat16 else 4) for s in sources if not s.additive))
     if store_rows:
         args = (_lib.ptr(out), _ld(out), _lib.ptr(out_idx32), act, _lib.ptr(resid), _ld(resid) if resid is not None else 0,
                 resid_col0, _lib.stream_handle(dev))
@@ -484,16 +498,22 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
             return y
         _lib.require_hip(agg_out)
         t_rows, t_seg, nt = tiles
-        fused_fn = lib.g4c_mlp_forward_bx6_agg if packed.precision == "bf16x6" else lib.g4c_mlp_forward_bf16_agg
-        call = lambda: _lib.check(fused_fn(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out),
-                                                              _ld(out) if out is not None else 128, act,
-                                                              _lib.ptr(t_rows), _lib.ptr(t_seg), _lib.ptr(csr.off), nt, _lib.ptr(agg_out),
-                                                              _ld(agg_out), 1 if agg_mean else 0, _lib.stream_handle(dev)))
+        tail = (_lib.ptr(t_rows), _lib.ptr(t_seg), _lib.ptr(csr.off), nt, _lib.ptr(agg_out), _ld(agg_out), 1 if agg_mean else 0,
+                _lib.stream_handle(dev))
+        o_ld = _ld(out) if out is not None else 128
+        if packed.precision == "bf16x6":
+            call = lambda: _lib.check(lib.g4c_mlp_forward_bx6_agg(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out), o_ld, act, *tail))
+        else:
+            if out is not None and out.dtype not in (torch.float32, torch.bfloat16):
+                raise TypeError(f"out: expected float32 or bfloat16, got {out.dtype}")
+            o_dt = 1 if (out is not None and out.dtype == torch.bfloat16) else 0
+            call = lambda: _lib.check(lib.g4c_mlp_forward_bf16_agg(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out), o_ld, o_dt,
+                                                                   act, *tail))
         if KernelTimer.active is None:
             call()
         else:
-            _timed("mlp_bx6_kernel", packed.flops_per_row * n_rows,
-                   4.0 * ((sum(packed.seg_widths) + (packed.n_out if store_rows else 0)) * n_rows + packed.n_out * csr.n_seg), call)
+            out_b = 0 if not store_rows else packed.n_out * (2 if out.dtype == torch.bfloat16 else 4)
+            _timed("mlp_bx6_kernel", packed.flops_per_row * n_rows, (in_bytes + out_b) * n_rows + 4.0 * packed.n_out * csr.n_seg, call)
     elif save is not None:
         if packed.precision != "bf16x6" or head_outs is not None or out_idx32 is not None or tile_mode is not None:
             raise NotImplementedError("save= needs the bf16x6 kernel without heads / output index / forced tile mode")
@@ -538,7 +558,7 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
         if KernelTimer.active is None:
             call()
         else:
-            _timed("mlp_bx6_kernel", packed.flops_per_row * n_rows, 4.0 * (sum(packed.seg_widths) + packed.n_out) * n_rows, call)
+            _timed("mlp_bx6_kernel", packed.flops_per_row * n_rows, (in_bytes + 4.0 * packed.n_out) * n_rows, call)
     elif head_outs is not None:
         if len(head_outs) != packed.n_heads or packed.n_heads == 0:
             raise ValueError(f"{len(head_outs)} head outputs for a packing with {packed.n_heads} heads")

@@ -555,7 +555,9 @@ class DistributedRollout:
                 self._pins = plan.snapshot()       # the graph bakes the plans' pointers in: keep them past cache eviction
                 try:
                     hg = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(hg):
+                    # (thread_local: the process group's watchdog thread polls its events while this thread captures; under
+                    # the default global mode a call from that thread can invalidate the capture)
+                    with torch.cuda.graph(hg, capture_error_mode="thread_local" if self.world > 1 else "global"):
                         self._one()
                 except Exception as exc:   # keep the rollout alive on stacks where the collective cannot be captured
                     hg, err = None, f"{type(exc).__name__}: {exc}"

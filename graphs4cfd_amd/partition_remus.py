@@ -285,7 +285,7 @@ class RemusHipImpl:
         blk, n_own = getattr(self.m, name), self.mesh.n_edges[lvl]
         out = self.buf("e", lvl)
         _, a_new = _mp_step(blk.angle_mlp, blk.edge_mlp, e, a, self.mesh.angle_index[lvl], blk.aggr, SELU, a_pending,
-                            n_targets=n_own, v_out=out[:n_own])
+                            n_targets=n_own, v_out=out[:n_own], compact_messages=True)
         return out, a_new
 
     def down(self, name: str, e_lo: torch.Tensor, e_hi: torch.Tensor, a_x: torch.Tensor, lvl: int):

@@ -92,6 +92,9 @@ int g4c_weighted_segment_mean(const float *x, int32_t x_ld, const int32_t *x_idx
  * Replaces `MLP.forward` (nn/blocks.py:117-144) together with the torch.cat / index ops that
  * feed it and the F.selu / torch.tanh / residual add that follow it at every call site
  * (nn/blocks.py:181,185,229,285,328,332,373,380,456; nn/mus_gnn.py:178-218). */
+#define G4C_DTYPE_F32 0
+#define G4C_DTYPE_BF16 1
+
 typedef struct {
     const float *ptr;   /* [rows, ld] row-major */
     const int32_t *idx; /* NULL: row r of the tile reads row r; else reads row idx[r] */
@@ -120,6 +123,9 @@ typedef struct {
     const int32_t *seg_perm; /* with seg_off: NULL = the segment's rows are [seg_off[r], seg_off[r+1]) themselves; else those are
                            positions in seg_perm, which holds the row numbers (pool_edge's fine -> coarse edge plan,
                            nn/blocks.py:67: the pooled coarse edge latents are formed while the first coarse edge MLP gathers them). */
+    int32_t dtype;      /* G4C_DTYPE_F32 (0): the rows are fp32.  G4C_DTYPE_BF16 (1), rounded-bf16 mode only (g4c_mlp_forward_bf16*),
+                           additive == 0, width 128, no seg_off: the rows are bf16 (ptr is a bf16 pointer, ld / col0 in elements) — the
+                           message rows a g4c_mlp_forward_bf16_agg launch stored with out_dtype = G4C_DTYPE_BF16. */
 } g4c_src_t;
 
 typedef struct {
@@ -205,9 +211,12 @@ int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs
                             int64_t n_rows, float *out, int32_t out_ld, int32_t act,
                             const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,
                             float *agg, int32_t agg_ld, int32_t agg_mean, void *stream);
-/* the same for the rounded-bf16 mode (g4c_mlp_forward_bf16: leading plane of the stream only) */
+/* the same for the rounded-bf16 mode (g4c_mlp_forward_bf16: leading plane of the stream only).  out_dtype = G4C_DTYPE_BF16 stores
+ * the rows as bf16 (out is then a bf16 pointer, out_ld in elements): in this mode the consumer of the rows rounds them to bf16 when
+ * it loads them anyway, and the launch is HBM-bound on exactly these rows (REMuS-GNN's angle latents, BASELINE config 3); the
+ * aggregate is computed from the fp32 tile and stays fp32. */
 int g4c_mlp_forward_bf16_agg(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
-                             int64_t n_rows, float *out, int32_t out_ld, int32_t act,
+                             int64_t n_rows, void *out, int32_t out_ld, int32_t out_dtype, int32_t act,
                              const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,
                              float *agg, int32_t agg_ld, int32_t agg_mean, void *stream);
 /* g4c_mlp_forward_heads for the bf16x6 stream (heads packed with g4c_mlp_pack_layer_bx6 right after the last layer) */

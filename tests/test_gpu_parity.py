@@ -247,6 +247,15 @@ def test_edge_mlp_with_fused_aggregation(case, prec, monkeypatch):
         y_ref = ops.mlp_forward(pk, srcs, E)
         agg_ref = ops.segment_reduce(y_ref, csr, mean)
         assert torch.equal(y, y_ref) and torch.equal(agg, agg_ref)
+        if prec == "bf16" and csr.tiles() is not None:
+            # message rows stored as bf16 (rows_dtype): the rounded rows, the same fp32 aggregate; as an input block they read
+            # exactly like their fp32 widening
+            agg16 = torch.full((n, H), float("nan"), device=DEV)
+            y16 = ops.mlp_forward(pk, srcs, E, agg=(csr, agg16, mean), rows_dtype=torch.bfloat16)
+            assert y16.dtype == torch.bfloat16 and torch.equal(y16, y_ref.to(torch.bfloat16)) and torch.equal(agg16, agg_ref)
+            nxt16 = ops.mlp_forward(pk, [ops.Source(y16, pre_act=_lib.ACT_SELU)] + srcs[1:], E)
+            nxt32 = ops.mlp_forward(pk, [ops.Source(y16.float(), pre_act=_lib.ACT_SELU)] + srcs[1:], E)
+            assert torch.equal(nxt16, nxt32)
         # and against an independent dense reduction
         dense = torch.zeros(n, H, device=DEV).index_add_(0, col.to(DEV), y_ref)
         if mean:
