@@ -175,16 +175,50 @@ __device__ __forceinline__ void epilogue_pair(const f32x16 &accE, unsigned char 
 #endif
 }
 
+// Last-layer epilogue of one accumulator IN THE MATRIX WAVE (this lane: row i, features fbase + 8 gq + e): LayerNorm from the
+// row statistics the four matrix waves exchanged through LDS at the end of the unit's interval, activation, 16-byte stores
+// through a buffer descriptor whose bounds end at the row tile's last row (rows beyond it are dropped by the hardware: no
+// exec-mask branch inside the MFMA-interleaved region), and what the next consumer of the row tile needs in LDS:
+// MODE 0 nothing, 1 the operand planes (the heads multiply the finished rows), 2 the fp32 rows (the helpers aggregate them).
+struct FinCtx {
+    float mean, rstd;
+    __amdgpu_buffer_rsrc_t orsrc;      // the unit's output rows [row0, row0 + n)
+    unsigned voff;                     // this lane's byte offset: row i, feature fbase
+    unsigned char *reg;                // this lane's row of the row-tile region
+    const float *gb;                   // sGB + fbase (gamma; beta NP floats further)
+    int fbase;
+};
+template <int SP, int MODE, int ACT>
+__device__ __forceinline__ void final_pair(const f32x16 &accE, int sl, const FinCtx &c, f32x2 &hold) {
+    const int gq = sl >> 1, pr = sl & 1;
+    const f32x2 g2 = *reinterpret_cast<const f32x2 *>(c.gb + 8 * gq + 2 * pr);
+    const f32x2 b2 = *reinterpret_cast<const f32x2 *>(c.gb + NP + 8 * gq + 2 * pr);
+    f32x2 x;
+    x[0] = accE[4 * gq + 2 * pr]; x[1] = accE[4 * gq + 2 * pr + 1];
+    f32x2 y = ((x - c.mean) * c.rstd) * g2 + b2;
+    if (ACT == G4C_ACT_SELU) y = selu2(y);
+    if (MODE == 1) put_split2<SP>(c.reg + 2 * (c.fbase + 8 * gq + 2 * pr), y);
+    if (pr == 0) {
+        hold = y;
+    } else {
+        f32x4 q;
+        q[0] = hold[0]; q[1] = hold[1]; q[2] = y[0]; q[3] = y[1];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, q), c.orsrc, (int)(c.voff + 32u * gq), 0, 0);
+        if (MODE == 2) *reinterpret_cast<f32x4 *>(c.reg + 4 * (c.fbase + 8 * gq)) = q;
+    }
+}
+
 // M phase: acc += W(block) * planes(rt) for one row tile.  W[s][pl]: this wave's stationary weight fragments (A operand);
 // B fragments of step s + 1 are read from LDS before the six MFMAs of step s issue.  REFILL: slot s is reloaded with the
-// next stage's fragments right after its last use.  EPI: the hidden-layer epilogue of the PREVIOUS unit's accumulator accE
-// (bias already in it) is interleaved with this unit's MFMAs — one quarter every second step, spread over the MFMA issue
-// slots by the scheduler (sched_group_barrier: 1 MFMA, then up to 4 vector ALU instructions, ...): the matrix pipe runs
-// while the vector ALUs split the previous tile.
-template <int SP, bool REFILL, bool EPI>
+// next stage's fragments right after its last use.  EPI: the epilogue of the PREVIOUS unit's accumulator accE (bias already
+// in it) is interleaved with this unit's MFMAs — one eighth per step, spread over the MFMA issue slots by the scheduler
+// (sched_group_barrier: 1 MFMA, then up to 4 vector ALU instructions, ...): the matrix pipe runs while the vector ALUs work on
+// the previous tile.  EPI 1: hidden layer (SELU, operand split, planes), EPI 2: last layer (final_pair).
+template <int SP, bool REFILL, int EPI, int MODE = 0, int ACT = 0>
 __device__ __forceinline__ void m_phase(const unsigned char *pa, bf16x8 (&W)[8][SP], f32x16 &acc, u32x4_t rs,
-                                        unsigned lo_b, unsigned nxt_b, const f32x16 &accE, unsigned char *dE, bool epw = true) {
+                                        unsigned lo_b, unsigned nxt_b, const f32x16 &accE, unsigned char *dE, const FinCtx &fc) {
     bf16x8 cur[SP], nx[SP];
+    f32x2 hold = {0.f, 0.f};
 #pragma unroll
     for (int pl = 0; pl < SP; ++pl) cur[pl] = *reinterpret_cast<const bf16x8 *>(pa + pl * PLB);
 #pragma unroll
@@ -195,7 +229,8 @@ __device__ __forceinline__ void m_phase(const unsigned char *pa, bf16x8 (&W)[8][
             for (int pl = 0; pl < SP; ++pl) nx[pl] = *reinterpret_cast<const bf16x8 *>(pa + pl * PLB + 32 * (s + 1));
         }
         if (!EPI) __builtin_amdgcn_sched_barrier(0);      // (the next step's fragments are in flight before this step's MFMAs issue)
-        if (EPI) epilogue_pair<SP>(accE, dE, s, epw);
+        if (EPI == 1) epilogue_pair<SP>(accE, dE, s);
+        if (EPI == 2) final_pair<SP, MODE, ACT>(accE, s, fc, hold);
 #ifdef G4C_PX_ABLATE_MFMA               // timing experiment: one MFMA per step instead of six
         if (false) {
 #else
@@ -210,7 +245,7 @@ __device__ __forceinline__ void m_phase(const unsigned char *pa, bf16x8 (&W)[8][
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], cur[0], acc, 0, 0, 0);
         if (EPI) {
             // issue order inside the region: the fragment reads, then each MFMA followed by a few epilogue instructions
-            __builtin_amdgcn_sched_group_barrier(0x100, SP, 0);                 // DS read
+            __builtin_amdgcn_sched_group_barrier(0x100, SP + (EPI == 2 ? 2 : 0), 0);   // DS read (+ gamma / beta)
 #pragma unroll
             for (int m = 0; m < (SP == 3 ? 6 : 1); ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
@@ -234,7 +269,8 @@ __device__ __forceinline__ void m_phase(const unsigned char *pa, bf16x8 (&W)[8][
 
 // MULTI: layer 0 has more than one weighted input block (its accumulators then persist over several stages: one per row
 // tile; otherwise the matrix waves hold a single accumulator)
-template <int SP, bool AGG, bool MULTI>
+// HEADS: the finished rows are also the operand of head blocks (their planes are written by the last layer's epilogue)
+template <int SP, bool AGG, bool MULTI, bool HEADS>
 __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[PX_LDS];
     unsigned char *const sHO = lds + 4 * RTB;                                   // two hand-over buffers
@@ -284,9 +320,9 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
     if (tid == 0) sCnt[0] = 0;
     unsigned sync_epoch = 0;
     for (int e = tid; e < (G4C_MAX_LAYERS + 1) * NP; e += 512) sBias[e] = (e < n_layers * NP) ? P.b[e] : 0.f;
-    if (P.gamma && tid < 2 * NP) {
+    if (tid < 2 * NP) {          // (no LayerNorm: gamma = 1, beta = 0 and the epilogue uses mean 0, rstd 1)
         const int f = tid & (NP - 1), ff = f < P.n_out ? f : 0;
-        sGB[tid] = tid < NP ? P.gamma[ff] : P.beta[ff];
+        sGB[tid] = P.gamma ? (tid < NP ? P.gamma[ff] : P.beta[ff]) : (tid < NP ? 1.f : 0.f);
     }
     {
         int base = 0;
@@ -339,24 +375,64 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
                 if (j == iters && st > 0) break;
                 const unsigned nxt_b = 2u * BLOCK6 * (unsigned)(st + 1 == NS ? 0 : st + 1);
                 const bool zero = (st == 0) || (st > st_l0);
-                const bool hand_over = (st >= st_fin);         // last layer / heads: the helpers take the accumulators over
+                const bool hand_over = (st > st_fin);          // heads: the helpers store the accumulators
                 const bool hidden = (st >= st_l0) && (st < st_fin);
+                const bool final_st = (st == st_fin);
                 const int pst = st > 0 ? st - 1 : NS - 1;
                 const bool phidden = (pst >= st_l0) && (pst < st_fin);     // stage of the unit before r = 0
+                const bool pfinal = (pst == st_fin);
                 // layer whose bias the accumulators of this stage start from (heads: the all-zero row)
                 const float *bp = sBias + (st <= st_fin ? (st == 0 ? 0 : st - st_l0) : G4C_MAX_LAYERS) * NP + (ct * 32 + 4 * (lane >> 5));
                 // one interval; the row tile is a compile-time constant (accumulators and prefetch registers are indexed by it)
                 auto interval = [&](auto rc) __attribute__((always_inline)) {
                     constexpr int r = decltype(rc)::value;
-                    if (j == iters && r >= 1) return;        // (the drain has one interval)
+                    if (j == iters && r >= 2) return;        // (the drain has two intervals)
                     PX_STAMP();
                     remat();
                     constexpr int pr = (r + 3) & 3;
                     constexpr int ia = MULTI ? r : (r & 1), ie = MULTI ? pr : ((r & 1) ^ 1);
                     if (r == 0) w_wait<SP>(W);              // this stage's weights (requested during the previous stage's last phase)
-                    // the previous unit's accumulator still has its hidden-layer epilogue to go through
-                    const bool ep = (r == 0) ? (phidden && (st == 0 ? p3n : cn[3]) > 0 && (j > 0 || st > 0)) : (hidden && cn[pr] > 0);
+                    // the previous unit's accumulator still has its epilogue to go through: 1 hidden layer, 2 last layer
+                    const int pn = (r == 0) ? ((st == 0) ? p3n : cn[3]) : cn[pr];
+                    const bool pvalid = pn > 0 && (r > 0 || j > 0 || st > 0) && !(j == iters && r == 1);
+                    const int ek = !pvalid ? 0 : ((r == 0) ? (phidden ? 1 : (pfinal ? 2 : 0)) : (hidden ? 1 : (final_st ? 2 : 0)));
                     unsigned char *dE = lds + pr * RTB + i * ROWB + 2 * fbase;
+                    FinCtx fc;
+                    fc.mean = 0.f; fc.rstd = 1.f; fc.voff = 0; fc.reg = lds + pr * RTB + i * ROWB; fc.gb = sGB + fbase; fc.fbase = fbase;
+                    fc.orsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P.w), 0, 0, 0x00020000);      // (nothing in bounds: every store dropped)
+                    if (ek == 2) {
+                        int prow0, pnn;
+                        rt_info((r == 0 && st == 0) ? j - 1 : j, pr, prow0, pnn);
+                        if (P.gamma) {
+                            const float *s0 = sStat + ((pr & 1) * 2 + 0) * 128 + i, *s1 = sStat + ((pr & 1) * 2 + 1) * 128 + i;
+                            const float inv_n = 1.0f / (float)NP;
+                            const float mean = (s0[0] + s0[32] + s0[64] + s0[96]) * inv_n;
+                            const float var = fmaxf((s1[0] + s1[32] + s1[64] + s1[96]) * inv_n - mean * mean, 0.f);
+                            fc.mean = mean; fc.rstd = rsqrtf(var + P.eps);
+                        }
+                        if (P.out) {
+                            float *ob = P.out + (long long)prow0 * P.out_ld;
+                            fc.orsrc = __builtin_amdgcn_make_buffer_rsrc(ob, 0, pnn * P.out_ld * 4, 0x00020000);
+                            fc.voff = (unsigned)(i * P.out_ld + fbase) * 4u;
+                        }
+                    }
+                    constexpr int MODE = AGG ? 2 : (HEADS ? 1 : 0);
+                    const bool selu_out = P.act == G4C_ACT_SELU;
+                    auto serial_epilogue = [&]() __attribute__((always_inline)) {
+                        if (ek == 1) {
+#pragma unroll
+                            for (int sl = 0; sl < 8; ++sl) epilogue_pair<SP>(acc[ie], dE, sl);
+                        } else if (ek == 2) {
+                            f32x2 hold = {0.f, 0.f};
+                            if (selu_out) {
+#pragma unroll
+                                for (int sl = 0; sl < 8; ++sl) final_pair<SP, MODE, G4C_ACT_SELU>(acc[ie], sl, fc, hold);
+                            } else {
+#pragma unroll
+                                for (int sl = 0; sl < 8; ++sl) final_pair<SP, MODE, G4C_ACT_NONE>(acc[ie], sl, fc, hold);
+                            }
+                        }
+                    };
                     const bool on = cn[r] > 0;
                     if (on) {
                         if (zero) {
@@ -382,17 +458,31 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
 #ifndef G4C_PX_ABLATE_M                 // (timing experiment: matrix waves idle)
                     if (r == 3) {
                         // the phase that refills the weights is ONE code path whatever the row tile's state (an inactive row
-                        // tile multiplies stale planes into an unused accumulator, a missing epilogue only drops its stores):
-                        // alternatives around the refill make hipcc keep a second copy of all 96 weight registers
-                        if (cn[0] > 0) m_phase<SP, true, true>(pa, W, acc[ia], rs, lo_b, nxt_b, acc[ie], dE, ep);
+                        // tile multiplies stale planes into an unused accumulator): alternatives around the refill make hipcc
+                        // keep a second copy of all 96 weight registers.  The previous unit's epilogue therefore runs in front
+                        // of it, not interleaved
+                        serial_epilogue();
+                        if (cn[0] > 0) m_phase<SP, true, 0>(pa, W, acc[ia], rs, lo_b, nxt_b, acc[ie], dE, fc);
                     } else if (on) {
-                        if (ep) m_phase<SP, false, true>(pa, W, acc[ia], rs, lo_b, nxt_b, acc[ie], dE);
-                        else m_phase<SP, false, false>(pa, W, acc[ia], rs, lo_b, nxt_b, acc[ie], dE);
-                    } else if (ep) {
-#pragma unroll
-                        for (int sl = 0; sl < 8; ++sl) epilogue_pair<SP>(acc[ie], dE, sl);
+                        if (ek == 1) m_phase<SP, false, 1>(pa, W, acc[ia], rs, lo_b, nxt_b, acc[ie], dE, fc);
+                        else if (ek == 2 && selu_out) m_phase<SP, false, 2, MODE, G4C_ACT_SELU>(pa, W, acc[ia], rs, lo_b, nxt_b, acc[ie], dE, fc);
+                        else if (ek == 2) m_phase<SP, false, 2, MODE, G4C_ACT_NONE>(pa, W, acc[ia], rs, lo_b, nxt_b, acc[ie], dE, fc);
+                        else m_phase<SP, false, 0>(pa, W, acc[ia], rs, lo_b, nxt_b, acc[ie], dE, fc);
+                    } else {
+                        serial_epilogue();
                     }
 #endif
+                    if (on && final_st && P.gamma) {
+                        // this wave's share of the row statistics (its 32 columns): sum and sum of squares, exchanged at the barrier
+                        float s = 0.f, q = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) { s += acc[ia][e]; q = fmaf(acc[ia][e], acc[ia][e], q); }
+                        s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+                        if (h == 0) {
+                            sStat[((r & 1) * 2 + 0) * 128 + ct * 32 + i] = s;
+                            sStat[((r & 1) * 2 + 1) * 128 + ct * 32 + i] = q;
+                        }
+                    }
                     if (on && hand_over) {
                         unsigned char *d = sHO + (r & 1) * HOB + (ct * 4 * 64 + lane_v) * 16;
 #pragma unroll
@@ -540,107 +630,35 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
         for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4 *>(d + gq * 1024) = x[gq];
     };
 
-    // ---- last layer of row tile r of tile fj: LayerNorm / activation / residual / store (/ aggregation) in the accumulator
-    // layout (this lane: row i, features fbase + 8 gq + e; row statistics exchanged between the four helper waves through
-    // LDS), then what refills the row tile's planes: the heads' operand planes, or the next tile's input rows
+    // ---- two intervals after the last layer of row tile r of tile fj (the matrix waves have normalised and stored its rows in the
+    // interval between): the per-target aggregation from the fp32 rows they left in the row tile's region, then what refills the
+    // region — the next tile's input rows (with heads the region holds the heads' operand planes until the last head is done)
     auto finish = [&](auto rc, int fj) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
-        unsigned char *reg = lds + r * RTB;
         int row0, n;
         rt_info(fj, r, row0, n);
-        const int n_out = P.n_out;
-        unsigned char *hs = sHO + (r & 1) * HOB + (ct * 4 * 64 + lane_v) * 16;
-        f32x4 x[4];
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) x[gq] = *reinterpret_cast<const f32x4 *>(hs + gq * 1024);
-        if (P.gamma) {
-            const float inv_n = 1.0f / (float)n_out;
-            float *st0 = sStat + ((r & 1) * 2 + 0) * 128, *st1 = sStat + ((r & 1) * 2 + 1) * 128;
-            float sum = 0.f;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sum += (fbase + 8 * gq + e < n_out) ? x[gq][e] : 0.f;
-            sum += __shfl_xor(sum, 32);
-            if (h == 0) st0[ct * 32 + i] = sum;
-            group_sync(sCnt, sync_epoch, lane_v);
-            const float mean = (st0[i] + st0[32 + i] + st0[64 + i] + st0[96 + i]) * inv_n;
-            float var = 0.f;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float dl = x[gq][e] - mean; var += (fbase + 8 * gq + e < n_out) ? dl * dl : 0.f; }
-            var += __shfl_xor(var, 32);
-            if (h == 0) st1[ct * 32 + i] = var;
-            group_sync(sCnt, sync_epoch, lane_v);
-            const float rstd = rsqrtf((st1[i] + st1[32 + i] + st1[64 + i] + st1[96 + i]) * inv_n + P.eps);
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const f32x4 g4 = *reinterpret_cast<const f32x4 *>(sGB + fbase + 8 * gq);
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sGB + NP + fbase + 8 * gq);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[gq][e] = fmaf((x[gq][e] - mean) * rstd, g4[e], b4[e]);
-            }
-        }
-        if (P.act == G4C_ACT_SELU) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) x[gq] = selu4(x[gq]);
-        } else if (P.act == G4C_ACT_TANH) {
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[gq][e] = g4c::tanh_f(x[gq][e]);
-        }
-        // ---- rows to global memory: 16-byte pieces (this lane's four runs of four features)
-        if (P.out && i < n) {
-            const long long grow = row0 + i;
-            const long long orow = P.out_idx ? P.out_idx[grow] : grow;
-            const bool fast = (n_out == NP) && ((P.out_ld & 3) == 0) && (((uintptr_t)P.out & 15) == 0) && (P.resid == nullptr);
-            float *op = P.out + orow * P.out_ld + fbase;
-            if (fast) {
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4 *>(op + 8 * gq) = x[gq];
-            } else {
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int c = fbase + 8 * gq + e;
-                        if (c < n_out) {
-                            float y = x[gq][e];
-                            if (P.resid) y += P.resid[grow * P.resid_ld + P.resid_col0 + c];
-                            op[8 * gq + e] = y;
-                        }
-                    }
-            }
-        }
+        if (n <= 0) return;
         if (AGG) {
-            // the finished rows back into the hand-over buffer, then every wave adds up its 32 columns of the row tile's
-            // segments in row order (= g4c_segment_reduce): lane -> (feature quad lane & 7, one of 8 segments at a time)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4 *>(hs + gq * 1024) = x[gq];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (only this wave's own columns are read back)
+            // every helper wave adds up its 32 columns of the row tile's segments in row order (= g4c_segment_reduce):
+            // lane -> (feature quad lane & 7, one of 8 segments at a time)
             const int fu = u_begin + 4 * fj + r;
             const int s0 = P.tile_seg[fu], s1 = P.tile_seg[fu + 1];
-            const int fq = lane_v & 7, gqa = fq >> 1, ha = fq & 1;
-            const unsigned char *hb = sHO + (r & 1) * HOB + ((ct * 4 + gqa) * 64 + ha * 32) * 16;
+            const int fq = lane_v & 7;
+            const unsigned char *rb = lds + r * RTB + 4 * (32 * ct + 4 * fq);
             for (int sg = s0 + (lane_v >> 3); sg < s1; sg += 8) {
                 const int b = P.seg_off[sg] - row0, e = P.seg_off[sg + 1] - row0;
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                for (int row = b; row < e; ++row) a += *reinterpret_cast<const f32x4 *>(hb + row * 16);
+                for (int row = b; row < e; ++row) a += *reinterpret_cast<const f32x4 *>(rb + row * ROWB);
                 if (P.agg_mean) {
                     const float cnt = (float)((e - b) > 1 ? (e - b) : 1);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) a[q] /= cnt;
                 }
-                *reinterpret_cast<f32x4 *>(P.agg + (long long)sg * P.agg_ld + ct * 32 + 4 * ha + 8 * gqa) = a;
+                *reinterpret_cast<f32x4 *>(P.agg + (long long)sg * P.agg_ld + ct * 32 + 4 * fq) = a;
             }
+            group_sync(sCnt, sync_epoch, lane_v);      // every helper wave has read the rows before any of them parks over them
         }
-        if (n_heads) {
-            // heads: the finished rows are the operand of the head blocks
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) put_split<SP>(reg + i * ROWB + 2 * (fbase + 8 * gq), x[gq]);
-        } else {
+        if (!HEADS) {
             int row0n, nn;
             rt_info(fj + 1, r, row0n, nn);
             if (nn > 0) park(rc, fj + 1, 0);
@@ -699,7 +717,7 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
             if (nst == NS) { nst = 0; nj = j + 1; }
             auto interval = [&](auto rc) __attribute__((always_inline)) {
                 constexpr int r = decltype(rc)::value;
-                if (j == iters && r >= 1) return;
+                if (j == iters && r >= 2) return;
                 PX_STAMP();
                 remat();
                 PX_SUB(0);
@@ -713,8 +731,6 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
                     if (un > 0) {
                         if (ust < st_l0) {
                             park(urc, uj, ust + 1);                   // next input block of layer 0; the accumulator carries on
-                        } else if (ust == st_fin) {
-                            finish(urc, uj);
                         } else if (ust > st_fin) {
                             // head: plain product of the finished rows, stored as it is
                             const unsigned char *hs = sHO + (ur & 1) * HOB + (ct * 4 * 64 + lane_v) * 16;
@@ -759,6 +775,9 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
                 {
                     constexpr int qr = (r + 2) & 3;
                     const int qj = (r < 2) ? pj : j, qs = (r < 2) ? pst : st;
+                    // (its last layer ran two intervals ago, the matrix waves' epilogue of it one interval ago)
+                    if (qj >= 0 && qs == st_fin) finish(std::integral_constant<int, qr>{}, qj);
+                    __builtin_amdgcn_sched_barrier(0);
                     int fj2 = n_src > 1 ? 0 : 1, fs = n_src > 1 ? 1 : 0;        // (before its first unit: what the prologue requested)
                     if (qj >= 0) next_park(qj, qs, fj2, fs);
                     fetch_always(std::integral_constant<int, qr>{}, fj2, fs);
@@ -803,6 +822,9 @@ bool px6_eligible(const Params &p, bool agg, bool save, bool all_vec) {
     for (int a = 0; a < p.n_add; ++a)
         if (p.add[a].width != NP || (p.add[a].ld & 3) || ((uintptr_t)p.add[a].ptr & 15)) return false;
     if (p.n_heads && (p.head_ld & 3)) return false;
+    // the last layer's epilogue runs in the matrix waves: whole 128-wide rows through 16-byte buffer stores, LayerNorm over 128
+    if (p.n_out != NP || p.resid || p.out_idx || (p.act != G4C_ACT_NONE && p.act != G4C_ACT_SELU)) return false;
+    if (p.out && ((p.out_ld & 3) || ((uintptr_t)p.out & 15) || (long long)p.out_ld * 4 * 32 >= (1LL << 31))) return false;
     return true;
 }
 
@@ -825,8 +847,11 @@ int px6_launch(const Params &p, bool round1, bool agg, hipStream_t st) {
     const bool multi = p.n_src > 1;
 #define PX_LAUNCH(SP, AGG)                                                                    \
     do {                                                                                      \
-        if (multi) mlp_px6_kernel<SP, AGG, true><<<grid, blk, 0, st>>>(p);                    \
-        else mlp_px6_kernel<SP, AGG, false><<<grid, blk, 0, st>>>(p);                         \
+        if (p.n_heads) {                                                                      \
+            if (multi) mlp_px6_kernel<SP, false, true, true><<<grid, blk, 0, st>>>(p);        \
+            else mlp_px6_kernel<SP, false, false, true><<<grid, blk, 0, st>>>(p);             \
+        } else if (multi) mlp_px6_kernel<SP, AGG, true, false><<<grid, blk, 0, st>>>(p);      \
+        else mlp_px6_kernel<SP, AGG, false, false><<<grid, blk, 0, st>>>(p);                  \
     } while (0)
     if (round1) { if (agg) PX_LAUNCH(1, true); else PX_LAUNCH(1, false); }
     else { if (agg) PX_LAUNCH(3, true); else PX_LAUNCH(3, false); }
