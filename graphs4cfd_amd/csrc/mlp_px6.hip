@@ -60,10 +60,14 @@ constexpr int PLB = HB * 2;            // bytes of one plane row (136 bf16)
 constexpr int ROWB = 3 * PLB;          // bytes per row of a row-tile region: three planes (or the fp32 row, 512 B)
 constexpr int RTB = 32 * ROWB;         // one row-tile region
 constexpr int NARW_MAX = 16;           // narrow input columns whose W1^T rows are staged in LDS
-constexpr int HOB = 64 * 16 * 16;         // one accumulator hand-over buffer: [ct][gq][lane] x 16 bytes
+constexpr int HOROW = 132 * 4;            // row pitch of the start-value form of a hand-over buffer: [32 rows][132 floats] (conflict-free both ways)
+constexpr int HOB = 32 * HOROW;           // one hand-over buffer: start values (helpers -> matrix waves, row-major), or a head's
+                                          // accumulators (matrix waves -> helpers, [ct][gq][lane] x 16 bytes = 16 KB)
 constexpr int IXB = 2 * 2 * 4 * 32 * 4;   // gather rows of the additive terms: [tile parity][source][rt][32 rows] int
 constexpr int STB = 2 * 2 * 128 * 4;      // LayerNorm partial statistics: [unit parity][pass][column tile][32 rows] float
-constexpr int PX_LDS = 4 * RTB + 2 * HOB + ((G4C_MAX_LAYERS + 1) * NP + 2 * NP + NARW_MAX * NP) * 4 + 16 + IXB + STB;
+constexpr int TRC = 1024;                 // AGG: first rows / first segments of this workgroup's units, cached in LDS (beyond: global)
+constexpr int TRB = 2 * (TRC + 1) * 4;
+constexpr int PX_LDS = 4 * RTB + 2 * HOB + ((G4C_MAX_LAYERS + 1) * NP + 2 * NP + NARW_MAX * NP) * 4 + 16 + IXB + STB + TRB;
 
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -280,6 +284,7 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
     unsigned *sCnt = reinterpret_cast<unsigned *>(sNarW + NARW_MAX * NP);      // arrival counter of group_sync
     int *sIx = reinterpret_cast<int *>(sCnt + 4);
     float *sStat = reinterpret_cast<float *>(sIx + IXB / 4);
+    int *sTR = reinterpret_cast<int *>(sStat + STB / 4);         // [TRC + 1] tile_rows, then [TRC + 1] tile_seg of units u_begin ...
 
     // the parameter block is read through a pointer to the kernarg segment
     typedef const __attribute__((address_space(4))) Params *ParamsPtr;
@@ -332,13 +337,20 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
         }
     }
 
+    if (AGG) {
+        const int cnt = (u_end - u_begin + 1) < (TRC + 1) ? (u_end - u_begin + 1) : (TRC + 1);
+        for (int e = tid; e < cnt; e += 512) { sTR[e] = P.tile_rows[u_begin + e]; sTR[TRC + 1 + e] = P.tile_seg[u_begin + e]; }
+        __syncthreads();
+    }
     // ---- row-tile bookkeeping (wave-uniform)
     auto rt_info = [&](int j, int r, int &row0, int &n) __attribute__((always_inline)) {
-        const int u = u_begin + 4 * j + r;
+        const int ul = 4 * j + r, u = u_begin + ul;
         row0 = 0; n = 0;
         if (j >= 0 && j < iters && u < u_end) {
-            if (AGG) { row0 = P.tile_rows[u]; n = P.tile_rows[u + 1] - row0; }
-            else { row0 = (int)P.row_base + u * 32; n = (int)P.M - row0; n = n < 32 ? n : 32; }
+            if (AGG) {
+                if (ul < TRC) { row0 = __builtin_amdgcn_readfirstlane(sTR[ul]); n = __builtin_amdgcn_readfirstlane(sTR[ul + 1]) - row0; }
+                else { row0 = P.tile_rows[u]; n = P.tile_rows[u + 1] - row0; }
+            } else { row0 = (int)P.row_base + u * 32; n = (int)P.M - row0; n = n < 32 ? n : 32; }
         }
     };
     int stamp_k = 0;
@@ -445,10 +457,10 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
                         }
                         if (st == st_l0 && pre_on) {
                             // gathered additive rows / narrow input blocks, summed by the helpers (hand-over layout)
-                            const unsigned char *hs = sHO + (r & 1) * HOB + (ct * 4 * 64 + lane_v) * 16;
+                            const unsigned char *hs = sHO + (r & 1) * HOB + i * HOROW + fbase * 4;
 #pragma unroll
                             for (int gq = 0; gq < 4; ++gq) {
-                                const f32x4 v = *reinterpret_cast<const f32x4 *>(hs + gq * 1024);
+                                const f32x4 v = *reinterpret_cast<const f32x4 *>(hs + gq * 32);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) acc[ia][4 * gq + e] += v[e];
                             }
@@ -515,8 +527,36 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
     // rows that are not needed are requested again or replaced by a dummy row).  A load under a wave-uniform condition
     // merges with the register's previous value at the join, hipcc copies it there, and the copy waits for the data — every
     // prefetch then costs its full memory latency (measured: 3000 cycles per row fetch).
+#ifndef G4C_PX_HELPER_PRIO
+#define G4C_PX_HELPER_PRIO 3
+#endif
+    // The SIMD's arbiter prefers the older wave: without this, the matrix wave's dense stretches (a serial epilogue, accumulator
+    // initialisation) keep the helper wave from issuing for thousands of cycles (seen as a late first stamp after the barrier);
+    // the helpers' work is the critical path of the heavy intervals, the matrix wave only needs one issue slot per MFMA
+    __builtin_amdgcn_s_setprio(G4C_PX_HELPER_PRIO);
     f32x4 xp[4][4];                      // xp[r] = this lane's 16 values of row `prow` of the rows row tile r is parked with next
     f32x4 ad[2][2][4];                   // ad[unit parity][source][gq]: gathered additive rows, in flight for two intervals
+    // gathers go through buffer descriptors (base in SGPRs, one 32-bit byte offset per lane, the column offsets as immediates):
+    // the helper wave shares its SIMD's issue slots with a matrix wave that issues MFMAs and epilogue arithmetic back to back,
+    // so every instruction of 64-bit address arithmetic it does not execute is ~10 cycles off the interval
+    const __amdgpu_buffer_rsrc_t ars0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(n_add > 0 ? P.add[0].ptr : P.w), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ars1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(n_add > 1 ? P.add[1].ptr : P.w), 0, 0x7fffffff, 0x00020000);
+    const int ald0 = n_add > 0 ? P.add[0].ld * 4 : 0, ald1 = n_add > 1 ? P.add[1].ld * 4 : 0;
+    // fields of the weighted input blocks, read from the kernarg segment once (selected by comparisons: a runtime index into
+    // a local array would live in scratch memory)
+    int sld_[G4C_MAX_SRC], scol_[G4C_MAX_SRC], swid_[G4C_MAX_SRC], sact_[G4C_MAX_SRC];
+    const int *sidx_[G4C_MAX_SRC];
+    const float *sptr_[G4C_MAX_SRC];
+#pragma unroll
+    for (int k = 0; k < G4C_MAX_SRC; ++k) {
+        const int kk = k < n_src ? k : 0;
+        sld_[k] = P.src[kk].ld; scol_[k] = P.src[kk].col0; swid_[k] = P.src[kk].width; sact_[k] = P.src[kk].pre_act;
+        sidx_[k] = P.src[kk].idx; sptr_[k] = P.src[kk].ptr;
+    }
+#define PX_PICK(a, s) ((s) == 0 ? a[0] : ((s) == 1 ? a[1] : ((s) == 2 ? a[2] : a[3])))
+    auto bld16 = [&](f32x4 &dst, __amdgpu_buffer_rsrc_t rsrc, int voff, int imm) __attribute__((always_inline)) {
+        dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + imm, 0, 0));
+    };
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -537,9 +577,14 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
     // park source s of tile j into row tile r (rows >= n are clamped copies of the last row: never stored)
     auto park = [&](auto rc, int j, int s) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
-        const int width = P.src[s].width;
-        const bool act = P.src[s].pre_act != 0;
+        const int width = PX_PICK(swid_, s);
+        const bool act = PX_PICK(sact_, s) != 0;
         unsigned char *d = lds + r * RTB + prow * ROWB + 2 * c4;
+        if (width == NP && act) {            // (the MP layers' input block: no column masks, SELU pending on the stored rows)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) put_split<SP>(d + 2 * q * KC, selu4(xp[r][q]));
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 v = xp[r][q];
@@ -556,13 +601,14 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
         rt_info(j, r, row0, n);
         if (n <= 0) { rt_info(0, 0, row0, n); s = 0; }         // (the first row tile always exists)
         const int rr = prow < n ? prow : n - 1;
-        long long gr = row0 + rr;
-        const int *ix = P.src[s].idx;
+        int gr = row0 + rr;
+        const int *ix = PX_PICK(sidx_, s);
         if (ix) gr = ix[gr];
-        const float *rp = P.src[s].ptr + gr * P.src[s].ld + P.src[s].col0 + c4;
-        const int width = P.src[s].width;
+        const int width = PX_PICK(swid_, s);
+        const int voff = (gr * PX_PICK(sld_, s) + PX_PICK(scol_, s) + c4) * 4;
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(PX_PICK(sptr_, s)), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ld16(xp[r][q], rp + ((q * KC + c4 < width) ? q * KC : -c4));
+        for (int q = 0; q < 4; ++q) bld16(xp[r][q], srs, (q * KC + c4 < width) ? voff + q * KC * 4 : voff - c4 * 4, 0);
     };
     // the park that follows the latest one of a row tile whose most recent unit is (tile qj, stage qs)
     auto next_park = [&](int qj, int qs, int &nj2, int &ns2) __attribute__((always_inline)) {
@@ -584,17 +630,25 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
         }
     };
     // gathers of unit (j, st_l0, r) (need) or of a dummy row (the load itself is unconditional, see above)
+    // (lane -> row prow of the row tile, 16-byte chunks at columns c4 + 32 q: eight lanes read 128 contiguous bytes of a row, an
+    // instruction touches 8 rows — in the accumulator layout it would touch 32 rows in 32-byte pieces, four times the cache lines,
+    // and these gathers share the CU's one address path with the matrix waves' weight refills and row stores)
     auto issue_adds = [&](auto rc, int j, bool need) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
+        const int *ixp = sIx + ((j & 1) * 2 * 4 + r) * 32 + prow;
+        int row0a = 0, row1a = 0;
+        if (need) { row0a = ixp[0]; row1a = n_add > 1 ? ixp[4 * 32] : 0; }
+        int v0 = row0a * ald0 + c4 * 4, v1 = row1a * ald1 + c4 * 4;
+#ifdef G4C_PX_TIMING
+        asm volatile("" : "+v"(v0), "+v"(v1));
+        __builtin_amdgcn_sched_barrier(0);
+        PX_SUB(5);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            if (a < n_add) {
-                const int row = need ? sIx[(((j & 1) * 2 + a) * 4 + r) * 32 + i] : 0;
-                const float *pr = P.add[a].ptr + (long long)row * P.add[a].ld + fbase;
+        for (int q = 0; q < 4; ++q) bld16(ad[r & 1][0][q], ars0, v0, q * KC * 4);
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) ld16(ad[r & 1][a][gq], pr + 8 * gq);
-            }
-        }
+        for (int q = 0; q < 4; ++q) bld16(ad[r & 1][1][q], ars1, v1, q * KC * 4);
     };
     // start values of unit (j, st_l0, r) beyond the bias: gathered rows + narrow input blocks, into the hand-over buffer
     auto presum = [&](auto rc, int j) __attribute__((always_inline)) {
@@ -603,31 +657,31 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
         rt_info(j, r, row0, n);
         f32x4 x[4];
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) x[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q) x[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (n_add > 0) {
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) { x[gq] = ad[r & 1][0][gq]; if (n_add > 1) x[gq] += ad[r & 1][1][gq]; }
+            for (int q = 0; q < 4; ++q) { x[q] = ad[r & 1][0][q]; if (n_add > 1) x[q] += ad[r & 1][1][q]; }
         }
         // narrow input blocks: x[row, k] * W1^T[k, :] in fp32 on the vector ALUs
         int base = 0;
-        const int gr = row0 + (i < n ? i : n - 1);
+        const int gr = row0 + (prow < n ? prow : n - 1);
         for (int a = 0; a < P.n_nar; ++a) {
             const float *xr = P.nar[a].ptr + (long long)gr * P.nar[a].ld;
             for (int kk = 0; kk < P.nar[a].width; ++kk) {
                 const float xv = xr[kk];
-                const float *wn = sNarW + (base + kk) * NP + fbase;
+                const float *wn = sNarW + (base + kk) * NP + c4;
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wn + 8 * gq);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wn + q * KC);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[gq][e] = fmaf(xv, w4[e], x[gq][e]);
+                    for (int e = 0; e < 4; ++e) x[q][e] = fmaf(xv, w4[e], x[q][e]);
                 }
             }
             base += P.nar[a].width;
         }
-        unsigned char *d = sHO + (r & 1) * HOB + (ct * 4 * 64 + lane_v) * 16;
+        unsigned char *d = sHO + (r & 1) * HOB + prow * HOROW + c4 * 4;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<f32x4 *>(d + gq * 1024) = x[gq];
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4 *>(d + q * KC * 4) = x[q];
     };
 
     // ---- two intervals after the last layer of row tile r of tile fj (the matrix waves have normalised and stored its rows in the
@@ -641,8 +695,9 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
         if (AGG) {
             // every helper wave adds up its 32 columns of the row tile's segments in row order (= g4c_segment_reduce):
             // lane -> (feature quad lane & 7, one of 8 segments at a time)
-            const int fu = u_begin + 4 * fj + r;
-            const int s0 = P.tile_seg[fu], s1 = P.tile_seg[fu + 1];
+            const int ful = 4 * fj + r, fu = u_begin + ful;
+            const int s0 = ful < TRC ? __builtin_amdgcn_readfirstlane(sTR[TRC + 1 + ful]) : P.tile_seg[fu];
+            const int s1 = ful < TRC ? __builtin_amdgcn_readfirstlane(sTR[TRC + 2 + ful]) : P.tile_seg[fu + 1];
             const int fq = lane_v & 7;
             const unsigned char *rb = lds + r * RTB + 4 * (32 * ct + 4 * fq);
             for (int sg = s0 + (lane_v >> 3); sg < s1; sg += 8) {
@@ -721,8 +776,8 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
                 PX_STAMP();
                 remat();
                 PX_SUB(0);
-                // ---------------------------------------------------------------- the previous unit
-                {
+                // ---------------------------------------------------------------- the previous unit (more layer-0 blocks to park, heads to store)
+                if constexpr (MULTI || HEADS) {
                     constexpr int ur = (r + 3) & 3;
                     const std::integral_constant<int, ur> urc{};
                     const int uj = (r == 0) ? pj : j, ust = (r == 0) ? pst : st;
@@ -763,6 +818,9 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
                 __builtin_amdgcn_sched_barrier(0);
                 PX_SUB(2);
                 // ---------------------------------------------------------------- gathers for the unit three ahead
+                // (loads are issued UNCONDITIONALLY, with a selected address: measured alternatives — the same loads under the
+                // condition, their registers declared dead first — save ~1000 cycles in the light intervals but make hipcc wait
+                // for ALL requests in flight wherever a loaded register is consumed, which costs more in the heavy ones)
                 if (n_add > 0) {
                     constexpr int gr = (r + 3) & 3;
                     const int gj = (r == 0) ? j : nj, gst = (r == 0) ? st : nst;
@@ -792,6 +850,7 @@ __global__ __launch_bounds__(512) void mlp_px6_kernel(const Params p) {
             interval(std::integral_constant<int, 3>{});
         }
     }
+#undef PX_PICK
 #undef P
 }
 
@@ -825,6 +884,11 @@ bool px6_eligible(const Params &p, bool agg, bool save, bool all_vec) {
     // the last layer's epilogue runs in the matrix waves: whole 128-wide rows through 16-byte buffer stores, LayerNorm over 128
     if (p.n_out != NP || p.resid || p.out_idx || (p.act != G4C_ACT_NONE && p.act != G4C_ACT_SELU)) return false;
     if (p.out && ((p.out_ld & 3) || ((uintptr_t)p.out & 15) || (long long)p.out_ld * 4 * 32 >= (1LL << 31))) return false;
+    // the helpers' gathers use 32-bit byte offsets from the tensors' bases
+    long long ldmax = 0;
+    for (int s = 0; s < p.n_src; ++s) ldmax = p.src[s].ld > ldmax ? p.src[s].ld : ldmax;
+    for (int a = 0; a < p.n_add; ++a) ldmax = p.add[a].ld > ldmax ? p.add[a].ld : ldmax;
+    if (p.M * ldmax * 4 >= (1LL << 31)) return false;
     return true;
 }
 

@@ -50,4 +50,4 @@ for k in range(1, 40):
     def d(q):
         v = int(s_[q] - b)
         return f"{v:6d}" if 0 <= v < 100000 else "     -"
-    print(f"  interval {k:3d}: " + "  ".join(d(q) for q in (0, 1, 2, 3, 4)) + f"   end {int(e - b):6d}")
+    print(f"  interval {k:3d}: " + "  ".join(d(q) for q in (0, 1, 2, 5, 3, 4)) + f"   end {int(e - b):6d}")
