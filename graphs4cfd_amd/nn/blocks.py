@@ -279,7 +279,7 @@ def edgeScalarToNodeVector(edge_attr: Tensor, edge_index: Tensor, edgeUnitVector
 
 # ------------------------------------------------------------------------------------- MP
 # G4C_COMPACT_MESSAGES=1 (opt-in, rounded-bf16 mode only): EdgeMP's message rows are stored as bf16.  Measured on REMuS-GNN, 100k nodes:
-# 63.5 -> 67.4 steps/s; deviation from the fp32 oracle at 20k nodes: mean unchanged (3.2e-3), max 3.6e-2 -> 6.5e-2 — outside the
+# 63.5 -> 67.4 steps/s; deviation from the fp32 reference forward at 20k nodes: mean unchanged (3.2e-3), max 3.6e-2 -> 6.5e-2 — outside the
 # margin the parity test of that mode allows, hence off by default.
 COMPACT_MESSAGES = __import__("os").environ.get("G4C_COMPACT_MESSAGES", "0") == "1"
 
