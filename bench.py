@@ -326,7 +326,7 @@ def partition_check(args, runner, model, graph_cpu, dev, rank, world, Rollout):
         single = Rollout(model, graph_cpu.clone().to(dev), 2, capture=False)
         single.run(2)
         torch.cuda.synchronize(dev)
-        diff = (full[:, : 2 * nf] - single.outputs[:, : 2 * nf]).abs().max().item()
+        diff = (full[:, : 2 * nf] - single.result()[:, : 2 * nf]).abs().max().item()
         out["max_abs_diff_vs_single_rank"] = diff
         out["ok"] = bool(diff <= out["tol"])
         single.close()

@@ -292,7 +292,7 @@ class GNN(nn.Module):
                 capture = n_out >= 4 and os.environ.get("G4C_HIPGRAPH", "1") != "0"
             with Rollout(self, graph, n_out, capture=capture) as ro:
                 ro.run(n_out)
-                return ro.outputs
+                return ro.result()
 
     def invalidate_packed(self) -> None:
         """Declare every packed weight image stale (they are rebuilt on the next launch).  The images are keyed on the parameters'
@@ -341,6 +341,9 @@ class GNN(nn.Module):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
 
 
+REORDER_MIN_NODES = 50_000      # below, the gathered rows stay in L2 whatever the numbering
+
+
 class Rollout:
     """Device-resident autoregressive rollout state for one (model, Graph) pair (GNN.solve,
     nn/model.py:303-321).
@@ -351,8 +354,19 @@ class Rollout:
     every later step is a replay: no host synchronisation, no per-kernel launch cost.
     The caller's `graph.field` is swapped for a private working copy and restored on close()."""
 
-    def __init__(self, model: "GNN", graph: Graph, max_steps: int, capture: bool = True):
+    def __init__(self, model: "GNN", graph: Graph, max_steps: int, capture: bool = True, reorder: Optional[bool] = None):
+        """`reorder` (default: meshes of >= REORDER_MIN_NODES nodes, unless G4C_REORDER=0): run on a copy of the Graph whose level-1
+        nodes are numbered along a Morton curve (reorder.py: the senders an edge tile gathers are then rows its neighbours
+        just touched) and map the output rows back in `result()`; Graph layouts the renumbering does not know run as they are."""
         _lib.require_hip(graph.field)
+        self._caller_graph, self._perm = graph, None
+        if reorder is None:
+            reorder = graph.num_nodes >= REORDER_MIN_NODES and os.environ.get("G4C_REORDER", "1") != "0"
+        if reorder:
+            from ..reorder import reorder_nodes
+            re = reorder_nodes(graph)
+            if re is not None:
+                graph, self._perm = re
         self.model, self.graph, self.capture = model, graph, capture
         self.nf = int(model.num_fields)
         self.max_steps = int(max_steps)
@@ -399,6 +413,14 @@ class Rollout:
         self.steps_done = 1 if self.steps_done > 0 else 0
         if self.steps_done:   # slot 0 is kept so that replays continue from slot 1
             self.step_counter.fill_(1)
+
+    def result(self) -> torch.Tensor:
+        """`outputs` with its rows in the caller's node numbering."""
+        if self._perm is None:
+            return self.outputs
+        out = torch.empty_like(self.outputs)
+        out[self._perm] = self.outputs
+        return out
 
     def close(self) -> None:
         self.graph.field = self._orig_field

@@ -515,6 +515,7 @@ class DistributedRollout:
         self.model, self.rank, self.world, self.device = model, rank, world, device
         program = model._PROGRAM
         self.n_global = int(graph_cpu.pos.size(0))
+        self._perm = None
         self.nf = int(model.num_fields)
         if hasattr(model, "_ENCODERS"):          # REMuS-GNN: latents on edges / angles, edge-latent halo (partition_remus.py)
             from . import partition_remus as PR
@@ -522,6 +523,13 @@ class DistributedRollout:
             self.mesh = PR.RemusLocalMesh(graph_cpu, parts[rank], device, rank, world)
             self.fwd = PR.RemusPartitionedForward(program, self.mesh, PR.RemusHipImpl(model, self.mesh), HaloExchanger(self.mesh, group))
         else:
+            # level-1 nodes numbered along a Morton curve first (reorder.py): a part's local numbering is its owned nodes in
+            # ascending global order, so it inherits the locality; gather_outputs maps the rows back
+            if self.n_global >= 50_000 and os.environ.get("G4C_REORDER", "1") != "0":
+                from .reorder import reorder_nodes
+                re = reorder_nodes(graph_cpu)
+                if re is not None:
+                    graph_cpu, self._perm = re[0], re[1].to(device)
             levels = 1 + sum(1 for n in program if n.startswith("down_mp"))
             parts = build_partition(graph_cpu, levels, world)
             self.mesh = LocalMesh(graph_cpu, levels, parts[rank], device, rank, world)
@@ -600,4 +608,8 @@ class DistributedRollout:
         full[self.mesh.owned_global[0]] = self.outputs
         if self.world > 1:
             dist.all_reduce(full)
+        if self._perm is not None:        # rows back in the caller's numbering
+            out = torch.empty_like(full)
+            out[self._perm] = full
+            return out
         return full

@@ -555,6 +555,26 @@ def test_rollouts_eager_and_hipgraph(golden):
         model.solve(g, 0)
 
 
+def test_rollout_on_the_renumbered_mesh(golden):
+    """Rollout(reorder=True) (the default from 50k nodes): same result rows, in the caller's numbering, up to the summation order
+    inside clusters / coarse edges; captured == eager; the caller's Graph is untouched."""
+    from graphs4cfd_amd.nn.model import Rollout
+    g = S.mus_graph(5000, levels=3, seed=61).to(DEV)
+    torch.manual_seed(62)
+    model = gfd.nn.NsThreeScaleGNN(arch=S.mus_arch("NsThreeScaleGNN", 128), device=DEV)
+    g.batch = torch.zeros(g.num_nodes, dtype=torch.long, device=DEV)
+    field0, ei0 = g.field.clone(), g.edge_index.clone()
+    outs = {}
+    for reorder, capture in ((False, False), (True, False), (True, True)):
+        with Rollout(model, g, 6, capture=capture, reorder=reorder) as ro:
+            ro.run(6)
+            assert (ro._perm is not None) == reorder
+            outs[(reorder, capture)] = ro.result().clone()
+    torch.testing.assert_close(outs[(True, False)], outs[(False, False)], rtol=1e-4, atol=1e-4)
+    assert torch.equal(outs[(True, True)], outs[(True, False)])
+    assert torch.equal(g.field, field0) and torch.equal(g.edge_index, ei0)
+
+
 def test_reference_checkpoint_loads_and_runs(golden):
     import os
     c = golden("checkpoint_io.pt")

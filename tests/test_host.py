@@ -189,3 +189,32 @@ def test_invalidate_packed_bumps_the_weights_epoch():
     model.float()
     assert e0 < e1 < e2 < ops.weights_epoch()
     assert not hasattr(model, "_require_inference")
+
+
+def test_locality_renumbering_keeps_the_mesh():
+    """reorder.reorder_nodes: a permutation of the level-1 nodes along a Morton curve; same edges, grouped by the new target with the
+    per-target order kept; level-2 maps carried along; layouts it does not know are left alone."""
+    from graphs4cfd_amd.reorder import reorder_nodes
+    g = S.mus_graph(3000, levels=3, seed=5)
+    g2, perm = reorder_nodes(g)
+    n = 3000
+    assert sorted(perm.tolist()) == list(range(n))
+    assert torch.equal(g2.pos, g.pos[perm]) and torch.equal(g2.field, g.field[perm]) and torch.equal(g2.idx1_to_idx2, g.idx1_to_idx2[perm])
+    assert torch.equal(g2.e_12, g.e_12[perm]) and g2.pos_2 is g.pos_2 and g2.idx2_to_idx3 is g.idx2_to_idx3
+    col = g2.edge_index[1]
+    assert bool((col[1:] >= col[:-1]).all()), "edges grouped by the new target"
+    old_edges = set(map(tuple, g.edge_index.t().tolist()))
+    new_edges = set((int(perm[r]), int(perm[c])) for r, c in g2.edge_index.t().tolist())
+    assert old_edges == new_edges
+    # per target: the same senders in the same order, with the same attributes
+    for tgt_new in (0, 17, n - 1):
+        tgt_old = int(perm[tgt_new])
+        a = g.edge_index[0][g.edge_index[1] == tgt_old]
+        b = perm[g2.edge_index[0][g2.edge_index[1] == tgt_new]]
+        assert torch.equal(a, b)
+        torch.testing.assert_close(g2.edge_attr[g2.edge_index[1] == tgt_new], g.edge_attr[g.edge_index[1] == tgt_old])
+    # neighbours get nearby numbers: mean |row - col| far below a random numbering's n / 3
+    assert float((g2.edge_index[0] - g2.edge_index[1]).abs().float().mean()) < 0.1 * float((g.edge_index[0] - g.edge_index[1]).abs().float().mean())
+    assert reorder_nodes(S.remus_graph(300, k=5, seed=1)) is None
+    g.extra = torch.zeros(7)
+    assert reorder_nodes(g) is None
