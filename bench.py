@@ -442,6 +442,9 @@ def main():
                        "edge-latent halo exchange per EdgeMP layer (RCCL)" if remus else "halo exchange per MP layer (RCCL)"))},
         "outputs_finite": finite,
     }
+    if getattr(runner, "_perm", None) is not None:
+        result["config"]["node_numbering"] = ("level-1 nodes renumbered along a Morton curve for the rollout (graphs4cfd_amd/reorder.py: same mesh, "
+                                              "output rows mapped back; G4C_REORDER=0 runs the mesh as numbered, -0.6 % steps/s)")
     # BASELINE.json's second figure: average over the step's MP layers of all levels (pool / unpool / encoders included)
     result["ms_per_mp_layer"] = result["ms_per_step"] / n_mp
     if check is not None:
