@@ -1,0 +1,434 @@
+// Dual-tile, software-pipelined form of the fused bf16x6 MLP ("bx6i") for the MP layers' message launch: the same arithmetic
+// as mlp_bx6_kernel (mlp_fused.hip) — gather -> [SELU on load] -> Linear/SELU chain on v_mfma_f32_32x32x16_bf16 with the exact
+// three-way operand split -> LayerNorm -> activation -> store (-> per-target aggregation) — replacing MLP.forward
+// (graphs4cfd/nn/blocks.py:117-144) with the torch.cat / index ops in front of it (nn/blocks.py:181,328) and, with AGG, the
+// scatter(e', col, reduce) behind it (nn/blocks.py:183,330).
+//
+// What is different: a workgroup (4 waves, one 32-column tile each, as in mlp_bx6_kernel) owns TWO 32-row tiles A and B and
+// alternates between them layer by layer:  M(A,0) M(B,0) M(A,1) M(B,1) ...  While a wave issues the MFMAs of one tile's
+// layer, the vector ALUs of the SAME wave work on the other tile: parking B's input rows under M(A,0), the hidden-layer
+// epilogue (bias is the accumulator's start value; SELU, exact split, planes) of B's layer l-1 under M(A,l), of A's layer l
+// under M(B,l), the last layer's fp32 rows under the other tile's last M phase.  In mlp_bx6_kernel a wave is either in an
+// MFMA phase or in a vector phase and relies on the other three waves of its SIMD to fill the pipe it leaves idle (measured:
+// matrix pipe 44 %, vector ALUs 38 % busy); here every wave keeps both busy, at three waves per SIMD.
+// (px6 showed the mechanism — sched_group_barrier interleaving of an epilogue with the next unit's MFMAs — at 2500-2900
+// cycles per 48-MFMA unit including its epilogue; this kernel keeps the tile kernel's streamed weights and occupancy.)
+//
+// Envelope (everything else runs mlp_bx6_kernel): exact-split mode, ONE weighted 128-wide 16-byte aligned input block (rows direct
+// or through an index, optional SELU on load), 0 or 2 additive 128-wide blocks, no narrow blocks, 2..4 layers, 128-wide output
+// rows without residual / output index / heads.
+#include "mlp_common.h"
+#include <cstdlib>
+using namespace g4cm;
+
+#ifdef G4C_BX6I_TIMING
+__device__ unsigned long long g4c_bx6i_stamps[256 * 32];
+extern "C" int g4c_bx6i_read_stamps(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4c_bx6i_stamps), sizeof(unsigned long long) * n);
+}
+#define BI_STAMP(k) do { if (pair < 256 && tid == 0) g4c_bx6i_stamps[pair * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BI_STAMP(k) do {} while (0)
+#endif
+
+namespace {
+
+constexpr int PLN = 32 * HB;                 // bf16 elements of one operand plane of a tile [32][136]
+constexpr int TILE_BF16 = 3 * PLN;           // one tile: three planes (the fp32 final rows [32][132] alias them)
+
+__device__ __forceinline__ f32x2 selu2i(f32x2 x) {
+    const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f;
+    const float scale = 1.0507009873554804934193349852946f;
+    f32x2 t, m;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { m[e] = fmaxf(x[e], 0.f); t[e] = fminf(x[e], 0.f); }
+    t = t * 1.4426950408889634f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) t[e] = __builtin_amdgcn_exp2f(t[e]);
+    return m * scale + (t * sa - sa);
+}
+
+// exact three-way split of a pair -> one packed pair per plane (planes PLN elements apart)
+__device__ __forceinline__ void put_pair(__bf16 *d, f32x2 y) {
+    f32x2 hf, mf, lf;
+    const unsigned hu = pack_bf16(y, hf);
+    const f32x2 r1 = y - hf;
+    const unsigned mu = pack_bf16(r1, mf);
+    const f32x2 r2 = r1 - mf;
+    const unsigned lu = pack_bf16(r2, lf);
+    *reinterpret_cast<unsigned *>(d) = hu;
+    *reinterpret_cast<unsigned *>(d + PLN) = mu;
+    *reinterpret_cast<unsigned *>(d + 2 * PLN) = lu;
+}
+
+// What the vector ALUs do for the OTHER tile while this tile's MFMAs issue, one slice per 16-k step (s = 0..7):
+//   EK 0 nothing;  1 hidden-layer epilogue of accE (pair s);  2 park chunk s/2 of the gathered input rows xe (odd s);
+//   3 last layer: fp32 rows of accE into the tile's final buffer (quad s/2, odd s)
+struct Other {
+    __bf16 *plane_acc;        // EK 1: this lane's element (row i, feature fbase) of the other tile's planes
+    __bf16 *plane_park;       // EK 2: (row grow_l, column c4)
+    float *fin;               // EK 3: (row i, feature fbase) of the other tile's fp32 rows
+    bool park_act;            // EK 2: SELU pending on the stored rows
+};
+
+template <int EK>
+__device__ __forceinline__ void other_slice(int s, const f32x16 &accE, const f32x4 (&xe)[4], const Other &o) {
+    if (EK == 1) {
+        const int gq = s >> 1, pr = s & 1;
+        f32x2 x;
+        x[0] = accE[4 * gq + 2 * pr]; x[1] = accE[4 * gq + 2 * pr + 1];
+        put_pair(o.plane_acc + 8 * gq + 2 * pr, selu2i(x));
+    } else if (EK == 2) {
+        if (s & 1) {
+            const int q = s >> 1;
+            f32x4 v = xe[q];
+            if (o.park_act) v = selu4(v);
+            bf16x4 vh, vm, vl;
+            split3x4<3>(v, vh, vm, vl);
+            __bf16 *d = o.plane_park + q * KC;
+            *reinterpret_cast<bf16x4 *>(d) = vh;
+            *reinterpret_cast<bf16x4 *>(d + PLN) = vm;
+            *reinterpret_cast<bf16x4 *>(d + 2 * PLN) = vl;
+        }
+    } else if (EK == 3) {
+        if (s & 1) {
+            const int gq = s >> 1;
+            f32x4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = accE[4 * gq + e];
+            *reinterpret_cast<f32x4 *>(o.fin + 8 * gq) = x;
+        }
+    }
+}
+
+// One 128-k block for one tile: acc += W(block) x planes.  The wave's 32-column slice of the layer's weights is STATIONARY in
+// registers for the two tiles of the pair (W[step][plane], 96 VGPRs: one fetch serves 64 rows, half the L1 -> register traffic of
+// mlp_bx6_kernel); REFILL (the second tile's phase): step s's fragments are replaced by the next layer's right after their last
+// use.  The phases of a pair are straight-line code (three layers, unrolled), so every refill is a plain redefinition.
+template <int EK, bool REFILL>
+__device__ __forceinline__ void m_block(const __bf16 *pa, bf16x8 (&W)[8][3], __amdgpu_buffer_rsrc_t rs, unsigned lo_b, unsigned wnext,
+                                        f32x16 &acc, const f32x16 &accE, const f32x4 (&xe)[4], const Other &o) {
+    bf16x8 cur[3], nx[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) cur[pl] = *reinterpret_cast<const bf16x8 *>(pa + pl * PLN);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s < 7) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) nx[pl] = *reinterpret_cast<const bf16x8 *>(pa + pl * PLN + 16 * (s + 1));
+        }
+        if (!EK) __builtin_amdgcn_sched_barrier(0);
+        other_slice<EK>(s, accE, xe, o);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], cur[2], acc, 0, 0, 0);     // small terms first (as mlp_bx6_kernel)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][2], cur[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][1], cur[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], cur[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][1], cur[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], cur[0], acc, 0, 0, 0);
+        if (EK) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                  // DS read
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);              // VALU
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);                  // DS write
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (REFILL) {
+            const unsigned so = wnext + 2u * s * STEP6;
+            W[s][0] = ldw(rs, lo_b, so);
+            W[s][1] = ldw(rs, lo_b + 1024u, so);
+            W[s][2] = ldw(rs, lo_b + 2048u, so);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (s < 7) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) cur[pl] = nx[pl];
+        }
+    }
+}
+
+template <bool AGG>
+__global__ __launch_bounds__(256, 2) void mlp_bx6i_kernel(const Params p) {
+    // two tiles' operand planes + gather indices: 52 992 B; 96 stationary weight registers -> two workgroups per CU
+    __shared__ __attribute__((aligned(16))) __bf16 sB[2 * TILE_BF16];
+    __shared__ int sIdx[2][3][32];          // [tile][weighted block, additive 0, additive 1][row]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int fbase = wave * 32 + 4 * h;
+    const int grow_l = (lane >> 3) + 8 * wave, c4 = (lane & 7) * 4;
+
+    // pair of tiles of this workgroup (XCD-aware order: each XCD gets a contiguous range of pairs)
+    const int n_pairs = (p.n_tiles + 1) >> 1;
+    int pair;
+    {
+        const int b = blockIdx.x, q = n_pairs >> 3, r = n_pairs & 7, x = b & 7, j = b >> 3;
+        pair = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    int row0[2], nrow[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int tile = 2 * pair + t;
+        if (tile >= p.n_tiles) { row0[t] = 0; nrow[t] = 0; }
+        else if (AGG) { row0[t] = p.tile_rows[tile]; nrow[t] = p.tile_rows[tile + 1] - row0[t]; }
+        else { row0[t] = (int)p.row_base + tile * 32; const int lim = (int)p.M - row0[t]; nrow[t] = lim < 32 ? lim : 32; }
+    }
+    BI_STAMP(0);
+    if (nrow[1] == 0) row0[1] = row0[0];        // (odd tile count: the second tile recomputes the first tile's rows and stores nothing)
+
+    // ---- gather indices of both tiles (rows past a tile's end are clamped copies of its last row: never stored)
+    if (tid < 192) {
+        const int t = tid / 96, k = (tid % 96) >> 5, r = tid & 31;
+        const int nn = nrow[t] > 0 ? nrow[t] : nrow[0];
+        const int gr = row0[t] + (r < nn ? r : nn - 1);
+        const int *ix = (k == 0) ? p.src[0].idx : ((k - 1 < p.n_add) ? p.add[k - 1].idx : nullptr);
+        sIdx[t][k][r] = ix ? ix[gr] : gr;
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, 0x7fffffff, 0x00020000);
+    const unsigned lo_b = 2u * (unsigned)(wave * 8 * STEP6 + lane * 8);
+    bf16x8 W[8][3];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        W[s][0] = ldw(rs, lo_b, 2u * s * STEP6);
+        W[s][1] = ldw(rs, lo_b + 1024u, 2u * s * STEP6);
+        W[s][2] = ldw(rs, lo_b + 2048u, 2u * s * STEP6);
+    }
+    __syncthreads();
+    BI_STAMP(1);
+
+    // ---- input rows of both tiles (park layout), additive rows of both (accumulator layout) + first bias: the start values
+    f32x4 xA[4], xB[4];
+    {
+        const float *ra = p.src[0].ptr + (long long)sIdx[0][0][grow_l] * p.src[0].ld + p.src[0].col0 + c4;
+        const float *rb = p.src[0].ptr + (long long)sIdx[1][0][grow_l] * p.src[0].ld + p.src[0].col0 + c4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { xA[q] = *reinterpret_cast<const f32x4 *>(ra + q * KC); xB[q] = *reinterpret_cast<const f32x4 *>(rb + q * KC); }
+    }
+    f32x16 accA, accB;
+    {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(p.b + fbase + 8 * gq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { accA[4 * gq + e] = b4[e]; accB[4 * gq + e] = b4[e]; }
+        }
+        if (p.n_add == 2) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float *p0 = p.add[0].ptr + (long long)sIdx[t][1][i] * p.add[0].ld + fbase;
+                const float *p1 = p.add[1].ptr + (long long)sIdx[t][2][i] * p.add[1].ld + fbase;
+                f32x4 a0[4], a1[4];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) { a0[gq] = *reinterpret_cast<const f32x4 *>(p0 + 8 * gq); a1[gq] = *reinterpret_cast<const f32x4 *>(p1 + 8 * gq); }
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (t == 0) accA[4 * gq + e] = (accA[4 * gq + e] + a0[gq][e]) + a1[gq][e];
+                        else accB[4 * gq + e] = (accB[4 * gq + e] + a0[gq][e]) + a1[gq][e];
+                    }
+            }
+        }
+    }
+    BI_STAMP(2);
+    const bool pact = p.src[0].pre_act != 0;
+    __bf16 *const sA = sB, *const sBt = sB + TILE_BF16;
+    // park tile A (not overlapped: nothing to multiply yet)
+    {
+        __bf16 *d = sA + grow_l * HB + c4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = xA[q];
+            if (pact) v = selu4(v);
+            bf16x4 vh, vm, vl;
+            split3x4<3>(v, vh, vm, vl);
+            *reinterpret_cast<bf16x4 *>(d + q * KC) = vh;
+            *reinterpret_cast<bf16x4 *>(d + PLN + q * KC) = vm;
+            *reinterpret_cast<bf16x4 *>(d + 2 * PLN + q * KC) = vl;
+        }
+    }
+    __syncthreads();
+    BI_STAMP(3);
+
+    Other oA, oB;       // what to do FOR tile A / FOR tile B while the other multiplies
+    oA.plane_acc = sA + i * HB + fbase;   oA.plane_park = sA + grow_l * HB + c4;   oA.fin = reinterpret_cast<float *>(sA) + i * HS + fbase;   oA.park_act = pact;
+    oB.plane_acc = sBt + i * HB + fbase;  oB.plane_park = sBt + grow_l * HB + c4;  oB.fin = reinterpret_cast<float *>(sBt) + i * HS + fbase;  oB.park_act = pact;
+    const __bf16 *paA = sA + i * HB + 8 * h, *paB = sBt + i * HB + 8 * h;
+    const int L = p.n_layers;
+    auto bias_init = [&](f32x16 &acc, int l) __attribute__((always_inline)) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(p.b + l * NP + fbase + 8 * gq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * gq + e] = b4[e];
+        }
+    };
+
+    (void)L;                                    // (the launcher admits three-layer MLPs only: the phases below are unrolled)
+    constexpr unsigned WB = 2u * BLOCK6;        // bytes of one layer's block of the stream
+    // layer 0
+    m_block<2, false>(paA, W, rs, lo_b, 0u, accA, accB, xB, oB);             // for B: park
+    BI_STAMP(4);
+    __syncthreads();
+    BI_STAMP(5);
+    m_block<1, true>(paB, W, rs, lo_b, WB, accB, accA, xB, oA);               // for A: epilogue of layer 0; refill with layer 1
+    bias_init(accA, 1);
+    BI_STAMP(6);
+    __syncthreads();
+    BI_STAMP(7);
+    // layer 1
+    m_block<1, false>(paA, W, rs, lo_b, 0u, accA, accB, xB, oB);             // for B: epilogue of layer 0
+    bias_init(accB, 1);
+    BI_STAMP(8);
+    __syncthreads();
+    BI_STAMP(9);
+    m_block<1, true>(paB, W, rs, lo_b, 2u * WB, accB, accA, xB, oA);          // for A: epilogue of layer 1; refill with layer 2
+    bias_init(accA, 2);
+    BI_STAMP(10);
+    __syncthreads();
+    BI_STAMP(11);
+    // layer 2
+    m_block<1, false>(paA, W, rs, lo_b, 0u, accA, accB, xB, oB);             // for B: epilogue of layer 1
+    bias_init(accB, 2);
+    BI_STAMP(12);
+    __syncthreads();
+    BI_STAMP(13);
+    m_block<3, false>(paB, W, rs, lo_b, 0u, accB, accA, xB, oA);             // for A: last layer's fp32 rows
+    BI_STAMP(14);
+    __syncthreads();
+    BI_STAMP(15);
+    // ---- B's last layer -> fp32 rows; then LayerNorm / activation / stores of both tiles, rows split over the waves
+    {
+        float *fb = oB.fin;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            f32x4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = accB[4 * gq + e];
+            *reinterpret_cast<f32x4 *>(fb + 8 * gq) = x;
+        }
+    }
+    __syncthreads();
+    BI_STAMP(20);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float *sH = reinterpret_cast<float *>(t == 0 ? sA : sBt);
+        // wave w owns rows [8 w, 8 w + 8): lane = part * 8 + row_local, each part = 16 consecutive columns
+        const int rloc = lane & 7, part = lane >> 3, myrow = wave * 8 + rloc, cb = part * 16;
+        float *rowp = sH + myrow * HS + cb;
+        float x[16];
+#pragma unroll
+        for (int c = 0; c < 16; c += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + c);
+            x[c] = v[0]; x[c + 1] = v[1]; x[c + 2] = v[2]; x[c + 3] = v[3];
+        }
+        if (p.gamma) {
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) sum += x[c];
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum * (1.0f / NP);
+            float var = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { const float dl = x[c] - mean; var += dl * dl; }
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) var += __shfl_xor(var, o);
+            const float rstd = rsqrtf(var * (1.0f / NP) + p.eps);
+#pragma unroll
+            for (int c = 0; c < 16; c += 4) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4 *>(p.gamma + cb + c), b4 = *reinterpret_cast<const f32x4 *>(p.beta + cb + c);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[c + u] = fmaf((x[c + u] - mean) * rstd, g4[u], b4[u]);
+            }
+        }
+        if (p.act == G4C_ACT_SELU) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = g4c::selu_f(x[c]);
+        } else if (p.act == G4C_ACT_TANH) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = g4c::tanh_f(x[c]);
+        }
+        if (AGG) {
+#pragma unroll
+            for (int c = 0; c < 16; c += 4) {
+                f32x4 v;
+                v[0] = x[c]; v[1] = x[c + 1]; v[2] = x[c + 2]; v[3] = x[c + 3];
+                *reinterpret_cast<f32x4 *>(rowp + c) = v;
+            }
+        }
+        if (p.out && myrow < nrow[t]) {
+            float *op = p.out + (long long)(row0[t] + myrow) * p.out_ld + cb;
+#pragma unroll
+            for (int c = 0; c < 16; c += 4) {
+                f32x4 v;
+                v[0] = x[c]; v[1] = x[c + 1]; v[2] = x[c + 2]; v[3] = x[c + 3];
+                *reinterpret_cast<f32x4 *>(op + c) = v;
+            }
+        }
+    }
+    BI_STAMP(21);
+    if (AGG) {
+        // aggregation of the targets whose messages the tiles hold (rows in CSR order): same summation order and the same mean
+        // formula as segment_reduce_kernel, so the result is bit-identical to the separate launch
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (nrow[t] == 0) continue;
+            const float *sH = reinterpret_cast<const float *>(t == 0 ? sA : sBt);
+            const int tile = 2 * pair + t;
+            const int s0 = p.tile_seg[tile], s1 = p.tile_seg[tile + 1];
+            const int col = tid & (NP - 1);
+            for (int sg = s0 + (tid >> 7); sg < s1; sg += 2) {
+                const int b = p.seg_off[sg] - row0[t], e = p.seg_off[sg + 1] - row0[t];
+                float a = 0.f;
+                for (int r = b; r < e; ++r) a += sH[r * HS + col];
+                if (p.agg_mean) a /= (float)((e - b) > 1 ? (e - b) : 1);
+                p.agg[(long long)sg * p.agg_ld + col] = a;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+namespace g4cm {
+
+static int g_bx6i = -1;
+int bx6i_enable(int on) {
+    if (g_bx6i < 0) g_bx6i = getenv("G4C_BX6I") ? atoi(getenv("G4C_BX6I")) : 0;
+    const int old = g_bx6i;
+    if (on >= 0) g_bx6i = on ? 1 : 0;
+    return old;
+}
+
+bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save) {
+    if (!bx6i_enable(-1) || round1 || save) return false;
+    if (p.n_src != 1 || p.n_nar != 0 || (p.n_add != 0 && p.n_add != 2) || p.n_heads) return false;
+    if (p.n_layers != 3 || p.n_out != NP || p.resid || p.out_idx || p.out_bf16) return false;
+    const Src &s = p.src[0];
+    if (s.width != NP || !s.vec || s.seg_off || s.bf16) return false;
+    for (int a = 0; a < p.n_add; ++a)
+        if (p.add[a].width != NP || (p.add[a].ld & 3) || ((uintptr_t)p.add[a].ptr & 15)) return false;
+    if (p.out && ((p.out_ld & 3) || ((uintptr_t)p.out & 15))) return false;
+    if (p.gamma && (((uintptr_t)p.gamma & 15) || ((uintptr_t)p.beta & 15))) return false;
+    if (((uintptr_t)p.b & 15)) return false;
+    if (p.M >= (1LL << 31)) return false;
+    (void)agg;
+    return true;
+}
+
+int bx6i_launch(const Params &p, bool agg, hipStream_t st) {
+    const int n_pairs = (p.n_tiles + 1) / 2;
+    if (n_pairs == 0) return G4C_OK;
+    if (agg) mlp_bx6i_kernel<true><<<dim3(n_pairs), dim3(256), 0, st>>>(p);
+    else mlp_bx6i_kernel<false><<<dim3(n_pairs), dim3(256), 0, st>>>(p);
+    return g4c::check_launch("g4c_mlp_forward (bx6i)");
+}
+
+}  // namespace g4cm
+
+extern "C" int g4c_mlp_bx6i_enable(int on) { return g4cm::bx6i_enable(on); }

@@ -1,0 +1,96 @@
+"""bx6i (dual-tile software-pipelined kernel, mlp_bx6i.hip) against the 32-row-tile kernel: the MP layers' message launch (first
+layer hoisted: one weighted block + two gathered additive blocks; or without additive blocks), with and without the fused
+aggregation, odd sizes; then same-process A/B timing.  Usage: python scripts/bx6i_check.py [--time] [--rows N]"""
+import argparse, os, statistics, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphs4cfd_amd import _lib, ops, plan
+from graphs4cfd_amd.nn import blocks as B
+ap = argparse.ArgumentParser(); ap.add_argument("--time", action="store_true"); ap.add_argument("--rows", type=int, default=600000)
+a = ap.parse_args()
+torch.set_grad_enabled(False)
+lib = _lib.load()
+dev = torch.device("cuda", 0); H = 128
+torch.manual_seed(0)
+blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(dev)
+bad = []
+
+
+def both(fn):
+    lib.g4c_mlp_bx6i_enable(0); ref = fn()
+    lib.g4c_mlp_bx6i_enable(1)
+    try:
+        got = fn()
+    finally:
+        lib.g4c_mlp_bx6i_enable(0)
+    return ref, got
+
+
+def cmp(name, ref, got, tol):
+    d = (ref - got).abs().max().item() if ref.numel() else 0.0
+    ok = d <= tol and bool(torch.isfinite(got).all())
+    print(f"{'ok  ' if ok else 'FAIL'} {name:58s} max|bx6i - tile| = {d:.2e} (tol {tol:g})")
+    if not ok: bad.append(name)
+
+
+for rows in (600000, 100000, 6001, 999, 65, 64, 33, 32, 7, 1):
+    n = max(rows // 6, 2)
+    e, v = torch.randn(rows, H, device=dev), torch.randn(n, H, device=dev)
+    row = torch.randint(0, n, (rows,), device=dev, dtype=torch.int32)
+    col = (torch.arange(rows, device=dev) // 6).clamp(max=n - 1).to(torch.int32)
+    W1 = blk.edge_mlp.state_dict()["MLP.linear_1.weight"]
+    pr, pc = (v @ W1[:, H:2 * H].T).contiguous(), (v @ W1[:, 2 * H:].T).contiguous()
+    pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+    src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=row, additive=True), ops.Source(pc, index=col, additive=True)]
+    cmp(f"edge hoisted rows={rows}", *both(lambda: ops.mlp_forward(pk, src, rows)), 2e-5)
+    idx = torch.randint(0, rows, (rows,), device=dev, dtype=torch.int32)
+    cmp(f"one block through an index, SELU out rows={rows}", *both(lambda: ops.mlp_forward(pk, [ops.Source(e, index=idx)], rows, _lib.ACT_SELU)), 2e-5)
+for rows, ragged in ((600000, False), (19972, True), (116, True)):
+    n = rows // 6
+    if ragged:
+        deg = torch.randint(0, 10, (n,)); deg[0] = 0; deg[-1] = 0
+        colh = torch.arange(n).repeat_interleave(deg)
+    else:
+        colh = torch.arange(n).repeat_interleave(6)
+    E = int(colh.numel())
+    ei = torch.stack([torch.randint(0, n, (E,)), colh]).to(dev)
+    ep, csr = plan.edge_csr(ei, n)
+    e, v = torch.randn(E, H, device=dev), torch.randn(n, H, device=dev)
+    W1 = blk.edge_mlp.state_dict()["MLP.linear_1.weight"]
+    pr, pc = (v @ W1[:, H:2 * H].T).contiguous(), (v @ W1[:, 2 * H:].T).contiguous()
+    pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+    src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+    for mean in (True, False):
+        def run():
+            agg = torch.full((n, H), float("nan"), device=dev)
+            y = ops.mlp_forward(pk, src, E, agg=(csr, agg, mean))
+            return y, agg
+        (y0, a0), (y1, a1) = both(run)
+        cmp(f"fused agg rows={E} ragged={ragged} mean={mean}: e'", y0, y1, 2e-5)
+        cmp(f"fused agg rows={E} ragged={ragged} mean={mean}: agg == reduce(e') bit-exact", ops.segment_reduce(y1, csr, mean), a1, 0.0)
+print("all bx6i checks passed" if not bad else "FAILED: " + ", ".join(bad))
+if a.time:
+    rows = a.rows; n = rows // 6
+    e, v = torch.randn(rows, H, device=dev), torch.randn(n, H, device=dev)
+    colh = torch.arange(n).repeat_interleave(6)
+    ei = torch.stack([torch.randint(0, n, (rows,)), colh]).to(dev)
+    ep, csr = plan.edge_csr(ei, n)
+    pr, pc = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev)
+    pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+    src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+    out, agg = torch.empty(rows, H, device=dev), torch.empty(n, H, device=dev)
+    cases = {"edge(hoisted)": lambda: ops.mlp_forward(pk, src, rows, 0, out=out),
+             "edge(hoisted)+agg": lambda: ops.mlp_forward(pk, src, rows, 0, out=out, agg=(csr, agg, True))}
+    for cname, fn in cases.items():
+        times = {0: [], 1: []}
+        for on in (0, 1):
+            lib.g4c_mlp_bx6i_enable(on); fn(); fn()
+        torch.cuda.synchronize()
+        for r in range(15):
+            for on in (0, 1):
+                lib.g4c_mlp_bx6i_enable(on)
+                s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(); fn(); fn(); fn(); t.record(); torch.cuda.synchronize()
+                times[on].append(s.elapsed_time(t) / 3 * 1e3)
+        lib.g4c_mlp_bx6i_enable(0)
+        print(f"{cname:20s} tile kernel median {statistics.median(times[0]):8.1f} us (min {min(times[0]):8.1f})   bx6i median {statistics.median(times[1]):8.1f} us (min {min(times[1]):8.1f})")
