@@ -397,16 +397,21 @@ __global__ __launch_bounds__(256, 2) void mlp_bx6i_kernel(const Params p) {
 
 namespace g4cm {
 
+// 0 off, 1 (default; environment G4C_BX6I) launches of at least G4C_BX6I_MIN_ROWS rows (default 400 000: at two workgroups per CU
+// the kernel needs a full machine; measured crossover against mlp_bx6_kernel at ~300 k rows), 2 every launch it can take (tests)
 static int g_bx6i = -1;
 int bx6i_enable(int on) {
-    if (g_bx6i < 0) g_bx6i = getenv("G4C_BX6I") ? atoi(getenv("G4C_BX6I")) : 0;
+    if (g_bx6i < 0) g_bx6i = getenv("G4C_BX6I") ? atoi(getenv("G4C_BX6I")) : 1;
     const int old = g_bx6i;
-    if (on >= 0) g_bx6i = on ? 1 : 0;
+    if (on >= 0) g_bx6i = on > 2 ? 2 : on;
     return old;
 }
 
-bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save) {
-    if (!bx6i_enable(-1) || round1 || save) return false;
+bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, long long row_count) {
+    static const long long min_rows = getenv("G4C_BX6I_MIN_ROWS") ? atoll(getenv("G4C_BX6I_MIN_ROWS")) : 400000;
+    const int mode = bx6i_enable(-1);
+    if (!mode || round1 || save) return false;
+    if (mode == 1 && row_count < min_rows) return false;
     if (p.n_src != 1 || p.n_nar != 0 || (p.n_add != 0 && p.n_add != 2) || p.n_heads) return false;
     if (p.n_layers != 3 || p.n_out != NP || p.resid || p.out_idx || p.out_bf16) return false;
     const Src &s = p.src[0];

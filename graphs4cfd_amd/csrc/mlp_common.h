@@ -164,7 +164,7 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
 
 // dual-tile software-pipelined kernel (mlp_bx6i.hip)
 int bx6i_enable(int on);
-bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save);
+bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, long long row_count);
 int bx6i_launch(const Params &p, bool agg, hipStream_t st);
 
 // persistent ping-pong kernel (mlp_px6.hip)

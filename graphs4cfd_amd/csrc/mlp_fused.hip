@@ -1251,11 +1251,6 @@ extern "C" int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp, const g4c_src_t *srcs, 
 }
 
 // launches below this many rows keep the 32-row-tile kernel (G4C_PX6_MIN_ROWS; tuning)
-static int64_t bx6i_min_rows() {
-    static const int64_t v = getenv("G4C_BX6I_MIN_ROWS") ? atoll(getenv("G4C_BX6I_MIN_ROWS")) : 0;
-    return v;
-}
-
 static int64_t px6_min_rows() {
     static const int64_t v = getenv("G4C_PX6_MIN_ROWS") ? atoll(getenv("G4C_PX6_MIN_ROWS")) : 0;
     return v;
@@ -1411,7 +1406,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
         if (p.n_tiles == 0) return G4C_OK;
         return px6_launch(p, round1, agg != nullptr, st);
-    } else if (bx6 && !force_tiles && bx6i_eligible(p, round1, agg != nullptr, save != nullptr) && row_count >= bx6i_min_rows()) {
+    } else if (bx6 && !force_tiles && bx6i_eligible(p, round1, agg != nullptr, save != nullptr, row_count)) {
         // dual-tile software-pipelined kernel (mlp_bx6i.hip): pairs of 32-row tiles (whole segments with aggregation)
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
         return bx6i_launch(p, agg != nullptr, st);

@@ -184,10 +184,11 @@ int g4c_mlp_pack_layer_bx6(const float *W, int32_t n_out, int32_t k_in, const in
 int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
                         int64_t n_rows, float *out, int32_t out_ld, const int32_t *out_idx,
                         int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
-/* Switches the dual-tile software-pipelined form of the exact-split kernel (mlp_bx6i.hip: a workgroup alternates between two
- * 32-row tiles, the vector work of one running under the MFMAs of the other) on (1) / off (0) for the launches it can take
- * (one weighted 128-wide block + 0 or 2 additive blocks, 2..4 layers, plain 128-wide output); -1 only queries.  Returns the
- * previous setting.  Environment default: G4C_BX6I. */
+/* The dual-tile software-pipelined form of the exact-split kernel (mlp_bx6i.hip: a workgroup alternates between two 32-row tiles,
+ * the vector work of one running under the MFMAs of the other, the layer's weights stationary in registers for both) takes the
+ * launches of the MP layers' message MLP (one weighted 128-wide block + 0 or 2 additive blocks, three layers, plain 128-wide output
+ * rows, with or without the fused aggregation): 0 = never, 1 = launches of at least G4C_BX6I_MIN_ROWS rows (default 400 000; the
+ * default mode, environment G4C_BX6I), 2 = every launch it can take (tests); -1 only queries.  Returns the previous setting. */
 int g4c_mlp_bx6i_enable(int on);
 
 /* The bf16x6 / bf16 entry points run on one of two kernels with identical arithmetic per 128 x 128 block: the persistent

@@ -18,7 +18,7 @@ bad = []
 
 def both(fn):
     lib.g4c_mlp_bx6i_enable(0); ref = fn()
-    lib.g4c_mlp_bx6i_enable(1)
+    lib.g4c_mlp_bx6i_enable(2)
     try:
         got = fn()
     finally:
@@ -84,11 +84,11 @@ if a.time:
     for cname, fn in cases.items():
         times = {0: [], 1: []}
         for on in (0, 1):
-            lib.g4c_mlp_bx6i_enable(on); fn(); fn()
+            lib.g4c_mlp_bx6i_enable(2 * on); fn(); fn()
         torch.cuda.synchronize()
         for r in range(15):
             for on in (0, 1):
-                lib.g4c_mlp_bx6i_enable(on)
+                lib.g4c_mlp_bx6i_enable(2 * on)
                 s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record(); fn(); fn(); fn(); t.record(); torch.cuda.synchronize()
                 times[on].append(s.elapsed_time(t) / 3 * 1e3)

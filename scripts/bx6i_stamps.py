@@ -18,7 +18,7 @@ row = torch.randint(0, n, (rows,), device=dev, dtype=torch.int32)
 col = (torch.arange(rows, device=dev) // 6).clamp(max=n - 1).to(torch.int32)
 pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
 src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=row, additive=True), ops.Source(pc, index=col, additive=True)]
-lib.g4c_mlp_bx6i_enable(1)
+lib.g4c_mlp_bx6i_enable(2)
 for _ in range(3): ops.mlp_forward(pk, src, rows)
 torch.cuda.synchronize()
 buf = np.zeros(256 * 32, dtype=np.uint64)

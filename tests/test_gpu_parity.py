@@ -1008,6 +1008,55 @@ def test_model_on_a_non_current_device():
     assert torch.equal(y0.cpu(), y1.cpu())
 
 
+# ------------------------------------------------------------------ the dual-tile kernel of the large message launches (mlp_bx6i.hip)
+@pytest.mark.parametrize("rows", [1, 33, 64, 6001, 90000])
+def test_bx6i_dual_tile_kernel_equals_tile_kernel(rows):
+    """g4c_mlp_bx6i_enable(2) (every eligible launch; the default mode takes launches of >= 400k rows, exercised by the at-size
+    tests): the dual-tile software-pipelined kernel against the 32-row-tile kernel on the hoisted message form, a plain one-block
+    form with SELU output, and the fused per-target aggregation (bit-exact reduction of the rows it stores, ragged segments)."""
+    lib = _lib.load()
+    H, n = 128, max(rows // 6, 2)
+    torch.manual_seed(rows)
+    blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
+    deg = torch.randint(0, 10, (n,)) if rows > 64 else torch.full((n,), max(rows // n, 1))
+    col = torch.arange(n).repeat_interleave(deg)
+    E = max(int(col.numel()), 1)
+    if int(col.numel()) == 0:
+        col = torch.zeros(1, dtype=torch.long)
+    edge_index = torch.stack([torch.randint(0, n, (E,)), col]).to(DEV)
+    ep, csr = plan.edge_csr(edge_index, n)
+    v, e = torch.randn(n, H, device=DEV), torch.randn(E, H, device=DEV)
+    W1 = blk.edge_mlp.state_dict()["MLP.linear_1.weight"]
+    pr, pc = (v @ W1[:, H:2 * H].T).contiguous(), (v @ W1[:, 2 * H:].T).contiguous()
+    pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+    src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+
+    def run():
+        out = {"edge": ops.mlp_forward(pk, src, E), "plain_selu": ops.mlp_forward(pk, [ops.Source(e, index=ep.row)], E, _lib.ACT_SELU)}
+        if csr.tiles() is not None:
+            for mean in (True, False):
+                a = torch.full((n, H), float("nan"), device=DEV)
+                out[f"rows_agg_{mean}"] = ops.mlp_forward(pk, src, E, agg=(csr, a, mean))
+                out[f"agg_{mean}"] = a
+                a2 = torch.full((n, H), float("nan"), device=DEV)
+                assert ops.mlp_forward(pk, src, E, agg=(csr, a2, mean), store_rows=False) is None
+                out[f"agg_only_{mean}"] = a2
+        return out
+    old = lib.g4c_mlp_bx6i_enable(0)
+    try:
+        ref = run()
+        lib.g4c_mlp_bx6i_enable(2)
+        got = run()
+    finally:
+        lib.g4c_mlp_bx6i_enable(old)
+    for k in ref:
+        torch.testing.assert_close(got[k], ref[k], rtol=2e-5, atol=2e-5, msg=lambda m: f"{k}: {m}")
+    for mean in (True, False):
+        if f"agg_{mean}" in got:
+            assert torch.equal(got[f"agg_{mean}"], ops.segment_reduce(got[f"rows_agg_{mean}"], csr, mean))
+            assert torch.equal(got[f"agg_only_{mean}"], got[f"agg_{mean}"])
+
+
 # ------------------------------------------------------------------ the opt-in persistent kernel (mlp_px6.hip)
 @pytest.mark.parametrize("rows", [33, 6000, 70000])
 def test_px6_persistent_kernel_equals_tile_kernel(rows):
