@@ -6,10 +6,12 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graphs4cfd_amd import _lib, ops, plan
 from graphs4cfd_amd.nn import blocks as B
-ap = argparse.ArgumentParser(); ap.add_argument("--time", action="store_true"); ap.add_argument("--rows", type=int, default=600000)
+ap = argparse.ArgumentParser(); ap.add_argument("--time", action="store_true"); ap.add_argument("--rows", type=int, default=600000); ap.add_argument("--kernel", default="bx6i", choices=["bx6i", "bx6w"])
 a = ap.parse_args()
 torch.set_grad_enabled(False)
 lib = _lib.load()
+enable = getattr(lib, f"g4c_mlp_{a.kernel}_enable")
+lib.g4c_mlp_bx6i_enable(0); lib.g4c_mlp_bx6w_enable(0)
 dev = torch.device("cuda", 0); H = 128
 torch.manual_seed(0)
 blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(dev)
@@ -17,19 +19,19 @@ bad = []
 
 
 def both(fn):
-    lib.g4c_mlp_bx6i_enable(0); ref = fn()
-    lib.g4c_mlp_bx6i_enable(2)
+    enable(0); ref = fn()
+    enable(2)
     try:
         got = fn()
     finally:
-        lib.g4c_mlp_bx6i_enable(0)
+        enable(0)
     return ref, got
 
 
 def cmp(name, ref, got, tol):
     d = (ref - got).abs().max().item() if ref.numel() else 0.0
     ok = d <= tol and bool(torch.isfinite(got).all())
-    print(f"{'ok  ' if ok else 'FAIL'} {name:58s} max|bx6i - tile| = {d:.2e} (tol {tol:g})")
+    print(f"{'ok  ' if ok else 'FAIL'} {name:58s} max|{a.kernel} - tile| = {d:.2e} (tol {tol:g})")
     if not ok: bad.append(name)
 
 
@@ -68,7 +70,7 @@ for rows, ragged in ((600000, False), (19972, True), (116, True)):
         (y0, a0), (y1, a1) = both(run)
         cmp(f"fused agg rows={E} ragged={ragged} mean={mean}: e'", y0, y1, 2e-5)
         cmp(f"fused agg rows={E} ragged={ragged} mean={mean}: agg == reduce(e') bit-exact", ops.segment_reduce(y1, csr, mean), a1, 0.0)
-print("all bx6i checks passed" if not bad else "FAILED: " + ", ".join(bad))
+print(f"all {a.kernel} checks passed" if not bad else "FAILED: " + ", ".join(bad))
 if a.time:
     rows = a.rows; n = rows // 6
     e, v = torch.randn(rows, H, device=dev), torch.randn(n, H, device=dev)
@@ -84,13 +86,13 @@ if a.time:
     for cname, fn in cases.items():
         times = {0: [], 1: []}
         for on in (0, 1):
-            lib.g4c_mlp_bx6i_enable(2 * on); fn(); fn()
+            enable(2 * on); fn(); fn()
         torch.cuda.synchronize()
         for r in range(15):
             for on in (0, 1):
-                lib.g4c_mlp_bx6i_enable(2 * on)
+                enable(2 * on)
                 s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record(); fn(); fn(); fn(); t.record(); torch.cuda.synchronize()
                 times[on].append(s.elapsed_time(t) / 3 * 1e3)
-        lib.g4c_mlp_bx6i_enable(0)
-        print(f"{cname:20s} tile kernel median {statistics.median(times[0]):8.1f} us (min {min(times[0]):8.1f})   bx6i median {statistics.median(times[1]):8.1f} us (min {min(times[1]):8.1f})")
+        enable(0)
+        print(f"{cname:20s} tile kernel median {statistics.median(times[0]):8.1f} us (min {min(times[0]):8.1f})   {a.kernel} median {statistics.median(times[1]):8.1f} us (min {min(times[1]):8.1f})")

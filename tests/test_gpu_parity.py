@@ -1009,8 +1009,9 @@ def test_model_on_a_non_current_device():
 
 
 # ------------------------------------------------------------------ the dual-tile kernel of the large message launches (mlp_bx6i.hip)
+@pytest.mark.parametrize("kernel", ["bx6i", "bx6w"])
 @pytest.mark.parametrize("rows", [1, 33, 64, 6001, 90000])
-def test_bx6i_dual_tile_kernel_equals_tile_kernel(rows):
+def test_bx6i_dual_tile_kernel_equals_tile_kernel(rows, kernel):
     """g4c_mlp_bx6i_enable(2) (every eligible launch; the default mode takes launches of >= 400k rows, exercised by the at-size
     tests): the dual-tile software-pipelined kernel against the 32-row-tile kernel on the hoisted message form, a plain one-block
     form with SELU output, and the fused per-target aggregation (bit-exact reduction of the rows it stores, ragged segments)."""
@@ -1042,13 +1043,15 @@ def test_bx6i_dual_tile_kernel_equals_tile_kernel(rows):
                 assert ops.mlp_forward(pk, src, E, agg=(csr, a2, mean), store_rows=False) is None
                 out[f"agg_only_{mean}"] = a2
         return out
-    old = lib.g4c_mlp_bx6i_enable(0)
+    # (bx6w: the 2 x 2 register-block form, mlp_bx6w.hip — same launches, same checks)
+    enable = getattr(lib, f"g4c_mlp_{kernel}_enable")
+    olds = lib.g4c_mlp_bx6i_enable(0), lib.g4c_mlp_bx6w_enable(0)
     try:
         ref = run()
-        lib.g4c_mlp_bx6i_enable(2)
+        enable(2)
         got = run()
     finally:
-        lib.g4c_mlp_bx6i_enable(old)
+        lib.g4c_mlp_bx6i_enable(olds[0]); lib.g4c_mlp_bx6w_enable(olds[1])
     for k in ref:
         torch.testing.assert_close(got[k], ref[k], rtol=2e-5, atol=2e-5, msg=lambda m: f"{k}: {m}")
     for mean in (True, False):
