@@ -162,11 +162,6 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
     l = (__bf16)(r1 - (float)m);
 }
 
-// 2 x 2 register-block kernel (mlp_bx6w.hip)
-int bx6w_enable(int on);
-bool bx6w_eligible(const Params &p, bool round1, bool agg, bool save, long long row_count);
-int bx6w_launch(const Params &p, bool agg, hipStream_t st);
-
 // dual-tile software-pipelined kernel (mlp_bx6i.hip)
 int bx6i_enable(int on);
 bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, long long row_count);

@@ -190,10 +190,6 @@ int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*h
  * rows, with or without the fused aggregation): 0 = never, 1 = launches of at least G4C_BX6I_MIN_ROWS rows (default 400 000; the
  * default mode, environment G4C_BX6I), 2 = every launch it can take (tests); -1 only queries.  Returns the previous setting. */
 int g4c_mlp_bx6i_enable(int on);
-/* the same switch for the 2 x 2 register-block form (mlp_bx6w.hip: a workgroup of two waves owns a 64-row tile, a wave 64 of its
- * 128 output columns — four accumulators, half the LDS and L1 operand traffic per MFMA); it takes the same launches and is asked
- * first.  Environment default: G4C_BX6W. */
-int g4c_mlp_bx6w_enable(int on);
 
 /* The bf16x6 / bf16 entry points run on one of two kernels with identical arithmetic per 128 x 128 block: the persistent
  * ping-pong kernel (mlp_px6.hip: one 8-wave workgroup per CU, every weight block held in registers for a whole stage,

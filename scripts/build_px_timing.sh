@@ -5,4 +5,4 @@ OUT=$(realpath -m "$1"); shift
 cd "$(dirname "$0")/../graphs4cfd_amd/csrc"
 mkdir -p build
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DG4C_PX_TIMING "$@" -c mlp_px6.hip -o build/mlp_px6_timing.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" build/error.o build/plan.o build/segment_reduce.o build/mlp_fused.o build/mlp_px6_timing.o build/mlp_bx6i.o build/mlp_bx6w.o build/remus_ops.o build/train_ops.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" build/error.o build/plan.o build/segment_reduce.o build/mlp_fused.o build/mlp_px6_timing.o build/mlp_bx6i.o build/remus_ops.o build/train_ops.o

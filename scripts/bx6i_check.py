@@ -6,12 +6,12 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graphs4cfd_amd import _lib, ops, plan
 from graphs4cfd_amd.nn import blocks as B
-ap = argparse.ArgumentParser(); ap.add_argument("--time", action="store_true"); ap.add_argument("--rows", type=int, default=600000); ap.add_argument("--kernel", default="bx6i", choices=["bx6i", "bx6w"])
+ap = argparse.ArgumentParser(); ap.add_argument("--time", action="store_true"); ap.add_argument("--rows", type=int, default=600000); ap.add_argument("--kernel", default="bx6i", choices=["bx6i"])
 a = ap.parse_args()
 torch.set_grad_enabled(False)
 lib = _lib.load()
 enable = getattr(lib, f"g4c_mlp_{a.kernel}_enable")
-lib.g4c_mlp_bx6i_enable(0); lib.g4c_mlp_bx6w_enable(0)
+lib.g4c_mlp_bx6i_enable(0)
 dev = torch.device("cuda", 0); H = 128
 torch.manual_seed(0)
 blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(dev)
