@@ -179,12 +179,19 @@ def reference_flop_per_step(model, g):
 
 def roofline_blocks(args, result, model, graph_cpu, dev, ops, Rollout):
     """Eager instrumented pass of the same step: HIP-event pair around every launch, on the launch stream."""
-    eager = Rollout(model, graph_cpu.clone().to(dev), 8, capture=False)
+    eager = Rollout(model, graph_cpu.clone().to(dev), 12, capture=False)
     eager.run(2)
     torch.cuda.synchronize(dev)
-    with ops.KernelTimer() as kt:
-        eager.run(3)
-    torch.cuda.synchronize(dev)
+    # three passes of three steps, the least disturbed one is kept (a single stalled launch — seen once: 8 ms — would otherwise
+    # halve the averages of a 43-launch step)
+    kt, best = None, None
+    for _ in range(3):
+        with ops.KernelTimer() as kt_try:
+            eager.run(3)
+        torch.cuda.synchronize(dev)
+        total = sum(a.elapsed_time(e) for _k, _f, _b, a, e in kt_try.records)
+        if best is None or total < best:
+            kt, best = kt_try, total
     summ = kt.summary()
     remus = args.model == "NsRotEquiTreeScaleGNN"
 
