@@ -35,17 +35,18 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 (v_mfma_f32_32x32x16_bf16), same guide
-BX6_PRODUCTS = 6                # bf16 partial products the default kernel executes per fp32 multiply-add
+BX6_PRODUCTS = 6                # bf16 partial products the exact-split kernel executes per fp32 multiply-add
+F16X3_PRODUCTS = 3              # fp16 partial products of the two-way split ("f16x3")
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
 
 WORKLOADS = {
-    "headline": {"model": "NsThreeScaleGNN", "nodes": 100_000, "dim": 2, "precision": "bf16x6",
+    "headline": {"model": "NsThreeScaleGNN", "nodes": 100_000, "dim": 2, "precision": "f16x3",
                  "metric": "rollout timesteps/s (100k-node 2D mesh)"},
-    "c2": {"model": "NsTwoScaleGNN", "nodes": 10_000, "dim": 2, "precision": "bf16x6",
+    "c2": {"model": "NsTwoScaleGNN", "nodes": 10_000, "dim": 2, "precision": "f16x3",
            "metric": "rollout timesteps/s (MuS-GNN 2-scale, 10k-node mesh, fp32)"},
     "c3": {"model": "NsRotEquiTreeScaleGNN", "nodes": 100_000, "dim": 2, "precision": "bf16",
            "metric": "rollout timesteps/s (REMuS-GNN 3-scale, 100k-node mesh, bf16 MLP operands)"},
-    "c5-1gpu": {"model": "NsFourScaleGNN", "nodes": 1_000_000, "dim": 3, "precision": "bf16x6",
+    "c5-1gpu": {"model": "NsFourScaleGNN", "nodes": 1_000_000, "dim": 3, "precision": "f16x3",
                 "metric": "rollout timesteps/s (MuS-GNN 4-scale, 1M-node 3D mesh, 1 GPU)"},
 }
 MUS_LEVELS = {"NsOneScaleGNN": 1, "NsTwoScaleGNN": 2, "NsThreeScaleGNN": 3, "NsFourScaleGNN": 4}
@@ -60,7 +61,7 @@ def parse():
     ap.add_argument("--nodes", type=int, default=None, help="override the workload's mesh size (then not a BASELINE configuration)")
     ap.add_argument("--model", default=None, help="override the workload's model class")
     ap.add_argument("--hidden", type=int, default=128)
-    ap.add_argument("--precision", default=None, choices=["bf16x6", "fp32", "bf16"],
+    ap.add_argument("--precision", default=None, choices=["bf16x6", "f16x3", "fp32", "bf16"],
                     help="arithmetic of the fused MLPs: bf16x6 (fp32-accurate split products on the bf16 matrix pipe), fp32 "
                          "(fp32 MFMA kernels) or bf16 (operands rounded to bf16, ~1e-2 deviation: config 3 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -202,12 +203,13 @@ def roofline_blocks(args, result, model, graph_cpu, dev, ops, Rollout):
         rounded-bf16 mode (config 3) one product per multiply-add."""
         alg = flops / seconds / 1e12
         if kind.startswith("mlp_bx6"):
-            prod = BX6_PRODUCTS if args.precision == "bf16x6" else 1
+            prod = {"bf16x6": BX6_PRODUCTS, "f16x3": F16X3_PRODUCTS}.get(args.precision, 1)
             out = {"achieved": prod * alg, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": prod * alg / PEAK_BF16_MFMA_TFLOPS,
-                   "mfma_dtype": "bf16 (6 exact partial products per fp32 MAC, fp32 accumulate)" if prod == 6 else
-                                 "bf16 (operands rounded to bf16, fp32 accumulate)",
+                   "mfma_dtype": {6: "bf16 (6 exact partial products per fp32 MAC, fp32 accumulate)",
+                                  3: "f16 (two-way fp16 operand split, 3 partial products per fp32 MAC, fp32 accumulate; same dense peak as bf16)",
+                                  1: "bf16 (operands rounded to bf16, fp32 accumulate)"}[prod],
                    "algorithmic_tflops": alg}
-            if prod == 6:
+            if prod > 1:
                 out["algorithmic_vs_fp32_mfma_peak"] = alg / PEAK_FP32_MFMA_TFLOPS
             return out
         return {"achieved": alg, "peak": PEAK_FP32_MFMA_TFLOPS, "frac": alg / PEAK_FP32_MFMA_TFLOPS, "mfma_dtype": "f32"}
@@ -442,6 +444,8 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": {"fp32": "f32", "bf16x6": "f32 (MLP products: exact 3-way bf16 split of both operands, 6 partial products on the bf16 MFMA "
                   "pipe, fp32 accumulate; error vs fp64 <= the fp32-MFMA kernels')",
+                  "f16x3": "f32 (MLP products: two-way fp16 split of both operands, 22 significand bits each, 3 partial products on the f16 "
+                  "MFMA pipe, fp32 accumulate; error vs fp64 within that of an fp32 GEMM)",
                   "bf16": "bf16 MLP operands (fp32 accumulate, bias, SELU, LayerNorm, aggregation)"}[args.precision], "data": "synthetic",
         "config": {"workload": what, "name": args.workload if not args.custom else "custom", "nodes": args.nodes,
                    "edges": int(graph_cpu.edge_index.size(1)), "mp_layers_per_step": n_mp,

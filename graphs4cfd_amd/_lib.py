@@ -44,7 +44,7 @@ class g4c_src_t(C.Structure):
 class g4c_mlp_t(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("k_pad", C.c_int32 * MAX_LAYERS), ("n_pad", C.c_int32 * MAX_LAYERS),
                 ("w", C.c_void_p * MAX_LAYERS), ("b", C.c_void_p * MAX_LAYERS),
-                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("n_out", C.c_int32)]
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("n_out", C.c_int32), ("w_format", C.c_int32)]
 
 
 _SIGNATURES = {
@@ -65,6 +65,8 @@ _SIGNATURES = {
                                        C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "g4c_mlp_pack_layer_bx6": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                          C.c_int32, C.c_int32, C.c_void_p]),
+    "g4c_mlp_pack_layer_f16x3": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                           C.c_int32, C.c_int32, C.c_void_p]),
     "g4c_mlp_forward_bx6": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_void_p,
                                       C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "g4c_mlp_forward_bx6_save": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_void_p, C.c_int32,

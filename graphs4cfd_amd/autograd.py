@@ -352,7 +352,7 @@ class _FusedMLP(torch.autograd.Function):
         db: List[Optional[Tensor]] = [None] * L
         need_dx_dense = any(needs[1 + j] for j in dense)
         gX = None
-        chain = (FUSED_CHAIN and ops.mlp_precision() == "bf16x6" and M >= FUSED_LINEAR_MIN_ROWS and kd == 128 and need_dx_dense
+        chain = (FUSED_CHAIN and ops.mlp_precision() in ("bf16x6", "f16x3") and M >= FUSED_LINEAR_MIN_ROWS and kd == 128 and need_dx_dense
                  and int(g.size(1)) == 128 and all(tuple(W[l].shape) == (128, 128) for l in range(1, L)) and N1 == 128
                  and all(a is not None and a.stride(1) == 1 for a in acts[1:]))
         if chain:

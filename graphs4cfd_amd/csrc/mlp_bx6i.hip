@@ -34,7 +34,7 @@ extern "C" int g4c_bx6i_read_stamps(unsigned long long *host, int n) {
 namespace {
 
 constexpr int PLN = 32 * HB;                 // bf16 elements of one operand plane of a tile [32][136]
-constexpr int TILE_BF16 = 3 * PLN;           // one tile: three planes (the fp32 final rows [32][132] alias them)
+// one tile: SP planes (the fp32 final rows [32][132] alias them: 16 896 B <= 2 planes = 17 408 B)
 
 __device__ __forceinline__ f32x2 selu2i(f32x2 x) {
     const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f;
@@ -48,9 +48,17 @@ __device__ __forceinline__ f32x2 selu2i(f32x2 x) {
     return m * scale + (t * sa - sa);
 }
 
-// exact three-way split of a pair -> one packed pair per plane (planes PLN elements apart)
+// exact three-way split of a pair -> one packed pair per plane (planes PLN elements apart); SP == 2: the two-way fp16 split
+template <int SP>
 __device__ __forceinline__ void put_pair(__bf16 *d, f32x2 y) {
     f32x2 hf, mf, lf;
+    if (SP == 2) {
+        const unsigned hu = pack_f16(y, hf);
+        const unsigned lu = pack_f16((y - hf) * F16_LO_SCALE, lf);
+        *reinterpret_cast<unsigned *>(d) = hu;
+        *reinterpret_cast<unsigned *>(d + PLN) = lu;
+        return;
+    }
     const unsigned hu = pack_bf16(y, hf);
     const f32x2 r1 = y - hf;
     const unsigned mu = pack_bf16(r1, mf);
@@ -71,31 +79,32 @@ struct Other {
     bool park_act;            // EK 2: SELU pending on the stored rows
 };
 
-template <int EK>
-__device__ __forceinline__ void other_slice(int s, const f32x16 &accE, const f32x4 (&xe)[4], const Other &o) {
+template <int EK, int SP>
+__device__ __forceinline__ void other_slice(int s, const f32x16 &accE, const f32x16 &accE1, const f32x4 (&xe)[4], const Other &o) {
     if (EK == 1) {
         const int gq = s >> 1, pr = s & 1;
         f32x2 x;
         x[0] = accE[4 * gq + 2 * pr]; x[1] = accE[4 * gq + 2 * pr + 1];
-        put_pair(o.plane_acc + 8 * gq + 2 * pr, selu2i(x));
+        if (SP == 2) { x[0] = fmaf(accE1[4 * gq + 2 * pr], F16_LO_UNSCALE, x[0]); x[1] = fmaf(accE1[4 * gq + 2 * pr + 1], F16_LO_UNSCALE, x[1]); }
+        put_pair<SP>(o.plane_acc + 8 * gq + 2 * pr, selu2i(x));
     } else if (EK == 2) {
         if (s & 1) {
             const int q = s >> 1;
             f32x4 v = xe[q];
             if (o.park_act) v = selu4(v);
             bf16x4 vh, vm, vl;
-            split3x4<3>(v, vh, vm, vl);
+            split3x4<SP>(v, vh, vm, vl);
             __bf16 *d = o.plane_park + q * KC;
             *reinterpret_cast<bf16x4 *>(d) = vh;
             *reinterpret_cast<bf16x4 *>(d + PLN) = vm;
-            *reinterpret_cast<bf16x4 *>(d + 2 * PLN) = vl;
+            if (SP == 3) *reinterpret_cast<bf16x4 *>(d + 2 * PLN) = vl;
         }
     } else if (EK == 3) {
         if (s & 1) {
             const int gq = s >> 1;
             f32x4 x;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = accE[4 * gq + e];
+            for (int e = 0; e < 4; ++e) x[e] = SP == 2 ? fmaf(accE1[4 * gq + e], F16_LO_UNSCALE, accE[4 * gq + e]) : accE[4 * gq + e];
             *reinterpret_cast<f32x4 *>(o.fin + 8 * gq) = x;
         }
     }
@@ -105,54 +114,69 @@ __device__ __forceinline__ void other_slice(int s, const f32x16 &accE, const f32
 // registers for the two tiles of the pair (W[step][plane], 96 VGPRs: one fetch serves 64 rows, half the L1 -> register traffic of
 // mlp_bx6_kernel); REFILL (the second tile's phase): step s's fragments are replaced by the next layer's right after their last
 // use.  The phases of a pair are straight-line code (three layers, unrolled), so every refill is a plain redefinition.
-template <int EK, bool REFILL>
-__device__ __forceinline__ void m_block(const __bf16 *pa, bf16x8 (&W)[8][3], __amdgpu_buffer_rsrc_t rs, unsigned lo_b, unsigned wnext,
-                                        f32x16 &acc, const f32x16 &accE, const f32x4 (&xe)[4], const Other &o) {
-    bf16x8 cur[3], nx[3];
+// SP == 2 (two-way fp16 split): two planes, W[step][2] (64 VGPRs), three products per step — the 2^-11 terms in acc1.
+#ifndef G4C_BX6I_VALU_PER_MFMA
+#define G4C_BX6I_VALU_PER_MFMA 8      // SP == 2: vector instructions interleaved after each of the step's three MFMAs
+#endif
+template <int EK, bool REFILL, int SP>
+__device__ __forceinline__ void m_block(const __bf16 *pa, bf16x8 (&W)[8][SP], __amdgpu_buffer_rsrc_t rs, unsigned lo_b, unsigned wnext,
+                                        f32x16 &acc, f32x16 &acc1, const f32x16 &accE, const f32x16 &accE1, const f32x4 (&xe)[4], const Other &o) {
+    bf16x8 cur[SP], nx[SP];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) cur[pl] = *reinterpret_cast<const bf16x8 *>(pa + pl * PLN);
+    for (int pl = 0; pl < SP; ++pl) cur[pl] = *reinterpret_cast<const bf16x8 *>(pa + pl * PLN);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         if (s < 7) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) nx[pl] = *reinterpret_cast<const bf16x8 *>(pa + pl * PLN + 16 * (s + 1));
+            for (int pl = 0; pl < SP; ++pl) nx[pl] = *reinterpret_cast<const bf16x8 *>(pa + pl * PLN + 16 * (s + 1));
         }
         if (!EK) __builtin_amdgcn_sched_barrier(0);
-        other_slice<EK>(s, accE, xe, o);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], cur[2], acc, 0, 0, 0);     // small terms first (as mlp_bx6_kernel)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][2], cur[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][1], cur[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], cur[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][1], cur[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], cur[0], acc, 0, 0, 0);
+        other_slice<EK, SP>(s, accE, accE1, xe, o);
+        if (SP == 2) {
+            acc1 = mfma_f16(W[s][0], cur[1], acc1);
+            acc1 = mfma_f16(W[s][1], cur[0], acc1);
+            acc = mfma_f16(W[s][0], cur[0], acc);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], cur[SP - 1], acc, 0, 0, 0);     // small terms first (as mlp_bx6_kernel)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][SP - 1], cur[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][1], cur[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], cur[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][1], cur[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[s][0], cur[0], acc, 0, 0, 0);
+        }
         if (EK) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                  // DS read
+            __builtin_amdgcn_sched_group_barrier(0x100, SP, 0);                 // DS read
 #pragma unroll
-            for (int m = 0; m < 6; ++m) {
+            for (int m = 0; m < (SP == 2 ? 3 : 6); ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);              // VALU
+                __builtin_amdgcn_sched_group_barrier(0x002, SP == 2 ? G4C_BX6I_VALU_PER_MFMA : 4, 0);              // VALU
             }
-            __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);                  // DS write
+            __builtin_amdgcn_sched_group_barrier(0x200, SP, 0);                 // DS write
         }
         __builtin_amdgcn_sched_barrier(0);
         if (REFILL) {
             const unsigned so = wnext + 2u * s * STEP6;
-            W[s][0] = ldw(rs, lo_b, so);
-            W[s][1] = ldw(rs, lo_b + 1024u, so);
-            W[s][2] = ldw(rs, lo_b + 2048u, so);
+#pragma unroll
+            for (int pl = 0; pl < SP; ++pl) W[s][pl] = ldw(rs, lo_b + 1024u * pl, so);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (s < 7) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) cur[pl] = nx[pl];
+            for (int pl = 0; pl < SP; ++pl) cur[pl] = nx[pl];
         }
     }
 }
 
-template <bool AGG>
-__global__ __launch_bounds__(256, 2) void mlp_bx6i_kernel(const Params p) {
+#ifndef G4C_BX6I_F16_WGS
+#define G4C_BX6I_F16_WGS 2
+#endif
+template <bool AGG, int SP>
+__global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_kernel(const Params p) {
     // two tiles' operand planes + gather indices: 52 992 B; 96 stationary weight registers -> two workgroups per CU
+    // (SP == 2: 35 584 B, 64 weight registers)
+    constexpr int TILE_BF16 = SP * PLN;
     __shared__ __attribute__((aligned(16))) __bf16 sB[2 * TILE_BF16];
+    if (SP == 2) f16_range_mode();
     __shared__ int sIdx[2][3][32];          // [tile][weighted block, additive 0, additive 1][row]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -189,13 +213,11 @@ __global__ __launch_bounds__(256, 2) void mlp_bx6i_kernel(const Params p) {
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, 0x7fffffff, 0x00020000);
     const unsigned lo_b = 2u * (unsigned)(wave * 8 * STEP6 + lane * 8);
-    bf16x8 W[8][3];
+    bf16x8 W[8][SP];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        W[s][0] = ldw(rs, lo_b, 2u * s * STEP6);
-        W[s][1] = ldw(rs, lo_b + 1024u, 2u * s * STEP6);
-        W[s][2] = ldw(rs, lo_b + 2048u, 2u * s * STEP6);
-    }
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int pl = 0; pl < SP; ++pl) W[s][pl] = ldw(rs, lo_b + 1024u * pl, 2u * s * STEP6);
     __syncthreads();
     BI_STAMP(1);
 
@@ -207,7 +229,9 @@ __global__ __launch_bounds__(256, 2) void mlp_bx6i_kernel(const Params p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { xA[q] = *reinterpret_cast<const f32x4 *>(ra + q * KC); xB[q] = *reinterpret_cast<const f32x4 *>(rb + q * KC); }
     }
-    f32x16 accA, accB;
+    f32x16 accA, accB, accA1, accB1;         // (acc?1: the 2^-11 terms, SP == 2 only)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { accA1[q] = 0.f; accB1[q] = 0.f; }
     {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
@@ -244,10 +268,10 @@ __global__ __launch_bounds__(256, 2) void mlp_bx6i_kernel(const Params p) {
             f32x4 v = xA[q];
             if (pact) v = selu4(v);
             bf16x4 vh, vm, vl;
-            split3x4<3>(v, vh, vm, vl);
+            split3x4<SP>(v, vh, vm, vl);
             *reinterpret_cast<bf16x4 *>(d + q * KC) = vh;
             *reinterpret_cast<bf16x4 *>(d + PLN + q * KC) = vm;
-            *reinterpret_cast<bf16x4 *>(d + 2 * PLN + q * KC) = vl;
+            if (SP == 3) *reinterpret_cast<bf16x4 *>(d + 2 * PLN + q * KC) = vl;
         }
     }
     __syncthreads();
@@ -258,45 +282,45 @@ __global__ __launch_bounds__(256, 2) void mlp_bx6i_kernel(const Params p) {
     oB.plane_acc = sBt + i * HB + fbase;  oB.plane_park = sBt + grow_l * HB + c4;  oB.fin = reinterpret_cast<float *>(sBt) + i * HS + fbase;  oB.park_act = pact;
     const __bf16 *paA = sA + i * HB + 8 * h, *paB = sBt + i * HB + 8 * h;
     const int L = p.n_layers;
-    auto bias_init = [&](f32x16 &acc, int l) __attribute__((always_inline)) {
+    auto bias_init = [&](f32x16 &acc, f32x16 &acc1, int l) __attribute__((always_inline)) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const f32x4 b4 = *reinterpret_cast<const f32x4 *>(p.b + l * NP + fbase + 8 * gq);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[4 * gq + e] = b4[e];
+            for (int e = 0; e < 4; ++e) { acc[4 * gq + e] = b4[e]; if (SP == 2) acc1[4 * gq + e] = 0.f; }
         }
     };
 
     (void)L;                                    // (the launcher admits three-layer MLPs only: the phases below are unrolled)
     constexpr unsigned WB = 2u * BLOCK6;        // bytes of one layer's block of the stream
     // layer 0
-    m_block<2, false>(paA, W, rs, lo_b, 0u, accA, accB, xB, oB);             // for B: park
+    m_block<2, false, SP>(paA, W, rs, lo_b, 0u, accA, accA1, accB, accB1, xB, oB);             // for B: park
     BI_STAMP(4);
     __syncthreads();
     BI_STAMP(5);
-    m_block<1, true>(paB, W, rs, lo_b, WB, accB, accA, xB, oA);               // for A: epilogue of layer 0; refill with layer 1
-    bias_init(accA, 1);
+    m_block<1, true, SP>(paB, W, rs, lo_b, WB, accB, accB1, accA, accA1, xB, oA);               // for A: epilogue of layer 0; refill with layer 1
+    bias_init(accA, accA1, 1);
     BI_STAMP(6);
     __syncthreads();
     BI_STAMP(7);
     // layer 1
-    m_block<1, false>(paA, W, rs, lo_b, 0u, accA, accB, xB, oB);             // for B: epilogue of layer 0
-    bias_init(accB, 1);
+    m_block<1, false, SP>(paA, W, rs, lo_b, 0u, accA, accA1, accB, accB1, xB, oB);             // for B: epilogue of layer 0
+    bias_init(accB, accB1, 1);
     BI_STAMP(8);
     __syncthreads();
     BI_STAMP(9);
-    m_block<1, true>(paB, W, rs, lo_b, 2u * WB, accB, accA, xB, oA);          // for A: epilogue of layer 1; refill with layer 2
-    bias_init(accA, 2);
+    m_block<1, true, SP>(paB, W, rs, lo_b, 2u * WB, accB, accB1, accA, accA1, xB, oA);          // for A: epilogue of layer 1; refill with layer 2
+    bias_init(accA, accA1, 2);
     BI_STAMP(10);
     __syncthreads();
     BI_STAMP(11);
     // layer 2
-    m_block<1, false>(paA, W, rs, lo_b, 0u, accA, accB, xB, oB);             // for B: epilogue of layer 1
-    bias_init(accB, 2);
+    m_block<1, false, SP>(paA, W, rs, lo_b, 0u, accA, accA1, accB, accB1, xB, oB);             // for B: epilogue of layer 1
+    bias_init(accB, accB1, 2);
     BI_STAMP(12);
     __syncthreads();
     BI_STAMP(13);
-    m_block<3, false>(paB, W, rs, lo_b, 0u, accB, accA, xB, oA);             // for A: last layer's fp32 rows
+    m_block<3, false, SP>(paB, W, rs, lo_b, 0u, accB, accB1, accA, accA1, xB, oA);             // for A: last layer's fp32 rows
     BI_STAMP(14);
     __syncthreads();
     BI_STAMP(15);
@@ -307,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void mlp_bx6i_kernel(const Params p) {
         for (int gq = 0; gq < 4; ++gq) {
             f32x4 x;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = accB[4 * gq + e];
+            for (int e = 0; e < 4; ++e) x[e] = SP == 2 ? fmaf(accB1[4 * gq + e], F16_LO_UNSCALE, accB[4 * gq + e]) : accB[4 * gq + e];
             *reinterpret_cast<f32x4 *>(fb + 8 * gq) = x;
         }
     }
@@ -426,11 +450,14 @@ bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, long long 
     return true;
 }
 
-int bx6i_launch(const Params &p, bool agg, hipStream_t st) {
+int bx6i_launch(const Params &p, bool agg, bool f16x2, hipStream_t st) {
     const int n_pairs = (p.n_tiles + 1) / 2;
     if (n_pairs == 0) return G4C_OK;
-    if (agg) mlp_bx6i_kernel<true><<<dim3(n_pairs), dim3(256), 0, st>>>(p);
-    else mlp_bx6i_kernel<false><<<dim3(n_pairs), dim3(256), 0, st>>>(p);
+    if (f16x2) {
+        if (agg) mlp_bx6i_kernel<true, 2><<<dim3(n_pairs), dim3(256), 0, st>>>(p);
+        else mlp_bx6i_kernel<false, 2><<<dim3(n_pairs), dim3(256), 0, st>>>(p);
+    } else if (agg) mlp_bx6i_kernel<true, 3><<<dim3(n_pairs), dim3(256), 0, st>>>(p);
+    else mlp_bx6i_kernel<false, 3><<<dim3(n_pairs), dim3(256), 0, st>>>(p);
     return g4c::check_launch("g4c_mlp_forward (bx6i)");
 }
 

@@ -130,8 +130,55 @@ __device__ __forceinline__ unsigned pack_bf16(f32x2 x, f32x2 &back) {
     back[1] = __builtin_bit_cast(float, u & 0xffff0000u);
     return u;
 }
+// ---- "f16x3": two-way fp16 split, three products (template parameter SP == 2 of the split kernels) -------------------------------
+// x = h + l * 2^-11 with h = fp16(x) (round to nearest) and l = fp16((x - h) * 2^11): 22 significand bits per operand (the
+// subtraction is exact; l keeps the magnitude range of x, and v_mfma_f32_32x32x16_f16 honours fp16 subnormals —
+// scripts/micro/f16_mfma_modes.hip — so small values lose nothing: DESIGN 4.1).  Products: (Wh, xh) into one accumulator, (Wh, xl) + (Wl, xh) into a second one that is folded in with a
+// factor 2^-11 when the layer ends; the dropped (Wl, xl) term is <= 2^-22 relative.  Planes 0 / 1 of the stream and of the LDS tile
+// hold h / l as fp16 BIT PATTERNS in the bf16-typed containers (plane 2 of the stream is unused).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float F16_LO_SCALE = 2048.f, F16_LO_UNSCALE = 1.f / 2048.f;
+__device__ __forceinline__ f32x16 mfma_f16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// Range: an activation beyond +-65504 converts to an infinity, and the row comes out as NaN — loud, not a silently clipped value
+// (the three-way bf16 split keeps the whole fp32 range and stays selectable).  -DG4C_F16_SATURATE=1 sets MODE.FP16_OVFL instead:
+// conversions saturate at +-65504 (scripts/micro/f16_mfma_modes.hip shows both behaviours).
+#ifndef G4C_F16_SATURATE
+#define G4C_F16_SATURATE 0
+#endif
+__device__ __forceinline__ void f16_range_mode() { if (G4C_F16_SATURATE) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
+__device__ __forceinline__ unsigned pack_f16(f32x2 x, f32x2 &back) {
+    f16x2 b;
+    b[0] = (_Float16)x[0]; b[1] = (_Float16)x[1];
+    back[0] = (float)b[0]; back[1] = (float)b[1];
+    return __builtin_bit_cast(unsigned, b);
+}
+__device__ __forceinline__ void split2x4(f32x4 x, bf16x4 &h, bf16x4 &l) {
+    unsigned hu[2], lu[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        f32x2 v, hf, lf;
+        v[0] = x[2 * j]; v[1] = x[2 * j + 1];
+        hu[j] = pack_f16(v, hf);
+        const f32x2 r = (v - hf) * F16_LO_SCALE;
+        lu[j] = pack_f16(r, lf);
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 hh, ll;
+    hh[0] = hu[0]; hh[1] = hu[1]; ll[0] = lu[0]; ll[1] = lu[1];
+    h = __builtin_bit_cast(bf16x4, hh); l = __builtin_bit_cast(bf16x4, ll);
+}
+__device__ __forceinline__ void split2(float x, __bf16 &h, __bf16 &l) {
+    const _Float16 a = (_Float16)x;
+    const _Float16 b = (_Float16)((x - (float)a) * F16_LO_SCALE);
+    h = __builtin_bit_cast(__bf16, a); l = __builtin_bit_cast(__bf16, b);
+}
+
 template <int SP = 3>
 __device__ __forceinline__ void split3x4(f32x4 x, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
+    if (SP == 2) { split2x4(x, h, m); l = m; return; }       // two-way fp16 split: h, l in the first two containers
     if (SP == 1 || (G4C_ABLATE & 512)) {          // SP == 1: round to bf16 (only h is stored)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { h[e] = (__bf16)x[e]; m[e] = h[e]; l[e] = h[e]; }
@@ -165,7 +212,7 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
 // dual-tile software-pipelined kernel (mlp_bx6i.hip)
 int bx6i_enable(int on);
 bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, long long row_count);
-int bx6i_launch(const Params &p, bool agg, hipStream_t st);
+int bx6i_launch(const Params &p, bool agg, bool f16x2, hipStream_t st);
 
 // persistent ping-pong kernel (mlp_px6.hip)
 int px6_enable(int on);

@@ -570,11 +570,14 @@ struct Ring6 { bf16x8 h[RD6], m[RD6], l[RD6]; };
 #ifndef G4C_BX6_TUNE
 #define G4C_BX6_TUNE 0      // tuning bits: 1 = s_setprio around the MFMAs, 2 = no sched_barriers in the MFMA loop
 #endif
+// SP == 2 (two-way fp16 split, mlp_common.h): planes h / l, three products per step — (Wh, xl) and (Wl, xh) into acc1 (the terms
+// that carry the factor 2^-11), (Wh, xh) into acc.
 template <int RT, int SP>
 __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6 &g, __amdgpu_buffer_rsrc_t rs, unsigned wofs, unsigned lo_b,
-                                              f32x16 (&acc)[RT]) {
+                                              f32x16 (&acc)[RT], f32x16 (&acc1)[RT]) {
     bf16x8 ah = *reinterpret_cast<const bf16x8 *>(pa), am = ah, al = ah;
-    if (SP == 3) { am = *reinterpret_cast<const bf16x8 *>(pa + plane); al = *reinterpret_cast<const bf16x8 *>(pa + 2 * plane); }
+    if (SP >= 2) am = *reinterpret_cast<const bf16x8 *>(pa + plane);
+    if (SP == 3) al = *reinterpret_cast<const bf16x8 *>(pa + 2 * plane);
     // ROLLED over groups of RD6 steps (ring slots are compile-time inside a group): unrolling all 8 steps lets hipcc give
     // every refill fresh registers, which costs a wave of occupancy
     unsigned so = wofs + 2u * RD6 * STEP6;          // byte offset of the step that refills slot 0 (RD6 steps ahead)
@@ -591,7 +594,7 @@ __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6
                 const __bf16 *pn = ((nr == RD6 && j == 8 / RD6 - 1) ? pa : pj + nr * 16) + nt * 32 * HB;
                 const bf16x8 nh = (G4C_ABLATE & 64) ? ah : *reinterpret_cast<const bf16x8 *>(pn),
                              nm = (SP == 1 || (G4C_ABLATE & 64)) ? am : *reinterpret_cast<const bf16x8 *>(pn + plane),
-                             nl = (SP == 1 || (G4C_ABLATE & 64)) ? al : *reinterpret_cast<const bf16x8 *>(pn + 2 * plane);
+                             nl = (SP != 3 || (G4C_ABLATE & 64)) ? al : *reinterpret_cast<const bf16x8 *>(pn + 2 * plane);
                 if (!(G4C_BX6_TUNE & 2)) __builtin_amdgcn_sched_barrier(0);
                 if (G4C_BX6_TUNE & 1) __builtin_amdgcn_s_setprio(1);
                 if (SP == 3 && !(G4C_ABLATE & 128)) {
@@ -603,12 +606,18 @@ __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6
                 } else if (SP == 3) {      // (ablation) keep every operand live with one cheap VALU op instead of five MFMAs
                     acc[t][0] += (float)al[0] + (float)am[0] + (float)g.l[r][0] + (float)g.m[r][0];
                 }
+                if (SP == 2) {
+                    acc1[t] = mfma_f16(g.h[r], am, acc1[t]);
+                    acc1[t] = mfma_f16(g.m[r], ah, acc1[t]);
+                    acc[t] = mfma_f16(g.h[r], ah, acc[t]);
+                } else
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], ah, acc[t], 0, 0, 0);
                 if (G4C_BX6_TUNE & 1) __builtin_amdgcn_s_setprio(0);
                 if (t + 1 == RT && !(G4C_ABLATE & 32)) {
                     const unsigned sx = (G4C_ABLATE & 1024) ? 0u : so + 2u * r * STEP6;     // (1024: always the same 3 KB -> L1 hits)
                     g.h[r] = ldw(rs, lo_b, sx);
-                    if (SP == 3) { g.m[r] = ldw(rs, lo_b + 1024u, sx); g.l[r] = ldw(rs, lo_b + 2048u, sx); }
+                    if (SP >= 2) g.m[r] = ldw(rs, lo_b + 1024u, sx);
+                    if (SP == 3) g.l[r] = ldw(rs, lo_b + 2048u, sx);
                 }
                 if (!(G4C_BX6_TUNE & 2)) __builtin_amdgcn_sched_barrier(0);
                 ah = nh; am = nm; al = nl;
@@ -628,13 +637,16 @@ __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6
 #ifndef G4C_BX6_MINW
 #define G4C_BX6_MINW 4
 #endif
+#ifndef G4C_F16_MINW
+#define G4C_F16_MINW 4          // workgroups per CU the SP == 2 instantiations are register-limited for
+#endif
 // RT = 1: 32-row tile.  RT = 2: 64-row tile — every weight fragment feeds two row tiles (half the L2 -> register weight
 // traffic per row, which is what this kernel stalls on) and every memory round trip of the tile's critical path serves
 // twice the rows.
 // FULL: every weighted input block and every additive block is exactly 128 wide and 16-byte aligned (the MP layers):
 // no column masks anywhere.
 template <int RT, bool VEC, bool FULL, int SP, bool SAVE = false>
-__global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kernel(const Params p) {
+__global__ __launch_bounds__(256, RT == 1 ? (SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) : 3) void mlp_bx6_kernel(const Params p) {
     constexpr int ROWS = 32 * RT, NW = 4;
     constexpr int PLN = ROWS * HB;              // one bf16 operand plane [ROWS][136]
     // three operand planes; the fp32 final tile [ROWS][132] aliases them
@@ -658,6 +670,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int ct0 = wave;
+    if (SP == 2) f16_range_mode();
 
     int tile;
     {
@@ -785,10 +798,8 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
                 bf16x4 vh, vm, vl;
                 split3x4<SP>(v, vh, vm, vl);
                 *reinterpret_cast<bf16x4 *>(d + q * KC) = vh;
-                if (SP == 3) {
-                    *reinterpret_cast<bf16x4 *>(d + PLN + q * KC) = vm;
-                    *reinterpret_cast<bf16x4 *>(d + 2 * PLN + q * KC) = vl;
-                }
+                if (SP >= 2) *reinterpret_cast<bf16x4 *>(d + PLN + q * KC) = vm;
+                if (SP == 3) *reinterpret_cast<bf16x4 *>(d + 2 * PLN + q * KC) = vl;
                 __builtin_amdgcn_sched_barrier(0);      // one group of four at a time: bounds the live temporaries
             }
         }
@@ -826,7 +837,8 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
 #pragma unroll
     for (int s = 0; s < RD6; ++s) {
         ring.h[s] = ldw(rs, lo_b, 2u * s * STEP6);
-        if (SP == 3) { ring.m[s] = ldw(rs, lo_b + 1024u, 2u * s * STEP6); ring.l[s] = ldw(rs, lo_b + 2048u, 2u * s * STEP6); }
+        if (SP >= 2) ring.m[s] = ldw(rs, lo_b + 1024u, 2u * s * STEP6);
+        if (SP == 3) ring.l[s] = ldw(rs, lo_b + 2048u, 2u * s * STEP6);
     }
     const bool direct0 = p.n_src > 0 && (p.src[0].idx == nullptr);
     if (direct0) gather(0, true);
@@ -851,11 +863,11 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
     // Operands are swapped in the MFMAs (weights as A, activations as B), so the accumulators are TRANSPOSED: this lane
     // holds sample row i (= lane & 31, + 32 per row tile) and the 16 output features 32*ct0 + 8*(q>>2) + 4*h + (q&3):
     // four runs of four consecutive features -> 16-byte gathers / LDS accesses instead of 16 scalar ones.
-    f32x16 acc[RT];
+    f32x16 acc[RT], acc1[RT];       // acc1: the 2^-11 terms of the two-way fp16 split (SP == 2 only)
 #pragma unroll
     for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+        for (int q = 0; q < 16; ++q) { acc[t][q] = 0.f; acc1[t][q] = 0.f; }
     const int fbase = ct0 * 32 + 4 * h;
     for (int a = 0; a < p.n_add; ++a) {
         const int width = p.add[a].width;
@@ -918,7 +930,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
         const bool more = s + 1 < p.n_src;
         if (more && RT == 1) gather(s + 1, false);          // (RT = 2: 32 more live registers would cost a wave per SIMD)
         __builtin_amdgcn_sched_barrier(0);
-        mma_block_bx6<RT, SP>(pa, PLN, ring, rs, wofs, lo_b, acc);
+        mma_block_bx6<RT, SP>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
         wofs += 2u * BLOCK6;
         __syncthreads();                   // everybody is done reading the planes
         if (more) {
@@ -940,7 +952,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
                     const f32x4 b4 = *reinterpret_cast<const f32x4 *>((LDS_BIAS ? sBias : p.b) + l * NP + fbase + 8 * gq);
                     f32x4 x;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = acc[t][4 * gq + e] + b4[e];
+                    for (int e = 0; e < 4; ++e) x[e] = (SP == 2 ? fmaf(acc1[t][4 * gq + e], F16_LO_UNSCALE, acc[t][4 * gq + e]) : acc[t][4 * gq + e]) + b4[e];
                     *reinterpret_cast<f32x4 *>(sH + (i + 32 * t) * HS + fbase + 8 * gq) = x;
                     if (SAVE) {
                         const long long gr = row0 + i + 32 * t;
@@ -959,7 +971,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
                 const f32x4 b4 = *reinterpret_cast<const f32x4 *>((LDS_BIAS ? sBias : p.b) + l * NP + fbase + 8 * gq);
                 f32x4 x;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = acc[t][4 * gq + e];
+                for (int e = 0; e < 4; ++e) x[e] = SP == 2 ? fmaf(acc1[t][4 * gq + e], F16_LO_UNSCALE, acc[t][4 * gq + e]) : acc[t][4 * gq + e];
                 bf16x4 vh, vm, vl;
                 f32x4 y;
                 if (SAVE && p.mul[l]) {
@@ -978,10 +990,8 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
                 split3x4<SP>(y, vh, vm, vl);
                 __bf16 *d = sB + (i + 32 * t) * HB + fbase + 8 * gq;
                 *reinterpret_cast<bf16x4 *>(d) = vh;
-                if (SP == 3) {
-                    *reinterpret_cast<bf16x4 *>(d + PLN) = vm;
-                    *reinterpret_cast<bf16x4 *>(d + 2 * PLN) = vl;
-                }
+                if (SP >= 2) *reinterpret_cast<bf16x4 *>(d + PLN) = vm;
+                if (SP == 3) *reinterpret_cast<bf16x4 *>(d + 2 * PLN) = vl;
                 __builtin_amdgcn_sched_barrier(0);
             }
         __syncthreads();
@@ -989,8 +999,8 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
-        mma_block_bx6<RT, SP>(pa, PLN, ring, rs, wofs, lo_b, acc);
+            for (int q = 0; q < 16; ++q) { acc[t][q] = 0.f; acc1[t][q] = 0.f; }
+        mma_block_bx6<RT, SP>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
         wofs += 2u * BLOCK6;
         __syncthreads();
         G4C_STAMPW(6 + 2 * l);
@@ -1030,18 +1040,16 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
                 split3x4<SP>(v[t][q], vh, vm, vl);
                 __bf16 *d = sB + (grow_l + 32 * t) * HB + q * KC + c4;
                 *reinterpret_cast<bf16x4 *>(d) = vh;
-                if (SP == 3) {
-                    *reinterpret_cast<bf16x4 *>(d + PLN) = vm;
-                    *reinterpret_cast<bf16x4 *>(d + 2 * PLN) = vl;
-                }
+                if (SP >= 2) *reinterpret_cast<bf16x4 *>(d + PLN) = vm;
+                if (SP == 3) *reinterpret_cast<bf16x4 *>(d + 2 * PLN) = vl;
             }
         __syncthreads();
         for (int hd = 0; hd < p.n_heads; ++hd) {
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
-            mma_block_bx6<RT, SP>(pa, PLN, ring, rs, wofs, lo_b, acc);
+                for (int q = 0; q < 16; ++q) { acc[t][q] = 0.f; acc1[t][q] = 0.f; }
+            mma_block_bx6<RT, SP>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
             wofs += 2u * BLOCK6;
             float *ho = p.head_out[hd];
 #pragma unroll
@@ -1052,7 +1060,7 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
                     for (int gq = 0; gq < 4; ++gq) {
                         f32x4 x;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) x[e] = acc[t][4 * gq + e];
+                        for (int e = 0; e < 4; ++e) x[e] = SP == 2 ? fmaf(acc1[t][4 * gq + e], F16_LO_UNSCALE, acc[t][4 * gq + e]) : acc[t][4 * gq + e];
                         *reinterpret_cast<f32x4 *>(ho + grow * p.head_ld + fbase + 8 * gq) = x;
                     }
                 }
@@ -1061,7 +1069,9 @@ __global__ __launch_bounds__(256, RT == 1 ? G4C_BX6_MINW : 3) void mlp_bx6_kerne
     }
 }
 
-// bf16x6 image of one layer: three planes (h, m, l) of the exact split of every weight
+// bf16x6 image of one layer: three planes (h, m, l) of the exact split of every weight.  F16: the two-way fp16 split (h, l * 2^11)
+// in planes 0 / 1 of the same layout, plane 2 zero.
+template <bool F16>
 __global__ void pack_layer_bx6_kernel(const float *__restrict__ W, int n_out, int k_in, PackSegs segs,
                                       __bf16 *__restrict__ packed, int k_pad) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1080,7 +1090,8 @@ __global__ void pack_layer_bx6_kernel(const float *__restrict__ W, int n_out, in
     if (k >= 0 && n < n_out) v = W[(long long)n * k_in + k];
     if (neg) v = -v;
     __bf16 a, b, c;
-    split3(v, a, b, c);
+    if (F16) { split2(v, a, b); c = (__bf16)0.f; }
+    else split3(v, a, b, c);
     const int kk = kp & 127;
     __bf16 *d = packed + (long long)(kp >> 7) * BLOCK6 + (n >> 5) * 8 * STEP6 + (kk >> 4) * STEP6 + (((kk >> 3) & 1) * 32 + (n & 31)) * 8 + (kk & 7);
     d[0] = a; d[512] = b; d[1024] = c;
@@ -1114,16 +1125,22 @@ extern "C" int g4c_mlp_pack_layer(const float *W, int32_t n_out, int32_t k_in, c
     return g4c::check_launch("g4c_mlp_pack_layer");
 }
 
-static int pack_layer_16(bool six, const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
+static int pack_layer_16(bool f16, const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
                          const int32_t *seg_negate, int32_t n_seg, void *packed, int32_t k_pad, int32_t n_pad, void *stream);
 
 extern "C" int g4c_mlp_pack_layer_bx6(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
                                       const int32_t *seg_negate, int32_t n_seg, void *packed,
                                       int32_t k_pad, int32_t n_pad, void *stream) {
+    return pack_layer_16(false, W, n_out, k_in, seg_width, seg_negate, n_seg, packed, k_pad, n_pad, stream);
+}
+
+extern "C" int g4c_mlp_pack_layer_f16x3(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
+                                        const int32_t *seg_negate, int32_t n_seg, void *packed,
+                                        int32_t k_pad, int32_t n_pad, void *stream) {
     return pack_layer_16(true, W, n_out, k_in, seg_width, seg_negate, n_seg, packed, k_pad, n_pad, stream);
 }
 
-static int pack_layer_16(bool six, const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
+static int pack_layer_16(bool f16, const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width,
                          const int32_t *seg_negate, int32_t n_seg, void *packed, int32_t k_pad, int32_t n_pad, void *stream) {
     G4C_REQUIRE(W && packed && seg_width, G4C_EINVAL, "g4c_mlp_pack_layer_bf16: null pointer");
     G4C_REQUIRE(n_seg >= 1 && n_seg <= G4C_MAX_SRC, G4C_EUNSUPPORTED, "g4c_mlp_pack_layer_bf16: %d input blocks (max %d)", n_seg, G4C_MAX_SRC);
@@ -1142,7 +1159,8 @@ static int pack_layer_16(bool six, const float *W, int32_t n_out, int32_t k_in, 
     G4C_REQUIRE(ksum == k_in, G4C_EINVAL, "g4c_mlp_pack_layer_bf16: blocks sum to %d columns, weight has %d", ksum, k_in);
     const int total = k_pad * NP;
     g4c::DeviceGuard on_device(packed);
-    pack_layer_bx6_kernel<<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(W, n_out, k_in, segs, (__bf16 *)packed, k_pad);
+    if (f16) pack_layer_bx6_kernel<true><<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(W, n_out, k_in, segs, (__bf16 *)packed, k_pad);
+    else pack_layer_bx6_kernel<false><<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(W, n_out, k_in, segs, (__bf16 *)packed, k_pad);
     return g4c::check_launch("g4c_mlp_pack_layer_bx6");
 }
 
@@ -1266,6 +1284,9 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     if (force_tiles) tile_rows -= 1;
     const bool round1 = (tile_rows == 3216);     // operands rounded to bf16: only the leading plane of the stream is used
     const bool bx6 = (tile_rows == 3248) || round1;   // weights: the three-plane stream of g4c_mlp_pack_layer_bx6
+    const bool f16x2 = bx6 && mlp && mlp->w_format == G4C_WFMT_F16X2;     // the stream holds the two-way fp16 split (g4c_mlp_pack_layer_f16x3)
+    G4C_REQUIRE(!(f16x2 && round1), G4C_EINVAL, "g4c_mlp_forward_bf16: the weights were packed by g4c_mlp_pack_layer_f16x3 (fp16 planes)");
+    G4C_REQUIRE(!mlp || mlp->w_format == 0 || f16x2, G4C_EINVAL, "g4c_mlp_forward: w_format %d does not match this entry point", mlp->w_format);
     const bool bf16 = bx6;                       // input blocks padded to 128 k
     const int wbytes = bx6 ? 6 : 4;
     if (bf16) tile_rows = 324;
@@ -1401,7 +1422,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     if (row_count == 0) return G4C_OK;
     p.row_base = row_begin;
     p.M = row_begin + row_count;          // rows past the range are neither gathered nor stored
-    if (bx6 && !force_tiles && px6_eligible(p, agg != nullptr, save != nullptr, all_vec) && row_count >= px6_min_rows()) {
+    if (bx6 && !f16x2 && !force_tiles && px6_eligible(p, agg != nullptr, save != nullptr, all_vec) && row_count >= px6_min_rows()) {
         // persistent ping-pong kernel (mlp_px6.hip): 32-row units (whole segments with aggregation), two per group tile
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
         if (p.n_tiles == 0) return G4C_OK;
@@ -1409,7 +1430,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     } else if (bx6 && !force_tiles && bx6i_eligible(p, round1, agg != nullptr, save != nullptr, row_count)) {
         // dual-tile software-pipelined kernel (mlp_bx6i.hip): pairs of 32-row tiles (whole segments with aggregation)
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
-        return bx6i_launch(p, agg != nullptr, st);
+        return bx6i_launch(p, agg != nullptr, f16x2, st);
     } else if (bx6) {
         static const int64_t rt2_rows = getenv("G4C_BX6_RT2_ROWS") ? atoll(getenv("G4C_BX6_RT2_ROWS")) : (1LL << 40);   // measured slower (2 waves per SIMD): off
         bool full = all_vec;
@@ -1417,7 +1438,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         for (int a = 0; a < p.n_add; ++a)
             full = full && p.add[a].width == NP && (p.add[a].ld & 3) == 0 && ((uintptr_t)p.add[a].ptr & 15) == 0;
         const dim3 blk(256);
-        const bool rt2 = !agg && !save && row_count >= rt2_rows && p.n_src <= 2 && p.n_add <= 2;      // 64-row tiles (tuning only)
+        const bool rt2 = !agg && !save && !f16x2 && row_count >= rt2_rows && p.n_src <= 2 && p.n_add <= 2;      // 64-row tiles (tuning only)
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + (rt2 ? 63 : 31)) / (rt2 ? 64 : 32));
         if (p.n_tiles == 0) return G4C_OK;
         const dim3 grid(p.n_tiles);
@@ -1427,11 +1448,16 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
             else if (all_vec) mlp_bx6_kernel<RT, true, false, SP><<<grid, blk, 0, st>>>(p);            \
             else mlp_bx6_kernel<RT, false, false, SP><<<grid, blk, 0, st>>>(p);                        \
         } while (0)
-        if (save) {
+        if (save && f16x2) {
+            if (full) mlp_bx6_kernel<1, true, true, 2, true><<<grid, blk, 0, st>>>(p);
+            else if (all_vec) mlp_bx6_kernel<1, true, false, 2, true><<<grid, blk, 0, st>>>(p);
+            else mlp_bx6_kernel<1, false, false, 2, true><<<grid, blk, 0, st>>>(p);
+        } else if (save) {
             if (full) mlp_bx6_kernel<1, true, true, 3, true><<<grid, blk, 0, st>>>(p);
             else if (all_vec) mlp_bx6_kernel<1, true, false, 3, true><<<grid, blk, 0, st>>>(p);
             else mlp_bx6_kernel<1, false, false, 3, true><<<grid, blk, 0, st>>>(p);
         }
+        else if (f16x2) G4C_BX6_LAUNCH(1, 2);
         else if (round1) { if (rt2) G4C_BX6_LAUNCH(2, 1); else G4C_BX6_LAUNCH(1, 1); }
         else { if (rt2) G4C_BX6_LAUNCH(2, 3); else G4C_BX6_LAUNCH(1, 3); }
 #undef G4C_BX6_LAUNCH

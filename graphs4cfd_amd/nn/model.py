@@ -13,6 +13,7 @@ host synchronisation and can be captured once in a hipGraph and replayed (`captu
 from __future__ import annotations
 
 import os
+import warnings
 from typing import Callable, List, Optional, Union
 
 import torch
@@ -292,7 +293,13 @@ class GNN(nn.Module):
                 capture = n_out >= 4 and os.environ.get("G4C_HIPGRAPH", "1") != "0"
             with Rollout(self, graph, n_out, capture=capture) as ro:
                 ro.run(n_out)
-                return ro.result()
+                out = ro.result()
+            if ops.mlp_precision() == "f16x3" and not bool(torch.isfinite(out).all()):
+                # the two-way fp16 operand split turns an activation beyond +-65504 into NaN rows on purpose (ops.py); a rollout
+                # that diverged in the model itself looks the same, so this is a hint, not an error
+                warnings.warn("solve(): non-finite outputs.  The default 'f16x3' MLP arithmetic needs |activation| <= 65504 (inputs that "
+                              "are not normalised can exceed it); gfd.set_mlp_precision('bf16x6') keeps the whole fp32 range.", RuntimeWarning)
+            return out
 
     def invalidate_packed(self) -> None:
         """Declare every packed weight image stale (they are rebuilt on the next launch).  The images are keyed on the parameters'

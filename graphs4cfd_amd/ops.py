@@ -223,13 +223,19 @@ def rollout_advance(field: Tensor, pred: Tensor, outputs: Tensor, step: Tensor, 
 
 
 # Arithmetic of the fused MLPs — all fp32 in, fp32 out:
-#   "bf16x6" (default)  fp32-accurate products on the bf16 matrix pipe: both operands split EXACTLY into three bf16 terms,
-#                       the six largest partial products accumulated in fp32 (g4c_mlp_forward_bx6); measured error
-#                       against fp64 <= that of the fp32-MFMA kernel (scripts/mlp_accuracy.py, test_mlp_precisions_vs_fp64);
-#                       MLPs outside its envelope (an input block wider than 128) use the fp32 kernels;
-#   "fp32"              v_mfma_f32_32x32x2_f32 (g4c_mlp_forward): the original kernels, every tile variant;
+#   "f16x3" (default)   fp32-class products on the f16 matrix pipe: both operands split two ways into fp16 terms,
+#                       x = h + l * 2^-11 (22 significand bits), three partial products, the 2^-11 terms in their own fp32
+#                       accumulator (g4c_mlp_pack_layer_f16x3 + the g4c_mlp_forward_bx6* entry points); measured error against fp64
+#                       below that of the fp32-MFMA kernel (scripts/mlp_accuracy.py, test_mlp_precisions_vs_fp64).  Range: an input
+#                       or hidden activation beyond +-65504 becomes a NaN row (loud; Model.solve warns) — normalised CFD fields and
+#                       LayerNorm'd latents are far inside; "bf16x6" has no such limit;
+#   "bf16x6"            the same kernels with both operands split EXACTLY into three bf16 terms (fp32 exponent range), the six
+#                       largest partial products accumulated in fp32 (g4c_mlp_forward_bx6): twice the matrix-pipe work;
+#                       MLPs outside the envelope of these two (an input block wider than 128) use the fp32 kernels;
+#   "fp32"              v_mfma_f32_32x32x2_f32 (g4c_mlp_forward): the original kernel;
 #   "bf16"              operands ROUNDED to bf16 (~1e-2 deviation): BASELINE config 3's "bf16 edge-MLP MFMA", opt-in only.
-_PRECISION = os.environ.get("G4C_MLP_PRECISION", "bf16x6")
+PRECISIONS = ("fp32", "bf16", "bf16x6", "f16x3")
+_PRECISION = os.environ.get("G4C_MLP_PRECISION", "f16x3")
 
 
 # Fused aggregation in the edge-MLP launch (g4c_mlp_forward_bx6_agg): bit-identical to the separate g4c_segment_reduce, and the
@@ -273,7 +279,7 @@ def grad_mode() -> bool:
 def can_fuse_aggregation(csr: CsrPlan, width: int) -> bool:
     """The edge launch itself can reduce its rows per target (g4c_mlp_forward_bx6_agg): rows in segment order, segments of
     at most 32 rows, the exact-split kernels, a 128-wide output, enough rows to be throughput-bound."""
-    return (FUSE_AGG and _PRECISION in ("bf16x6", "bf16") and width == 128 and csr.perm is None and csr.n >= FUSE_AGG_MIN_ROWS
+    return (FUSE_AGG and _PRECISION in ("bf16x6", "f16x3", "bf16") and width == 128 and csr.perm is None and csr.n >= FUSE_AGG_MIN_ROWS
             and not grad_mode() and csr.tiles() is not None)
 
 
@@ -299,8 +305,8 @@ def effective_precision(seg_widths: Sequence[int]) -> str:
 def set_mlp_precision(precision: str) -> str:
     """Select the arithmetic of every fused MLP launched from now on; returns the previous setting."""
     global _PRECISION
-    if precision not in ("fp32", "bf16", "bf16x6"):
-        raise ValueError(f"unknown MLP precision {precision!r} (fp32 | bf16 | bf16x6)")
+    if precision not in PRECISIONS:
+        raise ValueError(f"unknown MLP precision {precision!r} ({' | '.join(PRECISIONS)})")
     old, _PRECISION = _PRECISION, precision
     return old
 
@@ -318,6 +324,11 @@ class PackedMLP:
         fp32 on the vector ALUs by its rows of the first layer's weight (g4c_src_t.additive == 2) instead of being padded
         to a 128-k block of the matrix-pipe stream."""
         lib = _lib.load()
+        # "f16x3" is the "bf16x6" kernel family (same entry points, stream layout and launch envelope) on a stream written by
+        # g4c_mlp_pack_layer_f16x3; desc.w_format tells the library which arithmetic the stream is for
+        self.split = "f16x2" if precision == "f16x3" else ("bf16x3" if precision == "bf16x6" else None)
+        if precision == "f16x3":
+            precision = "bf16x6"
         self.precision = precision
         bf16 = precision in ("bf16", "bf16x6")
         narrow = tuple(bool(x) for x in narrow) if narrow is not None else (False,) * len(seg_widths)
@@ -337,6 +348,7 @@ class PackedMLP:
             raise NotImplementedError(f"MLP input concatenated from {len(seg_widths)} blocks (max {_lib.MAX_SRC})")
         self.desc = _lib.g4c_mlp_t()
         self.desc.n_layers = n_layers
+        self.desc.w_format = 1 if self.split == "f16x2" else 0
         self._keep: List[Tensor] = []
         stream = _lib.stream_handle(dev)
         KC, NP = 32, 128                       # kernel constants: K chunk, computed layer width
@@ -355,7 +367,7 @@ class PackedMLP:
         stream_buf = torch.zeros((sum(k_pads) + NP * len(heads) + (NP if bf16 else KC)) * NP * planes,
                                  dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
         esz = 2 * planes if bf16 else 4
-        pack = lib.g4c_mlp_pack_layer_bx6 if bf16 else lib.g4c_mlp_pack_layer
+        pack = (lib.g4c_mlp_pack_layer_f16x3 if self.split == "f16x2" else lib.g4c_mlp_pack_layer_bx6) if bf16 else lib.g4c_mlp_pack_layer
         bias_buf = torch.zeros(n_layers * NP, dtype=torch.float32, device=dev)
         self._keep += [stream_buf, bias_buf]
         off = 0

@@ -138,7 +138,11 @@ typedef struct {
     const float *ln_beta;
     float ln_eps;
     int32_t n_out;                   /* true output width of the last layer */
+    int32_t w_format;                /* 0: the format the entry point names (fp32 stream / three bf16 planes).  G4C_WFMT_F16X2: the
+                                        stream was written by g4c_mlp_pack_layer_f16x3 — the g4c_mlp_forward_bx6* entry points then run
+                                        their "f16x3" arithmetic (below). */
 } g4c_mlp_t;
+#define G4C_WFMT_F16X2 1
 
 /* Packs one nn.Linear weight W[n_out, k_in] (row-major, device) for the kernel.  The input
  * dimension is the concatenation of `n_seg` column blocks of widths seg_width[] (each padded
@@ -184,6 +188,19 @@ int g4c_mlp_pack_layer_bx6(const float *W, int32_t n_out, int32_t k_in, const in
 int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
                         int64_t n_rows, float *out, int32_t out_ld, const int32_t *out_idx,
                         int32_t act, const float *resid, int32_t resid_ld, int32_t resid_col0, void *stream);
+/* "f16x3": the same kernels with a TWO-way fp16 split of both operands, x = h + l * 2^-11 (h = fp16(x) rounded to nearest,
+ * l = fp16((x - h) * 2^11): 22 significand bits per operand), and three products per MAC — (Wh, xh) in one fp32 accumulator,
+ * (Wh, xl) + (Wl, xh) in a second one folded in with 2^-11 at the end of the layer; the dropped (Wl, xl) term and the operand
+ * representation are <= 2^-22 relative each: the result is within the rounding error of an fp32 GEMM of the same shape (measured
+ * against fp64: scripts/mlp_accuracy.py, test_mlp_precisions_vs_fp64) at half the matrix-pipe work and two thirds of the operand
+ * traffic of the six-product form.  Range: an input or hidden activation with |x| > 65504 converts to an fp16 infinity and its
+ * output row is NaN (loud, never a clipped value); small values lose nothing (the matrix pipe honours fp16 subnormals and l keeps
+ * x's magnitude).  The bf16 three-way split keeps the whole fp32 range and stays selectable.
+ * g4c_mlp_pack_layer_f16x3 writes planes 0 / 1 of the g4c_mlp_pack_layer_bx6 layout (same sizes, plane 2 zero); a g4c_mlp_t over
+ * such a stream sets w_format = G4C_WFMT_F16X2 and goes through g4c_mlp_forward_bx6 / _heads_bx6 / _bx6_agg / _bx6_save. */
+int g4c_mlp_pack_layer_f16x3(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width /*host*/,
+                             const int32_t *seg_negate /*host*/, int32_t n_seg, void *packed,
+                             int32_t k_pad, int32_t n_pad, void *stream);
 /* The dual-tile software-pipelined form of the exact-split kernel (mlp_bx6i.hip: a workgroup alternates between two 32-row tiles,
  * the vector work of one running under the MFMAs of the other, the layer's weights stationary in registers for both) takes the
  * launches of the MP layers' message MLP (one weighted 128-wide block + 0 or 2 additive blocks, three layers, plain 128-wide output

@@ -188,7 +188,7 @@ def test_mlp_bf16_variant(rows):
     assert (y.cpu() - ref).abs().mean().item() < 6e-3
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x6", "f16x3"])
 @pytest.mark.parametrize("rows", [33, 5000, 40000])
 def test_mlp_heads(rows, prec, monkeypatch):
     """g4c_mlp_forward_heads: the node MLP launch also emits W1[:, H:2H] y and W1[:, 2H:] y of the next edge MLP
@@ -212,7 +212,7 @@ def test_mlp_heads(rows, prec, monkeypatch):
     assert blk.node_mlp.run_with_heads([ops.Source(agg), ops.Source(v)], rows, _lib.ACT_SELU, nxt.edge_mlp, H, [H, H, H]) is None
 
 
-@pytest.mark.parametrize("prec", ["bf16x6", "bf16"])
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x6", "bf16"])
 @pytest.mark.parametrize("case", ["knn6", "ragged", "unsorted", "long_segment"])
 def test_edge_mlp_with_fused_aggregation(case, prec, monkeypatch):
     """ops.mlp_forward(agg=...): the edge launch also reduces its output rows per target (g4c_mlp_forward_bx6_agg on tiles
@@ -327,15 +327,17 @@ def test_node_mlp_aggregates_on_load(case):
 
 
 def test_mlp_precisions_vs_fp64():
-    """The default bf16x6 arithmetic (exact three-way bf16 split, six partial products on the bf16 matrix pipe) is as
-    accurate as the fp32-MFMA kernels: both against an fp64 evaluation of the same edge MLP (gathers, SELU-on-load,
-    LayerNorm); plain bf16 is the only mode that deviates (its stated ~1e-2)."""
+    """The default f16x3 arithmetic (two-way fp16 split, three partial products on the f16 matrix pipe, the 2^-11 terms in their
+    own accumulator) and bf16x6 (exact three-way bf16 split, six partial products) are as accurate as the fp32-MFMA kernels: all
+    against an fp64 evaluation of the same edge MLP (gathers, SELU-on-load, LayerNorm); plain bf16 is the only mode that deviates
+    (its stated ~1e-2).  Then the range contract of f16x3: activations beyond +-65504 give NaN rows (never clipped values), and only
+    in the rows that hold them; tiny activations lose nothing."""
     H, rows = 128, 20000
     n = rows // 6
     torch.manual_seed(11)
     blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
     e, v = 3.0 * torch.randn(rows, H, device=DEV), torch.randn(n, H, device=DEV)
-    e[::7] *= 1e3                                   # large magnitudes: bf16 keeps the fp32 exponent range
+    e[::7] *= 1e3                                   # large magnitudes (up to ~1.5e4: inside fp16's range, far outside bf16's 8 bits)
     e[5::11] *= 1e-4
     row = torch.randint(0, n, (rows,), device=DEV, dtype=torch.int32)
     col = torch.randint(0, n, (rows,), device=DEV, dtype=torch.int32)
@@ -350,16 +352,28 @@ def test_mlp_precisions_vs_fp64():
     err = {}
     old = ops.mlp_precision()
     try:
-        for prec in ("fp32", "bf16x6", "bf16"):
+        for prec in ("fp32", "bf16x6", "f16x3", "bf16"):
             ops.set_mlp_precision(prec)
             out = blk.edge_mlp.run_coded([ops.Source(e), ops.Source(v, index=row), ops.Source(v, index=col)], rows)
             d = (out.double() - ref).abs()
             err[prec] = (d.max().item(), d.mean().item())
+        ops.set_mlp_precision("f16x3")
+        e2 = e.clone()
+        e2[3] *= 1e-6                               # a row of tiny values: still fp32-class (fp16 subnormals are honoured)
+        e2[17, 5] = 1.0e5                           # one value beyond fp16: that row is NaN, no other row changes
+        out2 = blk.edge_mlp.run_coded([ops.Source(e2), ops.Source(v, index=row), ops.Source(v, index=col)], rows)
+        ops.set_mlp_precision("bf16x6")
+        ref2 = blk.edge_mlp.run_coded([ops.Source(e2), ops.Source(v, index=row), ops.Source(v, index=col)], rows)
     finally:
         ops.set_mlp_precision(old)
-    assert err["fp32"][0] < 2e-5 and err["bf16x6"][0] < 2e-5, err
+    assert err["fp32"][0] < 2e-5 and err["bf16x6"][0] < 2e-5 and err["f16x3"][0] < 2e-5, err
     assert err["bf16x6"][0] <= 2.0 * err["fp32"][0] + 1e-6 and err["bf16x6"][1] <= 1.5 * err["fp32"][1] + 1e-7, err
+    assert err["f16x3"][0] <= 2.0 * err["fp32"][0] + 1e-6 and err["f16x3"][1] <= 1.5 * err["fp32"][1] + 1e-7, err
     assert 1e-3 < err["bf16"][0] < 2e-1, err
+    assert torch.isnan(out2[17]).all() and torch.isfinite(ref2).all()
+    keep = torch.ones(rows, dtype=torch.bool, device=DEV); keep[17] = False
+    assert torch.isfinite(out2[keep]).all()
+    torch.testing.assert_close(out2[keep], ref2[keep], rtol=2e-5, atol=2e-5)
 
 
 def test_mp_chain_with_and_without_heads(monkeypatch):
@@ -468,8 +482,10 @@ def test_remus_helpers(golden):
 
 
 # ------------------------------------------------------------------ models vs golden
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x6"])
 @pytest.mark.parametrize("cls", sorted(S.MUS_LAYERS))
-def test_mus_models(golden, cls):
+def test_mus_models(golden, cls, prec, monkeypatch):
+    monkeypatch.setattr(ops, "_PRECISION", prec)
     c = golden("models_mus.pt")[cls]
     model = getattr(gfd.nn, cls)(arch=c["arch"], device=DEV)
     model.load_state_dict(c["weights"])
@@ -639,10 +655,10 @@ def test_models_bf16_mode_vs_oracle():
 
 # ------------------------------------------------------------------ BASELINE configs at size
 def test_headline_100k_vs_oracle():
-    """The bench workload itself (NsThreeScaleGNN, H = 128, 100k-node 2-D mesh, default bf16x6 kernels with the fused
+    """The bench workload itself (NsThreeScaleGNN, H = 128, 100k-node 2-D mesh, default f16x3 kernels with the fused
     per-target aggregation): forward vs the oracle at the stated fp32 tolerance, then the hipGraph-replayed rollout step
     vs the eager one, bit for bit."""
-    assert ops.mlp_precision() == "bf16x6"
+    assert ops.mlp_precision() == "f16x3"
     g = S.mus_graph(100_000, levels=3, seed=0)
     torch.manual_seed(1)
     model = gfd.nn.NsThreeScaleGNN(arch=S.mus_arch("NsThreeScaleGNN", 128), device=DEV)
@@ -655,7 +671,7 @@ def test_headline_100k_vs_oracle():
     assert torch.equal(cap, eag) and torch.isfinite(cap).all()
 
 
-@pytest.mark.parametrize("prec", ["bf16x6", "bf16"])
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x6", "bf16"])
 def test_remus_20k_vs_oracle(prec):
     """BASELINE config 3's model (REMuS-GNN 3-scale, H = 128) at 20k nodes / 100k level-1 edges, on the fp32-accurate default and on
     the config's bf16 edge-MLP MFMA variant (tolerance of SURVEY 8(c): ~1e-2 on O(1) outputs)."""
@@ -667,7 +683,7 @@ def test_remus_20k_vs_oracle(prec):
         ref = O.remus_forward(g.to_dict(), {k: v.cpu() for k, v in model.state_dict().items()})
         with torch.no_grad():
             y = model.forward(g.clone().to(DEV)).cpu()
-        if prec == "bf16x6":
+        if prec != "bf16":
             torch.testing.assert_close(y, ref, **FWD)
         else:
             d = (y - ref).abs()
@@ -1010,12 +1026,14 @@ def test_model_on_a_non_current_device():
 
 # ------------------------------------------------------------------ the dual-tile kernel of the large message launches (mlp_bx6i.hip)
 @pytest.mark.parametrize("kernel", ["bx6i"])
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x6"])
 @pytest.mark.parametrize("rows", [1, 33, 64, 6001, 90000])
-def test_bx6i_dual_tile_kernel_equals_tile_kernel(rows, kernel):
+def test_bx6i_dual_tile_kernel_equals_tile_kernel(rows, kernel, prec, monkeypatch):
     """g4c_mlp_bx6i_enable(2) (every eligible launch; the default mode takes launches of >= 400k rows, exercised by the at-size
     tests): the dual-tile software-pipelined kernel against the 32-row-tile kernel on the hoisted message form, a plain one-block
     form with SELU output, and the fused per-target aggregation (bit-exact reduction of the rows it stores, ragged segments)."""
     lib = _lib.load()
+    monkeypatch.setattr(ops, "_PRECISION", prec)
     H, n = 128, max(rows // 6, 2)
     torch.manual_seed(rows)
     blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
