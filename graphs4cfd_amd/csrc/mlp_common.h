@@ -142,11 +142,12 @@ constexpr float F16_LO_SCALE = 2048.f, F16_LO_UNSCALE = 1.f / 2048.f;
 __device__ __forceinline__ f32x16 mfma_f16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-// Range: an activation beyond +-65504 converts to an infinity, and the row comes out as NaN — loud, not a silently clipped value
-// (the three-way bf16 split keeps the whole fp32 range and stays selectable).  -DG4C_F16_SATURATE=1 sets MODE.FP16_OVFL instead:
-// conversions saturate at +-65504 (scripts/micro/f16_mfma_modes.hip shows both behaviours).
+// Range: the kernels set MODE.FP16_OVFL, so an activation beyond +-65504 is CLIPPED to 65504 (1 + 2^-11) by the conversions instead of
+// becoming an infinity (scripts/micro/f16_mfma_modes.hip shows both behaviours).  Letting it overflow is not "loud": inf - inf = NaN in
+// the accumulators, and the SELU's fminf / fmaxf (IEEE minNum / maxNum) turn a NaN pre-activation into 0 — a wrong finite row.  The
+// three-way bf16 split keeps the whole fp32 range and stays selectable.
 #ifndef G4C_F16_SATURATE
-#define G4C_F16_SATURATE 0
+#define G4C_F16_SATURATE 1
 #endif
 __device__ __forceinline__ void f16_range_mode() { if (G4C_F16_SATURATE) __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
 __device__ __forceinline__ unsigned pack_f16(f32x2 x, f32x2 &back) {

@@ -291,14 +291,11 @@ class GNN(nn.Module):
             graph.to(self.device)
             if capture is None:
                 capture = n_out >= 4 and os.environ.get("G4C_HIPGRAPH", "1") != "0"
+            if ops.mlp_precision() == "f16x3":
+                _warn_f16_range(graph)
             with Rollout(self, graph, n_out, capture=capture) as ro:
                 ro.run(n_out)
                 out = ro.result()
-            if ops.mlp_precision() == "f16x3" and not bool(torch.isfinite(out).all()):
-                # the two-way fp16 operand split turns an activation beyond +-65504 into NaN rows on purpose (ops.py); a rollout
-                # that diverged in the model itself looks the same, so this is a hint, not an error
-                warnings.warn("solve(): non-finite outputs.  The default 'f16x3' MLP arithmetic needs |activation| <= 65504 (inputs that "
-                              "are not normalised can exceed it); gfd.set_mlp_precision('bf16x6') keeps the whole fp32 range.", RuntimeWarning)
             return out
 
     def invalidate_packed(self) -> None:
@@ -349,6 +346,24 @@ class GNN(nn.Module):
 
 
 REORDER_MIN_NODES = 50_000      # below, the gathered rows stay in L2 whatever the numbering
+
+
+F16_INPUT_WARN = 4096.0
+
+
+def _warn_f16_range(graph: Graph) -> None:
+    """The default "f16x3" MLP arithmetic clips activations at +-65504 (ops.py).  Raw inputs go through the fp32 vector path, but
+    the first hidden layer they feed is split into fp16: inputs of this size mean un-normalised data, where that layer can get
+    there.  One small reduction per input tensor and one synchronisation per solve() call."""
+    big = []
+    for name in ("field", "edge_attr", "loc", "glob", "omega"):
+        x = getattr(graph, name, None)
+        if torch.is_tensor(x) and x.is_floating_point() and x.numel():
+            big.append(x.detach().abs().amax().reshape(1).float())
+    if big and float(torch.cat(big).amax()) > F16_INPUT_WARN:
+        warnings.warn(f"solve(): an input tensor has magnitudes beyond {F16_INPUT_WARN:g}; the default 'f16x3' MLP arithmetic clips "
+                      "activations at +-65504 — gfd.set_mlp_precision('bf16x6') keeps the whole fp32 range for un-normalised data.",
+                      RuntimeWarning)
 
 
 class Rollout:

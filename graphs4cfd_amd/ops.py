@@ -226,9 +226,10 @@ def rollout_advance(field: Tensor, pred: Tensor, outputs: Tensor, step: Tensor, 
 #   "f16x3" (default)   fp32-class products on the f16 matrix pipe: both operands split two ways into fp16 terms,
 #                       x = h + l * 2^-11 (22 significand bits), three partial products, the 2^-11 terms in their own fp32
 #                       accumulator (g4c_mlp_pack_layer_f16x3 + the g4c_mlp_forward_bx6* entry points); measured error against fp64
-#                       below that of the fp32-MFMA kernel (scripts/mlp_accuracy.py, test_mlp_precisions_vs_fp64).  Range: an input
-#                       or hidden activation beyond +-65504 becomes a NaN row (loud; Model.solve warns) — normalised CFD fields and
-#                       LayerNorm'd latents are far inside; "bf16x6" has no such limit;
+#                       below that of the fp32-MFMA kernel (scripts/mlp_accuracy.py, test_mlp_precisions_vs_fp64).  Range: an MLP
+#                       input or hidden activation beyond +-65504 is clipped there (no inf / NaN) — normalised CFD fields and
+#                       LayerNorm'd latents are far inside, raw inputs only pass the fp32 vector path; Model.solve warns about inputs
+#                       large enough to get near it; "bf16x6" has no such limit;
 #   "bf16x6"            the same kernels with both operands split EXACTLY into three bf16 terms (fp32 exponent range), the six
 #                       largest partial products accumulated in fp32 (g4c_mlp_forward_bx6): twice the matrix-pipe work;
 #                       MLPs outside the envelope of these two (an input block wider than 128) use the fp32 kernels;

@@ -193,9 +193,9 @@ int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*h
  * (Wh, xl) + (Wl, xh) in a second one folded in with 2^-11 at the end of the layer; the dropped (Wl, xl) term and the operand
  * representation are <= 2^-22 relative each: the result is within the rounding error of an fp32 GEMM of the same shape (measured
  * against fp64: scripts/mlp_accuracy.py, test_mlp_precisions_vs_fp64) at half the matrix-pipe work and two thirds of the operand
- * traffic of the six-product form.  Range: an input or hidden activation with |x| > 65504 converts to an fp16 infinity and its
- * output row is NaN (loud, never a clipped value); small values lose nothing (the matrix pipe honours fp16 subnormals and l keeps
- * x's magnitude).  The bf16 three-way split keeps the whole fp32 range and stays selectable.
+ * traffic of the six-product form.  Range: an input or hidden activation with |x| > 65504 is clipped to +-65504 (1 + 2^-11) when it
+ * is converted (MODE.FP16_OVFL; no infinities or NaNs are produced); small values lose nothing (the matrix pipe honours fp16
+ * subnormals and l keeps x's magnitude).  The bf16 three-way split keeps the whole fp32 range and stays selectable.
  * g4c_mlp_pack_layer_f16x3 writes planes 0 / 1 of the g4c_mlp_pack_layer_bx6 layout (same sizes, plane 2 zero); a g4c_mlp_t over
  * such a stream sets w_format = G4C_WFMT_F16X2 and goes through g4c_mlp_forward_bx6 / _heads_bx6 / _bx6_agg / _bx6_save. */
 int g4c_mlp_pack_layer_f16x3(const float *W, int32_t n_out, int32_t k_in, const int32_t *seg_width /*host*/,
