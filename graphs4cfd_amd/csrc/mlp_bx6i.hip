@@ -170,7 +170,15 @@ __device__ __forceinline__ void m_block(const __bf16 *pa, bf16x8 (&W)[8][SP], __
 #ifndef G4C_BX6I_F16_WGS
 #define G4C_BX6I_F16_WGS 3
 #endif
-template <bool AGG, int SP>
+#ifndef G4C_BX6I_ROW_STORES
+#define G4C_BX6I_ROW_STORES 0
+#endif
+#ifndef G4C_BX6I_DEFER_B
+#define G4C_BX6I_DEFER_B 0      // 1: tile B's additive rows are consumed after M(A,0) — 32 more live registers, 24-28 spilled: 469 us against 382
+#endif
+// DIRECT: the weighted block's rows are the tile's own rows (no gather index: the MP layers' edge latents) — their loads do not wait
+// for the index round trip.
+template <bool AGG, int SP, bool DIRECT>
 __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_kernel(const Params p) {
     // two tiles' operand planes + gather indices: 52 992 B; 96 stationary weight registers -> two workgroups per CU
     // (SP == 2: 35 584 B, 64 weight registers, 168 VGPRs -> three workgroups per CU: 385 us against 412 us at two, level-1 launch)
@@ -190,26 +198,50 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
     int pair;
     {
         const int b = blockIdx.x, q = n_pairs >> 3, r = n_pairs & 7, x = b & 7, j = b >> 3;
-        pair = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+        pair = __builtin_amdgcn_readfirstlane((x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j);
     }
     int row0[2], nrow[2];
+    if (AGG) {
+        // three independent scalar loads (tile 2 pair always exists; the entries of a missing second tile are clamped to the end of
+        // the table, which gives it zero rows) instead of two dependent vector round trips
+        const int t0 = 2 * pair, t1 = t0 + 1 < p.n_tiles ? t0 + 1 : p.n_tiles, t2 = t0 + 2 < p.n_tiles ? t0 + 2 : p.n_tiles;
+        const int r0 = p.tile_rows[t0], r1 = p.tile_rows[t1], r2 = p.tile_rows[t2];
+        row0[0] = r0; nrow[0] = r1 - r0; row0[1] = t0 + 1 < p.n_tiles ? r1 : 0; nrow[1] = r2 - r1;
+    } else {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int tile = 2 * pair + t;
-        if (tile >= p.n_tiles) { row0[t] = 0; nrow[t] = 0; }
-        else if (AGG) { row0[t] = p.tile_rows[tile]; nrow[t] = p.tile_rows[tile + 1] - row0[t]; }
-        else { row0[t] = (int)p.row_base + tile * 32; const int lim = (int)p.M - row0[t]; nrow[t] = lim < 32 ? lim : 32; }
+        for (int t = 0; t < 2; ++t) {
+            const int tile = 2 * pair + t;
+            if (tile >= p.n_tiles) { row0[t] = 0; nrow[t] = 0; }
+            else { row0[t] = (int)p.row_base + tile * 32; const int lim = (int)p.M - row0[t]; nrow[t] = lim < 32 ? lim : 32; }
+        }
     }
     BI_STAMP(0);
     if (nrow[1] == 0) row0[1] = row0[0];        // (odd tile count: the second tile recomputes the first tile's rows and stores nothing)
 
-    // ---- gather indices of both tiles (rows past a tile's end are clamped copies of its last row: never stored)
-    if (tid < 192) {
-        const int t = tid / 96, k = (tid % 96) >> 5, r = tid & 31;
+    // ---- Memory returns in order per wave, so the loads that head a dependent chain go first: the gather indices of both tiles
+    // (rows past a tile's end are clamped copies of its last row: never stored), then the input rows of both tiles (park layout; with
+    // DIRECT they do not depend on an index and are back when the index round trip ends: tile A is parked while the additive rows,
+    // which do, are in flight), then the weights.
+    int idx_val;
+    {
+        const int tt = tid < 192 ? tid : 0;
+        const int t = tt / 96, k = (tt % 96) >> 5, r = tt & 31;
         const int nn = nrow[t] > 0 ? nrow[t] : nrow[0];
         const int gr = row0[t] + (r < nn ? r : nn - 1);
-        const int *ix = (k == 0) ? p.src[0].idx : ((k - 1 < p.n_add) ? p.add[k - 1].idx : nullptr);
-        sIdx[t][k][r] = ix ? ix[gr] : gr;
+        // (selects among three uniform pointers: indexing p.add[] with the per-lane k is a load from the kernel argument segment,
+        // one more dependent round trip in front of the index load)
+        const int *ix0 = p.src[0].idx, *ix1 = p.n_add > 0 ? p.add[0].idx : nullptr, *ix2 = p.n_add > 1 ? p.add[1].idx : nullptr;
+        const int *ix = (k == 0) ? ix0 : (k == 1 ? ix1 : ix2);
+        idx_val = gr;
+        if (ix) idx_val = ix[gr];
+    }
+    f32x4 xA[4], xB[4];
+    if (DIRECT) {
+        const int nA = nrow[0], nB = nrow[1] > 0 ? nrow[1] : nrow[0];
+        const float *ra = p.src[0].ptr + (long long)(row0[0] + (grow_l < nA ? grow_l : nA - 1)) * p.src[0].ld + p.src[0].col0 + c4;
+        const float *rb = p.src[0].ptr + (long long)(row0[1] + (grow_l < nB ? grow_l : nB - 1)) * p.src[0].ld + p.src[0].col0 + c4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { xA[q] = *reinterpret_cast<const f32x4 *>(ra + q * KC); xB[q] = *reinterpret_cast<const f32x4 *>(rb + q * KC); }
     }
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, 0x7fffffff, 0x00020000);
     const unsigned lo_b = 2u * (unsigned)(wave * 8 * STEP6 + lane * 8);
@@ -218,12 +250,12 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
     for (int s = 0; s < 8; ++s)
 #pragma unroll
         for (int pl = 0; pl < SP; ++pl) W[s][pl] = ldw(rs, lo_b + 1024u * pl, 2u * s * STEP6);
+    if (tid < 192) sIdx[0][0][tid] = idx_val;          // [t][k][r] = [tid / 96][(tid % 96) / 32][tid % 32]
     __syncthreads();
     BI_STAMP(1);
 
-    // ---- input rows of both tiles (park layout), additive rows of both (accumulator layout) + first bias: the start values
-    f32x4 xA[4], xB[4];
-    {
+    // ---- additive rows of both tiles (accumulator layout) + first bias: the start values
+    if (!DIRECT) {
         const float *ra = p.src[0].ptr + (long long)sIdx[0][0][grow_l] * p.src[0].ld + p.src[0].col0 + c4;
         const float *rb = p.src[0].ptr + (long long)sIdx[1][0][grow_l] * p.src[0].ld + p.src[0].col0 + c4;
 #pragma unroll
@@ -232,35 +264,30 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
     f32x16 accA, accB, accA1, accB1;         // (acc?1: the 2^-11 terms, SP == 2 only)
 #pragma unroll
     for (int q = 0; q < 16; ++q) { accA1[q] = 0.f; accB1[q] = 0.f; }
-    {
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(p.b + fbase + 8 * gq);
+    for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(p.b + fbase + 8 * gq);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { accA[4 * gq + e] = b4[e]; accB[4 * gq + e] = b4[e]; }
-        }
-        if (p.n_add == 2) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float *p0 = p.add[0].ptr + (long long)sIdx[t][1][i] * p.add[0].ld + fbase;
-                const float *p1 = p.add[1].ptr + (long long)sIdx[t][2][i] * p.add[1].ld + fbase;
-                f32x4 a0[4], a1[4];
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) { a0[gq] = *reinterpret_cast<const f32x4 *>(p0 + 8 * gq); a1[gq] = *reinterpret_cast<const f32x4 *>(p1 + 8 * gq); }
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (t == 0) accA[4 * gq + e] = (accA[4 * gq + e] + a0[gq][e]) + a1[gq][e];
-                        else accB[4 * gq + e] = (accB[4 * gq + e] + a0[gq][e]) + a1[gq][e];
-                    }
-            }
-        }
+        for (int e = 0; e < 4; ++e) { accA[4 * gq + e] = b4[e]; accB[4 * gq + e] = b4[e]; }
     }
-    BI_STAMP(2);
+    const bool adds = p.n_add == 2;
+    f32x4 a0[4], a1[4];
+    auto issue_adds = [&](int t) __attribute__((always_inline)) {
+        const float *p0 = p.add[0].ptr + (long long)sIdx[t][1][i] * p.add[0].ld + fbase;
+        const float *p1 = p.add[1].ptr + (long long)sIdx[t][2][i] * p.add[1].ld + fbase;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) { a0[gq] = *reinterpret_cast<const f32x4 *>(p0 + 8 * gq); a1[gq] = *reinterpret_cast<const f32x4 *>(p1 + 8 * gq); }
+    };
+    auto take_adds = [&](f32x16 &acc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * gq + e] = (acc[4 * gq + e] + a0[gq][e]) + a1[gq][e];
+    };
+    if (adds) issue_adds(0);
     const bool pact = p.src[0].pre_act != 0;
     __bf16 *const sA = sB, *const sBt = sB + TILE_BF16;
-    // park tile A (not overlapped: nothing to multiply yet)
+    // park tile A (not overlapped with MFMAs: nothing to multiply yet — but under tile A's additive gathers)
     {
         __bf16 *d = sA + grow_l * HB + c4;
 #pragma unroll
@@ -274,6 +301,9 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
             if (SP == 3) *reinterpret_cast<bf16x4 *>(d + 2 * PLN + q * KC) = vl;
         }
     }
+    BI_STAMP(2);
+    if (adds) { take_adds(accA); issue_adds(1); }
+    if (adds && !G4C_BX6I_DEFER_B) take_adds(accB);
     __syncthreads();
     BI_STAMP(3);
 
@@ -295,6 +325,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
     constexpr unsigned WB = 2u * BLOCK6;        // bytes of one layer's block of the stream
     // layer 0
     m_block<2, false, SP>(paA, W, rs, lo_b, 0u, accA, accA1, accB, accB1, xB, oB);             // for B: park
+    if (adds && G4C_BX6I_DEFER_B) take_adds(accB);
     BI_STAMP(4);
     __syncthreads();
     BI_STAMP(5);
@@ -384,7 +415,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
                 *reinterpret_cast<f32x4 *>(rowp + c) = v;
             }
         }
-        if (p.out && myrow < nrow[t]) {
+        if (!(AGG && G4C_BX6I_ROW_STORES) && p.out && myrow < nrow[t]) {
             float *op = p.out + (long long)(row0[t] + myrow) * p.out_ld + cb;
 #pragma unroll
             for (int c = 0; c < 16; c += 4) {
@@ -399,6 +430,20 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
         // aggregation of the targets whose messages the tiles hold (rows in CSR order): same summation order and the same mean
         // formula as segment_reduce_kernel, so the result is bit-identical to the separate launch
         __syncthreads();
+        if (G4C_BX6I_ROW_STORES && p.out) {
+            // the finished rows are in LDS for the reduction anyway: store them from there, 32 lanes along a row (every store
+            // instruction of a wave writes two complete 512-byte rows instead of a 16-byte piece of each 64-byte chunk of 8 rows)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float *sH = reinterpret_cast<const float *>(t == 0 ? sA : sBt);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = it * 8 + (tid >> 5), c = (tid & 31) * 4;
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(sH + r * HS + c);
+                    if (r < nrow[t]) *reinterpret_cast<f32x4 *>(p.out + (long long)(row0[t] + r) * p.out_ld + c) = v;
+                }
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (nrow[t] == 0) continue;
@@ -453,11 +498,15 @@ bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, long long 
 int bx6i_launch(const Params &p, bool agg, bool f16x2, hipStream_t st) {
     const int n_pairs = (p.n_tiles + 1) / 2;
     if (n_pairs == 0) return G4C_OK;
-    if (f16x2) {
-        if (agg) mlp_bx6i_kernel<true, 2><<<dim3(n_pairs), dim3(256), 0, st>>>(p);
-        else mlp_bx6i_kernel<false, 2><<<dim3(n_pairs), dim3(256), 0, st>>>(p);
-    } else if (agg) mlp_bx6i_kernel<true, 3><<<dim3(n_pairs), dim3(256), 0, st>>>(p);
-    else mlp_bx6i_kernel<false, 3><<<dim3(n_pairs), dim3(256), 0, st>>>(p);
+    const dim3 grid(n_pairs), blk(256);
+#define G4C_BX6I_LAUNCH(AGG, SP)                                                                     \
+    do {                                                                                             \
+        if (p.src[0].idx) mlp_bx6i_kernel<AGG, SP, false><<<grid, blk, 0, st>>>(p);                  \
+        else mlp_bx6i_kernel<AGG, SP, true><<<grid, blk, 0, st>>>(p);                                \
+    } while (0)
+    if (f16x2) { if (agg) G4C_BX6I_LAUNCH(true, 2); else G4C_BX6I_LAUNCH(false, 2); }
+    else { if (agg) G4C_BX6I_LAUNCH(true, 3); else G4C_BX6I_LAUNCH(false, 3); }
+#undef G4C_BX6I_LAUNCH
     return g4c::check_launch("g4c_mlp_forward (bx6i)");
 }
 

@@ -678,8 +678,12 @@ __global__ __launch_bounds__(256, RT == 1 ? (SP == 2 ? G4C_F16_MINW : G4C_BX6_MI
         const int q = nt >> 3, r = nt & 7, x = b & 7, j = b >> 3;
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
     }
-    long long row0 = p.row_base + (long long)tile * ROWS, mlim = p.M;
-    if (p.tile_rows) { row0 = p.tile_rows[tile]; mlim = p.tile_rows[tile + 1]; }      // tile of whole segments (<= ROWS rows)
+    // (wave-uniform 32-bit values in scalar registers — the launcher checks n_rows < 2^31: as 64-bit per-lane values they were the
+    // registers the SP == 2 instantiations spilled, and a spilled uniform costs 64 lanes of scratch traffic per wave)
+    int row0 = __builtin_amdgcn_readfirstlane((int)(p.row_base + (long long)tile * ROWS)), mlim = __builtin_amdgcn_readfirstlane((int)p.M);
+    if (p.tile_rows) {      // tile of whole segments (<= ROWS rows)
+        row0 = __builtin_amdgcn_readfirstlane(p.tile_rows[tile]); mlim = __builtin_amdgcn_readfirstlane(p.tile_rows[tile + 1]);
+    }
     G4C_STAMPW(0);
 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, 0x7fffffff, 0x00020000);
@@ -817,9 +821,14 @@ __global__ __launch_bounds__(256, RT == 1 ? (SP == 2 ? G4C_F16_MINW : G4C_BX6_MI
         const int slot = e / ROWS, r = e % ROWS;
         long long gr = row0 + r;
         if (gr >= mlim) gr = mlim - 1;
+        // selects among the (uniform) index pointers: p.src[slot] with the per-lane slot would be a load from the kernel argument
+        // segment — one more dependent round trip in front of every tile's index loads
         const int *ix = nullptr;
-        if (slot < NSLOT) { if (slot < p.n_src) ix = p.src[slot].idx; }
-        else { if (slot - NSLOT < p.n_add) ix = p.add[slot - NSLOT].idx; }
+#pragma unroll
+        for (int s2 = 0; s2 < NSLOT; ++s2) {
+            const int *is = s2 < p.n_src ? p.src[s2].idx : nullptr, *ia = s2 < p.n_add ? p.add[s2].idx : nullptr;
+            ix = slot == s2 ? is : (slot == NSLOT + s2 ? ia : ix);
+        }
         idx_v[it] = ix ? ix[gr] : (int)gr;
     }
     float bias_v[(G4C_MAX_LAYERS * NP) / (64 * NW)], gb_v = 0.f;

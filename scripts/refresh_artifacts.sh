@@ -29,8 +29,13 @@ hipcc -w --offload-arch=gfx950 -O3 -o /tmp/mfma_peak scripts/micro/mfma_peak.hip
   timeout 300 python bench.py --model NsRotEquiTreeScaleGNN --nodes 100000 --steps 20 --no-cpu-baseline --no-roofline | tail -1
   timeout 300 python scripts/bench_mugs.py 2>&1 | tail -2
   timeout 300 python bench.py --precision fp32 --steps 20 --no-cpu-baseline | tail -1
+  timeout 300 python bench.py --precision bf16x6 --steps 100 --no-cpu-baseline | tail -1
   timeout 300 python bench.py --precision bf16 --steps 50 --no-cpu-baseline --no-roofline | tail -1
 } > $A/${TAG}_side_configs.log 2>&1
+timeout 300 python scripts/step_breakdown.py > $A/${TAG}_step_breakdown.log 2>&1
+timeout 300 python scripts/mlp_accuracy.py > $A/${TAG}_mlp_accuracy.log 2>&1
+timeout 300 python scripts/bx6i_check.py --time 2>&1 | tail -4 > $A/${TAG}_bx6i_check_and_ab.log
+G4C_MLP_PRECISION=bf16x6 timeout 300 python scripts/bx6i_check.py --time 2>&1 | tail -3 >> $A/${TAG}_bx6i_check_and_ab.log
 # training path: step time + per-phase HIP-event times + the CPU leg
 timeout -k 10 900 python scripts/bench_train.py --steps 10 --cpu-steps 1 --phases 2> $A/train_stderr.log | tail -1 > $A/${TAG}_train_bench_100k.json
 ls -la $A
