@@ -171,7 +171,7 @@ __device__ __forceinline__ void m_block(const __bf16 *pa, bf16x8 (&W)[8][SP], __
 #define G4C_BX6I_F16_WGS 3
 #endif
 #ifndef G4C_BX6I_ROW_STORES
-#define G4C_BX6I_ROW_STORES 0
+#define G4C_BX6I_ROW_STORES 1
 #endif
 #ifndef G4C_BX6I_DEFER_B
 #define G4C_BX6I_DEFER_B 0      // 1: tile B's additive rows are consumed after M(A,0) — 32 more live registers, 24-28 spilled: 469 us against 382
