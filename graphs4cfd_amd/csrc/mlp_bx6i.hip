@@ -173,6 +173,9 @@ __device__ __forceinline__ void m_block(const __bf16 *pa, bf16x8 (&W)[8][SP], __
 #ifndef G4C_BX6I_ROW_STORES
 #define G4C_BX6I_ROW_STORES 1
 #endif
+#ifndef G4C_BX6I_LATE_W
+#define G4C_BX6I_LATE_W 1
+#endif
 #ifndef G4C_BX6I_DEFER_B
 #define G4C_BX6I_DEFER_B 0      // 1: tile B's additive rows are consumed after M(A,0) — 32 more live registers, 24-28 spilled: 469 us against 382
 #endif
@@ -246,10 +249,16 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, 0x7fffffff, 0x00020000);
     const unsigned lo_b = 2u * (unsigned)(wave * 8 * STEP6 + lane * 8);
     bf16x8 W[8][SP];
+    auto load_w = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
+        for (int s = 0; s < 8; ++s)
 #pragma unroll
-        for (int pl = 0; pl < SP; ++pl) W[s][pl] = ldw(rs, lo_b + 1024u * pl, 2u * s * STEP6);
+            for (int pl = 0; pl < SP; ++pl) W[s][pl] = ldw(rs, lo_b + 1024u * pl, 2u * s * STEP6);
+    };
+    // LATE_W: the first layer's weights (L2 hits) are fetched after tile A's additive rows are consumed, which leaves the registers
+    // for BOTH tiles' additive gathers to be in flight together — one round trip instead of two in front of the first matrix phase
+    constexpr bool LATE_W = G4C_BX6I_LATE_W && SP == 2;
+    if (!LATE_W) load_w();
     if (tid < 192) sIdx[0][0][tid] = idx_val;          // [t][k][r] = [tid / 96][(tid % 96) / 32][tid % 32]
     __syncthreads();
     BI_STAMP(1);
@@ -271,20 +280,20 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
         for (int e = 0; e < 4; ++e) { accA[4 * gq + e] = b4[e]; accB[4 * gq + e] = b4[e]; }
     }
     const bool adds = p.n_add == 2;
-    f32x4 a0[4], a1[4];
-    auto issue_adds = [&](int t) __attribute__((always_inline)) {
+    f32x4 a0[4], a1[4], b0[4], b1[4];
+    auto issue_adds = [&](int t, f32x4 (&u0)[4], f32x4 (&u1)[4]) __attribute__((always_inline)) {
         const float *p0 = p.add[0].ptr + (long long)sIdx[t][1][i] * p.add[0].ld + fbase;
         const float *p1 = p.add[1].ptr + (long long)sIdx[t][2][i] * p.add[1].ld + fbase;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) { a0[gq] = *reinterpret_cast<const f32x4 *>(p0 + 8 * gq); a1[gq] = *reinterpret_cast<const f32x4 *>(p1 + 8 * gq); }
+        for (int gq = 0; gq < 4; ++gq) { u0[gq] = *reinterpret_cast<const f32x4 *>(p0 + 8 * gq); u1[gq] = *reinterpret_cast<const f32x4 *>(p1 + 8 * gq); }
     };
-    auto take_adds = [&](f32x16 &acc) __attribute__((always_inline)) {
+    auto take_adds = [&](f32x16 &acc, const f32x4 (&u0)[4], const f32x4 (&u1)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[4 * gq + e] = (acc[4 * gq + e] + a0[gq][e]) + a1[gq][e];
+            for (int e = 0; e < 4; ++e) acc[4 * gq + e] = (acc[4 * gq + e] + u0[gq][e]) + u1[gq][e];
     };
-    if (adds) issue_adds(0);
+    if (adds) { issue_adds(0, a0, a1); if (LATE_W) issue_adds(1, b0, b1); }
     const bool pact = p.src[0].pre_act != 0;
     __bf16 *const sA = sB, *const sBt = sB + TILE_BF16;
     // park tile A (not overlapped with MFMAs: nothing to multiply yet — but under tile A's additive gathers)
@@ -302,8 +311,16 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
         }
     }
     BI_STAMP(2);
-    if (adds) { take_adds(accA); issue_adds(1); }
-    if (adds && !G4C_BX6I_DEFER_B) take_adds(accB);
+    if (LATE_W) {
+        if (adds) take_adds(accA, a0, a1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w();
+        __builtin_amdgcn_sched_barrier(0);
+        if (adds) take_adds(accB, b0, b1);
+    } else {
+        if (adds) { take_adds(accA, a0, a1); issue_adds(1, a0, a1); }
+        if (adds && !G4C_BX6I_DEFER_B) take_adds(accB, a0, a1);
+    }
     __syncthreads();
     BI_STAMP(3);
 
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
     constexpr unsigned WB = 2u * BLOCK6;        // bytes of one layer's block of the stream
     // layer 0
     m_block<2, false, SP>(paA, W, rs, lo_b, 0u, accA, accA1, accB, accB1, xB, oB);             // for B: park
-    if (adds && G4C_BX6I_DEFER_B) take_adds(accB);
+    if (adds && G4C_BX6I_DEFER_B && !LATE_W) take_adds(accB, a0, a1);
     BI_STAMP(4);
     __syncthreads();
     BI_STAMP(5);

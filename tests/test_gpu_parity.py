@@ -659,6 +659,31 @@ def test_models_bf16_mode_vs_oracle():
         ops.set_mlp_precision(old)
 
 
+def test_solve_warns_about_inputs_near_the_fp16_range(golden):
+    """The default f16x3 arithmetic clips activations at +-65504: solve() says so when an input tensor is large enough for
+    the first hidden layer to get there (un-normalised data), and only then; bf16x6 never warns."""
+    import warnings
+    c = golden("rollout.pt")["two_scale"]
+    model = gfd.nn.NsTwoScaleGNN(arch=c["arch"], device=DEV)
+    model.load_state_dict(c["weights"])
+    g = gfd.Graph(**cu(c["graph"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model.solve(g.clone(), 2)
+    big = g.clone()
+    big.field = big.field * 1.0e5
+    with pytest.warns(RuntimeWarning, match="f16x3"):
+        out = model.solve(big, 2)
+    assert torch.isfinite(out).all()
+    old = ops.set_mlp_precision("bf16x6")
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            model.solve(big.clone(), 2)
+    finally:
+        ops.set_mlp_precision(old)
+
+
 # ------------------------------------------------------------------ BASELINE configs at size
 def test_headline_100k_vs_oracle():
     """The bench workload itself (NsThreeScaleGNN, H = 128, 100k-node 2-D mesh, default f16x3 kernels with the fused
