@@ -1,21 +1,23 @@
-// Dual-tile, software-pipelined form of the fused bf16x6 MLP ("bx6i") for the MP layers' message launch: the same arithmetic
-// as mlp_bx6_kernel (mlp_fused.hip) — gather -> [SELU on load] -> Linear/SELU chain on v_mfma_f32_32x32x16_bf16 with the exact
-// three-way operand split -> LayerNorm -> activation -> store (-> per-target aggregation) — replacing MLP.forward
+// Dual-tile, software-pipelined form of the fused split-operand MLP ("bx6i") for the MP layers' message launch: the same arithmetic
+// as mlp_bx6_kernel (mlp_fused.hip) — gather -> [SELU on load] -> Linear/SELU chain on the 16-bit matrix pipe (SP = 2: two-way fp16
+// split, three products, v_mfma_f32_32x32x16_f16, the default; SP = 3: exact three-way bf16 split, six products,
+// v_mfma_f32_32x32x16_bf16) -> LayerNorm -> activation -> store (-> per-target aggregation) — replacing MLP.forward
 // (graphs4cfd/nn/blocks.py:117-144) with the torch.cat / index ops in front of it (nn/blocks.py:181,328) and, with AGG, the
 // scatter(e', col, reduce) behind it (nn/blocks.py:183,330).
 //
 // What is different: a workgroup (4 waves, one 32-column tile each, as in mlp_bx6_kernel) owns TWO 32-row tiles A and B and
 // alternates between them layer by layer:  M(A,0) M(B,0) M(A,1) M(B,1) ...  While a wave issues the MFMAs of one tile's
 // layer, the vector ALUs of the SAME wave work on the other tile: parking B's input rows under M(A,0), the hidden-layer
-// epilogue (bias is the accumulator's start value; SELU, exact split, planes) of B's layer l-1 under M(A,l), of A's layer l
+// epilogue (bias is the accumulator's start value; SELU, operand split, planes) of B's layer l-1 under M(A,l), of A's layer l
 // under M(B,l), the last layer's fp32 rows under the other tile's last M phase.  In mlp_bx6_kernel a wave is either in an
-// MFMA phase or in a vector phase and relies on the other three waves of its SIMD to fill the pipe it leaves idle (measured:
-// matrix pipe 44 %, vector ALUs 38 % busy); here every wave keeps both busy, at three waves per SIMD.
-// (px6 showed the mechanism — sched_group_barrier interleaving of an epilogue with the next unit's MFMAs — at 2500-2900
-// cycles per 48-MFMA unit including its epilogue; this kernel keeps the tile kernel's streamed weights and occupancy.)
+// MFMA phase or in a vector phase and relies on the other waves of its SIMD to fill the pipe it leaves idle; here every wave
+// keeps both busy.  The wave's slice of the layer's weights is stationary in registers for the pair (one fetch serves 64 rows).
+// The phases are straight-line code on purpose: in a loop hipcc duplicates the stationary weight registers across the back edge.
+// Prologue order: gather indices, directly addressed input rows, [weights]; tile A is parked while the additive
+// rows of both tiles are in flight.  With AGG the finished rows are stored from their LDS copy, whole rows per store instruction.
 //
-// Envelope (everything else runs mlp_bx6_kernel): exact-split mode, ONE weighted 128-wide 16-byte aligned input block (rows direct
-// or through an index, optional SELU on load), 0 or 2 additive 128-wide blocks, no narrow blocks, 2..4 layers, 128-wide output
+// Envelope (everything else runs mlp_bx6_kernel): split-operand modes, ONE weighted 128-wide 16-byte aligned input block (rows direct
+// or through an index, optional SELU on load), 0 or 2 additive 128-wide blocks, no narrow blocks, three layers, 128-wide output
 // rows without residual / output index / heads.
 #include "mlp_common.h"
 #include <cstdlib>
