@@ -32,6 +32,11 @@ hipcc -w --offload-arch=gfx950 -O3 -o /tmp/mfma_peak scripts/micro/mfma_peak.hip
   timeout 300 python bench.py --precision bf16x6 --steps 100 --no-cpu-baseline | tail -1
   timeout 300 python bench.py --precision bf16 --steps 50 --no-cpu-baseline --no-roofline | tail -1
 } > $A/${TAG}_side_configs.log 2>&1
+# functional check of the partitioned path on the one GPU of the box (both ranks on cuda:0, gloo transport): partition_check in the line
+for wl in headline c3; do
+  G4C_BENCH_SAME_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
+      bench.py --gpus 2 --workload $wl --steps 20 --warmup 3 2> $A/bench_${wl}_2rank_stderr.log | tail -1 > $A/${TAG}_bench_${wl}_2rank_samegpu.json
+done
 timeout 300 python scripts/step_breakdown.py > $A/${TAG}_step_breakdown.log 2>&1
 timeout 300 python scripts/mlp_accuracy.py > $A/${TAG}_mlp_accuracy.log 2>&1
 timeout 300 python scripts/bx6i_check.py --time 2>&1 | tail -4 > $A/${TAG}_bx6i_check_and_ab.log
