@@ -1,13 +1,11 @@
 mkdir -p gpurun_out/f16
-run() { env "$@" timeout 300 python bench.py $WL --no-cpu-baseline --no-roofline --steps 200 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), round(d['ms_per_step'],4))"; }
-( for WL in "--workload headline" "--model NsFourScaleGNN --nodes 100000"; do
-    echo "=== $WL"
-    for rep in 1 2 3; do
-      echo -n "default: "; run A=1
-      echo -n "FUSE 20000: "; run G4C_FUSE_AGG_MIN_ROWS=20000
-      echo -n "FUSE 20000 + AOL 20000: "; run G4C_FUSE_AGG_MIN_ROWS=20000 G4C_AGG_ON_LOAD_MIN_ROWS=20000
-      echo -n "FUSE 20000 + AOL 20000 + HOIST 50000: "; run G4C_FUSE_AGG_MIN_ROWS=20000 G4C_AGG_ON_LOAD_MIN_ROWS=20000 G4C_HOIST_MIN_ROWS=50000
-    done
+( for n in 4 8; do
+    echo "--- headline, $n ranks on one GPU"
+    G4C_BENCH_SAME_GPU=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2953$n bench.py --gpus $n --steps 10 --warmup 2 2>gpurun_out/f16/rank_err_$n.log | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); pc=d['partition_check']
+print(d['value'], d['n_gpus'], pc['ok'], pc['max_abs_diff_vs_single_rank'], pc.get('capture'), pc.get('capture_note'), [ (r['owned_nodes'], r['compute_ms'], r['in_exchanges_ms']) for r in pc['per_rank']])"
+    tail -3 gpurun_out/f16/rank_err_$n.log
   done
-) > gpurun_out/f16/run10.log 2>&1
-cat gpurun_out/f16/run10.log
+) > gpurun_out/f16/run11.log 2>&1
+cat gpurun_out/f16/run11.log
