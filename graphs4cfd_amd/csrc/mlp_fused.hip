@@ -637,6 +637,9 @@ __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6
 #ifndef G4C_BX6_MINW
 #define G4C_BX6_MINW 4
 #endif
+#ifndef G4C_F16_RT2_MINW
+#define G4C_F16_RT2_MINW 2      // (RT = 2, SP = 2: 44 registers spilled at three workgroups per CU)
+#endif
 #ifndef G4C_F16_MINW
 #define G4C_F16_MINW 4          // workgroups per CU the SP == 2 instantiations are register-limited for
 #endif
@@ -646,11 +649,11 @@ __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6
 // FULL: every weighted input block and every additive block is exactly 128 wide and 16-byte aligned (the MP layers):
 // no column masks anywhere.
 template <int RT, bool VEC, bool FULL, int SP, bool SAVE = false>
-__global__ __launch_bounds__(256, RT == 1 ? (SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) : 3) void mlp_bx6_kernel(const Params p) {
+__global__ __launch_bounds__(256, RT == 1 ? (SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) : (SP == 2 ? G4C_F16_RT2_MINW : 3)) void mlp_bx6_kernel(const Params p) {
     constexpr int ROWS = 32 * RT, NW = 4;
     constexpr int PLN = ROWS * HB;              // one bf16 operand plane [ROWS][136]
     // three operand planes; the fp32 final tile [ROWS][132] aliases them
-    constexpr int BUF_FLOATS = 3 * PLN / 2;
+    constexpr int BUF_FLOATS = (SP == 2 ? 2 : 3) * PLN / 2;      // (SP == 2: two planes; [ROWS][132] floats still fit in [2][ROWS][136] halves)
     static_assert(BUF_FLOATS >= ROWS * HS, "final tile must fit");
     // RT = 2 keeps three workgroups per CU (<= 54.6 KB of LDS each): two index slots per kind (the launcher checks) and the
     // biases read from global memory (L1 hits) instead of an LDS copy
@@ -1447,7 +1450,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         for (int a = 0; a < p.n_add; ++a)
             full = full && p.add[a].width == NP && (p.add[a].ld & 3) == 0 && ((uintptr_t)p.add[a].ptr & 15) == 0;
         const dim3 blk(256);
-        const bool rt2 = !agg && !save && !f16x2 && row_count >= rt2_rows && p.n_src <= 2 && p.n_add <= 2;      // 64-row tiles (tuning only)
+        const bool rt2 = !agg && !save && row_count >= rt2_rows && p.n_src <= 2 && p.n_add <= 2;      // 64-row tiles (tuning only)
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + (rt2 ? 63 : 31)) / (rt2 ? 64 : 32));
         if (p.n_tiles == 0) return G4C_OK;
         const dim3 grid(p.n_tiles);
@@ -1466,7 +1469,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
             else if (all_vec) mlp_bx6_kernel<1, true, false, 3, true><<<grid, blk, 0, st>>>(p);
             else mlp_bx6_kernel<1, false, false, 3, true><<<grid, blk, 0, st>>>(p);
         }
-        else if (f16x2) G4C_BX6_LAUNCH(1, 2);
+        else if (f16x2) { if (rt2) G4C_BX6_LAUNCH(2, 2); else G4C_BX6_LAUNCH(1, 2); }
         else if (round1) { if (rt2) G4C_BX6_LAUNCH(2, 1); else G4C_BX6_LAUNCH(1, 1); }
         else { if (rt2) G4C_BX6_LAUNCH(2, 3); else G4C_BX6_LAUNCH(1, 3); }
 #undef G4C_BX6_LAUNCH
