@@ -218,3 +218,21 @@ def test_locality_renumbering_keeps_the_mesh():
     assert reorder_nodes(S.remus_graph(300, k=5, seed=1)) is None
     g.extra = torch.zeros(7)
     assert reorder_nodes(g) is None
+
+
+def test_mlp_precision_names_and_f16_range_warning():
+    """The arithmetic modes the host accepts, and the input-magnitude hint of the default one: solve() warns when an
+    input tensor is large enough for a hidden activation to reach fp16's range (the f16x3 kernels clip there), and only then."""
+    import warnings
+    from graphs4cfd_amd import ops
+    from graphs4cfd_amd.nn import model as M
+    assert ops.PRECISIONS == ("fp32", "bf16", "bf16x6", "f16x3") and ops.mlp_precision() in ops.PRECISIONS
+    with pytest.raises(ValueError):
+        ops.set_mlp_precision("fp16")
+    g = S.mus_graph(300, levels=1, seed=3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        M._warn_f16_range(g)
+    g.field = g.field * (2.0 * M.F16_INPUT_WARN / float(g.field.abs().max()))
+    with pytest.warns(RuntimeWarning, match="f16x3"):
+        M._warn_f16_range(g)
