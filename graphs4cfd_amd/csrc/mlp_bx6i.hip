@@ -435,7 +435,8 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
             }
         }
         if (!(AGG && G4C_BX6I_ROW_STORES) && p.out && myrow < nrow[t]) {
-            float *op = p.out + (long long)(row0[t] + myrow) * p.out_ld + cb;
+            const long long orow = (!AGG && p.out_idx) ? p.out_idx[row0[t] + myrow] : row0[t] + myrow;      // (g4c_mlp_forward's out_idx)
+            float *op = p.out + orow * p.out_ld + cb;
 #pragma unroll
             for (int c = 0; c < 16; c += 4) {
                 f32x4 v;
@@ -485,8 +486,8 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
 
 namespace g4cm {
 
-// 0 off, 1 (default; environment G4C_BX6I) launches of at least G4C_BX6I_MIN_ROWS rows (default 400 000: at two workgroups per CU
-// the kernel needs a full machine; measured crossover against mlp_bx6_kernel at ~300 k rows), 2 every launch it can take (tests)
+// 0 off, 1 (default; environment G4C_BX6I) launches of at least G4C_BX6I_MIN_ROWS rows (default 100 000 in f16x3 mode, 400 000 in bf16x6
+// mode: the kernel needs a full machine of its larger workgroups), 2 every launch it can take (tests)
 static int g_bx6i = -1;
 int bx6i_enable(int on) {
     if (g_bx6i < 0) g_bx6i = getenv("G4C_BX6I") ? atoi(getenv("G4C_BX6I")) : 1;
@@ -495,13 +496,17 @@ int bx6i_enable(int on) {
     return old;
 }
 
-bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, long long row_count) {
-    static const long long min_rows = getenv("G4C_BX6I_MIN_ROWS") ? atoll(getenv("G4C_BX6I_MIN_ROWS")) : 400000;
+bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count) {
+    // f16x3 mode (three workgroups per CU, shorter pairs): the kernel is ahead from ~100 k rows (level-2 launches of the 100k mesh: +0.5 %
+    // of the step; the interior launches of a 2- / 4-way partition); bf16x6 mode (two workgroups per CU): from ~300 k
+    static const long long min_env = getenv("G4C_BX6I_MIN_ROWS") ? atoll(getenv("G4C_BX6I_MIN_ROWS")) : -1;
+    const long long min_rows = min_env >= 0 ? min_env : (f16x2 ? 100000 : 400000);
     const int mode = bx6i_enable(-1);
     if (!mode || round1 || save) return false;
     if (mode == 1 && row_count < min_rows) return false;
     if (p.n_src != 1 || p.n_nar != 0 || (p.n_add != 0 && p.n_add != 2) || p.n_heads) return false;
-    if (p.n_layers != 3 || p.n_out != NP || p.resid || p.out_idx || p.out_bf16) return false;
+    if (p.n_layers != 3 || p.n_out != NP || p.resid || p.out_bf16) return false;
+    if (p.out_idx && (agg || !p.out)) return false;          // (scattered output rows: the plain launch only)
     const Src &s = p.src[0];
     if (s.width != NP || !s.vec || s.seg_off || s.bf16) return false;
     for (int a = 0; a < p.n_add; ++a)
@@ -510,7 +515,6 @@ bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, long long 
     if (p.gamma && (((uintptr_t)p.gamma & 15) || ((uintptr_t)p.beta & 15))) return false;
     if (((uintptr_t)p.b & 15)) return false;
     if (p.M >= (1LL << 31)) return false;
-    (void)agg;
     return true;
 }
 

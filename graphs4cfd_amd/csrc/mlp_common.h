@@ -212,7 +212,7 @@ __device__ __forceinline__ void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l)
 
 // dual-tile software-pipelined kernel (mlp_bx6i.hip)
 int bx6i_enable(int on);
-bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, long long row_count);
+bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count);
 int bx6i_launch(const Params &p, bool agg, bool f16x2, hipStream_t st);
 
 // persistent ping-pong kernel (mlp_px6.hip)

@@ -1439,7 +1439,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
         if (p.n_tiles == 0) return G4C_OK;
         return px6_launch(p, round1, agg != nullptr, st);
-    } else if (bx6 && !force_tiles && bx6i_eligible(p, round1, agg != nullptr, save != nullptr, row_count)) {
+    } else if (bx6 && !force_tiles && bx6i_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
         // dual-tile software-pipelined kernel (mlp_bx6i.hip): pairs of 32-row tiles (whole segments with aggregation)
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
         return bx6i_launch(p, agg != nullptr, f16x2, st);

@@ -1081,8 +1081,17 @@ def test_bx6i_dual_tile_kernel_equals_tile_kernel(rows, kernel, prec, monkeypatc
     pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
     src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
 
+    ids = torch.randperm(E, device=DEV)[: max(E // 2, 1)].to(torch.int32)
+    sub = [ops.Source(e, index=ids, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row[ids.long()].contiguous(), additive=True),
+           ops.Source(pc, index=ep.col[ids.long()].contiguous(), additive=True)]
+
     def run():
         out = {"edge": ops.mlp_forward(pk, src, E), "plain_selu": ops.mlp_forward(pk, [ops.Source(e, index=ep.row)], E, _lib.ACT_SELU)}
+        # a subset of the rows gathered through an index and scattered back through out_idx (the interior / boundary launches of the
+        # partitioned forward, partition.py)
+        buf = torch.zeros(E, H, device=DEV)
+        ops.mlp_forward(pk, sub, int(ids.numel()), out=buf, out_idx32=ids)
+        out["subset_scattered"] = buf
         if csr.tiles() is not None:
             for mean in (True, False):
                 a = torch.full((n, H), float("nan"), device=DEV)
