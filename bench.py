@@ -230,7 +230,7 @@ def roofline_blocks(args, result, model, graph_cpu, dev, ops, Rollout):
     tot_t = sum(summ[k]["seconds"] for k in mlp_kinds)
     fallback = sum(summ[k]["launches"] // 3 for k in mlp_kinds if not k.startswith("mlp_bx6"))
     result["roofline"] = {
-        "bound": "mfma", "kernel": (dom + "<1, *, *> + mlp_bx6i_kernel for the message launches of >= 100k rows (bf16x6: 400k) (g4c_mlp_forward_bx6 / _heads_bx6 / _agg)") if dom.startswith("mlp_bx6")
+        "bound": "mfma", "kernel": (dom + "<1, *, *> + mlp_bx6i_kernel for the message launches of >= 20k rows (bf16x6: 400k) (g4c_mlp_forward_bx6 / _heads_bx6 / _agg)") if dom.startswith("mlp_bx6")
         else dom.replace(">", ", *>") + " (g4c_mlp_forward)",
         "achieved": big["achieved"], "peak": big["peak"], "unit": "TFLOP/s", "frac": big["frac"], "mfma_dtype": big["mfma_dtype"],
         "algorithmic_tflops": big.get("algorithmic_tflops", big["achieved"]),

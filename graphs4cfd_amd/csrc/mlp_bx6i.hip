@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
 
 namespace g4cm {
 
-// 0 off, 1 (default; environment G4C_BX6I) launches of at least G4C_BX6I_MIN_ROWS rows (default 100 000 in f16x3 mode, 400 000 in bf16x6
+// 0 off, 1 (default; environment G4C_BX6I) launches of at least G4C_BX6I_MIN_ROWS rows (default 20 000 in f16x3 mode, 400 000 in bf16x6
 // mode: the kernel needs a full machine of its larger workgroups), 2 every launch it can take (tests)
 static int g_bx6i = -1;
 int bx6i_enable(int on) {
@@ -497,10 +497,10 @@ int bx6i_enable(int on) {
 }
 
 bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count) {
-    // f16x3 mode (three workgroups per CU, shorter pairs): the kernel is ahead from ~100 k rows (level-2 launches of the 100k mesh: +0.5 %
+    // f16x3 mode (three workgroups per CU, shorter pairs): the kernel is ahead from ~20 k rows (6k-node mesh +1 %, 12.5k-node mesh and 2-scale 10k-node mesh +5 %, 25k / 50k-node meshes +6 / +10 %, level-2 launches of the 100k mesh +0.5 %
     // of the step; the interior launches of a 2- / 4-way partition); bf16x6 mode (two workgroups per CU): from ~300 k
     static const long long min_env = getenv("G4C_BX6I_MIN_ROWS") ? atoll(getenv("G4C_BX6I_MIN_ROWS")) : -1;
-    const long long min_rows = min_env >= 0 ? min_env : (f16x2 ? 100000 : 400000);
+    const long long min_rows = min_env >= 0 ? min_env : (f16x2 ? 20000 : 400000);
     const int mode = bx6i_enable(-1);
     if (!mode || round1 || save) return false;
     if (mode == 1 && row_count < min_rows) return false;

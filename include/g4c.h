@@ -205,7 +205,7 @@ int g4c_mlp_pack_layer_f16x3(const float *W, int32_t n_out, int32_t k_in, const 
  * the vector work of one running under the MFMAs of the other, the layer's weights stationary in registers for both) takes the
  * launches of the MP layers' message MLP (one weighted 128-wide block + 0 or 2 additive blocks, three layers, plain 128-wide output
  * rows — through out_idx too — with or without the fused aggregation): 0 = never, 1 = launches of at least G4C_BX6I_MIN_ROWS rows
- * (default 100 000 for the f16x3 stream, 400 000 for the bf16x6 stream; the
+ * (default 20 000 for the f16x3 stream, 400 000 for the bf16x6 stream; the
  * default mode, environment G4C_BX6I), 2 = every launch it can take (tests); -1 only queries.  Returns the previous setting. */
 int g4c_mlp_bx6i_enable(int on);
 
