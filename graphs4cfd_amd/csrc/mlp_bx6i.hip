@@ -175,6 +175,9 @@ __device__ __forceinline__ void m_block(const __bf16 *pa, bf16x8 (&W)[8][SP], __
 #ifndef G4C_BX6I_ROW_STORES
 #define G4C_BX6I_ROW_STORES 1
 #endif
+#ifndef G4C_BX6I_ROW_STORES_PLAIN
+#define G4C_BX6I_ROW_STORES_PLAIN 1      // the same for the launches without aggregation (one more barrier)
+#endif
 #ifndef G4C_BX6I_LATE_W
 #define G4C_BX6I_LATE_W 1
 #endif
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
 #pragma unroll
             for (int c = 0; c < 16; ++c) x[c] = g4c::tanh_f(x[c]);
         }
-        if (AGG) {
+        if (AGG || G4C_BX6I_ROW_STORES_PLAIN) {
 #pragma unroll
             for (int c = 0; c < 16; c += 4) {
                 f32x4 v;
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
                 *reinterpret_cast<f32x4 *>(rowp + c) = v;
             }
         }
-        if (!(AGG && G4C_BX6I_ROW_STORES) && p.out && myrow < nrow[t]) {
+        if (!(AGG ? G4C_BX6I_ROW_STORES : G4C_BX6I_ROW_STORES_PLAIN) && p.out && myrow < nrow[t]) {
             const long long orow = (!AGG && p.out_idx) ? p.out_idx[row0[t] + myrow] : row0[t] + myrow;      // (g4c_mlp_forward's out_idx)
             float *op = p.out + orow * p.out_ld + cb;
 #pragma unroll
@@ -446,6 +449,23 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
         }
     }
     BI_STAMP(21);
+    if (!AGG && G4C_BX6I_ROW_STORES_PLAIN && p.out) {
+        // whole rows per store instruction from the LDS copy (as with AGG below); out_idx scatters them (g4c_mlp_forward's out_idx)
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float *sH = reinterpret_cast<const float *>(t == 0 ? sA : sBt);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + (tid >> 5), c = (tid & 31) * 4;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(sH + r * HS + c);
+                if (r < nrow[t]) {
+                    const long long orow = p.out_idx ? p.out_idx[row0[t] + r] : row0[t] + r;
+                    *reinterpret_cast<f32x4 *>(p.out + orow * p.out_ld + c) = v;
+                }
+            }
+        }
+    }
     if (AGG) {
         // aggregation of the targets whose messages the tiles hold (rows in CSR order): same summation order and the same mean
         // formula as segment_reduce_kernel, so the result is bit-identical to the separate launch
