@@ -30,6 +30,43 @@ def knn_neighbours(points: np.ndarray, queries: np.ndarray, k: int) -> np.ndarra
     return np.asarray(nbr).reshape(len(queries), k)
 
 
+def knn_neighbours_device(pos: torch.Tensor, k: int) -> torch.Tensor:
+    """[n, k] int64 indices of the k nearest OTHER points of every point of `pos` (a device tensor), nearest first:
+    the k-d-tree query of `connect_knn` as a cell-grid search on the GPU (`g4c_knn_grid`, csrc/knn_grid.hip).  The binning
+    is done here with device ops: cells of ~2k/pi (2-D) or ~2k/4.2 (3-D) points, so that one ring of cells almost always
+    holds the k neighbours; cell coordinates in fp64 so that a point lies geometrically inside its cell."""
+    from . import _lib
+    lib = _lib.load()
+    pos = pos.detach()
+    dev = _lib.require_hip(pos)
+    n, dim = int(pos.size(0)), int(pos.size(1))
+    p32 = pos.float().contiguous()
+    lo, hi = p32.min(0)[0].cpu(), p32.max(0)[0].cpu()
+    ext = (hi.double() - lo.double())
+    live = ext[ext > 0]
+    per_cell = 2.0 * k / (np.pi if dim == 2 else 4.0 * np.pi / 3.0)
+    h = float(np.float32((float(live.prod()) * per_cell / n) ** (1.0 / live.numel()))) if live.numel() else 1.0
+    n_cells = [int(np.floor(float(e) / h)) + 1 for e in ext] + [1] * (3 - dim)
+    origin = [float(v) for v in lo] + [0.0] * (3 - dim)
+    coord = ((p32.double() - lo.double().to(dev)) / h).floor().long()
+    stride = [1, n_cells[0], n_cells[0] * n_cells[1]]
+    cell = torch.zeros(n, dtype=torch.long, device=dev)
+    for ax in range(dim):
+        cell += coord[:, ax].clamp_(0, n_cells[ax] - 1) * stride[ax]
+    cell_sorted, order = torch.sort(cell, stable=True)
+    total = n_cells[0] * n_cells[1] * n_cells[2]
+    cell_start = torch.searchsorted(cell_sorted, torch.arange(total + 1, device=dev)).int()
+    pos_sorted = p32[order].contiguous()
+    order32, cell32 = order.int(), cell_sorted.int()
+    out = torch.empty((n, k), dtype=torch.long, device=dev)
+    import ctypes as C
+    nc = (C.c_int32 * 3)(*n_cells)
+    org = (C.c_float * 3)(*origin)
+    _lib.check(lib.g4c_knn_grid(_lib.ptr(pos_sorted), _lib.ptr(cell32), _lib.ptr(order32), _lib.ptr(cell_start), n, dim,
+                                nc, org, C.c_float(h), k, _lib.ptr(out), _lib.stream_handle(dev)))
+    return out
+
+
 def connect_knn(pos: torch.Tensor, k: int, period=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """`connect_knn` (transforms/connect.py:9-72): edges neighbour -> centre, grouped by centre, k per centre, nearest
     first; edge_attr = pos[col] - pos[row].  `period`: one entry per axis — None (not periodic), a length, or "auto" (the
@@ -41,6 +78,12 @@ def connect_knn(pos: torch.Tensor, k: int, period=None) -> Tuple[torch.Tensor, t
     per = [None] * dim if (period is None or all(d is None for d in period)) else list(period)
     if len(per) != dim:
         raise ValueError(f"period needs {dim} entries")
+    if pos.is_cuda and all(d is None for d in per):
+        # positions resident on the GPU, no periodic axis: the search runs there (the result is the host path's)
+        n = int(pos.size(0))
+        row = knn_neighbours_device(pos, k).reshape(-1)
+        col = torch.arange(n, device=pos.device).repeat_interleave(k)
+        return torch.stack([row, col], 0), pos[col] - pos[row]
     lengths, cols = [], []
     for ax in range(dim):
         x = pos[:, ax].detach().cpu().double()
@@ -76,18 +119,30 @@ def connect_knn(pos: torch.Tensor, k: int, period=None) -> Tuple[torch.Tensor, t
 def grid_clustering(pos_1: torch.Tensor, cell_size_2: float):
     """`grid_clustering` (transforms/mus.py:9-38): voxel-grid clusters -> (pos_2, cluster_2, mask_2,
     idx1_to_idx2, e_12).  Voxel id = sum_d floor((p_d - min_d)/size) * stride_d with
-    stride = exclusive cumprod of floor((max-min)/size)+1 (torch_cluster.grid_cluster)."""
+    stride = exclusive cumprod of floor((max-min)/size)+1 (torch_cluster.grid_cluster).
+
+    With `pos_1` on the GPU everything stays there: the voxel ids and their sorted unique set are device tensors and the
+    cluster centres are one `g4c_segment_reduce` launch over the clusters' CSR (rows summed in node order, then divided by
+    the count: the same bits as the host path's sequential `index_add_`).  Divisors are device tensors, not Python
+    scalars, so that the quotients are true divisions on both sides (a host scalar divisor becomes a multiplication by
+    its reciprocal in torch's device kernel)."""
     n, dim = pos_1.shape
-    size = torch.full((dim,), float(cell_size_2), dtype=pos_1.dtype)
+    dev = pos_1.device
+    size = torch.full((dim,), float(cell_size_2), dtype=pos_1.dtype, device=dev)
     start, end = pos_1.min(0)[0], pos_1.max(0)[0]
     nvox = (end - start).true_divide(size).to(torch.long) + 1
-    stride = torch.cat([torch.ones(1, dtype=torch.long), nvox.cumprod(0)[:-1]])
+    stride = torch.cat([torch.ones(1, dtype=torch.long, device=dev), nvox.cumprod(0)[:-1]])
     cluster_2 = ((pos_1 - start).true_divide(size).to(torch.long) * stride).sum(1)
     mask_2, idx1_to_idx2 = torch.unique(cluster_2, sorted=True, return_inverse=True)
     n2 = mask_2.numel()
-    cnt = torch.bincount(idx1_to_idx2, minlength=n2).clamp(min=1).to(pos_1.dtype)
-    pos_2 = torch.zeros(n2, dim, dtype=pos_1.dtype).index_add_(0, idx1_to_idx2, pos_1) / cnt[:, None]
-    e_12 = (pos_2[idx1_to_idx2] - pos_1) / cell_size_2
+    if pos_1.is_cuda:
+        from . import ops, plan
+        pos_2 = ops.segment_reduce(pos_1.detach().float().contiguous(), plan.build_csr(idx1_to_idx2, n2, dev), mean=True)
+        pos_2 = pos_2.to(pos_1.dtype)
+    else:
+        cnt = torch.bincount(idx1_to_idx2, minlength=n2).clamp(min=1).to(pos_1.dtype)
+        pos_2 = torch.zeros(n2, dim, dtype=pos_1.dtype).index_add_(0, idx1_to_idx2, pos_1) / cnt[:, None]
+    e_12 = (pos_2[idx1_to_idx2] - pos_1) / size[0]
     return pos_2, cluster_2, mask_2, idx1_to_idx2, e_12
 
 

@@ -262,6 +262,17 @@ int g4c_edge_scalar_to_node_vector(const float *e, int32_t e_ld, const float *un
                                    int64_t n_nodes, int32_t n_feat, float *out, int32_t out_ld,
                                    void *stream);
 
+/* ---------------------------------------------------------------- pre-processing
+ * The neighbour search of connect_knn (transforms/connect.py:9-72; torch_cluster.knn / k-d tree on the host in the
+ * reference): for every point its k nearest OTHER points, ascending distance, exact.  The caller bins the cloud into a
+ * uniform grid of `cell_size` cells starting at `origin` (cell id = x + n_cells[0]*(y + n_cells[1]*z)) and hands over the
+ * points in cell-sorted order: pos_sorted [n, dim] fp32, cell_sorted [n] their cell ids, order [n] their original
+ * indices, cell_start [prod(n_cells)+1] the first sorted point of each cell (all device, int32).  n_cells and origin are
+ * host arrays of 3.  out [n, k] int64 (device): row = original index of the query, entries = original indices. */
+int g4c_knn_grid(const float *pos_sorted, const int32_t *cell_sorted, const int32_t *order,
+                 const int32_t *cell_start, int64_t n, int32_t dim, const int32_t *n_cells, const float *origin,
+                 float cell_size, int32_t k, int64_t *out, void *stream);
+
 /* ---------------------------------------------------------------- rollout (nn/model.py:303-327)
  * One step's bookkeeping without host involvement: t = *step;
  * outputs[:, nf*t : nf*(t+1)] = pred;  field = roll(field, -nf, dim=1); field[:, -nf:] = pred;

@@ -1,0 +1,91 @@
+"""`GridClustering` (transforms/mus.py:9-65) with the node positions resident on the GPU — voxel
+ids and their sorted unique set as device tensors, cluster centres through `g4c_segment_reduce` — against the reference
+transform's own outputs (tests/golden/transforms.pt) and, at the headline mesh size, against the host path that the CPU
+suite pins to those fixtures.  Integer outputs bit-equal; positions / relative positions bit-equal with the host path
+(same summation order, true divisions) and within the fixture tolerance of tests/test_synthetic.py against the golden."""
+import pytest
+import torch
+
+from graphs4cfd_amd import synthetic as S
+from graphs4cfd_amd.graph import Graph
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _levels(g, n_levels):
+    names = []
+    for lvl in range(2, n_levels + 2):
+        names += [f"pos_{lvl}", f"cluster_{lvl}", f"mask_{lvl}", f"idx{lvl - 1}_to_idx{lvl}", f"e_{lvl - 1}{lvl}"]
+    return names
+
+
+@pytest.mark.parametrize("tag", ["mus_2d", "mus_3d"])
+def test_grid_clustering_on_device_vs_reference_outputs(golden, tag):
+    c = golden("transforms.pt")[tag]
+    ref = c["graph"]
+    g = S.add_grid_levels(Graph(pos=ref["pos"].to(DEV)), c["cells"])
+    for name in _levels(g, len(c["cells"])):
+        got, want = getattr(g, name), ref[name]
+        assert got.device.type == "cuda", name
+        if want.dtype == torch.int64:
+            assert torch.equal(got.cpu(), want), f"{tag}.{name}"
+        else:
+            torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-6, msg=lambda m: f"{tag}.{name}: {m}")
+
+
+@pytest.mark.parametrize("n,dim,levels", [(100_000, 2, 3), (60_000, 3, 3), (1, 2, 1), (7, 3, 2)])
+def test_grid_clustering_on_device_equals_host_path(n, dim, levels):
+    pos = torch.rand(n, dim, generator=torch.Generator().manual_seed(n + dim))
+    cells = S.default_cells(max(n, 8), dim, levels + 1)
+    host = S.add_grid_levels(Graph(pos=pos.clone()), cells)
+    dev = S.add_grid_levels(Graph(pos=pos.to(DEV)), cells)
+    for name in _levels(host, levels):
+        a, b = getattr(dev, name).cpu(), getattr(host, name)
+        assert a.dtype == b.dtype and a.shape == b.shape, name
+        assert torch.equal(a, b), f"{name}: {(a.double() - b.double()).abs().max().item()}"
+
+
+# ------------------------------------------------------------------ ConnectKNN (transforms/connect.py:9-92) on the device
+@pytest.mark.parametrize("tag", ["mus_2d", "mus_3d"])
+def test_connect_knn_on_device_vs_reference_outputs(golden, tag):
+    """The reference transform's own edges (k-d tree / torch_cluster.knn on the host) from the cell-grid search
+    (`g4c_knn_grid`): edge_index bit-equal, edge_attr equal."""
+    c = golden("transforms.pt")[tag]
+    ref = c["graph"]
+    edge_index, edge_attr = S.connect_knn(ref["pos"].to(DEV), c["k"])
+    assert edge_index.device.type == "cuda" and edge_index.dtype == torch.int64
+    assert torch.equal(edge_index.cpu(), ref["edge_index"]), tag
+    torch.testing.assert_close((edge_attr / (2 * c["r"])).cpu(), ref["edge_attr"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,dim,k", [(100_000, 2, 6), (200_000, 3, 6), (5_000, 2, 5), (9, 2, 6), (3_000, 3, 12), (40_000, 2, 16)])
+def test_connect_knn_on_device_equals_host_path(n, dim, k):
+    """Bit-equal edges with the host path (pinned to the reference's outputs by tests/test_synthetic.py) at the
+    headline mesh size, in 3-D, on a thin strip (elongated cell grid), with barely more points than neighbours
+    and at the largest k of the kernel."""
+    pos = torch.rand(n, dim, generator=torch.Generator().manual_seed(7 * n + k))
+    if n == 5_000:
+        pos[:, 1] *= 0.02
+    ei_h, ea_h = S.connect_knn(pos.clone(), k)
+    ei_d, ea_d = S.connect_knn(pos.to(DEV), k)
+    assert ei_d.shape == (2, n * k)
+    assert torch.equal(ei_d.cpu(), ei_h)
+    assert torch.equal(ea_d.cpu(), ea_h)
+
+
+def test_connect_knn_on_device_clustered_cloud():
+    """A strongly non-uniform cloud (most cells empty, a few crowded: the ring search has to widen): still exact."""
+    g = torch.Generator().manual_seed(3)
+    centres = torch.rand(20, 2, generator=g)
+    pos = (centres[torch.randint(0, 20, (30_000,), generator=g)] + 0.002 * torch.randn(30_000, 2, generator=g)).float()
+    ei_h, _ = S.connect_knn(pos.clone(), 6)
+    ei_d, _ = S.connect_knn(pos.to(DEV), 6)
+    assert torch.equal(ei_d.cpu(), ei_h)
+
+
+def test_knn_grid_rejects_bad_arguments():
+    with pytest.raises(ValueError, match="g4c_knn_grid"):
+        S.knn_neighbours_device(torch.rand(5, 2, device=DEV), 6)      # not more points than neighbours
+    with pytest.raises(ValueError, match="g4c_knn_grid"):
+        S.knn_neighbours_device(torch.rand(100, 2, device=DEV), 17)   # k beyond the kernel's register budget
