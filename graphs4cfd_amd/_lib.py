@@ -96,6 +96,8 @@ _SIGNATURES = {
                                                  C.c_void_p, C.c_int32, C.c_void_p]),
     "g4c_knn_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
                                C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+    "g4c_knn_grid_query": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "g4c_rollout_advance": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                       C.c_void_p, C.c_int64, C.c_void_p]),
     "g4c_activation_inplace": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),

@@ -15,28 +15,32 @@ namespace {
 
 constexpr int KMAX = 16;
 
-template <int DIM>
+// SELF: the queries are the cloud's own points (query s = sorted point s, itself excluded, result row = its original
+// index); otherwise m separate query points qpos / qcell (their cell in the cloud's grid, clamped), result row = s.
+template <int DIM, bool SELF>
 __global__ __launch_bounds__(256) void knn_grid_kernel(
     const float *__restrict__ pos,        // [n, DIM] points in cell-sorted order
-    const int *__restrict__ cell,         // [n] cell id of each sorted point
+    const int *__restrict__ cell,         // [n] cell id of each sorted point (SELF)
     const int *__restrict__ order,        // [n] original index of each sorted point
     const int *__restrict__ cell_start,   // [n_cells + 1] first sorted point of each cell
-    long long n, int nc0, int nc1, int nc2, float o0, float o1, float o2, float h, int k,
-    int64_t *__restrict__ out) {          // [n, k] original indices, ascending distance, row = original index of the query
+    const float *__restrict__ qpos, const int *__restrict__ qcell, long long m,
+    int nc0, int nc1, int nc2, float o0, float o1, float o2, float h, int k,
+    int64_t *__restrict__ out) {          // [m, k] original indices, ascending distance
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
+    if (s >= m) return;
+    if (SELF) { qpos = pos; qcell = cell; }
     const int nc[3] = {nc0, nc1, nc2};
     const float org[3] = {o0, o1, o2};
     double q[DIM];
     int c[3] = {0, 0, 0};
     {
-        int id = cell[s];
+        int id = qcell[s];
         c[0] = id % nc0; id /= nc0;
         c[1] = id % nc1; id /= nc1;
         c[2] = id;
     }
 #pragma unroll
-    for (int a = 0; a < DIM; ++a) q[a] = (double)pos[s * DIM + a];
+    for (int a = 0; a < DIM; ++a) q[a] = (double)qpos[s * DIM + a];
 
     double best_d[KMAX];
     int best_j[KMAX];
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(
                 const long long line = ((long long)z * nc1 + y) * nc0;
                 const int beg = cell_start[line + lo[0]], end = cell_start[line + hi[0] + 1];
                 for (int j = beg; j < end; ++j) {
-                    if (j == s) continue;
+                    if (SELF && j == s) continue;
                     double d = 0.0;
 #pragma unroll
                     for (int a = 0; a < DIM; ++a) {
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(
         safe -= 1e-5 * (double)h;
         if (safe > 0.0 && kth <= safe * safe) break;
     }
-    const long long row = order[s];
+    const long long row = SELF ? (long long)order[s] : s;
 #pragma unroll
     for (int u = 0; u < KMAX; ++u)
         if (u < k) out[row * k + u] = best_j[u] >= 0 ? (int64_t)order[best_j[u]] : (int64_t)-1;
@@ -111,11 +115,38 @@ extern "C" int g4c_knn_grid(const float *pos_sorted, const int32_t *cell_sorted,
                 G4C_EINVAL, "g4c_knn_grid: bad grid %d x %d x %d, cell %g", n_cells[0], n_cells[1], n_cells[2], (double)cell_size);
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     if (dim == 2)
-        knn_grid_kernel<2><<<grid, block, 0, (hipStream_t)stream>>>(pos_sorted, cell_sorted, order, cell_start, n, n_cells[0],
-                                                                   n_cells[1], 1, origin[0], origin[1], 0.f, cell_size, k, out);
+        knn_grid_kernel<2, true><<<grid, block, 0, (hipStream_t)stream>>>(pos_sorted, cell_sorted, order, cell_start, nullptr, nullptr,
+                                                                         n, n_cells[0], n_cells[1], 1, origin[0], origin[1], 0.f,
+                                                                         cell_size, k, out);
     else
-        knn_grid_kernel<3><<<grid, block, 0, (hipStream_t)stream>>>(pos_sorted, cell_sorted, order, cell_start, n, n_cells[0],
-                                                                   n_cells[1], n_cells[2], origin[0], origin[1], origin[2],
-                                                                   cell_size, k, out);
+        knn_grid_kernel<3, true><<<grid, block, 0, (hipStream_t)stream>>>(pos_sorted, cell_sorted, order, cell_start, nullptr, nullptr,
+                                                                         n, n_cells[0], n_cells[1], n_cells[2], origin[0], origin[1],
+                                                                         origin[2], cell_size, k, out);
     return g4c::check_launch("g4c_knn_grid");
+}
+
+extern "C" int g4c_knn_grid_query(const float *pos_sorted, const int32_t *order, const int32_t *cell_start, int64_t n, int32_t dim,
+                                  const int32_t *n_cells /*host[3]*/, const float *origin /*host[3]*/, float cell_size,
+                                  const float *q_pos, const int32_t *q_cell, int64_t m, int32_t k, int64_t *out, void *stream) {
+    G4C_REQUIRE(pos_sorted && order && cell_start && n_cells && origin && (m == 0 || (q_pos && q_cell && out)), G4C_EINVAL,
+                "g4c_knn_grid_query: null pointer");
+    g4c::DeviceGuard on_device(pos_sorted);
+    G4C_REQUIRE(dim == 2 || dim == 3, G4C_EINVAL, "g4c_knn_grid_query: dim=%d, must be 2 or 3", dim);
+    G4C_REQUIRE(k >= 1 && k <= KMAX, G4C_EINVAL, "g4c_knn_grid_query: k=%d outside [1, %d]", k, KMAX);
+    G4C_REQUIRE(n >= k && n < (1LL << 31) && m >= 0 && m < (1LL << 31), G4C_EINVAL,
+                "g4c_knn_grid_query: n=%lld points for k=%d neighbours, m=%lld queries", (long long)n, k, (long long)m);
+    G4C_REQUIRE(cell_size > 0.f && n_cells[0] >= 1 && n_cells[1] >= 1 && n_cells[2] >= 1 && (dim == 3 || n_cells[2] == 1) &&
+                    (long long)n_cells[0] * n_cells[1] * n_cells[2] < (1LL << 31),
+                G4C_EINVAL, "g4c_knn_grid_query: bad grid %d x %d x %d, cell %g", n_cells[0], n_cells[1], n_cells[2], (double)cell_size);
+    if (m == 0) return G4C_OK;
+    const dim3 grid((unsigned)((m + 255) / 256)), block(256);
+    if (dim == 2)
+        knn_grid_kernel<2, false><<<grid, block, 0, (hipStream_t)stream>>>(pos_sorted, nullptr, order, cell_start, q_pos, q_cell, m,
+                                                                          n_cells[0], n_cells[1], 1, origin[0], origin[1], 0.f,
+                                                                          cell_size, k, out);
+    else
+        knn_grid_kernel<3, false><<<grid, block, 0, (hipStream_t)stream>>>(pos_sorted, nullptr, order, cell_start, q_pos, q_cell, m,
+                                                                          n_cells[0], n_cells[1], n_cells[2], origin[0], origin[1],
+                                                                          origin[2], cell_size, k, out);
+    return g4c::check_launch("g4c_knn_grid_query");
 }

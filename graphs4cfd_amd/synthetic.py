@@ -30,40 +30,69 @@ def knn_neighbours(points: np.ndarray, queries: np.ndarray, k: int) -> np.ndarra
     return np.asarray(nbr).reshape(len(queries), k)
 
 
-def knn_neighbours_device(pos: torch.Tensor, k: int) -> torch.Tensor:
-    """[n, k] int64 indices of the k nearest OTHER points of every point of `pos` (a device tensor), nearest first:
-    the k-d-tree query of `connect_knn` as a cell-grid search on the GPU (`g4c_knn_grid`, csrc/knn_grid.hip).  The binning
-    is done here with device ops: cells of ~2k/pi (2-D) or ~2k/4.2 (3-D) points, so that one ring of cells almost always
-    holds the k neighbours; cell coordinates in fp64 so that a point lies geometrically inside its cell."""
+def _bin_cloud(pos: torch.Tensor, k: int) -> dict:
+    """Uniform cell grid over a device point cloud for `g4c_knn_grid[_query]`: cells of ~2k/pi (2-D) or ~2k/4.2 (3-D)
+    points, so that one ring of cells almost always holds the k neighbours; cell coordinates in fp64 so that a point lies
+    geometrically inside its cell; points stable-sorted by cell id."""
+    import ctypes as C
     from . import _lib
-    lib = _lib.load()
-    pos = pos.detach()
     dev = _lib.require_hip(pos)
     n, dim = int(pos.size(0)), int(pos.size(1))
-    p32 = pos.float().contiguous()
+    p32 = pos.detach().float().contiguous()
     lo, hi = p32.min(0)[0].cpu(), p32.max(0)[0].cpu()
     ext = (hi.double() - lo.double())
     live = ext[ext > 0]
     per_cell = 2.0 * k / (np.pi if dim == 2 else 4.0 * np.pi / 3.0)
     h = float(np.float32((float(live.prod()) * per_cell / n) ** (1.0 / live.numel()))) if live.numel() else 1.0
     n_cells = [int(np.floor(float(e) / h)) + 1 for e in ext] + [1] * (3 - dim)
-    origin = [float(v) for v in lo] + [0.0] * (3 - dim)
-    coord = ((p32.double() - lo.double().to(dev)) / h).floor().long()
-    stride = [1, n_cells[0], n_cells[0] * n_cells[1]]
-    cell = torch.zeros(n, dtype=torch.long, device=dev)
-    for ax in range(dim):
-        cell += coord[:, ax].clamp_(0, n_cells[ax] - 1) * stride[ax]
-    cell_sorted, order = torch.sort(cell, stable=True)
+    grid = dict(dev=dev, n=n, dim=dim, h=h, n_cells=n_cells, lo=lo.double().to(dev),
+                nc=(C.c_int32 * 3)(*n_cells), org=(C.c_float * 3)(*([float(v) for v in lo] + [0.0] * (3 - dim))))
+    cell_sorted, order = torch.sort(_cell_ids(p32, grid), stable=True)
     total = n_cells[0] * n_cells[1] * n_cells[2]
-    cell_start = torch.searchsorted(cell_sorted, torch.arange(total + 1, device=dev)).int()
-    pos_sorted = p32[order].contiguous()
-    order32, cell32 = order.int(), cell_sorted.int()
-    out = torch.empty((n, k), dtype=torch.long, device=dev)
+    grid.update(cell_sorted=cell_sorted.int(), order=order.int(), pos_sorted=p32[order].contiguous(),
+                cell_start=torch.searchsorted(cell_sorted, torch.arange(total + 1, device=dev)).int())
+    return grid
+
+
+def _cell_ids(p32: torch.Tensor, grid: dict) -> torch.Tensor:
+    coord = ((p32.double() - grid["lo"]) / grid["h"]).floor().long()
+    nc = grid["n_cells"]
+    stride = [1, nc[0], nc[0] * nc[1]]
+    cell = torch.zeros(p32.size(0), dtype=torch.long, device=p32.device)
+    for ax in range(grid["dim"]):
+        cell += coord[:, ax].clamp_(0, nc[ax] - 1) * stride[ax]
+    return cell
+
+
+def knn_neighbours_device(pos: torch.Tensor, k: int) -> torch.Tensor:
+    """[n, k] int64 indices of the k nearest OTHER points of every point of `pos` (a device tensor), nearest first:
+    the k-d-tree query of `connect_knn` as an exact cell-grid search on the GPU (`g4c_knn_grid`, csrc/knn_grid.hip)."""
     import ctypes as C
-    nc = (C.c_int32 * 3)(*n_cells)
-    org = (C.c_float * 3)(*origin)
-    _lib.check(lib.g4c_knn_grid(_lib.ptr(pos_sorted), _lib.ptr(cell32), _lib.ptr(order32), _lib.ptr(cell_start), n, dim,
-                                nc, org, C.c_float(h), k, _lib.ptr(out), _lib.stream_handle(dev)))
+    from . import _lib
+    lib = _lib.load()
+    g = _bin_cloud(pos, k)
+    out = torch.empty((g["n"], k), dtype=torch.long, device=g["dev"])
+    _lib.check(lib.g4c_knn_grid(_lib.ptr(g["pos_sorted"]), _lib.ptr(g["cell_sorted"]), _lib.ptr(g["order"]),
+                                _lib.ptr(g["cell_start"]), g["n"], g["dim"], g["nc"], g["org"], C.c_float(g["h"]), k,
+                                _lib.ptr(out), _lib.stream_handle(g["dev"])))
+    return out
+
+
+def knn_query_device(points: torch.Tensor, queries: torch.Tensor, k: int) -> torch.Tensor:
+    """[len(queries), k] int64 indices of the k nearest `points` of every query (device tensors), nearest first
+    (`g4c_knn_grid_query`): `knn_neighbours` on the GPU."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    g = _bin_cloud(points, k)
+    q32 = queries.detach().float().contiguous()
+    _lib.require_hip(g["pos_sorted"], q32)
+    q_cell = _cell_ids(q32, g).int()
+    m = int(q32.size(0))
+    out = torch.empty((m, k), dtype=torch.long, device=g["dev"])
+    _lib.check(lib.g4c_knn_grid_query(_lib.ptr(g["pos_sorted"]), _lib.ptr(g["order"]), _lib.ptr(g["cell_start"]), g["n"],
+                                      g["dim"], g["nc"], g["org"], C.c_float(g["h"]), _lib.ptr(q32), _lib.ptr(q_cell), m, k,
+                                      _lib.ptr(out), _lib.stream_handle(g["dev"])))
     return out
 
 
@@ -213,8 +242,9 @@ def extend_graph(edge_index: torch.Tensor, edge_attr: torch.Tensor, k: int):
     # node r are the block starting at k * (rank of r among the receivers)
     receivers = col[::k].contiguous()
     rank = torch.searchsorted(receivers, row)
-    a_row = (rank[:, None] * k + torch.arange(k)[None, :]).reshape(-1)
-    a_col = torch.arange(n_edges).repeat_interleave(k)
+    dev = edge_index.device      # host or GPU: index arithmetic and torch elementwise ops only
+    a_row = (rank[:, None] * k + torch.arange(k, device=dev)[None, :]).reshape(-1)
+    a_col = torch.arange(n_edges, device=dev).repeat_interleave(k)
     cos = (unit[a_row] * unit[a_col]).sum(1)
     sin = unit[a_row, 0] * unit[a_col, 1] - unit[a_row, 1] * unit[a_col, 0]
     attr = torch.cat([size[a_row], size[a_col], cos[:, None], sin[:, None]], dim=1)
@@ -225,7 +255,7 @@ def angle_index_down(edge_index1, edge_attr1, edge_index2, edge_attr2, coarse_in
     """`BuildRemusGraph.angleIndexDownMP` (transforms/remus.py:151-176), vectorised."""
     recv1 = edge_index1[1][::k].contiguous()
     rank1 = torch.searchsorted(recv1, coarse_index2)
-    in_edges = rank1[:, None] * k + torch.arange(k)[None, :]          # [n2, k] level-1 edges entering each coarse node
+    in_edges = rank1[:, None] * k + torch.arange(k, device=rank1.device)[None, :]   # [n2, k] level-1 edges entering each coarse node
     # level-2 edges leaving each coarse node, in edge order
     snd2 = edge_index2[0]
     order = torch.argsort(snd2, stable=True)
@@ -245,9 +275,11 @@ def angle_index_down(edge_index1, edge_attr1, edge_index2, edge_attr2, coarse_in
 def knn_interp_weights(pos_x: torch.Tensor, pos_y: torch.Tensor, k: int):
     """`get_knn_interpolate_weights` (transforms/interpolate.py:110-131): for every node of pos_y its k
     nearest nodes of pos_x; weights = 1 / max(squared distance, 1e-16)."""
-    nbr = knn_neighbours(pos_x.double().numpy(), pos_y.double().numpy(), k)
-    y_idx = torch.arange(pos_y.size(0)).repeat_interleave(k)
-    x_idx = torch.from_numpy(nbr.reshape(-1).astype(np.int64))
+    if pos_x.is_cuda:     # both clouds resident on the GPU: the search runs there (same neighbours, same order)
+        x_idx = knn_query_device(pos_x, pos_y, k).reshape(-1)
+    else:
+        x_idx = torch.from_numpy(knn_neighbours(pos_x.double().numpy(), pos_y.double().numpy(), k).reshape(-1).astype(np.int64))
+    y_idx = torch.arange(pos_y.size(0), device=pos_x.device).repeat_interleave(k)
     diff = pos_x[x_idx] - pos_y[y_idx]
     w = 1.0 / torch.clamp((diff * diff).sum(-1, keepdim=True), min=1e-16)
     return y_idx, x_idx, w

@@ -273,6 +273,13 @@ int g4c_knn_grid(const float *pos_sorted, const int32_t *cell_sorted, const int3
                  const int32_t *cell_start, int64_t n, int32_t dim, const int32_t *n_cells, const float *origin,
                  float cell_size, int32_t k, int64_t *out, void *stream);
 
+/* The same search for m separate query points (get_knn_interpolate_weights, transforms/interpolate.py:110-131: the k
+ * nearest nodes of pos_x for every node of pos_y): q_pos [m, dim] fp32 and q_cell [m] (each query's cell in the cloud's
+ * grid, coordinates clamped into it) in any order; no point is excluded; out [m, k] int64, row = query. */
+int g4c_knn_grid_query(const float *pos_sorted, const int32_t *order, const int32_t *cell_start, int64_t n, int32_t dim,
+                       const int32_t *n_cells, const float *origin, float cell_size, const float *q_pos,
+                       const int32_t *q_cell, int64_t m, int32_t k, int64_t *out, void *stream);
+
 /* ---------------------------------------------------------------- rollout (nn/model.py:303-327)
  * One step's bookkeeping without host involvement: t = *step;
  * outputs[:, nf*t : nf*(t+1)] = pred;  field = roll(field, -nf, dim=1); field[:, -nf:] = pred;

@@ -24,6 +24,11 @@ def timed(fn, reps):
 def main():
     dev = torch.device("cuda", 0)
     for n, dim in ((100_000, 2), (1_000_000, 3)):
+        gq = torch.Generator().manual_seed(1)
+        px = torch.rand(n // 4, dim, generator=gq)
+        py = torch.rand(n, dim, generator=gq)
+        pxd, pyd = px.to(dev), py.to(dev)
+        print(f"n={n} dim={dim}: knn_interp_weights ({n // 4} -> {n} nodes, k=3) host {timed(lambda: S.knn_interp_weights(px, py, 3), 1):.1f} ms, device {timed(lambda: S.knn_interp_weights(pxd, pyd, 3), 5):.2f} ms")
         pos = torch.rand(n, dim, generator=torch.Generator().manual_seed(0))
         pos_d = pos.to(dev)
         cells = S.default_cells(n, dim, 3)

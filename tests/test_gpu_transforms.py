@@ -89,3 +89,44 @@ def test_knn_grid_rejects_bad_arguments():
         S.knn_neighbours_device(torch.rand(5, 2, device=DEV), 6)      # not more points than neighbours
     with pytest.raises(ValueError, match="g4c_knn_grid"):
         S.knn_neighbours_device(torch.rand(100, 2, device=DEV), 17)   # k beyond the kernel's register budget
+
+
+# ------------------------------------------------- get_knn_interpolate_weights (transforms/interpolate.py:110-131)
+@pytest.mark.parametrize("n_x,n_y,dim,k", [(25_000, 100_000, 2, 3), (100_000, 30_000, 3, 4), (4, 50, 2, 4), (2_000, 0, 2, 3)])
+def test_knn_interp_weights_on_device_equals_host_path(n_x, n_y, dim, k):
+    """Queries from a second cloud (coarse -> fine interpolation of gMuS / REMuS), some of them outside the bounding
+    box of the searched cloud, fewer points than one cell ring, and no queries at all: indices bit-equal, weights
+    (torch ops on the same pairs) to the last bits."""
+    g = torch.Generator().manual_seed(n_x + n_y)
+    pos_x = torch.rand(n_x, dim, generator=g)
+    pos_y = torch.rand(n_y, dim, generator=g) * 1.2 - 0.1
+    y_h, x_h, w_h = S.knn_interp_weights(pos_x, pos_y, k)
+    y_d, x_d, w_d = S.knn_interp_weights(pos_x.to(DEV), pos_y.to(DEV), k)
+    assert x_d.device.type == "cuda"
+    assert torch.equal(y_d.cpu(), y_h) and torch.equal(x_d.cpu(), x_h)
+    torch.testing.assert_close(w_d.cpu(), w_h, rtol=1e-6, atol=0.0)     # torch's own sum / reciprocal on either side
+
+
+# ------------------------------------------------- REMuS tables (transforms/remus.py:9-45, 151-176) from device tensors
+def test_remus_angle_tables_on_device_equal_host_path():
+    """`extend_graph` and `angleIndexDownMP` are index arithmetic + elementwise ops: with the edges on the GPU the angle
+    indices are bit-equal to the host path's (itself pinned to the reference transform by tests/test_synthetic.py), the
+    angle attributes (norms, cos, sin through torch ops on either side) equal to 1e-6."""
+    k = 5
+    pos = torch.rand(20_000, 2, generator=torch.Generator().manual_seed(11))
+    ei_h, ea_h = S.connect_knn(pos, k)
+    ei_d, ea_d = S.connect_knn(pos.to(DEV), k)
+    assert torch.equal(ei_d.cpu(), ei_h)
+    u_h, ai_h, aa_h = S.extend_graph(ei_h, ea_h, k)
+    u_d, ai_d, aa_d = S.extend_graph(ei_d, ea_d, k)
+    assert ai_d.device.type == "cuda" and torch.equal(ai_d.cpu(), ai_h)
+    torch.testing.assert_close(u_d.cpu(), u_h, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(aa_d.cpu(), aa_h, rtol=1e-5, atol=1e-6)
+    # a coarse level: every third node, kNN among them, the down-MP angle table between the two levels
+    coarse = torch.arange(0, pos.size(0), 3)
+    ei2_h, ea2_h = S.connect_knn(pos[coarse], k)
+    ei2_h = coarse[ei2_h]                                   # coarse edges in level-1 numbering (transforms/remus.py:120-128)
+    di_h, da_h = S.angle_index_down(ei_h, ea_h, ei2_h, ea2_h, coarse, k)
+    di_d, da_d = S.angle_index_down(ei_d, ea_d, ei2_h.to(DEV), ea2_h.to(DEV), coarse.to(DEV), k)
+    assert torch.equal(di_d.cpu(), di_h)
+    torch.testing.assert_close(da_d.cpu(), da_h, rtol=1e-5, atol=1e-6)
