@@ -196,24 +196,33 @@ def default_cells(n: int, dim: int, levels: int) -> List[float]:
     return [2.0 * h * (2 ** i) for i in range(levels - 1)]
 
 
+def true_divide_by(t: torch.Tensor, divisor: float) -> torch.Tensor:
+    """t / divisor as a true division on either side (a host-scalar divisor is a multiplication by its reciprocal in
+    torch's device kernel: one ulp away from the host result)."""
+    return t / torch.full((), float(divisor), dtype=t.dtype, device=t.device) if t.is_cuda else t / divisor
+
+
 def mus_graph(n: int, levels: int = 1, k: int = 6, dim: int = 2, nf: int = 3, n_in: int = 1, seed: int = 0,
-              r: Optional[float] = None, cells: Optional[Sequence[float]] = None, loc: bool = False) -> Graph:
+              r: Optional[float] = None, cells: Optional[Sequence[float]] = None, loc: bool = False, device=None) -> Graph:
     """Synthetic MuS-GNN input: uniform random points in [0,1]^dim, kNN edges scaled by 1/(2r),
-    grid-clustered coarse levels, `field ~ N(0,1)`, `glob ~ U(0,1)`, `omega = U(0,1) > 0.9`."""
+    grid-clustered coarse levels, `field ~ N(0,1)`, `glob ~ U(0,1)`, `omega = U(0,1) > 0.9`.  With `device` (a GPU) the
+    points are uploaded first and the edges / levels are built there (§4.5 of DESIGN.md): the same graph, bit for bit."""
     gen = torch.Generator().manual_seed(seed)
     pos = torch.rand(n, dim, generator=gen)
+    if device is not None:
+        pos = pos.to(device)
     g = Graph(pos=pos)
     g.edge_index, ea = connect_knn(pos, k)
     if r is None:
         r = 2.0 * float(n) ** (-1.0 / dim)   # keeps |edge_attr| = O(1) at every mesh size
-    g.edge_attr = ea / (2 * r)
+    g.edge_attr = true_divide_by(ea, 2 * r)
     if levels > 1:
         add_grid_levels(g, cells if cells is not None else default_cells(n, dim, levels))
-    g.field = torch.randn(n, nf * n_in, generator=gen)
+    g.field = torch.randn(n, nf * n_in, generator=gen).to(pos.device)
     if loc:
-        g.loc = torch.randn(n, 2, generator=gen)
-    g.glob = torch.rand(n, 1, generator=gen)
-    g.omega = (torch.rand(n, 1, generator=gen) > 0.9).float()
+        g.loc = torch.randn(n, 2, generator=gen).to(pos.device)
+    g.glob = torch.rand(n, 1, generator=gen).to(pos.device)
+    g.omega = (torch.rand(n, 1, generator=gen) > 0.9).float().to(pos.device)
     return g
 
 

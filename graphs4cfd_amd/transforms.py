@@ -51,7 +51,7 @@ class ScaleEdgeAttr:
         self.r = r
 
     def __call__(self, graph: Graph) -> Graph:
-        graph.edge_attr = graph.edge_attr / (2 * self.r)
+        graph.edge_attr = S.true_divide_by(graph.edge_attr, 2 * self.r)
         return graph
 
 

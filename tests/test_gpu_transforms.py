@@ -130,3 +130,38 @@ def test_remus_angle_tables_on_device_equal_host_path():
     di_d, da_d = S.angle_index_down(ei_d, ea_d, ei2_h.to(DEV), ea2_h.to(DEV), coarse.to(DEV), k)
     assert torch.equal(di_d.cpu(), di_h)
     torch.testing.assert_close(da_d.cpu(), da_h, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------- the transform classes and the model on a device-built graph
+@pytest.mark.parametrize("tag", ["mus_2d", "mus_3d"])
+def test_transform_classes_on_device_reproduce_the_reference_pipeline(golden, tag):
+    """`Compose([ConnectKNN, ScaleEdgeAttr, GridClustering])` (examples/training/NsMuSGNN/*.py) applied to a Graph whose
+    positions are on the GPU == the attributes the reference's own pipeline produced."""
+    import graphs4cfd_amd as gfd
+    T = gfd.transforms
+    c = golden("transforms.pt")[tag]
+    g = T.Compose([T.ConnectKNN(c["k"]), T.ScaleEdgeAttr(c["r"]), T.GridClustering(c["cells"])])(Graph(pos=c["graph"]["pos"].to(DEV)))
+    for name, want in c["graph"].items():
+        got = getattr(g, name)
+        assert got.device.type == "cuda", name
+        if want.dtype == torch.int64:
+            assert torch.equal(got.cpu(), want), f"{tag}.{name}"
+        else:
+            torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-6, msg=lambda m: f"{tag}.{name}: {m}")
+
+
+def test_device_built_mesh_is_the_host_built_mesh_and_feeds_the_model():
+    """`mus_graph(device=...)`: kNN edges, scaling and three grid levels built on the GPU are bit-equal to the host-built
+    mesh, and the model's rollout from it is the rollout from the uploaded host mesh, bit for bit."""
+    import graphs4cfd_amd as gfd
+    host = S.mus_graph(30_000, levels=3, seed=5)
+    dev = S.mus_graph(30_000, levels=3, seed=5, device=DEV)
+    for name, want in host.to_dict().items():
+        got = getattr(dev, name)
+        assert got.device.type == "cuda" and torch.equal(got.cpu(), want), name
+    torch.manual_seed(2)
+    model = gfd.nn.NsThreeScaleGNN(arch=S.mus_arch("NsThreeScaleGNN", 128), device=DEV)
+    with torch.no_grad():
+        a = model.solve(dev, 3)
+        b = model.solve(host.clone().to(DEV), 3)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
