@@ -230,14 +230,14 @@ def mus_graph(n: int, levels: int = 1, k: int = 6, dim: int = 2, nf: int = 3, n_
 def guillard_coarsening(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
     """Node-nested greedy coarsening (transforms/mugs.py:8-29): visit nodes in order; a node still
     marked coarse removes all its k senders.  Sequential by definition."""
-    row = edge_index[0].numpy()
+    row = edge_index[0].cpu().numpy()          # the visiting order is the algorithm: host loop, mask returned where the edges live
     k = int((edge_index[1] == 0).sum())
     senders = row.reshape(-1, k)
     coarse = np.ones(num_nodes, dtype=bool)
     for i in range(senders.shape[0]):
         if coarse[i]:
             coarse[senders[i]] = False
-    return torch.from_numpy(coarse)
+    return torch.from_numpy(coarse).to(edge_index.device)
 
 
 def extend_graph(edge_index: torch.Tensor, edge_attr: torch.Tensor, k: int):
@@ -353,29 +353,34 @@ def mugs_graph(n: int, levels: int = 2, k: int = 6, seed: int = 0, nf: int = 3) 
 
 
 def remus_graph(n: int, k: int = 5, seed: int = 0, scale: Optional[Sequence[float]] = None,
-                pos: Optional[torch.Tensor] = None, period=None) -> Graph:
+                pos: Optional[torch.Tensor] = None, period=None, device=None) -> Graph:
     """Synthetic 3-level REMuS-GNN input: `BuildRemusGraph(num_levels=3, k, scale_edge_length)` +
-    `BuildKnnInterpWeights(k)` (transforms/remus.py:84-148, interpolate.py:134-155)."""
+    `BuildKnnInterpWeights(k)` (transforms/remus.py:84-148, interpolate.py:134-155).  With the positions on a GPU (`device`,
+    or a device `pos`) the three kNN searches, the interpolation searches and the angle tables are built there (DESIGN.md
+    §4.5); the two Guillard coarsenings (sequential) and the pseudo-inverses (SVD, as in the reference) stay on the host."""
     gen = torch.Generator().manual_seed(seed)
     if pos is None:
         pos = torch.rand(n, 2, generator=gen)
+    if device is not None:
+        pos = pos.to(device)
+    dev = pos.device
     n = pos.size(0)
     if scale is None:
         h = 2.0 * float(n) ** -0.5
         scale = (h, 2 * h, 4 * h)
     g = Graph(pos=pos)
     g.edge_index, g.edge_attr = connect_knn(pos, k, period=period)
-    g.edge_attr = g.edge_attr / (2 * scale[0])
+    g.edge_attr = true_divide_by(g.edge_attr, 2 * scale[0])
     g.coarse_mask2 = guillard_coarsening(g.edge_index, n)
     ci2 = g.coarse_mask2.nonzero().reshape(-1)
     ei2, ea2 = connect_knn(pos[ci2], k, period=period)
-    ea2 = ea2 / (2 * scale[1])
-    m3 = torch.zeros(n, dtype=torch.bool)
+    ea2 = true_divide_by(ea2, 2 * scale[1])
+    m3 = torch.zeros(n, dtype=torch.bool, device=dev)
     m3[g.coarse_mask2] = guillard_coarsening(ei2, ci2.numel())
     g.coarse_mask3 = m3
     ci3 = m3.nonzero().reshape(-1)
     ei3, ea3 = connect_knn(pos[ci3], k, period=period)
-    ea3 = ea3 / (2 * scale[2])
+    ea3 = true_divide_by(ea3, 2 * scale[2])
     g.edge_index2, g.edge_attr2 = ci2[ei2], ea2
     g.edge_index3, g.edge_attr3 = ci3[ei3], ea3
     for s, cnt in (("", n), ("2", ci2.numel()), ("3", ci3.numel())):
@@ -383,14 +388,14 @@ def remus_graph(n: int, k: int = 5, seed: int = 0, scale: Optional[Sequence[floa
         setattr(g, f"edgeUnitVector{s}", u)
         setattr(g, f"angle_index{s}", ai)
         setattr(g, f"angle_attr{s}", aa)
-        setattr(g, f"edgeUnitVectorInverse{s}", torch.linalg.pinv(u.reshape(cnt, -1, 2)))
+        setattr(g, f"edgeUnitVectorInverse{s}", torch.linalg.pinv(u.reshape(cnt, -1, 2).cpu()).to(dev))
     g.angle_index12, g.angle_attr12 = angle_index_down(g.edge_index, g.edge_attr, g.edge_index2, g.edge_attr2, ci2, k)
     g.angle_index23, g.angle_attr23 = angle_index_down(g.edge_index2, g.edge_attr2, g.edge_index3, g.edge_attr3, ci3, k)
     g.y_idx_21, g.x_idx_21, g.weights_21 = knn_interp_weights(pos[ci2], pos, k)
     g.y_idx_32, g.x_idx_32, g.weights_32 = knn_interp_weights(pos[ci3], pos[ci2], k)
-    g.field = torch.randn(n, 2, generator=gen)
-    g.glob = torch.rand(n, 1, generator=gen)
-    g.omega = (torch.rand(n, 1, generator=gen) > 0.9).float()
+    g.field = torch.randn(n, 2, generator=gen).to(dev)
+    g.glob = torch.rand(n, 1, generator=gen).to(dev)
+    g.omega = (torch.rand(n, 1, generator=gen) > 0.9).float().to(dev)
     return g
 
 

@@ -165,3 +165,31 @@ def test_device_built_mesh_is_the_host_built_mesh_and_feeds_the_model():
         a = model.solve(dev, 3)
         b = model.solve(host.clone().to(DEV), 3)
     assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_device_built_remus_graph_is_the_host_built_one_and_feeds_the_model():
+    """`remus_graph(device=...)` / `BuildRemusGraph` on a device Graph: index tensors bit-equal to the host-built graph (which
+    tests/test_synthetic.py pins to the reference transform's output), float tables (norms, cos / sin, weights: torch ops on
+    either side) to 1e-5, and REMuS-GNN's forward from it equal to the forward from the uploaded host graph at the FWD
+    tolerance of test_gpu_parity.py."""
+    import graphs4cfd_amd as gfd
+    host = S.remus_graph(20_000, k=5, seed=21)
+    dev = S.remus_graph(20_000, k=5, seed=21, device=DEV)
+    for name, want in host.to_dict().items():
+        got = getattr(dev, name)
+        assert got.device.type == "cuda", name
+        if want.dtype in (torch.int64, torch.bool):
+            assert torch.equal(got.cpu(), want), name
+        elif "Inverse" in name:
+            torch.testing.assert_close(got.cpu(), want, rtol=1e-4, atol=1e-5, msg=lambda m: f"{name}: {m}")
+        else:
+            torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-6, msg=lambda m: f"{name}: {m}")
+    built = gfd.transforms.BuildRemusGraph(3, 5, scale_edge_length=tuple(2.0 * 20_000 ** -0.5 * f for f in (1, 2, 4)))(
+        Graph(pos=host.pos.to(DEV)))
+    assert built.angle_index12.device.type == "cuda" and torch.equal(built.angle_index12.cpu(), host.angle_index12)
+    torch.manual_seed(22)
+    model = gfd.nn.NsRotEquiTreeScaleGNN(arch=S.remus_arch(128), device=DEV)
+    with torch.no_grad():
+        a = model.forward(dev)
+        b = model.forward(host.clone().to(DEV))
+    torch.testing.assert_close(a, b, rtol=5e-4, atol=5e-4)
