@@ -13,11 +13,11 @@
 
 namespace {
 
-constexpr int KMAX = 16;
+constexpr int KMAX = 16;   // candidate registers: instantiated for 8 (k <= 8: half the swap chain) and 16
 
 // SELF: the queries are the cloud's own points (query s = sorted point s, itself excluded, result row = its original
 // index); otherwise m separate query points qpos / qcell (their cell in the cloud's grid, clamped), result row = s.
-template <int DIM, bool SELF>
+template <int DIM, bool SELF, int KM>
 __global__ __launch_bounds__(256) void knn_grid_kernel(
     const float *__restrict__ pos,        // [n, DIM] points in cell-sorted order
     const int *__restrict__ cell,         // [n] cell id of each sorted point (SELF)
@@ -42,15 +42,15 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(
 #pragma unroll
     for (int a = 0; a < DIM; ++a) q[a] = (double)qpos[s * DIM + a];
 
-    double best_d[KMAX];
-    int best_j[KMAX];
+    double best_d[KM];
+    int best_j[KM];
     int max_r = 0;
 #pragma unroll
     for (int a = 0; a < DIM; ++a) max_r = max(max_r, max(c[a], nc[a] - 1 - c[a]));
 
     for (int R = 1;; ++R) {
 #pragma unroll
-        for (int u = 0; u < KMAX; ++u) { best_d[u] = 1e300; best_j[u] = -1; }
+        for (int u = 0; u < KM; ++u) { best_d[u] = 1e300; best_j[u] = -1; }
         int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
 #pragma unroll
         for (int a = 0; a < DIM; ++a) { lo[a] = max(c[a] - R, 0); hi[a] = min(c[a] + R, nc[a] - 1); }
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(
                     int jj = j;
                     // sorted insertion by a swap chain: static register indexing only
 #pragma unroll
-                    for (int u = 0; u < KMAX; ++u) {
+                    for (int u = 0; u < KM; ++u) {
                         if (u < k && d < best_d[u]) {
                             const double td = best_d[u]; best_d[u] = d; d = td;
                             const int tj = best_j[u]; best_j[u] = jj; jj = tj;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(
             }
         double kth = 1e300;
 #pragma unroll
-        for (int u = 0; u < KMAX; ++u)
+        for (int u = 0; u < KM; ++u)
             if (u == k - 1) kth = best_d[u];
         if (R >= max_r) break;   // the block is the whole grid
         // distance to the nearest face of the block with cells behind it (shrunk by a rounding margin)
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void knn_grid_kernel(
     }
     const long long row = SELF ? (long long)order[s] : s;
 #pragma unroll
-    for (int u = 0; u < KMAX; ++u)
+    for (int u = 0; u < KM; ++u)
         if (u < k) out[row * k + u] = best_j[u] >= 0 ? (int64_t)order[best_j[u]] : (int64_t)-1;
 }
 
@@ -114,14 +114,16 @@ extern "C" int g4c_knn_grid(const float *pos_sorted, const int32_t *cell_sorted,
                     (long long)n_cells[0] * n_cells[1] * n_cells[2] < (1LL << 31),
                 G4C_EINVAL, "g4c_knn_grid: bad grid %d x %d x %d, cell %g", n_cells[0], n_cells[1], n_cells[2], (double)cell_size);
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    if (dim == 2)
-        knn_grid_kernel<2, true><<<grid, block, 0, (hipStream_t)stream>>>(pos_sorted, cell_sorted, order, cell_start, nullptr, nullptr,
-                                                                         n, n_cells[0], n_cells[1], 1, origin[0], origin[1], 0.f,
-                                                                         cell_size, k, out);
-    else
-        knn_grid_kernel<3, true><<<grid, block, 0, (hipStream_t)stream>>>(pos_sorted, cell_sorted, order, cell_start, nullptr, nullptr,
-                                                                         n, n_cells[0], n_cells[1], n_cells[2], origin[0], origin[1],
-                                                                         origin[2], cell_size, k, out);
+#define G4C_KNN_LAUNCH(DIM_, SELF_, KM_, ...) knn_grid_kernel<DIM_, SELF_, KM_><<<grid, block, 0, (hipStream_t)stream>>>(__VA_ARGS__)
+#define G4C_KNN_DISPATCH(SELF_, ...)                                                  \
+    do {                                                                              \
+        if (dim == 2 && k <= 8) G4C_KNN_LAUNCH(2, SELF_, 8, __VA_ARGS__);             \
+        else if (dim == 2) G4C_KNN_LAUNCH(2, SELF_, 16, __VA_ARGS__);                 \
+        else if (k <= 8) G4C_KNN_LAUNCH(3, SELF_, 8, __VA_ARGS__);                    \
+        else G4C_KNN_LAUNCH(3, SELF_, 16, __VA_ARGS__);                               \
+    } while (0)
+    G4C_KNN_DISPATCH(true, pos_sorted, cell_sorted, order, cell_start, nullptr, nullptr, n, n_cells[0], n_cells[1],
+                     dim == 3 ? n_cells[2] : 1, origin[0], origin[1], dim == 3 ? origin[2] : 0.f, cell_size, k, out);
     return g4c::check_launch("g4c_knn_grid");
 }
 
@@ -140,13 +142,7 @@ extern "C" int g4c_knn_grid_query(const float *pos_sorted, const int32_t *order,
                 G4C_EINVAL, "g4c_knn_grid_query: bad grid %d x %d x %d, cell %g", n_cells[0], n_cells[1], n_cells[2], (double)cell_size);
     if (m == 0) return G4C_OK;
     const dim3 grid((unsigned)((m + 255) / 256)), block(256);
-    if (dim == 2)
-        knn_grid_kernel<2, false><<<grid, block, 0, (hipStream_t)stream>>>(pos_sorted, nullptr, order, cell_start, q_pos, q_cell, m,
-                                                                          n_cells[0], n_cells[1], 1, origin[0], origin[1], 0.f,
-                                                                          cell_size, k, out);
-    else
-        knn_grid_kernel<3, false><<<grid, block, 0, (hipStream_t)stream>>>(pos_sorted, nullptr, order, cell_start, q_pos, q_cell, m,
-                                                                          n_cells[0], n_cells[1], n_cells[2], origin[0], origin[1],
-                                                                          origin[2], cell_size, k, out);
+    G4C_KNN_DISPATCH(false, pos_sorted, nullptr, order, cell_start, q_pos, q_cell, m, n_cells[0], n_cells[1],
+                     dim == 3 ? n_cells[2] : 1, origin[0], origin[1], dim == 3 ? origin[2] : 0.f, cell_size, k, out);
     return g4c::check_launch("g4c_knn_grid_query");
 }
