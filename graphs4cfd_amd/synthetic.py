@@ -230,14 +230,49 @@ def mus_graph(n: int, levels: int = 1, k: int = 6, dim: int = 2, nf: int = 3, n_
 def guillard_coarsening(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
     """Node-nested greedy coarsening (transforms/mugs.py:8-29): visit nodes in order; a node still
     marked coarse removes all its k senders.  Sequential by definition."""
-    row = edge_index[0].cpu().numpy()          # the visiting order is the algorithm: host loop, mask returned where the edges live
+    if edge_index.is_cuda:
+        return guillard_coarsening_rounds(edge_index, num_nodes)
+    row = edge_index[0].numpy()
     k = int((edge_index[1] == 0).sum())
     senders = row.reshape(-1, k)
     coarse = np.ones(num_nodes, dtype=bool)
     for i in range(senders.shape[0]):
         if coarse[i]:
             coarse[senders[i]] = False
-    return torch.from_numpy(coarse).to(edge_index.device)
+    return torch.from_numpy(coarse)
+
+
+def guillard_coarsening_rounds(edge_index: torch.Tensor, num_nodes: int, max_rounds: int = 100000) -> torch.Tensor:
+    """The same mask as the sequential visit of `guillard_coarsening`, by rounds of data-parallel tensor ops (any device).
+    Node l is *active* (still coarse when it is visited, so it removes its k senders) iff no active node visited before it
+    lists l among its senders: a lexicographically-first recursion over the arcs l -> j (j a sender of l, l < j).  Each round
+    decides every node all of whose earlier removers are decided — inactive as soon as one of them is active, active once
+    all are inactive; the number of rounds is the longest chain of such arcs, not the number of nodes.  The final mask:
+    a node stays coarse iff no active node (earlier or later) removes it."""
+    dev = edge_index.device
+    k = int((edge_index[1] == 0).sum())
+    remover = torch.arange(num_nodes, device=dev).repeat_interleave(k)        # node l, visited in index order ...
+    removed = edge_index[0]                                                     # ... removes its sender j
+    fwd = remover < removed                                                     # arcs that act before j's own visit
+    a_l, a_j = remover[fwd], removed[fwd]
+    UNDECIDED, ACTIVE, INACTIVE = 0, 1, 2
+    state = torch.zeros(num_nodes, dtype=torch.int8, device=dev)
+    ones = torch.ones_like(a_j, dtype=torch.int32)
+    n_pred = torch.zeros(num_nodes, dtype=torch.int32, device=dev).index_add_(0, a_j, ones)
+    for _ in range(max_rounds):
+        s_l = state[a_l]
+        n_act = torch.zeros(num_nodes, dtype=torch.int32, device=dev).index_add_(0, a_j, (s_l == ACTIVE).int())
+        n_ina = torch.zeros(num_nodes, dtype=torch.int32, device=dev).index_add_(0, a_j, (s_l == INACTIVE).int())
+        open_ = state == UNDECIDED
+        new_state = torch.where(open_ & (n_act > 0), torch.full_like(state, INACTIVE),
+                                torch.where(open_ & (n_ina == n_pred), torch.full_like(state, ACTIVE), state))
+        if torch.equal(new_state, state):
+            break
+        state = new_state
+    if bool((state == UNDECIDED).any()):
+        raise RuntimeError("guillard_coarsening_rounds: undecided nodes left (cyclic arcs cannot occur: l < j)")
+    hit = torch.zeros(num_nodes, dtype=torch.int32, device=dev).index_add_(0, removed, (state[remover] == ACTIVE).int())
+    return hit == 0
 
 
 def extend_graph(edge_index: torch.Tensor, edge_attr: torch.Tensor, k: int):
@@ -357,7 +392,7 @@ def remus_graph(n: int, k: int = 5, seed: int = 0, scale: Optional[Sequence[floa
     """Synthetic 3-level REMuS-GNN input: `BuildRemusGraph(num_levels=3, k, scale_edge_length)` +
     `BuildKnnInterpWeights(k)` (transforms/remus.py:84-148, interpolate.py:134-155).  With the positions on a GPU (`device`,
     or a device `pos`) the three kNN searches, the interpolation searches and the angle tables are built there (DESIGN.md
-    §4.5); the two Guillard coarsenings (sequential) and the pseudo-inverses (SVD, as in the reference) stay on the host."""
+    §4.5), the two Guillard coarsenings as data-parallel rounds; the pseudo-inverses (SVD, as in the reference) stay on the host."""
     gen = torch.Generator().manual_seed(seed)
     if pos is None:
         pos = torch.rand(n, 2, generator=gen)

@@ -45,6 +45,11 @@ def main():
             S.knn_neighbours_device(pos_d, 6)
         e1.record()
         torch.cuda.synchronize()
+        if dim == 2:
+            eh, _ = S.connect_knn(pos, 5)
+            ed = eh.to(dev)
+            assert torch.equal(S.guillard_coarsening(ed, n).cpu(), S.guillard_coarsening(eh, n))
+            print(f"n={n}: guillard coarsening host (sequential) {timed(lambda: S.guillard_coarsening(eh, n), 1):.1f} ms, device (rounds) {timed(lambda: S.guillard_coarsening(ed, n), 3):.2f} ms; remus_graph host {timed(lambda: S.remus_graph(n, seed=1), 1):.0f} ms, device {timed(lambda: S.remus_graph(n, seed=1, device=dev), 2):.1f} ms")
         print(f"n={n} dim={dim}: connect_knn host {host_knn:.1f} ms, device {dev_knn:.2f} ms "
               f"(search + binning, stream time {e0.elapsed_time(e1) / 5:.2f} ms); "
               f"grid clustering (2 levels) host {host_grid:.1f} ms, device {dev_grid:.2f} ms; nbr {tuple(nbr.shape)}")
