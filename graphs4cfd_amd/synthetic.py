@@ -355,21 +355,24 @@ def mugs_arch(model: str, hidden: int = 128, nf: int = 3, node_in: int = 5, dim:
     return arch
 
 
-def mugs_graph(n: int, levels: int = 2, k: int = 6, seed: int = 0, nf: int = 3) -> Graph:
+def mugs_graph(n: int, levels: int = 2, k: int = 6, seed: int = 0, nf: int = 3, device=None) -> Graph:
     """Synthetic gMuS-GNN input with the attribute layout of `GuillardCoarseningAndConnectKNN` + `BuildKnnInterpWeights`
     (transforms/mugs.py:32-89, interpolate.py:133-155): kNN level 1, node-nested Guillard coarsening, kNN per coarse level
     (edge_index{l} in level-1 ids), interpolation indices / weights between consecutive levels."""
     gen = torch.Generator().manual_seed(seed)
     pos = torch.rand(n, 2, generator=gen)
+    if device is not None:
+        pos = pos.to(device)       # every level is then built on the GPU (DESIGN.md §4.5)
+    dev = pos.device
     g = Graph(pos=pos)
     r = 2.0 * float(n) ** -0.5
     g.edge_index, ea = connect_knn(pos, k)
-    g.edge_attr = ea / (2 * r)
-    masks = [torch.ones(n, dtype=torch.bool)]
+    g.edge_attr = true_divide_by(ea, 2 * r)
+    masks = [torch.ones(n, dtype=torch.bool, device=dev)]
     ei_local = g.edge_index
     for l in range(2, levels + 1):
         prev = masks[-1]
-        cm = torch.zeros(n, dtype=torch.bool)
+        cm = torch.zeros(n, dtype=torch.bool, device=dev)
         cm[prev] = guillard_coarsening(ei_local, int(prev.sum()))
         idx = cm.nonzero().reshape(-1)
         if idx.numel() <= k:
@@ -377,13 +380,13 @@ def mugs_graph(n: int, levels: int = 2, k: int = 6, seed: int = 0, nf: int = 3) 
         ei_local, ea = connect_knn(pos[idx], k)
         setattr(g, f"coarse_mask{l}", cm)
         setattr(g, f"edge_index{l}", idx[ei_local])
-        setattr(g, f"edge_attr{l}", ea / (2 * r * 2 ** (l - 1)))
+        setattr(g, f"edge_attr{l}", true_divide_by(ea, 2 * r * 2 ** (l - 1)))
         y, x, w = knn_interp_weights(pos[cm], pos[prev], k)
         setattr(g, f"y_idx_{l}{l - 1}", y); setattr(g, f"x_idx_{l}{l - 1}", x); setattr(g, f"weights_{l}{l - 1}", w)
         masks.append(cm)
-    g.field = torch.randn(n, nf, generator=gen)
-    g.glob = torch.rand(n, 1, generator=gen)
-    g.omega = (torch.rand(n, 1, generator=gen) > 0.9).float()
+    g.field = torch.randn(n, nf, generator=gen).to(dev)
+    g.glob = torch.rand(n, 1, generator=gen).to(dev)
+    g.omega = (torch.rand(n, 1, generator=gen) > 0.9).float().to(dev)
     return g
 
 

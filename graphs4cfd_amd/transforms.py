@@ -82,17 +82,17 @@ class GuillardCoarseningAndConnectKNN:
     def __call__(self, graph: Graph) -> Graph:
         pos, n = graph.pos, int(graph.pos.size(0))
         graph.edge_index, ea = S.connect_knn(pos, self.k[0], period=self.period)
-        graph.edge_attr = ea if self.scale_edge_attr[0] is None else ea / (2 * self.scale_edge_attr[0])
-        prev, ei_local = torch.ones(n, dtype=torch.bool), graph.edge_index
+        graph.edge_attr = ea if self.scale_edge_attr[0] is None else S.true_divide_by(ea, 2 * self.scale_edge_attr[0])
+        prev, ei_local = torch.ones(n, dtype=torch.bool, device=pos.device), graph.edge_index
         for l in range(2, len(self.k) + 1):
-            cm = torch.zeros(n, dtype=torch.bool)
+            cm = torch.zeros(n, dtype=torch.bool, device=pos.device)
             cm[prev] = S.guillard_coarsening(ei_local, int(prev.sum()))
             idx = cm.nonzero().reshape(-1)
             ei_local, ea = S.connect_knn(pos[idx], self.k[l - 1], period=self.period)      # ("auto": the extent of this level's nodes, as the reference)
             sc = self.scale_edge_attr[l - 1]
             setattr(graph, f"coarse_mask{l}", cm)
             setattr(graph, f"edge_index{l}", idx[ei_local])
-            setattr(graph, f"edge_attr{l}", ea if sc is None else ea / (2 * sc))
+            setattr(graph, f"edge_attr{l}", ea if sc is None else S.true_divide_by(ea, 2 * sc))
             prev = cm
         return graph
 

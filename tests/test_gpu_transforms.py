@@ -193,3 +193,35 @@ def test_device_built_remus_graph_is_the_host_built_one_and_feeds_the_model():
         a = model.forward(dev)
         b = model.forward(host.clone().to(DEV))
     torch.testing.assert_close(a, b, rtol=5e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize("cls,levels", [("NsTwoGuillardScaleGNN", 2), ("NsThreeGuillardScaleGNN", 3), ("NsFourGuillardScaleGNN", 4)])
+def test_gmus_transforms_on_device_reproduce_the_reference_pipeline(golden, cls, levels):
+    """`Compose([GuillardCoarseningAndConnectKNN, BuildKnnInterpWeights])` (examples/training/NsMuGSGNN/*.py) on a Graph whose
+    positions are on the GPU == the graph the reference's own transforms produced (tests/golden/models_mugs.pt)."""
+    import graphs4cfd_amd as gfd
+    T = gfd.transforms
+    ref = golden("models_mugs.pt")[cls]["graph"]
+    g = T.Compose([T.GuillardCoarseningAndConnectKNN(k=(6,) * levels, period=None, scale_edge_attr=(0.1, 0.2, 0.4, 0.8)[:levels]),
+                   T.BuildKnnInterpWeights(6)])(Graph(pos=ref["pos"].to(DEV)))
+    for name, want in ref.items():
+        if name in ("field", "glob", "omega", "batch"):
+            continue
+        got = getattr(g, name)
+        assert got.device.type == "cuda", name
+        if want.dtype in (torch.int64, torch.bool):
+            assert torch.equal(got.cpu(), want), f"{cls}.{name}"
+        else:
+            torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-6, msg=lambda m: f"{cls}.{name}: {m}")
+
+
+def test_device_built_gmus_graph_is_the_host_built_one():
+    host = S.mugs_graph(40_000, levels=3, seed=4)
+    dev = S.mugs_graph(40_000, levels=3, seed=4, device=DEV)
+    for name, want in host.to_dict().items():
+        got = getattr(dev, name)
+        assert got.device.type == "cuda", name
+        if want.dtype in (torch.int64, torch.bool):
+            assert torch.equal(got.cpu(), want), name
+        else:
+            torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=0.0, msg=lambda m: f"{name}: {m}")
