@@ -83,8 +83,8 @@ _SIGNATURES = {
                                            C.c_int32, C.c_void_p]),
     "g4c_mlp_forward": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_void_p,
                                   C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
-    "g4c_mlp_px6_enable": (C.c_int, [C.c_int]),
     "g4c_mlp_bx6i_enable": (C.c_int, [C.c_int]),
+    "g4c_mlp_ws_enable": (C.c_int, [C.c_int]),
     "g4c_mlp_forward_rows": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                                        C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_void_p]),

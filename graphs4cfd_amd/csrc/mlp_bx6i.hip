@@ -55,8 +55,8 @@ template <int SP>
 __device__ __forceinline__ void put_pair(__bf16 *d, f32x2 y) {
     f32x2 hf, mf, lf;
     if (SP == 2) {
-        const unsigned hu = pack_f16(y, hf);
-        const unsigned lu = pack_f16((y - hf) * F16_LO_SCALE, lf);
+        unsigned hu, lu;
+        split_pair_f16(y, hu, lu);
         *reinterpret_cast<unsigned *>(d) = hu;
         *reinterpret_cast<unsigned *>(d + PLN) = lu;
         return;
@@ -87,7 +87,7 @@ __device__ __forceinline__ void other_slice(int s, const f32x16 &accE, const f32
         const int gq = s >> 1, pr = s & 1;
         f32x2 x;
         x[0] = accE[4 * gq + 2 * pr]; x[1] = accE[4 * gq + 2 * pr + 1];
-        if (SP == 2) { x[0] = fmaf(accE1[4 * gq + 2 * pr], F16_LO_UNSCALE, x[0]); x[1] = fmaf(accE1[4 * gq + 2 * pr + 1], F16_LO_UNSCALE, x[1]); }
+        if (SP == 2) { f32x2 x1; x1[0] = accE1[4 * gq + 2 * pr]; x1[1] = accE1[4 * gq + 2 * pr + 1]; x = x1 * F16_LO_UNSCALE + x; }      // (one v_pk_fma_f32)
         put_pair<SP>(o.plane_acc + 8 * gq + 2 * pr, selu2i(x));
     } else if (EK == 2) {
         if (s & 1) {

@@ -1,4 +1,4 @@
-// Shared declarations of the fused-MLP kernels (mlp_fused.hip: tile kernels, mlp_px6.hip: persistent ping-pong kernel):
+// Shared declarations of the fused-MLP kernels (mlp_fused.hip: tile kernels, mlp_bx6i.hip: dual-tile kernel, mlp_ws.hip: weight-stationary persistent kernel):
 // launch parameter block, LDS / stream constants, operand split and activation helpers.
 #pragma once
 #include "g4c_common.h"
@@ -156,15 +156,37 @@ __device__ __forceinline__ unsigned pack_f16(f32x2 x, f32x2 &back) {
     back[0] = (float)b[0]; back[1] = (float)b[1];
     return __builtin_bit_cast(unsigned, b);
 }
+// Two-way fp16 split of a PAIR in four vector instructions: hu = (fp16(y0), fp16(y1)) by one v_cvt_pk_f16_f32, then
+// l = fp16((y - h) * 2^11) as fp16(fma(h, -2^11, y * 2^11)) by v_fma_mixlo_f16 / v_fma_mixhi_f16, which read the fp16 halves of hu
+// directly (no widening conversion) and write the fp16 halves of lu directly (no narrowing one).  Bit-identical to converting,
+// subtracting and scaling: y * 2^11 and h * 2^11 are exact, y - h is exactly representable (it is the part of y's significand below
+// h's), so the fused multiply-add returns exactly (y - h) * 2^11 and the only rounding is the final one to fp16 — as before.
+// (Written as inline assembly: hipcc widens the halves with v_cvt_f32_f16 instead of folding them into the fma.)
+#ifndef G4C_SPLIT_MIX
+#define G4C_SPLIT_MIX 1
+#endif
+__device__ __forceinline__ void split_pair_f16(f32x2 y, unsigned &hu, unsigned &lu) {
+    f16x2 b;
+    b[0] = (_Float16)y[0]; b[1] = (_Float16)y[1];
+    hu = __builtin_bit_cast(unsigned, b);
+    if (G4C_SPLIT_MIX) {
+        const f32x2 ys = y * F16_LO_SCALE;
+        const float c = -F16_LO_SCALE;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lu) : "v"(hu), "s"(c), "v"(ys[0]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu) : "v"(hu), "s"(c), "v"(ys[1]));
+    } else {
+        f32x2 hf, lf;
+        hf[0] = (float)b[0]; hf[1] = (float)b[1];
+        lu = pack_f16((y - hf) * F16_LO_SCALE, lf);
+    }
+}
 __device__ __forceinline__ void split2x4(f32x4 x, bf16x4 &h, bf16x4 &l) {
     unsigned hu[2], lu[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        f32x2 v, hf, lf;
+        f32x2 v;
         v[0] = x[2 * j]; v[1] = x[2 * j + 1];
-        hu[j] = pack_f16(v, hf);
-        const f32x2 r = (v - hf) * F16_LO_SCALE;
-        lu[j] = pack_f16(r, lf);
+        split_pair_f16(v, hu[j], lu[j]);
     }
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     u32x2 hh, ll;
@@ -215,9 +237,9 @@ int bx6i_enable(int on);
 bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count);
 int bx6i_launch(const Params &p, bool agg, bool f16x2, hipStream_t st);
 
-// persistent ping-pong kernel (mlp_px6.hip)
-int px6_enable(int on);
-bool px6_eligible(const Params &p, bool agg, bool save, bool all_vec);
-int px6_launch(const Params &p, bool round1, bool agg, hipStream_t st);
+// weight-stationary persistent kernel (mlp_ws.hip): f16x3 stream only
+int ws_enable(int on);
+bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count);
+int ws_launch(const Params &p, bool agg, hipStream_t st);
 
 }  // namespace g4cm

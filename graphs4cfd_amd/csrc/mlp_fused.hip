@@ -1280,12 +1280,6 @@ extern "C" int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp, const g4c_src_t *srcs, 
                       nullptr, 0, nullptr, 0, stream);
 }
 
-// launches below this many rows keep the 32-row-tile kernel (G4C_PX6_MIN_ROWS; tuning)
-static int64_t px6_min_rows() {
-    static const int64_t v = getenv("G4C_PX6_MIN_ROWS") ? atoll(getenv("G4C_PX6_MIN_ROWS")) : 0;
-    return v;
-}
-
 static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                       int64_t row_begin, int64_t row_count, int32_t tile_rows,
                       float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
@@ -1434,11 +1428,10 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     if (row_count == 0) return G4C_OK;
     p.row_base = row_begin;
     p.M = row_begin + row_count;          // rows past the range are neither gathered nor stored
-    if (bx6 && !f16x2 && !force_tiles && px6_eligible(p, agg != nullptr, save != nullptr, all_vec) && row_count >= px6_min_rows()) {
-        // persistent ping-pong kernel (mlp_px6.hip): 32-row units (whole segments with aggregation), two per group tile
+    if (bx6 && !force_tiles && ws_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
+        // weight-stationary persistent kernel (mlp_ws.hip): pairs of 32-row tiles (whole segments with aggregation), one workgroup per CU
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
-        if (p.n_tiles == 0) return G4C_OK;
-        return px6_launch(p, round1, agg != nullptr, st);
+        return ws_launch(p, agg != nullptr, st);
     } else if (bx6 && !force_tiles && bx6i_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
         // dual-tile software-pipelined kernel (mlp_bx6i.hip): pairs of 32-row tiles (whole segments with aggregation)
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);

@@ -1,0 +1,623 @@
+// Weight-stationary persistent form of the fused split-operand MLP ("ws") for the MP layers' message launch — the same arithmetic as
+// mlp_bx6_kernel<.., SP = 2> (mlp_fused.hip): gather -> [SELU on load] -> Linear/SELU chain as two-way fp16 split products on
+// v_mfma_f32_16x16x32_f16 -> LayerNorm -> activation -> store (-> per-target aggregation).  Replaces MLP.forward
+// (graphs4cfd/nn/blocks.py:117-144) with the torch.cat / index ops in front of it (nn/blocks.py:181,328) and, with AGG, the
+// scatter(e', col, reduce) behind it (nn/blocks.py:183,330).
+//
+// What is different from the tile kernels:
+//   * ONE 8-wave workgroup per CU (two waves per SIMD, 256 VGPRs each), persistent over a contiguous range of tile pairs;
+//   * wave w owns output features [16 w, 16 w + 16) of EVERY layer and keeps its slice of ALL THREE layers' weights in registers
+//     (3 layers x 4 k-steps x 2 planes x 16 bytes per lane = 96 VGPRs) for the whole launch: no weight stream at all after the
+//     first tile, and — because the weights are loop-invariant — the pair loop is an ordinary loop (the single-layer stationary form
+//     of mlp_bx6i_kernel redefines its weight registers per layer, which hipcc duplicates across a back edge);
+//   * the loop is software-pipelined over pairs: gather indices and segment offsets are fetched two pairs ahead (into LDS), input rows
+//     and additive rows one pair ahead (into registers), the next pair's first tile is parked before the current pair's
+//     LayerNorm / store / aggregation tail, so no dependent memory round trip is left on a pair's critical path;
+//   * inside a pair the two tiles alternate layer by layer as in mlp_bx6i_kernel: while a wave issues the MFMAs of one tile its
+//     vector ALUs run the other tile's epilogue (bias is the accumulator start value; SELU, fp16 split, planes).
+// Envelope (everything else keeps mlp_bx6_kernel / mlp_bx6i_kernel): f16x3 stream, ONE weighted 128-wide 16-byte aligned input block
+// (rows direct or through an index, optional SELU on load), 0 or 2 additive 128-wide blocks, three layers, 128-wide output rows
+// without residual / heads; an output index only without the fused aggregation.
+#include "mlp_common.h"
+#include <cstdlib>
+using namespace g4cm;
+
+#ifdef G4C_WS_TIMING
+__device__ unsigned long long g4c_ws_stamps[256 * 32];
+extern "C" int g4c_ws_read_stamps(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4c_ws_stamps), sizeof(unsigned long long) * n);
+}
+#define WS_STAMP(k) do { if (it == 1 && tid == 0 && blockIdx.x < 256) g4c_ws_stamps[blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WS_STAMP(k) do {} while (0)
+#endif
+
+// timing-only ablations (wrong results): 1 no epilogue work inside the matrix phases, 2 no MFMAs, 4 no B-fragment reads,
+// 8 no plane writes, 16 no SELU (identity), 32 no fp16 split (h only), 64 plane writes of constant zeros, 128 plane writes to
+// lane-linear (conflict-free) addresses
+#ifndef G4C_WS_ABLATE
+#define G4C_WS_ABLATE 0
+#endif
+
+namespace {
+
+// Operand planes: [32 rows][128 k] fp16, NO padding; the 16-byte granule c of row r is stored at granule c ^ (r & 15).  The B
+// fragment reads of v_mfma_f32_16x16x32 (lane (n, g): row n, granule 4 ks + g; a ds_read_b128 is served in groups of 16 lanes that
+// mix two values of g) are then conflict-free: within a group the granules (4 ks + g) ^ n are all different.  With the padded
+// [32][136] layout of the tile kernels 45 % of this kernel's LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).
+constexpr int PS = 128;                 // row stride of a plane (elements)
+constexpr int PLN = 32 * PS;            // elements of one operand plane of a 32-row tile
+constexpr int TILE_BF16 = 2 * PLN;      // two planes (h, l * 2^11)
+constexpr int FIN = 32 * HS;            // floats of a tile's fp32 final rows [32][132]
+constexpr int SEGCAP = 64;              // segment offsets of a tile staged in LDS (more segments: read from global memory)
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// rows [r0, r0 + n) and segments [s0, s1) of the two tiles of a pair (wave-uniform)
+struct Meta { int r0[2], n[2], s0[2], s1[2]; };
+
+// What the vector ALUs do for the OTHER tile while this tile's MFMAs issue, one piece per slice s = 0..7 (unit u = s / 4 = sample
+// row block / row half, piece s % 4):
+//   EK 0 nothing;  1 hidden-layer epilogue of accE[u] (sample rows 16 u + n);  2 park rows prow + 16 u of the gathered input
+//   (PACT: SELU pending on the stored rows);  3 last layer: fp32 rows of accE[u] into the tile's final buffer.
+// EK 1 / 2 work on one PAIR of values at a time: pieces 0 / 2 = [fold,] SELU of pair 0 / 1, pieces 1 / 3 = fp16 split + plane writes.
+struct Other {
+    __bf16 *plane_acc;        // EK 1: this lane's element (row n, feature fcol) of the other tile's planes (swizzled address)
+    __bf16 *plane_park;       // EK 2: (row prow, column pc) (swizzled address)
+    float *fin;               // EK 3: (row n, feature fcol) of the other tile's fp32 rows
+    int lin_off;              // (timing ablation 128: element offset of plane_acc inside its tile)
+};
+
+#ifndef G4C_WS_SCALAR_MATH
+#define G4C_WS_SCALAR_MATH 0      // 1: no packed-f32 vector ALU instructions in the epilogue (v_pk_* beside MFMAs; MI355X_MICROARCH.md)
+#endif
+__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ f32x2 selu2w(f32x2 x) {
+    if (G4C_WS_ABLATE & 16) return x;
+    const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f;
+    const float scale = 1.0507009873554804934193349852946f;
+    if (G4C_WS_SCALAR_MATH) {
+        f32x2 y;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float m = fmaxf(x[e], 0.f);
+            const float t = __builtin_amdgcn_exp2f(opaque(fminf(x[e], 0.f) * 1.4426950408889634f));
+            y[e] = fmaf(m, scale, opaque(fmaf(t, sa, -sa)));
+        }
+        return y;
+    }
+    f32x2 t, m;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { m[e] = fmaxf(x[e], 0.f); t[e] = fminf(x[e], 0.f); }
+    t = t * 1.4426950408889634f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) t[e] = __builtin_amdgcn_exp2f(t[e]);
+    return m * scale + (t * sa - sa);
+}
+
+// two-way fp16 split of a pair -> one packed pair per plane (split_pair_f16, mlp_common.h: four vector instructions)
+__device__ __forceinline__ void put_pair_f16(__bf16 *d, f32x2 y) {
+    unsigned hu, lu;
+    split_pair_f16(y, hu, lu);
+    if (G4C_WS_ABLATE & 8) { asm volatile("" :: "v"(hu), "v"(lu)); return; }
+    *reinterpret_cast<unsigned *>(d) = hu;
+    *reinterpret_cast<unsigned *>(d + PLN) = lu;
+}
+
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));    // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));    // row_mirror
+    return v;
+}
+
+// plane writes: 0 = one ds_write2st64_b32 per pair as soon as it is split; 1 = two ds_write_b64 per unit (after its second pair);
+// 2 = all four ds_write_b64 of the block after its last MFMA.  LDS operations complete in order per wave, so a write between the B
+// fragment reads delays the reads behind it: with mode 0 a matrix phase took 1736 cycles, without the writes 888.
+#ifndef G4C_WS_WRITE_MODE
+#define G4C_WS_WRITE_MODE 2
+#endif
+struct Pend { unsigned h[2][2], l[2][2]; };       // [unit][pair] packed fp16 pairs waiting to be written
+
+template <int EK>
+__device__ __forceinline__ void flush_unit(int u, const Other &o, const Pend &w) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    __bf16 *d = (EK == 1 ? o.plane_acc : o.plane_park) + u * 16 * PS;
+    u32x2 hh, ll;
+    hh[0] = w.h[u][0]; hh[1] = w.h[u][1]; ll[0] = w.l[u][0]; ll[1] = w.l[u][1];
+    if (G4C_WS_ABLATE & 8) { asm volatile("" :: "v"(hh), "v"(ll)); return; }
+    if (G4C_WS_ABLATE & 64) { asm volatile("" :: "v"(hh), "v"(ll)); hh[0] = 0; hh[1] = 0; ll = hh; }            // constant data: no dependency on the VALU chain
+    if (G4C_WS_ABLATE & 128) d = const_cast<__bf16 *>(o.plane_acc) - o.lin_off + 4 * (threadIdx.x & 63) + u * 1024 + (EK == 1 ? 0 : 256);   // lane-linear addresses: conflict-free
+    *reinterpret_cast<u32x2 *>(d) = hh;
+    *reinterpret_cast<u32x2 *>(d + PLN) = ll;
+}
+
+template <int EK, bool PACT>
+__device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, f32x2 &hold, Pend &w) {
+    const int u = s >> 2, pc4 = s & 3, pr = pc4 >> 1;
+    if (EK == 1) {
+        if ((pc4 & 1) == 0) {
+            f32x2 x, x1;
+            x[0] = accE[u][2 * pr]; x[1] = accE[u][2 * pr + 1];
+            x1[0] = accE1[u][2 * pr]; x1[1] = accE1[u][2 * pr + 1];
+            hold = selu2w(x1 * F16_LO_UNSCALE + x);         // (the fold is one v_pk_fma_f32)
+        } else if (G4C_WS_WRITE_MODE == 0) {
+            put_pair_f16(o.plane_acc + u * 16 * PS + 2 * pr, hold);
+        } else {
+            split_pair_f16(hold, w.h[u][pr], w.l[u][pr]);
+            if (G4C_WS_WRITE_MODE == 1 && pr == 1) flush_unit<EK>(u, o, w);
+        }
+    } else if (EK == 2) {
+        if ((pc4 & 1) == 0) {
+            f32x2 x;
+            x[0] = xe[u][2 * pr]; x[1] = xe[u][2 * pr + 1];
+            hold = PACT ? selu2w(x) : x;
+        } else if (G4C_WS_WRITE_MODE == 0) {
+            put_pair_f16(o.plane_park + u * 16 * PS + 2 * pr, hold);
+        } else {
+            split_pair_f16(hold, w.h[u][pr], w.l[u][pr]);
+            if (G4C_WS_WRITE_MODE == 1 && pr == 1) flush_unit<EK>(u, o, w);
+        }
+    } else if (EK == 3) {
+        if (pc4 == 0) {
+            f32x4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = fmaf(accE1[u][e], F16_LO_UNSCALE, accE[u][e]);
+            *reinterpret_cast<f32x4 *>(o.fin + u * 16 * HS) = x;
+        }
+    }
+}
+
+#ifndef G4C_WS_VALU_PER_MFMA
+#define G4C_WS_VALU_PER_MFMA 4
+#endif
+
+// One 128-k block for one tile: acc += W(layer) x planes, 8 slices (k-step ks = s / 2, sample row block rb = s % 2) of three
+// products each: (Wh, xl) and (Wl, xh) into acc1 (the 2^-11 terms), (Wh, xh) into acc.  pa[ks]: this lane's B-operand address
+// (row n, granule (4 ks + g) ^ n) in the tile's h plane.
+template <int EK, bool PACT = false>
+__device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16x8 (&W)[4][2], f32x4 (&acc)[2], f32x4 (&acc1)[2],
+                                        const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o) {
+    // B fragments (h, l planes) of slice s: row block s % 2, k-step s / 2; fetched two slices ahead of their MFMAs
+    bf16x8 fh[3], fl[3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const __bf16 *pn = pa[s >> 1] + (s & 1) * 16 * PS;
+        fh[s] = *reinterpret_cast<const bf16x8 *>(pn); fl[s] = *reinterpret_cast<const bf16x8 *>(pn + PLN);
+    }
+    f32x2 hold = {0.f, 0.f};
+    Pend w;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int ks = s >> 1, rb = s & 1;
+        if (s + 2 < 8 && !(G4C_WS_ABLATE & 4)) {
+            const __bf16 *pn = pa[(s + 2) >> 1] + ((s + 2) & 1) * 16 * PS;
+            fh[(s + 2) % 3] = *reinterpret_cast<const bf16x8 *>(pn);
+            fl[(s + 2) % 3] = *reinterpret_cast<const bf16x8 *>(pn + PLN);
+        }
+        if (!EK) __builtin_amdgcn_sched_barrier(0);
+        if (!(G4C_WS_ABLATE & 1)) other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, w);
+        const bf16x8 ch = fh[s % 3], cl = fl[s % 3];
+        if (G4C_WS_ABLATE & 2) {
+            asm volatile("" :: "v"(ch), "v"(cl));
+        } else {
+        acc1[rb] = mfma16(W[ks][0], cl, acc1[rb]);
+        acc[rb] = mfma16(W[ks][0], ch, acc[rb]);
+        acc1[rb] = mfma16(W[ks][1], ch, acc1[rb]);
+        }
+        if (EK) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                  // DS read (fragments two slices ahead)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, G4C_WS_VALU_PER_MFMA, 0);      // VALU
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                  // DS write
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if ((EK == 1 || EK == 2) && G4C_WS_WRITE_MODE == 2 && !(G4C_WS_ABLATE & 1)) { flush_unit<EK>(0, o, w); flush_unit<EK>(1, o, w); }
+}
+
+// a whole unit outside a matrix phase (the first tile of a pair is parked with nothing to overlap with; B's last rows)
+template <int EK, bool PACT>
+__device__ __forceinline__ void other_all(const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o) {
+    f32x2 hold = {0.f, 0.f};
+    Pend w;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, w);
+    if ((EK == 1 || EK == 2) && G4C_WS_WRITE_MODE == 2) { flush_unit<EK>(0, o, w); flush_unit<EK>(1, o, w); }
+}
+
+template <bool AGG, bool DIRECT, bool ADDS>
+__global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const int n_pairs) {
+    __shared__ __attribute__((aligned(16))) __bf16 sP[2 * TILE_BF16];      // operand planes of tiles A, B (34 816 B)
+    __shared__ __attribute__((aligned(16))) float sF[2 * FIN];             // fp32 final rows of tiles A, B (33 792 B)
+    __shared__ int sIdx[2][2 * 3 * 32];          // ring of 2: [tile][weighted block, additive 0, additive 1][row]
+    __shared__ int sSeg[4][2 * (SEGCAP + 1)];    // ring of 4: [tile][segment offsets seg_off[s0 .. s0 + SEGCAP]]
+    // biases and LayerNorm parameters are read from LDS: a global load inside a phase would make the wave wait for every older
+    // load of its queue (memory returns in order per wave) — the prefetched rows of the next pair among them
+    __shared__ __attribute__((aligned(16))) float sBias[3 * NP];
+    __shared__ __attribute__((aligned(16))) float sGB[2 * NP];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int fcol = 16 * wave + 4 * g;                     // this lane's four output features (accumulator layout), sample rows n, n + 16
+    const int prow = tid >> 5, pc = (tid & 31) * 4;         // park layout: rows prow, prow + 16, four columns from pc
+
+    // contiguous range of pairs of this workgroup (XCD-aware: each XCD gets a contiguous share when the grid is a multiple of 8)
+    int p_begin, p_end;
+    {
+        const int G = gridDim.x, b = blockIdx.x;
+        const int slot = (G & 7) ? b : (b & 7) * (G >> 3) + (b >> 3);
+        p_begin = __builtin_amdgcn_readfirstlane((int)(((long long)slot * n_pairs) / G));
+        p_end = __builtin_amdgcn_readfirstlane((int)(((long long)(slot + 1) * n_pairs) / G));
+    }
+    if (p_begin >= p_end) return;
+
+    // (the loads are issued where load_meta is called; fix_meta — the v_readfirstlanes that wait for them — an iteration later)
+    auto load_meta = [&](int pair) __attribute__((always_inline)) {
+        Meta m;
+        if (pair > n_pairs - 1) pair = n_pairs - 1;          // (prefetch past the end: a valid pair again, never used)
+        const int t0 = 2 * pair;
+        if (AGG) {
+            const int t1 = t0 + 1 < p.n_tiles ? t0 + 1 : p.n_tiles, t2 = t0 + 2 < p.n_tiles ? t0 + 2 : p.n_tiles;
+            const int r0 = p.tile_rows[t0], r1 = p.tile_rows[t1], r2 = p.tile_rows[t2];
+            const int q0 = p.tile_seg[t0], q1 = p.tile_seg[t1], q2 = p.tile_seg[t2];
+            m.r0[0] = r0; m.n[0] = r1 - r0; m.r0[1] = r1; m.n[1] = r2 - r1;
+            m.s0[0] = q0; m.s1[0] = q1; m.s0[1] = q1; m.s1[1] = q2;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int tile = t0 + t;
+                m.s0[t] = 0; m.s1[t] = 0;
+                if (tile >= p.n_tiles) { m.r0[t] = 0; m.n[t] = 0; }
+                else { m.r0[t] = (int)p.row_base + tile * 32; const int lim = (int)p.M - m.r0[t]; m.n[t] = lim < 32 ? lim : 32; }
+            }
+        }
+        if (m.n[1] == 0) m.r0[1] = m.r0[0];       // (odd tile count: the second tile recomputes the first tile's rows and stores nothing)
+        return m;
+    };
+    auto fix_meta = [&](const Meta &r) __attribute__((always_inline)) {          // wave-uniform: into scalar registers
+        Meta m;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            m.r0[t] = __builtin_amdgcn_readfirstlane(r.r0[t]); m.n[t] = __builtin_amdgcn_readfirstlane(r.n[t]);
+            m.s0[t] = __builtin_amdgcn_readfirstlane(r.s0[t]); m.s1[t] = __builtin_amdgcn_readfirstlane(r.s1[t]);
+        }
+        return m;
+    };
+    // one int per thread of a pair's tables: threads [0, 192) the gather indices [tile][kind][row] (rows past a tile's end are
+    // clamped copies of its last row: never stored), threads [256, 256 + 2 (SEGCAP + 1)) the segment offsets of the tiles' targets
+    const int *const dummy = reinterpret_cast<const int *>(p.b);
+    auto load_tables = [&](const Meta &m) __attribute__((always_inline)) {
+        const int *ix0 = p.src[0].idx, *ix1 = ADDS ? p.add[0].idx : nullptr, *ix2 = ADDS ? p.add[1].idx : nullptr;
+        const int tt = tid < 192 ? tid : 0;
+        const int t = tt / 96, k = (tt % 96) >> 5, r = tt & 31;
+        const int nn = m.n[t] > 0 ? m.n[t] : m.n[0];
+        const int gr = m.r0[t] + (r < nn ? r : nn - 1);
+        const int *ix = (k == 0) ? ix0 : (k == 1 ? ix1 : ix2);
+        const int *addr = ix ? ix + gr : dummy;
+        int j = 0, ts = 0;
+        if (AGG) {
+            const int q = tid - 256;
+            const bool is_seg = q >= 0 && q < 2 * (SEGCAP + 1);
+            ts = is_seg && q >= SEGCAP + 1 ? 1 : 0;
+            j = is_seg ? q - ts * (SEGCAP + 1) : 0;
+            int sg = m.s0[ts] + j;
+            if (sg > m.s1[ts]) sg = m.s1[ts];
+            if (is_seg) addr = p.seg_off + sg;
+        }
+        const int v = *addr;
+        return (tid < 192 && !ix) ? gr : v;
+    };
+    auto store_tables = [&](int v, int it) __attribute__((always_inline)) {
+        if (tid < 192) sIdx[it & 1][tid] = v;
+        if (AGG && tid >= 256 && tid < 256 + 2 * (SEGCAP + 1)) sSeg[it & 3][tid - 256] = v;
+    };
+    // input rows of the weighted block (park layout) and additive rows (accumulator layout) of a pair whose indices are in sIdx[ring].
+    // Three batches of four 16-byte loads per lane, issued in three different phases: a CU's share of the HBM bandwidth is ~13 bytes
+    // per clock, and all eight waves firing twelve loads at once fill the memory pipeline's queue and block the waves' instruction
+    // issue for ~4 k cycles (measured: the phase behind the burst took 5.8 k cycles instead of 1.7 k)
+    auto gather_x = [&](const Meta &m, int ring, f32x4 (&xr)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int nn = m.n[t] > 0 ? m.n[t] : m.n[0];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int r = prow + 16 * hh;
+                const int gr = DIRECT ? m.r0[t] + (r < nn ? r : nn - 1) : sIdx[ring][t * 96 + r];
+                xr[t][hh] = *reinterpret_cast<const f32x4 *>(p.src[0].ptr + (long long)gr * p.src[0].ld + p.src[0].col0 + pc);
+            }
+        }
+    };
+    auto gather_adds = [&](int t, int ring, f32x4 (&ad)[2][2]) __attribute__((always_inline)) {
+        if (ADDS) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int r = n + 16 * rb;
+                ad[rb][0] = *reinterpret_cast<const f32x4 *>(p.add[0].ptr + (long long)sIdx[ring][t * 96 + 32 + r] * p.add[0].ld + fcol);
+                ad[rb][1] = *reinterpret_cast<const f32x4 *>(p.add[1].ptr + (long long)sIdx[ring][t * 96 + 64 + r] * p.add[1].ld + fcol);
+            }
+        }
+    };
+
+    // ---- this wave's slice of all three layers' weights: 16 output features x 128 k x 2 planes per layer, stationary for the launch.
+    // A operand of v_mfma_f32_16x16x32: lane (n, g) holds W[feature 16 wave + n][k = 32 ks + 8 g .. + 7] — in the packed stream
+    // (pack_layer_bx6_kernel: [column tile][16-k step][plane][(k / 8 % 2) * 32 + feature % 32][k % 8]) one 16-byte piece per (ks, plane)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, 0x7fffffff, 0x00020000);
+    const unsigned lo_b = 2u * (unsigned)((wave >> 1) * 8 * STEP6 + (g >> 1) * STEP6 + ((g & 1) * 32 + 16 * (wave & 1) + n) * 8);
+    bf16x8 W[3][4][2];
+    f16_range_mode();
+
+    Meta m0 = fix_meta(load_meta(p_begin)), m1 = fix_meta(load_meta(p_begin + 1)), m2 = fix_meta(load_meta(p_begin + 2));
+    {
+        const int v0 = load_tables(m0), v1 = load_tables(m1);
+        store_tables(v0, 0);
+        store_tables(v1, 1);
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) W[l][ks][pl] = ldw(rs, lo_b + 1024u * pl, (unsigned)l * 2u * BLOCK6 + (unsigned)ks * 4u * STEP6);
+    if (tid < 3 * NP) sBias[tid] = p.b[tid];
+    if (tid < 2 * NP) sGB[tid] = p.gamma ? (tid < NP ? p.gamma[tid] : p.beta[tid - NP]) : 0.f;
+    __syncthreads();
+
+    const bool pact = p.src[0].pre_act != 0;
+    __bf16 *const sA = sP, *const sB = sP + TILE_BF16;
+    float *const fA = sF, *const fB = sF + FIN;
+    Other oA, oB;       // what to do FOR tile A / FOR tile B while the other multiplies
+    {
+        const int l32 = tid & 31;
+        const int acc_off = n * PS + 8 * ((2 * wave + (g >> 1)) ^ n) + 4 * (g & 1);            // features fcol .. fcol + 3 of row n
+        const int park_off = prow * PS + 8 * ((l32 >> 1) ^ prow) + 4 * (l32 & 1);               // columns pc .. pc + 3 of row prow
+        oA.plane_acc = sA + acc_off; oA.plane_park = sA + park_off; oA.fin = fA + n * HS + fcol; oA.lin_off = acc_off;
+        oB.plane_acc = sB + acc_off; oB.plane_park = sB + park_off; oB.fin = fB + n * HS + fcol; oB.lin_off = acc_off;
+    }
+    const __bf16 *paA[4], *paB[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { paA[ks] = sA + n * PS + 8 * ((4 * ks + g) ^ n); paB[ks] = paA[ks] + TILE_BF16; }
+
+    f32x4 accA[2], accB[2], accA1[2], accB1[2];
+    f32x4 xr[2][2], ad[2][2][2];
+    auto bias_init = [&](f32x4 (&acc)[2], f32x4 (&acc1)[2], int l) __attribute__((always_inline)) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sBias + l * NP + fcol);
+        acc[0] = b4; acc[1] = b4;
+        acc1[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    // start of a pair: tile A's input rows -> planes (nothing to overlap with yet), both tiles' start values = bias + additive rows
+    auto open_pair = [&](const f32x4 (&x)[2][2], const f32x4 (&a)[2][2][2]) __attribute__((always_inline)) {
+        if (pact) other_all<2, true>(accA, accA1, x[0], oA);
+        else other_all<2, false>(accA, accA1, x[0], oA);
+        bias_init(accA, accA1, 0);
+        bias_init(accB, accB1, 0);
+        if (ADDS) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    accA[rb][e] = (accA[rb][e] + a[0][rb][0][e]) + a[0][rb][1][e];
+                    accB[rb][e] = (accB[rb][e] + a[1][rb][0][e]) + a[1][rb][1][e];
+                }
+        }
+    };
+    gather_x(m0, 0, xr);
+    gather_adds(0, 0, ad[0]);
+    gather_adds(1, 0, ad[1]);
+    open_pair(xr, ad);
+    __syncthreads();                                       // tile A's planes of the first pair visible
+
+    for (int it = 0, pair = p_begin; pair < p_end; ++pair, ++it) {
+        WS_STAMP(0);
+        // ---- tables two pairs ahead (their meta was loaded an iteration ago), meta three pairs ahead
+        const Meta m3raw = load_meta(pair + 3);
+        const int tv = load_tables(m2);
+        // (no barrier here: tile A's planes were written by open_pair in front of the previous iteration's LayerNorm barrier — the
+        // one before the loop for the first pair — and nothing the stragglers of the previous tail still read is written in this phase)
+        WS_STAMP(1);
+        if (pact) m_block<2, true>(paA, W[0], accA, accA1, accB, accB1, xr[1], oB);                 // for B: park
+        else m_block<2, false>(paA, W[0], accA, accA1, accB, accB1, xr[1], oB);
+        __syncthreads();
+        WS_STAMP(2);
+        // ---- rows one pair ahead (indices in LDS since the previous iteration)
+        f32x4 nxr[2][2], nad[2][2][2];
+        gather_x(m1, (it + 1) & 1, nxr);
+        m_block<1>(paB, W[0], accB, accB1, accA, accA1, xr[1], oA);                 // for A: epilogue of layer 0
+        bias_init(accA, accA1, 1);
+        __syncthreads();
+        WS_STAMP(3);
+        gather_adds(0, (it + 1) & 1, nad[0]);
+        m_block<1>(paA, W[1], accA, accA1, accB, accB1, xr[1], oB);                 // for B: epilogue of layer 0
+        bias_init(accB, accB1, 1);
+        __syncthreads();
+        WS_STAMP(4);
+        gather_adds(1, (it + 1) & 1, nad[1]);
+        m_block<1>(paB, W[1], accB, accB1, accA, accA1, xr[1], oA);                 // for A: epilogue of layer 1
+        bias_init(accA, accA1, 2);
+        __syncthreads();
+        WS_STAMP(5);
+        m_block<1>(paA, W[2], accA, accA1, accB, accB1, xr[1], oB);                 // for B: epilogue of layer 1
+        bias_init(accB, accB1, 2);
+        __syncthreads();
+        WS_STAMP(6);
+        m_block<3>(paB, W[2], accB, accB1, accA, accA1, xr[1], oA);                 // for A: last layer's fp32 rows
+        other_all<3, false>(accB, accB1, xr[1], oB);                                // B's last layer -> fp32 rows
+        __syncthreads();
+        WS_STAMP(7);
+        // ---- the next pair opens BEFORE this pair's tail: its rows were gathered four phases ago, and the tail's stores are then
+        // not in front of any load the next iteration waits for
+        open_pair(nxr, nad);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) xr[1][hh] = nxr[1][hh];
+        // the tables fetched at the top of this iteration (older than every other load in flight) go to the ring slot of the pair
+        // whose rows were gathered in the previous iteration; the next iteration's top barrier publishes them
+        store_tables(tv, it + 2);
+        WS_STAMP(8);
+
+        // ---- tail of this pair: LayerNorm / activation of both tiles.  16 lanes per row (8 columns each), so the row sums are
+        // reduced inside a 16-lane DPP row (quad_perm, row_half_mirror, row_mirror: no LDS round trips); a wave takes 4 rows per
+        // pass, the workgroup a whole tile per pass.  The finished rows are stored straight from the registers (16 lanes = one
+        // 512-byte row); only the aggregation needs them back in LDS.
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = wave * 4 + g;
+            float *rowp = (t == 0 ? fA : fB) + row * HS + n * 8;
+            float x[8];
+#pragma unroll
+            for (int c = 0; c < 8; c += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + c);
+                x[c] = v[0]; x[c + 1] = v[1]; x[c + 2] = v[2]; x[c + 3] = v[3];
+            }
+            if (p.gamma) {
+                float sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) sum += x[c];
+                sum = row16_sum(sum);
+                const float mean = sum * (1.0f / NP);
+                float var = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { const float dl = x[c] - mean; var += dl * dl; }
+                var = row16_sum(var);
+                const float rstd = rsqrtf(var * (1.0f / NP) + p.eps);
+#pragma unroll
+                for (int c = 0; c < 8; c += 4) {
+                    const f32x4 g4 = *reinterpret_cast<const f32x4 *>(sGB + n * 8 + c), b4 = *reinterpret_cast<const f32x4 *>(sGB + NP + n * 8 + c);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[c + u] = fmaf((x[c + u] - mean) * rstd, g4[u], b4[u]);
+                }
+            }
+            if (p.act == G4C_ACT_SELU) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) x[c] = g4c::selu_f(x[c]);
+            } else if (p.act == G4C_ACT_TANH) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) x[c] = g4c::tanh_f(x[c]);
+            }
+            f32x4 v0, v1;
+            v0[0] = x[0]; v0[1] = x[1]; v0[2] = x[2]; v0[3] = x[3]; v1[0] = x[4]; v1[1] = x[5]; v1[2] = x[6]; v1[3] = x[7];
+            if (AGG) { *reinterpret_cast<f32x4 *>(rowp) = v0; *reinterpret_cast<f32x4 *>(rowp + 4) = v1; }
+            if (p.out && row < m0.n[t]) {
+                const long long orow = (!AGG && p.out_idx) ? p.out_idx[m0.r0[t] + row] : m0.r0[t] + row;
+                float *op = p.out + orow * p.out_ld + n * 8;
+                *reinterpret_cast<f32x4 *>(op) = v0; *reinterpret_cast<f32x4 *>(op + 4) = v1;
+            }
+        }
+        WS_STAMP(9);
+        if (AGG) {
+            __syncthreads();
+            // aggregation of the targets whose messages the tiles hold (rows in CSR order): the rows of a segment are added in order
+            // (clamped loads, predicated adds) and divided by max(count, 1) like segment_reduce_kernel does, so the result is
+            // bit-identical to the separate launch.  32 lanes per target (16 bytes each), 16 targets per pass over both tiles.
+            const int c4 = (tid & 31) * 4;
+            const int *sg_tab = sSeg[it & 3];
+            const int nsA = m0.s1[0] - m0.s0[0], nsB = m0.s1[1] - m0.s0[1];
+            auto reduce_rows = [&](const float *sH, int b, int e, int sg) __attribute__((always_inline)) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                for (int r0 = b; r0 < e; r0 += 8) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(sH + (r0 + u < e ? r0 + u : e - 1) * HS + c4);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool on = r0 + u < e;
+#pragma unroll
+                        for (int el = 0; el < 4; ++el) a[el] += on ? v[u][el] : 0.f;
+                    }
+                }
+                if (p.agg_mean) {
+                    const float cnt = (float)((e - b) > 1 ? (e - b) : 1);
+#pragma unroll
+                    for (int el = 0; el < 4; ++el) a[el] /= cnt;
+                }
+                *reinterpret_cast<f32x4 *>(p.agg + (long long)sg * p.agg_ld + c4) = a;
+            };
+            for (int q = tid >> 5; q < nsA + nsB; q += 16) {
+                const int t = q >= nsA ? 1 : 0, j = q - (t ? nsA : 0);
+                if (j < SEGCAP) {
+                    const int b = sg_tab[t * (SEGCAP + 1) + j] - m0.r0[t], e = sg_tab[t * (SEGCAP + 1) + j + 1] - m0.r0[t];
+                    reduce_rows(t ? fB : fA, b, e, m0.s0[t] + j);
+                }
+            }
+            if (nsA > SEGCAP || nsB > SEGCAP) {          // (a tile with a long run of empty segments: their offsets from global memory)
+                for (int q = tid >> 5; q < nsA + nsB; q += 16) {
+                    const int t = q >= nsA ? 1 : 0, j = q - (t ? nsA : 0);
+                    if (j >= SEGCAP) {
+                        const int sg = m0.s0[t] + j;
+                        reduce_rows(t ? fB : fA, p.seg_off[sg] - m0.r0[t], p.seg_off[sg + 1] - m0.r0[t], sg);
+                    }
+                }
+            }
+        }
+        WS_STAMP(10);
+        m0 = m1; m1 = m2; m2 = fix_meta(m3raw);
+    }
+}
+
+}  // namespace
+
+namespace g4cm {
+
+// 0 off, 1 (default; environment G4C_WS) launches WITH the fused aggregation of at least G4C_WS_MIN_ROWS rows (measured on the
+// level-1 message launch: 322 us against 339 us for mlp_bx6i_kernel with the aggregation, 288 against 292 without — the plain
+// launches stay on mlp_bx6i_kernel), 2 every launch it can take (tests), 3 like 1 but plain launches as well
+static int g_ws = -1;
+int ws_enable(int on) {
+    if (g_ws < 0) g_ws = getenv("G4C_WS") ? atoi(getenv("G4C_WS")) : 1;
+    const int old = g_ws;
+    if (on >= 0) g_ws = on > 3 ? 3 : on;
+    return old;
+}
+
+bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count) {
+    static const long long min_env = getenv("G4C_WS_MIN_ROWS") ? atoll(getenv("G4C_WS_MIN_ROWS")) : -1;
+    const long long min_rows = min_env >= 0 ? min_env : 20000;
+    const int mode = ws_enable(-1);
+    if (!mode || round1 || save || !f16x2) return false;
+    if ((mode == 1 || mode == 3) && row_count < min_rows) return false;
+    if (mode == 1 && !agg) return false;
+    if (p.n_src != 1 || p.n_nar != 0 || (p.n_add != 0 && p.n_add != 2) || p.n_heads) return false;
+    if (p.n_layers != 3 || p.n_out != NP || p.resid || p.out_bf16) return false;
+    if (p.out_idx && (agg || !p.out)) return false;          // (scattered output rows: the plain launch only)
+    const Src &s = p.src[0];
+    if (s.width != NP || !s.vec || s.seg_off || s.bf16) return false;
+    for (int a = 0; a < p.n_add; ++a)
+        if (p.add[a].width != NP || (p.add[a].ld & 3) || ((uintptr_t)p.add[a].ptr & 15)) return false;
+    if (p.out && ((p.out_ld & 3) || ((uintptr_t)p.out & 15))) return false;
+    if (p.gamma && (((uintptr_t)p.gamma & 15) || ((uintptr_t)p.beta & 15))) return false;
+    if (((uintptr_t)p.b & 15)) return false;
+    if (p.M >= (1LL << 31)) return false;
+    return true;
+}
+
+int ws_launch(const Params &p, bool agg, hipStream_t st) {
+    const int n_pairs = (p.n_tiles + 1) / 2;
+    if (n_pairs == 0) return G4C_OK;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    const dim3 grid(n_pairs < n_cu ? n_pairs : n_cu), blk(512);
+    const bool direct = p.src[0].idx == nullptr, adds = p.n_add == 2;
+#define G4C_WS_LAUNCH(AGG, DIRECT)                                                                   \
+    do {                                                                                             \
+        if (adds) mlp_ws_kernel<AGG, DIRECT, true><<<grid, blk, 0, st>>>(p, n_pairs);                \
+        else mlp_ws_kernel<AGG, DIRECT, false><<<grid, blk, 0, st>>>(p, n_pairs);                    \
+    } while (0)
+    if (agg) { if (direct) G4C_WS_LAUNCH(true, true); else G4C_WS_LAUNCH(true, false); }
+    else { if (direct) G4C_WS_LAUNCH(false, true); else G4C_WS_LAUNCH(false, false); }
+#undef G4C_WS_LAUNCH
+    return g4c::check_launch("g4c_mlp_forward (ws)");
+}
+
+}  // namespace g4cm
+
+extern "C" int g4c_mlp_ws_enable(int on) { return g4cm::ws_enable(on); }

@@ -209,12 +209,15 @@ int g4c_mlp_pack_layer_f16x3(const float *W, int32_t n_out, int32_t k_in, const 
  * default mode, environment G4C_BX6I), 2 = every launch it can take (tests); -1 only queries.  Returns the previous setting. */
 int g4c_mlp_bx6i_enable(int on);
 
-/* The bf16x6 / bf16 entry points run on one of two kernels with identical arithmetic per 128 x 128 block: the persistent
- * ping-pong kernel (mlp_px6.hip: one 8-wave workgroup per CU, every weight block held in registers for a whole stage,
- * matrix phases of one wave group overlapped with the vector / memory phases of the other) for the launches inside its
- * envelope, the 32-row-tile kernel otherwise (training saves, aggregation on load, unaligned inputs).
- * g4c_mlp_px6_enable(1 | 0) switches the former on / off, (-1) only queries; returns the previous setting. */
-int g4c_mlp_px6_enable(int on);
+/* Weight-stationary persistent form of the same launches for the f16x3 stream (mlp_ws.hip: one 8-wave workgroup per CU, every wave
+ * keeps its 16-column slice of all three layers' weights in registers for the whole launch, the loop over tile pairs prefetches the
+ * next pair's indices and rows): same envelope and the same per-element arithmetic as g4c_mlp_bx6i_enable's kernel (sums over k in a
+ * different association: equal to it within fp32 rounding, the fused aggregation still bit-identical to g4c_segment_reduce of the
+ * stored rows).  0 = never, 1 = launches with the fused aggregation of at least G4C_WS_MIN_ROWS rows (default 20 000; the default
+ * mode, environment G4C_WS), 2 = every launch it can take (tests), 3 = like 1 plus the launches without aggregation; -1 only
+ * queries.  Returns the previous setting.  Takes precedence over the dual-tile kernel. */
+int g4c_mlp_ws_enable(int on);
+
 /* Rounded-bf16 variant (opt-in only; BASELINE config 3 "bf16 edge-MLP MFMA"): the same stream and kernel structure, but
  * only the LEADING bf16 term of every operand is used (one product per multiply-add): weights and the activations
  * entering each Linear are rounded to bf16, accumulation / bias / SELU / LayerNorm / additive sources / residual stay

@@ -1,0 +1,28 @@
+"""A few launches of the level-1 message MLP (600k rows, first layer hoisted, fused aggregation) on one kernel, for rocprofv3 --pmc
+passes (scripts/pmc_ws.sh).  Usage: python scripts/ws_pmc.py ws|bx6i|tile [--node]"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphs4cfd_amd import _lib, ops, plan
+from graphs4cfd_amd.nn import blocks as B
+kernel = sys.argv[1] if len(sys.argv) > 1 else "ws"
+torch.set_grad_enabled(False)
+lib = _lib.load()
+lib.g4c_mlp_ws_enable(2 if kernel == "ws" else 0); lib.g4c_mlp_bx6i_enable(2 if kernel == "bx6i" else 0)
+dev = torch.device("cuda", 0); H = 128; rows = 600000; n = rows // 6
+torch.manual_seed(0)
+blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(dev)
+e, pr, pc = torch.randn(rows, H, device=dev), torch.randn(n, H, device=dev), torch.randn(n, H, device=dev)
+colh = torch.arange(n).repeat_interleave(6)
+ei = torch.stack([torch.randint(0, n, (rows,)), colh]).to(dev)
+ep, csr = plan.edge_csr(ei, n)
+pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+out, agg = torch.empty(rows, H, device=dev), torch.empty(n, H, device=dev)
+if "--node" in sys.argv:
+    v = torch.randn(n, H, device=dev)
+    pkn = blk.node_mlp.packed([H, H], [False, False])
+    for _ in range(6): ops.mlp_forward(pkn, [ops.Source(agg), ops.Source(v)], n, _lib.ACT_SELU)
+else:
+    for _ in range(6): ops.mlp_forward(pk, src, rows, 0, out=out, agg=(csr, agg, True))
+torch.cuda.synchronize()

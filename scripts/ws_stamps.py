@@ -1,0 +1,40 @@
+"""Cycle stamps of the weight-stationary kernel (mlp_ws.hip), level-1 message launch with the fused aggregation: per workgroup the
+SECOND pair of its range (steady state of the software pipeline), wave 0.  Needs a -DG4C_WS_TIMING build of mlp_ws.hip:
+  bash scripts/build_ws_timing.sh ; python scripts/ws_stamps.py graphs4cfd_amd/lib/libg4c_ws_timing.so"""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from graphs4cfd_amd import _lib, ops, plan
+from graphs4cfd_amd.nn import blocks as B
+lib = C.CDLL(os.path.abspath(sys.argv[1]))
+for name, (res, args) in _lib._SIGNATURES.items():
+    fn = getattr(lib, name); fn.restype, fn.argtypes = res, args
+_lib._lib = lib
+torch.set_grad_enabled(False)
+dev = torch.device("cuda", 0); H = 128; rows = 600000; n = rows // 6
+torch.manual_seed(0)
+blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(dev)
+e, pr, pc = torch.randn(rows, H, device=dev), torch.randn(n, H, device=dev), torch.randn(n, H, device=dev)
+colh = torch.arange(n).repeat_interleave(6)
+ei = torch.stack([torch.randint(0, n, (rows,)), colh]).to(dev)
+ep, csr = plan.edge_csr(ei, n)
+pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+out, agg = torch.empty(rows, H, device=dev), torch.empty(n, H, device=dev)
+lib.g4c_mlp_ws_enable(2)
+for _ in range(3): ops.mlp_forward(pk, src, rows, 0, out=out, agg=(csr, agg, True))
+torch.cuda.synchronize()
+buf = np.zeros(256 * 32, dtype=np.uint64)
+lib.g4c_ws_read_stamps.argtypes = [C.c_void_p, C.c_int]
+lib.g4c_ws_read_stamps(buf.ctypes.data, buf.size)
+st = buf.reshape(256, 32).astype(np.int64)
+names = {0: "loop top", 1: "meta + table loads issued", 2: "M(A,0) + park B, barrier", 3: "tables -> LDS, gathers issued, M(B,0) + E(A,0), barrier",
+         4: "M(A,1) + E(B,0), barrier", 5: "M(B,1) + E(A,1), barrier", 6: "M(A,2) + E(B,1), barrier", 7: "M(B,2) + F(A), F(B), barrier",
+         8: "open next pair (park A', start values)", 9: "LayerNorm + row stores", 10: "[barrier,] aggregation"}
+keys = sorted(names)
+prev = keys[0]
+for k in keys[1:]:
+    d = st[:, k] - st[:, prev]
+    print(f"{names[k]:62s} median {int(np.median(d)):7d}  (p10 {int(np.percentile(d, 10)):7d}, p90 {int(np.percentile(d, 90)):7d})")
+    prev = k
+print("pair period (loop top -> end of tail) median", int(np.median(st[:, 10] - st[:, 0])))

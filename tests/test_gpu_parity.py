@@ -1117,45 +1117,54 @@ def test_bx6i_dual_tile_kernel_equals_tile_kernel(rows, kernel, prec, monkeypatc
             assert torch.equal(got[f"agg_only_{mean}"], got[f"agg_{mean}"])
 
 
-# ------------------------------------------------------------------ the opt-in persistent kernel (mlp_px6.hip)
-@pytest.mark.parametrize("rows", [33, 6000, 70000])
-def test_px6_persistent_kernel_equals_tile_kernel(rows):
-    """G4C_PX6 / g4c_mlp_px6_enable(1): the persistent role-specialised bf16x6 kernel against the default 32-row-tile kernel on the
-    hoisted edge form, the node form with heads, and the fused per-target aggregation (bit-exact reduction of equal rows)."""
+# ------------------------------------------------------------------ the weight-stationary persistent kernel (mlp_ws.hip)
+@pytest.mark.parametrize("rows", [1, 33, 6000, 70000])
+def test_ws_persistent_kernel_equals_tile_kernel(rows):
+    """g4c_mlp_ws_enable(2): the weight-stationary persistent f16x3 kernel against the 32-row-tile kernel on the message form (first
+    layer hoisted, rows direct / through an index / scattered through an output index), with the fused per-target aggregation on
+    regular and ragged segments (bit-exact reduction of the rows it stores, same aggregate when the rows are not stored)."""
+    if ops.mlp_precision() != "f16x3":
+        pytest.skip("the weight-stationary kernel takes the f16x3 stream only")
     lib = _lib.load()
     H, n = 128, max(rows // 6, 2)
     torch.manual_seed(rows)
     blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
-    v, e = torch.randn(n, H, device=DEV), torch.randn(n * 6, H, device=DEV)
-    col = torch.arange(n).repeat_interleave(6)
-    edge_index = torch.stack([torch.randint(0, n, (n * 6,)), col]).to(DEV)
+    v = torch.randn(n, H, device=DEV)
+    deg = torch.full((n,), 6, dtype=torch.long) if rows != 6000 else torch.randint(0, 10, (n,))
+    col = torch.arange(n).repeat_interleave(deg)
+    E = int(col.numel())
+    edge_index = torch.stack([torch.randint(0, n, (E,)), col]).to(DEV)
+    e = torch.randn(E, H, device=DEV)
     ep, csr = plan.edge_csr(edge_index, n)
-    E = n * 6
     W1 = blk.edge_mlp.state_dict()["MLP.linear_1.weight"]
     pr, pc = (v @ W1[:, H:2 * H].T).contiguous(), (v @ W1[:, 2 * H:].T).contiguous()
-    pk_e = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
-    src_e = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
-    pk_3 = blk.edge_mlp.packed([H, H, H], [False] * 3)
-    src_3 = [ops.Source(e), ops.Source(v, index=ep.row), ops.Source(v, index=ep.col)]
-    pk_v = blk.node_mlp.packed([H, H], [False, False])
-    agg_in = torch.randn(n, H, device=DEV)
-    src_v = [ops.Source(agg_in), ops.Source(v)]
+    pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+    src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+    idx = torch.randint(0, E, (E,), device=DEV, dtype=torch.int32)
+    oidx = torch.randperm(E, device=DEV).to(torch.int32)
 
     def run():
-        out = {"edge": ops.mlp_forward(pk_e, src_e, E), "edge3": ops.mlp_forward(pk_3, src_3, E),
-               "node": ops.mlp_forward(pk_v, src_v, n, _lib.ACT_SELU)}
+        out = {"edge": ops.mlp_forward(pk, src, E), "indexed": ops.mlp_forward(pk, [ops.Source(e, index=idx)], E, _lib.ACT_SELU),
+               "scattered": ops.mlp_forward(pk, src, E, out=torch.zeros(E, H, device=DEV), out_idx32=oidx)}
         if csr.tiles() is not None:
-            a = torch.full((n, H), float("nan"), device=DEV)
-            out["edge_agg_rows"] = ops.mlp_forward(pk_e, src_e, E, agg=(csr, a, True))
-            out["edge_agg"] = a
+            for mean in (True, False):
+                a = torch.full((n, H), float("nan"), device=DEV)
+                out[f"rows_{mean}"] = ops.mlp_forward(pk, src, E, agg=(csr, a, mean))
+                out[f"agg_{mean}"] = a
+                a2 = torch.full((n, H), float("nan"), device=DEV)
+                ops.mlp_forward(pk, src, E, agg=(csr, a2, mean), store_rows=False)
+                out[f"agg_only_{mean}"] = a2
         return out
-    ref = run()
-    lib.g4c_mlp_px6_enable(1)
+    old_ws, old_i = lib.g4c_mlp_ws_enable(0), lib.g4c_mlp_bx6i_enable(0)
     try:
+        ref = run()
+        lib.g4c_mlp_ws_enable(2)
         got = run()
     finally:
-        lib.g4c_mlp_px6_enable(0)
+        lib.g4c_mlp_ws_enable(old_ws); lib.g4c_mlp_bx6i_enable(old_i)
     for k in ref:
         torch.testing.assert_close(got[k], ref[k], rtol=2e-5, atol=2e-5, msg=lambda m: f"{k}: {m}")
-    if "edge_agg" in got:
-        assert torch.equal(got["edge_agg"], ops.segment_reduce(got["edge_agg_rows"], csr, True))
+    for mean in (True, False):
+        if f"agg_{mean}" in got:
+            assert torch.equal(got[f"agg_{mean}"], ops.segment_reduce(got[f"rows_{mean}"], csr, mean))
+            assert torch.equal(got[f"agg_only_{mean}"], got[f"agg_{mean}"])
