@@ -165,12 +165,23 @@ __device__ __forceinline__ unsigned pack_f16(f32x2 x, f32x2 &back) {
 #ifndef G4C_SPLIT_MIX
 #define G4C_SPLIT_MIX 1
 #endif
+// Packed-f32 vector instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) issued beside MFMAs cost ~4 ns each instead of ~0.5
+// in isolation (scripts/micro/mfma_fillers.hip: two v_pk_fma_f32 per 32x32x16 MFMA, two waves per SIMD: 22.4 ns per MFMA against 15.0
+// with two v_fma_f32).  G4C_NO_PK = 1 keeps the epilogue math of the matrix phases on plain instructions (the empty asm stops hipcc's
+// SLP vectoriser from re-packing them) — in the kernels here that is 16 more instructions per phase and measured no faster (a phase
+// of mlp_ws_kernel: 1868 against 1736 cycles), because every vector instruction beyond ~2 per 16x16x32 MFMA is exposed anyway: off.
+#ifndef G4C_NO_PK
+#define G4C_NO_PK 0
+#endif
+__device__ __forceinline__ float opaque_f32(float x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ void split_pair_f16(f32x2 y, unsigned &hu, unsigned &lu) {
     f16x2 b;
     b[0] = (_Float16)y[0]; b[1] = (_Float16)y[1];
     hu = __builtin_bit_cast(unsigned, b);
     if (G4C_SPLIT_MIX) {
-        const f32x2 ys = y * F16_LO_SCALE;
+        f32x2 ys;
+        if (G4C_NO_PK) { ys[0] = opaque_f32(y[0] * F16_LO_SCALE); ys[1] = opaque_f32(y[1] * F16_LO_SCALE); }
+        else ys = y * F16_LO_SCALE;
         const float c = -F16_LO_SCALE;
         asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lu) : "v"(hu), "s"(c), "v"(ys[0]));
         asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu) : "v"(hu), "s"(c), "v"(ys[1]));

@@ -70,10 +70,8 @@ struct Other {
     int lin_off;              // (timing ablation 128: element offset of plane_acc inside its tile)
 };
 
-#ifndef G4C_WS_SCALAR_MATH
-#define G4C_WS_SCALAR_MATH 0      // 1: no packed-f32 vector ALU instructions in the epilogue (v_pk_* beside MFMAs; MI355X_MICROARCH.md)
-#endif
-__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
+#define G4C_WS_SCALAR_MATH G4C_NO_PK      // no packed-f32 vector ALU instructions in the epilogue (mlp_common.h)
+__device__ __forceinline__ float opaque(float x) { return opaque_f32(x); }
 __device__ __forceinline__ f32x2 selu2w(f32x2 x) {
     if (G4C_WS_ABLATE & 16) return x;
     const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f;
@@ -116,10 +114,9 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // plane writes: 0 = one ds_write2st64_b32 per pair as soon as it is split; 1 = two ds_write_b64 per unit (after its second pair);
-// 2 = all four ds_write_b64 of the block after its last MFMA.  LDS operations complete in order per wave, so a write between the B
-// fragment reads delays the reads behind it: with mode 0 a matrix phase took 1736 cycles, without the writes 888.
+// 2 = all four ds_write_b64 of the block after its last MFMA.  Measured per-pair period: 15 706 / 15 714 / 15 950 cycles.
 #ifndef G4C_WS_WRITE_MODE
-#define G4C_WS_WRITE_MODE 2
+#define G4C_WS_WRITE_MODE 0
 #endif
 struct Pend { unsigned h[2][2], l[2][2]; };       // [unit][pair] packed fp16 pairs waiting to be written
 
@@ -136,6 +133,71 @@ __device__ __forceinline__ void flush_unit(int u, const Other &o, const Pend &w)
     *reinterpret_cast<u32x2 *>(d + PLN) = ll;
 }
 
+// Stage-per-slice form of the hidden-layer epilogue / the park (EK 1 / 2): every slice of the block applies ONE stage to all
+// eight values of the phase, so the vector instructions of a slice are independent of each other.  A wave issues in order: in the
+// pair-at-a-time form below every instruction waits for the one before it (fold -> min -> mul -> exp -> fma -> fma -> cvt -> mul ->
+// mix: ten levels, two values wide), and a stalled vector instruction also holds back the wave's next MFMA.
+#ifndef G4C_WS_STAGED
+#define G4C_WS_STAGED 0          // (measured the same as the pair-at-a-time form: 1784 against 1736 cycles per phase)
+#endif
+struct Stage8 { float x[8], m[8]; };
+template <int EK, bool PACT>
+__device__ __forceinline__ void other_stage(int s, const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, Stage8 &q, Pend &w) {
+    const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f;
+    const float scale = 1.0507009873554804934193349852946f;
+    const bool act = EK == 1 || PACT;
+    if (s == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q.x[i] = EK == 1 ? fmaf(accE1[i >> 2][i & 3], F16_LO_UNSCALE, accE[i >> 2][i & 3]) : xe[i >> 2][i & 3];
+    } else if (s == 1) {
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { if (G4C_WS_ABLATE & 512) { q.m[i] = q.x[i]; continue; } q.m[i] = fmaxf(q.x[i], 0.f); q.x[i] = fminf(q.x[i], 0.f); }
+        }
+    } else if (s == 2) {
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q.x[i] = (G4C_WS_ABLATE & 1024) ? q.x[i] : opaque(q.x[i] * 1.4426950408889634f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q.x[i] = (G4C_WS_ABLATE & 256) ? opaque(q.x[i] + 1.f) : __builtin_amdgcn_exp2f(q.x[i]);
+        }
+    } else if (s == 3) {
+        if (act) {
+#pragma unroll
+            for (int i = 4; i < 8; ++i) q.x[i] = (G4C_WS_ABLATE & 256) ? opaque(q.x[i] + 1.f) : __builtin_amdgcn_exp2f(q.x[i]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q.x[i] = (G4C_WS_ABLATE & 1024) ? q.x[i] : opaque(fmaf(q.x[i], sa, -sa));
+        }
+    } else if (s == 4) {
+        if (act) {
+#pragma unroll
+            for (int i = 4; i < 8; ++i) q.x[i] = (G4C_WS_ABLATE & 1024) ? q.x[i] : opaque(fmaf(q.x[i], sa, -sa));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q.x[i] = (G4C_WS_ABLATE & 1024) ? q.x[i] + q.m[i] : fmaf(q.m[i], scale, q.x[i]);
+        }
+    } else if (s == 5) {
+        // h = fp16(y) for the four pairs; m <- y * 2^11
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f16x2 b;
+            b[0] = (_Float16)q.x[2 * j]; b[1] = (_Float16)q.x[2 * j + 1];
+            w.h[j >> 1][j & 1] = __builtin_bit_cast(unsigned, b);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q.m[i] = opaque(q.x[i] * F16_LO_SCALE);
+    } else if (s == 6) {
+        const float c = -F16_LO_SCALE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(w.l[j >> 1][j & 1]) : "v"(w.h[j >> 1][j & 1]), "s"(c), "v"(q.m[2 * j]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(w.l[j >> 1][j & 1]) : "v"(w.h[j >> 1][j & 1]), "s"(c), "v"(q.m[2 * j + 1]));
+    } else if (s == 7) {
+        flush_unit<EK>(0, o, w); flush_unit<EK>(1, o, w);
+    }
+}
+
 template <int EK, bool PACT>
 __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, f32x2 &hold, Pend &w) {
     const int u = s >> 2, pc4 = s & 3, pr = pc4 >> 1;
@@ -144,7 +206,9 @@ __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const
             f32x2 x, x1;
             x[0] = accE[u][2 * pr]; x[1] = accE[u][2 * pr + 1];
             x1[0] = accE1[u][2 * pr]; x1[1] = accE1[u][2 * pr + 1];
-            hold = selu2w(x1 * F16_LO_UNSCALE + x);         // (the fold is one v_pk_fma_f32)
+            if (G4C_NO_PK) { x[0] = fmaf(x1[0], F16_LO_UNSCALE, x[0]); x[1] = fmaf(x1[1], F16_LO_UNSCALE, x[1]); }
+            else x = x1 * F16_LO_UNSCALE + x;
+            hold = selu2w(x);
         } else if (G4C_WS_WRITE_MODE == 0) {
             put_pair_f16(o.plane_acc + u * 16 * PS + 2 * pr, hold);
         } else {
@@ -175,6 +239,9 @@ __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const
 #ifndef G4C_WS_VALU_PER_MFMA
 #define G4C_WS_VALU_PER_MFMA 4
 #endif
+#ifndef G4C_WS_CLUSTER
+#define G4C_WS_CLUSTER 0          // 0: one MFMA, a few vector instructions, ...; 1 / 2: the MFMAs of one / two slices back to back, then the vector work
+#endif
 
 // One 128-k block for one tile: acc += W(layer) x planes, 8 slices (k-step ks = s / 2, sample row block rb = s % 2) of three
 // products each: (Wh, xl) and (Wl, xh) into acc1 (the 2^-11 terms), (Wh, xh) into acc.  pa[ks]: this lane's B-operand address
@@ -191,6 +258,8 @@ __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16
     }
     f32x2 hold = {0.f, 0.f};
     Pend w;
+    Stage8 q;
+    constexpr bool STAGED = G4C_WS_STAGED && (EK == 1 || EK == 2);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int ks = s >> 1, rb = s & 1;
@@ -200,7 +269,7 @@ __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16
             fl[(s + 2) % 3] = *reinterpret_cast<const bf16x8 *>(pn + PLN);
         }
         if (!EK) __builtin_amdgcn_sched_barrier(0);
-        if (!(G4C_WS_ABLATE & 1)) other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, w);
+        if (!(G4C_WS_ABLATE & 1)) { if (STAGED) other_stage<EK, PACT>(s, accE, accE1, xe, o, q, w); else other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, w); }
         const bf16x8 ch = fh[s % 3], cl = fl[s % 3];
         if (G4C_WS_ABLATE & 2) {
             asm volatile("" :: "v"(ch), "v"(cl));
@@ -209,7 +278,7 @@ __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16
         acc[rb] = mfma16(W[ks][0], ch, acc[rb]);
         acc1[rb] = mfma16(W[ks][1], ch, acc1[rb]);
         }
-        if (EK) {
+        if (EK && G4C_WS_CLUSTER == 0) {
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                  // DS read (fragments two slices ahead)
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
@@ -217,10 +286,17 @@ __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16
                 __builtin_amdgcn_sched_group_barrier(0x002, G4C_WS_VALU_PER_MFMA, 0);      // VALU
             }
             __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                  // DS write
+        } else if (EK && (G4C_WS_CLUSTER == 1 || (s & 1))) {
+            // MFMAs in bursts (one or two slices' worth), the vector work behind them: the two waves of a SIMD then run in anti-phase,
+            // one in its matrix burst while the other is in its vector burst
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * G4C_WS_CLUSTER, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * G4C_WS_CLUSTER, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 40, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        if (G4C_WS_CLUSTER < 2 || (s & 1)) __builtin_amdgcn_sched_barrier(0);
     }
-    if ((EK == 1 || EK == 2) && G4C_WS_WRITE_MODE == 2 && !(G4C_WS_ABLATE & 1)) { flush_unit<EK>(0, o, w); flush_unit<EK>(1, o, w); }
+    if (!STAGED && (EK == 1 || EK == 2) && G4C_WS_WRITE_MODE == 2 && !(G4C_WS_ABLATE & 1)) { flush_unit<EK>(0, o, w); flush_unit<EK>(1, o, w); }
 }
 
 // a whole unit outside a matrix phase (the first tile of a pair is parked with nothing to overlap with; B's last rows)
@@ -228,9 +304,11 @@ template <int EK, bool PACT>
 __device__ __forceinline__ void other_all(const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o) {
     f32x2 hold = {0.f, 0.f};
     Pend w;
+    Stage8 q;
+    constexpr bool STAGED = G4C_WS_STAGED && (EK == 1 || EK == 2);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, w);
-    if ((EK == 1 || EK == 2) && G4C_WS_WRITE_MODE == 2) { flush_unit<EK>(0, o, w); flush_unit<EK>(1, o, w); }
+    for (int s = 0; s < 8; ++s) { if (STAGED) other_stage<EK, PACT>(s, accE, accE1, xe, o, q, w); else other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, w); }
+    if (!STAGED && (EK == 1 || EK == 2) && G4C_WS_WRITE_MODE == 2) { flush_unit<EK>(0, o, w); flush_unit<EK>(1, o, w); }
 }
 
 template <bool AGG, bool DIRECT, bool ADDS>
