@@ -35,6 +35,23 @@ def _narrow_flags(sources: Sequence[Source]) -> List[bool]:
     return [s.width <= _lib.NARROW_MAX and s.index is None and s.pre_act == _lib.ACT_NONE and not s.additive for s in sources]
 
 
+def _split_wide(sources: Sequence[Source]) -> List[Source]:
+    """Input blocks wider than 128 columns as consecutive column chunks of at most 128 of the same tensor (same rows, same index):
+    the split-operand kernels take 128-wide blocks, and `cat` of the chunks is the block.  Unchanged when nothing is wider, when the
+    chunks would exceed the kernels' block count (the caller then hoists or the MLP runs on the fp32-MFMA kernels), and while a
+    call is recorded for autograd."""
+    if ops.grad_mode() or not any(s.width > 128 and not s.additive and s.segments is None for s in sources):
+        return list(sources)
+    out: List[Source] = []
+    for s in sources:
+        if s.width > 128 and not s.additive and s.segments is None:
+            for c in range(0, s.width, 128):
+                out.append(Source(s.tensor, s.index, s.col0 + c, min(128, s.width - c), s.negate, s.pre_act))
+        else:
+            out.append(s)
+    return out if len(out) <= _lib.MAX_SRC else list(sources)
+
+
 def _ld_of(t: Tensor) -> int:
     return int(t.stride(0)) if t.dim() == 2 else int(t.numel())
 
@@ -104,11 +121,13 @@ class MLP(nn.Module):
         code = _lib.act_code(activation)
         if code is None and resid is not None:
             raise NotImplementedError("a residual after a non-fusable activation")
+        sources = _split_wide(sources)
         pk = self.packed([s.width for s in sources], [s.negate for s in sources], _narrow_flags(sources))
         y = ops.mlp_forward(pk, sources, n_rows, _lib.ACT_NONE if code is None else code, out, out_idx32, resid, resid_col0)
         return _finish(y, activation, code)
 
     def run_coded(self, sources: Sequence[Source], n_rows: int, act_code: int = _lib.ACT_NONE, **kw) -> Tensor:
+        sources = _split_wide(sources)
         pk = self.packed([s.width for s in sources], [s.negate for s in sources], _narrow_flags(sources))
         return ops.mlp_forward(pk, sources, n_rows, act_code, **kw)
 
@@ -125,6 +144,7 @@ class MLP(nn.Module):
             return None
         if ops.grad_mode():          # recorded for autograd: the plain launches are the differentiable ones
             return None
+        sources = _split_wide(sources)
         prec = ops.effective_precision([s.width for s in sources])
         if prec == "bf16":
             return None
@@ -185,8 +205,13 @@ class MLP(nn.Module):
         Below HOIST_MIN_ROWS the launch is latency-bound and the extra product launches cost more than the MFMA
         work they save (measured crossover ~25k rows, scripts/sweep_tile_modes.py): one plain fused launch then.
         `products` (from the producer's launch, MLP.run_with_heads): the per-node terms, already multiplied."""
-        if (n_rows < HOIST_MIN_ROWS or ops.mlp_precision() == "bf16" or ops.grad_mode()) and products is None:   # (plain bf16 MFMAs are ~free: never hoist)
-            return self.run_coded(list(k_sources) + [Source(t, index=idx) for t, idx in gathered], n_rows, act_code, **kw)
+        plain = list(k_sources) + [Source(t, index=idx) for t, idx in gathered]
+        # (a gathered block wider than 128 whose chunks would exceed the kernels' block count — gMuS-GNN's 2H-wide latents after an
+        # up-sampling — is hoisted at any size: its products are formed from 128-wide chunks, the launch itself keeps one block)
+        too_many = (sum((s.width + 127) // 128 for s in plain) > _lib.MAX_SRC and any(s.width > 128 for s in plain)
+                    and ops.mlp_precision() in ("bf16x6", "f16x3") and not ops.grad_mode())
+        if (n_rows < HOIST_MIN_ROWS or ops.mlp_precision() == "bf16" or ops.grad_mode()) and products is None and not too_many:   # (plain bf16 MFMAs are ~free: never hoist)
+            return self.run_coded(plain, n_rows, act_code, **kw)
         kw_widths = [s.width for s in k_sources]
         off = sum(kw_widths)
         adds = []
@@ -195,8 +220,9 @@ class MLP(nn.Module):
             if products is not None:
                 part = products[j]
             else:
-                pk1 = self._packed_cols("hoist1", off, off + w_t, [w_t], [False], True)
-                part = ops.mlp_forward(pk1, [Source(t)], int(t.size(0)))
+                chunks = [(c, min(128, w_t - c)) for c in range(0, w_t, 128)] if (w_t > 128 and not ops.grad_mode()) else [(0, w_t)]
+                pk1 = self._packed_cols("hoist1", off, off + w_t, [w for _, w in chunks], [False] * len(chunks), True)
+                part = ops.mlp_forward(pk1, [Source(t, col0=c, width=w) for c, w in chunks], int(t.size(0)))
             adds.append(Source(part, index=idx, additive=True))
             off += w_t
         if off != self.input_size:
@@ -337,7 +363,7 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
     if next_msg is not None:
         nxt = None
         if ep.n_edges >= HOIST_MIN_ROWS:     # the consumer will hoist: give it its node-side terms from this launch
-            w = int(v.size(1))
+            w = upd_mlp.output_size          # (width of v', the node input of the next layer's message MLP)
             nxt = upd_mlp.run_with_heads([agg_src, Source(v)], int(v.size(0)), act_code, next_msg,
                                          next_msg.input_size - 2 * w, [w, w])
         if nxt is None:

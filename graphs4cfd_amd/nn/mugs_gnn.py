@@ -11,7 +11,8 @@ interpreted by one forward over the fused HIP blocks:
     [n, 2H] node-latent buffer of the next MP layer, the stashed fine latents copied into the right half
     (the reference's `torch.cat`, nn/mugs_gnn.py:115-116);
   * MP layers as in MuS-GNN (deferred SELU of the edge latents, heads between consecutive layers of a level); the 2H-wide
-    first layer after an up-sampling runs on the fp32-MFMA kernels (input block wider than 128).
+    latents after an up-sampling enter the MLPs as two 128-wide column chunks (blocks._split_wide; their first-layer products are
+    hoisted at any size), so every launch stays on the split-operand kernels.
 
 The Graph is never mutated.
 """

@@ -17,4 +17,12 @@ model = getattr(gfd.nn, a.model)(arch=S.mugs_arch(a.model, 128), device=dev)
 ro = Rollout(model, g.to(dev), a.steps + 4, capture=True)
 ro.run(3); torch.cuda.synchronize()
 t0 = time.perf_counter(); ro.run(a.steps); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+# one eager step with every launch recorded: which kernel family ran the MLPs (fp32-MFMA fallback = launches outside the split-operand kernels)
+from graphs4cfd_amd import ops
+with torch.no_grad(), ops.KernelTimer() as kt:
+    model.forward(g.to(dev))
+torch.cuda.synchronize()
+summ = kt.summary()
+kinds = {k: v["launches"] for k, v in summ.items() if k.startswith("mlp_")}
+print("mlp launches per step:", kinds, " fp32_mfma_fallback =", sum(n for k, n in kinds.items() if not k.startswith("mlp_bx6")))
 print(f"{a.model}, {a.nodes} nodes: {a.steps / dt:.2f} steps/s ({1e3 * dt / a.steps:.2f} ms/step), finite={bool(torch.isfinite(ro.outputs).all())}")

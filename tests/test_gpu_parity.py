@@ -524,17 +524,19 @@ def test_mugs_models(golden, cls):
 
 
 def test_mugs_three_scale_h128_vs_oracle():
-    """Production width: heads between consecutive layers, the 2H-wide first layer after each up-sampling on the
-    fp32-MFMA kernels, hipGraph-captured rollout == eager."""
+    """Production width: heads between consecutive layers, the 2H-wide latents after each up-sampling as two 128-wide column chunks
+    on the split-operand kernels (no launch on the fp32-MFMA fallback), hipGraph-captured rollout == eager."""
     g = S.mugs_graph(9000, levels=3, seed=8)
     torch.manual_seed(9)
     model = gfd.nn.NsThreeGuillardScaleGNN(arch=S.mugs_arch("NsThreeGuillardScaleGNN", 128), device=DEV)
     w = {k: v.cpu() for k, v in model.state_dict().items()}
     ref = O.mugs_forward("NsThreeGuillardScaleGNN", g.to_dict(), w, 3)
     gd = g.clone().to(DEV)
-    with torch.no_grad():
+    with torch.no_grad(), ops.KernelTimer() as kt:
         y = model.forward(gd)
     torch.testing.assert_close(y.cpu(), ref, **FWD)
+    if ops.mlp_precision() in ("f16x3", "bf16x6"):
+        assert not [k for k in kt.summary() if k.startswith("mlp_") and not k.startswith("mlp_bx6")], kt.summary().keys()
     torch.testing.assert_close(model.solve(gd, 3, capture=True), model.solve(gd, 3, capture=False), rtol=0, atol=0)
 
 
