@@ -65,9 +65,10 @@ def parse():
                     help="arithmetic of the fused MLPs: bf16x6 (fp32-accurate split products on the bf16 matrix pipe), fp32 "
                          "(fp32 MFMA kernels) or bf16 (operands rounded to bf16, ~1e-2 deviation: config 3 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strict-range", action="store_true", help="skip the bf16x6 (fp32 exponent range) rollout beside an f16x3 headline")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-partition-check", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--cpu-budget-s", type=float, default=45.0)
     a = ap.parse_args()
     w = WORKLOADS[a.workload]
     a.custom = a.nodes is not None or a.model is not None or (a.precision is not None and a.precision != w["precision"])
@@ -114,23 +115,40 @@ def cpu_baseline(args, S, weights, nf, budget_s):
     else:
         graph = S.mus_graph(n_sample, levels=MUS_LEVELS[args.model], dim=args.dim, seed=0)
     g = graph.to_dict()
-    t0 = time.perf_counter()
-    steps = 0
+
+    def one(g):
+        pred = O.remus_forward(g, weights) if remus else O.mus_forward(args.model, g, weights, nf)
+        g = dict(g)
+        g["field"] = O.shift_and_replace(g["field"], pred, nf)
+        return g
     with torch.no_grad():
+        tw = time.perf_counter()
+        g = one(g)                          # untimed warm-up step (allocator, thread pool, first-touch of the plan tensors)
+        warm_s = time.perf_counter() - tw
+        t0 = time.perf_counter()
+        steps = 0
         while True:
-            pred = O.remus_forward(g, weights) if remus else O.mus_forward(args.model, g, weights, nf)
-            g = dict(g)
-            g["field"] = O.shift_and_replace(g["field"], pred, nf)
+            g = one(g)
             steps += 1
             el = time.perf_counter() - t0
-            if steps >= 3 or el + el / steps > budget_s:
+            if steps >= 5 or el + el / steps > budget_s:
                 break
+    cpu_model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     scale = n_sample / args.nodes          # cost per step is linear in the mesh size (every op is per node / edge / angle)
     sample = (f"{steps} rollout step(s) of " + (f"the same {args.nodes}-node mesh" if n_sample == args.nodes else
               f"a {n_sample}-node mesh of the same kind (value = measured steps/s x {scale:.3g}: the path is linear in the mesh size)")
               + f" and weights, oracle (op-for-op torch restatement of the reference CPU path, per-step pool_edge rebuild), "
-              f"{torch.get_num_threads()} torch threads, {el:.1f} s")
-    return {"value": steps / el * scale, "unit": "rollout timesteps/s", "cores": cores, "kind": "port", "sample": sample}
+              f"{torch.get_num_threads()} torch threads, {el:.1f} s after one untimed warm-up step ({warm_s:.1f} s)"
+              + ("" if steps >= 5 else f"; fewer than 5 steps: the next one would have exceeded the {budget_s:.0f} s budget (--cpu-budget-s)"))
+    return {"value": steps / el * scale, "unit": "rollout timesteps/s", "cores": cores, "kind": "port", "sample": sample,
+            "cpu": cpu_model, "hw_threads": os.cpu_count(), "steps_timed": steps}
 
 
 def pmc_traffic(workload="headline"):
@@ -460,6 +478,28 @@ def main():
     result["ms_per_mp_layer"] = result["ms_per_step"] / n_mp
     if check is not None:
         result["partition_check"] = check
+
+    if rank == 0:
+        # did any launch of the timed rollout clip a value at the end of the fp16 range?  (default arithmetic only; ops.f16_range_report)
+        result["f16_range_clipped_in"] = ops.f16_range_report(dev) if args.precision == "f16x3" else None
+    if rank == 0 and world == 1 and args.precision == "f16x3" and not args.no_strict_range:
+        # the same workload, same process, in the arithmetic that keeps fp32's exponent range (three-way bf16 split, six products):
+        # the figure to quote where activations may leave the fp16 range (the reference computes in fp32: nn/model.py:303-321)
+        ops.set_mlp_precision("bf16x6")
+        model.invalidate_packed()
+        n_strict = max(10, args.steps // 4)
+        r2 = Rollout(model, graph_cpu.clone().to(dev), n_strict + args.warmup + 4, capture=True)
+        r2.run(2 + args.warmup)
+        torch.cuda.synchronize(dev)
+        ts = time.perf_counter()
+        r2.run(n_strict)
+        torch.cuda.synchronize(dev)
+        es = time.perf_counter() - ts
+        result["strict_fp32_range"] = {"value": n_strict / es, "unit": "rollout timesteps/s", "ms_per_step": 1e3 * es / n_strict, "steps": n_strict,
+                                       "precision": "bf16x6", "outputs_finite": bool(torch.isfinite(r2.outputs).all().item())}
+        r2.close()
+        ops.set_mlp_precision(args.precision)
+        model.invalidate_packed()
 
     if rank == 0 and world == 1 and not args.no_roofline:
         roofline_blocks(args, result, model, graph_cpu, dev, ops, Rollout)

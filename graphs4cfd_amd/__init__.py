@@ -14,6 +14,7 @@ the reference's name (`import graphs4cfd as gfd`, the alias package at the repos
 from .graph import Graph
 from . import nn, plan, ops, synthetic, transforms, metrics, datasets
 from .loader import DataLoader, Collater
+from .ops import check_f16_range, f16_range_report     # clipped values of the default arithmetic are reported, never silent (ops.py)
 from .ops import mlp_precision, set_mlp_precision      # "f16x3" (default: fp32-class two-way fp16 split on the matrix pipe) | "bf16x6" | "fp32" | "bf16" (opt-in)
 
 __version__ = "0.1.0"

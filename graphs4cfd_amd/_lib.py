@@ -44,7 +44,8 @@ class g4c_src_t(C.Structure):
 class g4c_mlp_t(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("k_pad", C.c_int32 * MAX_LAYERS), ("n_pad", C.c_int32 * MAX_LAYERS),
                 ("w", C.c_void_p * MAX_LAYERS), ("b", C.c_void_p * MAX_LAYERS),
-                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("n_out", C.c_int32), ("w_format", C.c_int32)]
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("n_out", C.c_int32), ("w_format", C.c_int32),
+                ("range_flag", C.c_void_p), ("range_slot", C.c_int32)]
 
 
 _SIGNATURES = {

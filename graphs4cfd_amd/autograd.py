@@ -138,8 +138,12 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int = _lib.AC
         y = torch.mm(x, weight.t()) if bias is None else torch.addmm(bias, x, weight.t())
         return y if act == _lib.ACT_NONE else ops.activation_(y, act)
     blocks = k // 128
+    # (this is the backward pass: x may hold gradient rows — 1e-6 .. 1e-9 per row for a mean loss over 1e5+ nodes, i.e. fp16's
+    # subnormal range, where the two-way fp16 split keeps a few bits only and nothing below 1.5e-11.  Like backward_chain, these
+    # products use the three-way bf16 split, which has fp32's exponent range, whatever the forward's arithmetic is.)
+    prec = ops.effective_precision([128] * blocks)
     pk = ops.PackedMLP([weight.detach()], [None if bias is None else bias.detach()], None, [128] * blocks, [False] * blocks,
-                       precision=ops.effective_precision([128] * blocks))
+                       precision="bf16x6" if prec == "f16x3" else prec)
     pk.params = None                                        # (never differentiated through)
     return ops.mlp_forward(pk, [Source(x, col0=128 * j, width=128) for j in range(blocks)], int(x.size(0)), act)
 

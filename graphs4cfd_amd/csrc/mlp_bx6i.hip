@@ -522,7 +522,9 @@ bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2
     static const long long min_env = getenv("G4C_BX6I_MIN_ROWS") ? atoll(getenv("G4C_BX6I_MIN_ROWS")) : -1;
     const long long min_rows = min_env >= 0 ? min_env : (f16x2 ? 20000 : 400000);
     const int mode = bx6i_enable(-1);
-    if (!mode || round1 || save) return false;
+    // (the f16x3 stream goes to the weight-stationary kernel, mlp_ws.hip, which also tracks the fp16 range; this kernel's two-way
+    // instantiation sits at its register limit — one more live register and it spills a hundred — and is no longer launched)
+    if (!mode || round1 || save || f16x2) return false;
     if (mode == 1 && row_count < min_rows) return false;
     if (p.n_src != 1 || p.n_nar != 0 || (p.n_add != 0 && p.n_add != 2) || p.n_heads) return false;
     if (p.n_layers != 3 || p.n_out != NP || p.resid || p.out_bf16) return false;
@@ -547,8 +549,8 @@ int bx6i_launch(const Params &p, bool agg, bool f16x2, hipStream_t st) {
         if (p.src[0].idx) mlp_bx6i_kernel<AGG, SP, false><<<grid, blk, 0, st>>>(p);                  \
         else mlp_bx6i_kernel<AGG, SP, true><<<grid, blk, 0, st>>>(p);                                \
     } while (0)
-    if (f16x2) { if (agg) G4C_BX6I_LAUNCH(true, 2); else G4C_BX6I_LAUNCH(false, 2); }
-    else { if (agg) G4C_BX6I_LAUNCH(true, 3); else G4C_BX6I_LAUNCH(false, 3); }
+    if (f16x2) return G4C_EUNSUPPORTED;
+    if (agg) G4C_BX6I_LAUNCH(true, 3); else G4C_BX6I_LAUNCH(false, 3);
 #undef G4C_BX6I_LAUNCH
     return g4c::check_launch("g4c_mlp_forward (bx6i)");
 }

@@ -87,6 +87,9 @@ struct Params {
     // after layer, writing every g through save[]
     const float *mul[G4C_MAX_LAYERS];
     int mul_ld;
+    // f16x3 arithmetic: range_flag[range_slot] = 1 when a value converted to fp16 reached the end of the fp16 range (g4c_mlp_t)
+    int *range_flag;
+    int range_slot;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -174,6 +177,34 @@ __device__ __forceinline__ unsigned pack_f16(f32x2 x, f32x2 &back) {
 #define G4C_NO_PK 0
 #endif
 __device__ __forceinline__ float opaque_f32(float x) { asm volatile("" : "+v"(x)); return x; }
+// Range tracking of the f16x3 arithmetic: every value that is converted to fp16 (MLP inputs when they are parked, hidden
+// activations in the epilogues) is also compared with the end of the fp16 range; a wave that saw a clipped value writes the flag word
+// once, at the end of the kernel (a plain store of 1: nothing is written on the fast path).  Two trackers:
+//   RangeV  one v_max3_f32 per PAIR into a per-lane running maximum of |value| (one live VGPR; mlp_ws_kernel)
+//   RangeS  per QUAD a maximum into a temporary, one v_cmp and an s_or into a wave-uniform lane mask (three vector instructions per
+//           four values, no live VGPR: mlp_bx6_kernel sits at its register limit and spills 10 - 20 registers with RangeV)
+constexpr float F16_RANGE_END = 65504.f;
+struct RangeV { float m = 0.f; };
+struct RangeS { unsigned long long any = 0ull; };
+__device__ __forceinline__ void range_track(RangeV &r, f32x2 y) { r.m = fmaxf(fmaxf(r.m, fabsf(y[0])), fabsf(y[1])); }       // v_max3_f32 |.|
+__device__ __forceinline__ void range_track(RangeS &r, f32x2 y) {
+    r.any |= __builtin_amdgcn_ballot_w64(fmaxf(fabsf(y[0]), fabsf(y[1])) >= F16_RANGE_END);
+}
+__device__ __forceinline__ void range_track(RangeV &r, f32x4 y) {
+    f32x2 a, b; a[0] = y[0]; a[1] = y[1]; b[0] = y[2]; b[1] = y[3];
+    range_track(r, a); range_track(r, b);
+}
+__device__ __forceinline__ void range_track(RangeS &r, f32x4 y) {
+    r.any |= __builtin_amdgcn_ballot_w64(fmaxf(fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fabsf(y[2])), fabsf(y[3])) >= F16_RANGE_END);
+}
+__device__ __forceinline__ bool range_hit(const RangeV &r) { return __builtin_amdgcn_ballot_w64(r.m >= F16_RANGE_END) != 0ull; }
+__device__ __forceinline__ bool range_hit(const RangeS &r) { return r.any != 0ull; }
+template <class R>
+__device__ __forceinline__ void range_report(const Params &p, const R &r) {
+    if (p.range_flag && range_hit(r)) {
+        if ((threadIdx.x & 63) == 0) p.range_flag[p.range_slot] = 1;
+    }
+}
 __device__ __forceinline__ void split_pair_f16(f32x2 y, unsigned &hu, unsigned &lu) {
     f16x2 b;
     b[0] = (_Float16)y[0]; b[1] = (_Float16)y[1];
@@ -191,7 +222,16 @@ __device__ __forceinline__ void split_pair_f16(f32x2 y, unsigned &hu, unsigned &
         lu = pack_f16((y - hf) * F16_LO_SCALE, lf);
     }
 }
-__device__ __forceinline__ void split2x4(f32x4 x, bf16x4 &h, bf16x4 &l) {
+template <class R>
+__device__ __forceinline__ void split_pair_f16(f32x2 y, unsigned &hu, unsigned &lu, R &rng) {
+    range_track(rng, y);
+    split_pair_f16(y, hu, lu);
+}
+struct RangeNone {};
+__device__ __forceinline__ void range_track(RangeNone &, f32x4) {}
+template <class R>
+__device__ __forceinline__ void split2x4(f32x4 x, bf16x4 &h, bf16x4 &l, R &rng) {
+    range_track(rng, x);
     unsigned hu[2], lu[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -210,9 +250,12 @@ __device__ __forceinline__ void split2(float x, __bf16 &h, __bf16 &l) {
     h = __builtin_bit_cast(__bf16, a); l = __builtin_bit_cast(__bf16, b);
 }
 
+template <int SP, class R> __device__ __forceinline__ void split3x4(f32x4 x, bf16x4 &h, bf16x4 &m, bf16x4 &l, R &rng);
 template <int SP = 3>
-__device__ __forceinline__ void split3x4(f32x4 x, bf16x4 &h, bf16x4 &m, bf16x4 &l) {
-    if (SP == 2) { split2x4(x, h, m); l = m; return; }       // two-way fp16 split: h, l in the first two containers
+__device__ __forceinline__ void split3x4(f32x4 x, bf16x4 &h, bf16x4 &m, bf16x4 &l) { RangeNone none; split3x4<SP>(x, h, m, l, none); }
+template <int SP, class R>
+__device__ __forceinline__ void split3x4(f32x4 x, bf16x4 &h, bf16x4 &m, bf16x4 &l, R &rng) {
+    if (SP == 2) { split2x4(x, h, m, rng); l = m; return; }       // two-way fp16 split: h, l in the first two containers
     if (SP == 1 || (G4C_ABLATE & 512)) {          // SP == 1: round to bf16 (only h is stored)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { h[e] = (__bf16)x[e]; m[e] = h[e]; l[e] = h[e]; }

@@ -674,6 +674,7 @@ __global__ __launch_bounds__(256, RT == 1 ? (SP == 2 ? G4C_F16_MINW : G4C_BX6_MI
     const int i = lane & 31, h = lane >> 5;
     const int ct0 = wave;
     if (SP == 2) f16_range_mode();
+    RangeS rng;                       // lanes that converted a value beyond the fp16 range (SP == 2: mlp_common.h range_track)
 
     int tile;
     {
@@ -803,7 +804,7 @@ __global__ __launch_bounds__(256, RT == 1 ? (SP == 2 ? G4C_F16_MINW : G4C_BX6_MI
                 }
                 if (ACT) v = selu4(v);
                 bf16x4 vh, vm, vl;
-                split3x4<SP>(v, vh, vm, vl);
+                split3x4<SP>(v, vh, vm, vl, rng);
                 *reinterpret_cast<bf16x4 *>(d + q * KC) = vh;
                 if (SP >= 2) *reinterpret_cast<bf16x4 *>(d + PLN + q * KC) = vm;
                 if (SP == 3) *reinterpret_cast<bf16x4 *>(d + 2 * PLN + q * KC) = vl;
@@ -999,7 +1000,7 @@ __global__ __launch_bounds__(256, RT == 1 ? (SP == 2 ? G4C_F16_MINW : G4C_BX6_MI
                     const long long gr = row0 + i + 32 * t;
                     if (p.save[l] && gr < mlim) *reinterpret_cast<f32x4 *>(p.save[l] + gr * p.save_ld + fbase + 8 * gq) = y;
                 }
-                split3x4<SP>(y, vh, vm, vl);
+                split3x4<SP>(y, vh, vm, vl, rng);
                 __bf16 *d = sB + (i + 32 * t) * HB + fbase + 8 * gq;
                 *reinterpret_cast<bf16x4 *>(d) = vh;
                 if (SP >= 2) *reinterpret_cast<bf16x4 *>(d + PLN) = vm;
@@ -1049,7 +1050,7 @@ __global__ __launch_bounds__(256, RT == 1 ? (SP == 2 ? G4C_F16_MINW : G4C_BX6_MI
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 bf16x4 vh, vm, vl;
-                split3x4<SP>(v[t][q], vh, vm, vl);
+                split3x4<SP>(v[t][q], vh, vm, vl, rng);
                 __bf16 *d = sB + (grow_l + 32 * t) * HB + q * KC + c4;
                 *reinterpret_cast<bf16x4 *>(d) = vh;
                 if (SP >= 2) *reinterpret_cast<bf16x4 *>(d + PLN) = vm;
@@ -1079,6 +1080,7 @@ __global__ __launch_bounds__(256, RT == 1 ? (SP == 2 ? G4C_F16_MINW : G4C_BX6_MI
             }
         }
     }
+    if (SP == 2) range_report(p, rng);
 }
 
 // bf16x6 image of one layer: three planes (h, m, l) of the exact split of every weight.  F16: the two-way fp16 split (h, l * 2^11)
@@ -1412,6 +1414,8 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
             p.mul_ld = save->mul_ld;
         }
     }
+    p.range_flag = f16x2 ? mlp->range_flag : nullptr; p.range_slot = mlp->range_slot;
+    G4C_REQUIRE(!p.range_flag || p.range_slot >= 0, G4C_EINVAL, "g4c_mlp_forward: negative range_slot");
     p.n_heads = n_heads; p.head_ld = head_ld;
     for (int hd = 0; hd < G4C_MAX_HEADS; ++hd) p.head_out[hd] = hd < n_heads ? head_out[hd] : nullptr;
     if (n_heads) {

@@ -96,9 +96,9 @@ __device__ __forceinline__ f32x2 selu2w(f32x2 x) {
 }
 
 // two-way fp16 split of a pair -> one packed pair per plane (split_pair_f16, mlp_common.h: four vector instructions)
-__device__ __forceinline__ void put_pair_f16(__bf16 *d, f32x2 y) {
+__device__ __forceinline__ void put_pair_f16(__bf16 *d, f32x2 y, RangeV &rng) {
     unsigned hu, lu;
-    split_pair_f16(y, hu, lu);
+    split_pair_f16(y, hu, lu, rng);
     if (G4C_WS_ABLATE & 8) { asm volatile("" :: "v"(hu), "v"(lu)); return; }
     *reinterpret_cast<unsigned *>(d) = hu;
     *reinterpret_cast<unsigned *>(d + PLN) = lu;
@@ -142,7 +142,7 @@ __device__ __forceinline__ void flush_unit(int u, const Other &o, const Pend &w)
 #endif
 struct Stage8 { float x[8], m[8]; };
 template <int EK, bool PACT>
-__device__ __forceinline__ void other_stage(int s, const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, Stage8 &q, Pend &w) {
+__device__ __forceinline__ void other_stage(int s, const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, Stage8 &q, Pend &w, RangeV &rng) {
     const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f;
     const float scale = 1.0507009873554804934193349852946f;
     const bool act = EK == 1 || PACT;
@@ -181,6 +181,7 @@ __device__ __forceinline__ void other_stage(int s, const f32x4 (&accE)[2], const
         for (int j = 0; j < 4; ++j) {
             f16x2 b;
             b[0] = (_Float16)q.x[2 * j]; b[1] = (_Float16)q.x[2 * j + 1];
+            { f32x2 yy; yy[0] = q.x[2 * j]; yy[1] = q.x[2 * j + 1]; range_track(rng, yy); }
             w.h[j >> 1][j & 1] = __builtin_bit_cast(unsigned, b);
         }
 #pragma unroll
@@ -199,7 +200,7 @@ __device__ __forceinline__ void other_stage(int s, const f32x4 (&accE)[2], const
 }
 
 template <int EK, bool PACT>
-__device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, f32x2 &hold, Pend &w) {
+__device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, f32x2 &hold, Pend &w, RangeV &rng) {
     const int u = s >> 2, pc4 = s & 3, pr = pc4 >> 1;
     if (EK == 1) {
         if ((pc4 & 1) == 0) {
@@ -210,9 +211,9 @@ __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const
             else x = x1 * F16_LO_UNSCALE + x;
             hold = selu2w(x);
         } else if (G4C_WS_WRITE_MODE == 0) {
-            put_pair_f16(o.plane_acc + u * 16 * PS + 2 * pr, hold);
+            put_pair_f16(o.plane_acc + u * 16 * PS + 2 * pr, hold, rng);
         } else {
-            split_pair_f16(hold, w.h[u][pr], w.l[u][pr]);
+            split_pair_f16(hold, w.h[u][pr], w.l[u][pr], rng);
             if (G4C_WS_WRITE_MODE == 1 && pr == 1) flush_unit<EK>(u, o, w);
         }
     } else if (EK == 2) {
@@ -221,9 +222,9 @@ __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const
             x[0] = xe[u][2 * pr]; x[1] = xe[u][2 * pr + 1];
             hold = PACT ? selu2w(x) : x;
         } else if (G4C_WS_WRITE_MODE == 0) {
-            put_pair_f16(o.plane_park + u * 16 * PS + 2 * pr, hold);
+            put_pair_f16(o.plane_park + u * 16 * PS + 2 * pr, hold, rng);
         } else {
-            split_pair_f16(hold, w.h[u][pr], w.l[u][pr]);
+            split_pair_f16(hold, w.h[u][pr], w.l[u][pr], rng);
             if (G4C_WS_WRITE_MODE == 1 && pr == 1) flush_unit<EK>(u, o, w);
         }
     } else if (EK == 3) {
@@ -248,7 +249,7 @@ __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const
 // (row n, granule (4 ks + g) ^ n) in the tile's h plane.
 template <int EK, bool PACT = false>
 __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16x8 (&W)[4][2], f32x4 (&acc)[2], f32x4 (&acc1)[2],
-                                        const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o) {
+                                        const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, RangeV &rng) {
     // B fragments (h, l planes) of slice s: row block s % 2, k-step s / 2; fetched two slices ahead of their MFMAs
     bf16x8 fh[3], fl[3];
 #pragma unroll
@@ -269,7 +270,7 @@ __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16
             fl[(s + 2) % 3] = *reinterpret_cast<const bf16x8 *>(pn + PLN);
         }
         if (!EK) __builtin_amdgcn_sched_barrier(0);
-        if (!(G4C_WS_ABLATE & 1)) { if (STAGED) other_stage<EK, PACT>(s, accE, accE1, xe, o, q, w); else other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, w); }
+        if (!(G4C_WS_ABLATE & 1)) { if (STAGED) other_stage<EK, PACT>(s, accE, accE1, xe, o, q, w, rng); else other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, w, rng); }
         const bf16x8 ch = fh[s % 3], cl = fl[s % 3];
         if (G4C_WS_ABLATE & 2) {
             asm volatile("" :: "v"(ch), "v"(cl));
@@ -301,13 +302,13 @@ __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16
 
 // a whole unit outside a matrix phase (the first tile of a pair is parked with nothing to overlap with; B's last rows)
 template <int EK, bool PACT>
-__device__ __forceinline__ void other_all(const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o) {
+__device__ __forceinline__ void other_all(const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, RangeV &rng) {
     f32x2 hold = {0.f, 0.f};
     Pend w;
     Stage8 q;
     constexpr bool STAGED = G4C_WS_STAGED && (EK == 1 || EK == 2);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { if (STAGED) other_stage<EK, PACT>(s, accE, accE1, xe, o, q, w); else other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, w); }
+    for (int s = 0; s < 8; ++s) { if (STAGED) other_stage<EK, PACT>(s, accE, accE1, xe, o, q, w, rng); else other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, w, rng); }
     if (!STAGED && (EK == 1 || EK == 2) && G4C_WS_WRITE_MODE == 2) { flush_unit<EK>(0, o, w); flush_unit<EK>(1, o, w); }
 }
 
@@ -432,6 +433,7 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
     const unsigned lo_b = 2u * (unsigned)((wave >> 1) * 8 * STEP6 + (g >> 1) * STEP6 + ((g & 1) * 32 + 16 * (wave & 1) + n) * 8);
     bf16x8 W[3][4][2];
     f16_range_mode();
+    RangeV rng;                       // running max |value converted to fp16| (mlp_common.h range_track)
 
     Meta m0 = fix_meta(load_meta(p_begin)), m1 = fix_meta(load_meta(p_begin + 1)), m2 = fix_meta(load_meta(p_begin + 2));
     {
@@ -473,8 +475,8 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
     };
     // start of a pair: tile A's input rows -> planes (nothing to overlap with yet), both tiles' start values = bias + additive rows
     auto open_pair = [&](const f32x4 (&x)[2][2], const f32x4 (&a)[2][2][2]) __attribute__((always_inline)) {
-        if (pact) other_all<2, true>(accA, accA1, x[0], oA);
-        else other_all<2, false>(accA, accA1, x[0], oA);
+        if (pact) other_all<2, true>(accA, accA1, x[0], oA, rng);
+        else other_all<2, false>(accA, accA1, x[0], oA, rng);
         bias_init(accA, accA1, 0);
         bias_init(accB, accB1, 0);
         if (ADDS) {
@@ -501,33 +503,33 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         // (no barrier here: tile A's planes were written by open_pair in front of the previous iteration's LayerNorm barrier — the
         // one before the loop for the first pair — and nothing the stragglers of the previous tail still read is written in this phase)
         WS_STAMP(1);
-        if (pact) m_block<2, true>(paA, W[0], accA, accA1, accB, accB1, xr[1], oB);                 // for B: park
-        else m_block<2, false>(paA, W[0], accA, accA1, accB, accB1, xr[1], oB);
+        if (pact) m_block<2, true>(paA, W[0], accA, accA1, accB, accB1, xr[1], oB, rng);                 // for B: park
+        else m_block<2, false>(paA, W[0], accA, accA1, accB, accB1, xr[1], oB, rng);
         __syncthreads();
         WS_STAMP(2);
         // ---- rows one pair ahead (indices in LDS since the previous iteration)
         f32x4 nxr[2][2], nad[2][2][2];
         gather_x(m1, (it + 1) & 1, nxr);
-        m_block<1>(paB, W[0], accB, accB1, accA, accA1, xr[1], oA);                 // for A: epilogue of layer 0
+        m_block<1>(paB, W[0], accB, accB1, accA, accA1, xr[1], oA, rng);                 // for A: epilogue of layer 0
         bias_init(accA, accA1, 1);
         __syncthreads();
         WS_STAMP(3);
         gather_adds(0, (it + 1) & 1, nad[0]);
-        m_block<1>(paA, W[1], accA, accA1, accB, accB1, xr[1], oB);                 // for B: epilogue of layer 0
+        m_block<1>(paA, W[1], accA, accA1, accB, accB1, xr[1], oB, rng);                 // for B: epilogue of layer 0
         bias_init(accB, accB1, 1);
         __syncthreads();
         WS_STAMP(4);
         gather_adds(1, (it + 1) & 1, nad[1]);
-        m_block<1>(paB, W[1], accB, accB1, accA, accA1, xr[1], oA);                 // for A: epilogue of layer 1
+        m_block<1>(paB, W[1], accB, accB1, accA, accA1, xr[1], oA, rng);                 // for A: epilogue of layer 1
         bias_init(accA, accA1, 2);
         __syncthreads();
         WS_STAMP(5);
-        m_block<1>(paA, W[2], accA, accA1, accB, accB1, xr[1], oB);                 // for B: epilogue of layer 1
+        m_block<1>(paA, W[2], accA, accA1, accB, accB1, xr[1], oB, rng);                 // for B: epilogue of layer 1
         bias_init(accB, accB1, 2);
         __syncthreads();
         WS_STAMP(6);
-        m_block<3>(paB, W[2], accB, accB1, accA, accA1, xr[1], oA);                 // for A: last layer's fp32 rows
-        other_all<3, false>(accB, accB1, xr[1], oB);                                // B's last layer -> fp32 rows
+        m_block<3>(paB, W[2], accB, accB1, accA, accA1, xr[1], oA, rng);                 // for A: last layer's fp32 rows
+        other_all<3, false>(accB, accB1, xr[1], oB, rng);                                // B's last layer -> fp32 rows
         __syncthreads();
         WS_STAMP(7);
         // ---- the next pair opens BEFORE this pair's tail: its rows were gathered four phases ago, and the tail's stores are then
@@ -637,20 +639,21 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         WS_STAMP(10);
         m0 = m1; m1 = m2; m2 = fix_meta(m3raw);
     }
+    range_report(p, rng);
 }
 
 }  // namespace
 
 namespace g4cm {
 
-// 0 off, 1 (default; environment G4C_WS) launches WITH the fused aggregation of at least G4C_WS_MIN_ROWS rows (measured on the
-// level-1 message launch: 322 us against 339 us for mlp_bx6i_kernel with the aggregation, 288 against 292 without — the plain
-// launches stay on mlp_bx6i_kernel), 2 every launch it can take (tests), 3 like 1 but plain launches as well
+// 0 off, 1 (default; environment G4C_WS) launches of at least G4C_WS_MIN_ROWS rows (measured on the level-1 message launch against
+// the two-way instantiation of mlp_bx6i_kernel, which it replaces: 322 us against 339 us with the fused aggregation, 288 against 292
+// without), 2 every launch it can take (tests)
 static int g_ws = -1;
 int ws_enable(int on) {
     if (g_ws < 0) g_ws = getenv("G4C_WS") ? atoi(getenv("G4C_WS")) : 1;
     const int old = g_ws;
-    if (on >= 0) g_ws = on > 3 ? 3 : on;
+    if (on >= 0) g_ws = on > 2 ? 2 : on;
     return old;
 }
 
@@ -659,8 +662,7 @@ bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, 
     const long long min_rows = min_env >= 0 ? min_env : 20000;
     const int mode = ws_enable(-1);
     if (!mode || round1 || save || !f16x2) return false;
-    if ((mode == 1 || mode == 3) && row_count < min_rows) return false;
-    if (mode == 1 && !agg) return false;
+    if (mode == 1 && row_count < min_rows) return false;
     if (p.n_src != 1 || p.n_nar != 0 || (p.n_add != 0 && p.n_add != 2) || p.n_heads) return false;
     if (p.n_layers != 3 || p.n_out != NP || p.resid || p.out_bf16) return false;
     if (p.out_idx && (agg || !p.out)) return false;          // (scattered output rows: the plain launch only)

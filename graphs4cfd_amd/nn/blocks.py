@@ -90,6 +90,7 @@ class MLP(nn.Module):
         self.MLP = nn.Sequential(mods)
         self.input_size, self.output_size = sizes[0], sizes[-1]
         self._packed = {}
+        self._site = None         # name in reports of clipped fp16 values (ops.f16_range_report); models set "<Model>.<attribute path>"
 
     # -- kernel-side weight cache ---------------------------------------------------------
     def _linears(self) -> List[nn.Linear]:
@@ -110,7 +111,8 @@ class MLP(nn.Module):
             lin = self._linears()
             ln = getattr(self.MLP, "layer_norm", None)
             pk = ops.PackedMLP([l.weight for l in lin], [l.bias for l in lin],
-                               None if ln is None else (ln.weight, ln.bias, ln.eps), key[0], key[1], precision=prec, narrow=narrow)
+                               None if ln is None else (ln.weight, ln.bias, ln.eps), key[0], key[1], precision=prec, narrow=narrow,
+                               site=self._site)
             self._packed[key] = (sig, pk)
             hit = self._packed[key]
         return hit[1]
@@ -164,7 +166,7 @@ class MLP(nn.Module):
                 return None
             pk = ops.PackedMLP([l.weight for l in lin], [l.bias for l in lin],
                                None if ln is None else (ln.weight, ln.bias, ln.eps), key[4], key[5], heads=heads, precision=prec,
-                               narrow=narrow)
+                               narrow=narrow, site=self._site)
             self._packed[key] = (sig, pk)
             hit = self._packed[key]
         pk = hit[1]
@@ -188,11 +190,11 @@ class MLP(nn.Module):
             lin = self._linears()
             w1 = lin[0].weight.detach()[:, a:b].contiguous()
             if first_only:
-                pk = ops.PackedMLP([w1], [None], None, key[3], key[4], precision=prec)
+                pk = ops.PackedMLP([w1], [None], None, key[3], key[4], precision=prec, site=self._site)
             else:
                 ln = getattr(self.MLP, "layer_norm", None)
                 pk = ops.PackedMLP([w1] + [l.weight for l in lin[1:]], [l.bias for l in lin],
-                                   None if ln is None else (ln.weight, ln.bias, ln.eps), key[3], key[4], precision=prec)
+                                   None if ln is None else (ln.weight, ln.bias, ln.eps), key[3], key[4], precision=prec, site=self._site)
             self._packed[key] = (sig, pk)
             hit = self._packed[key]
         return hit[1]

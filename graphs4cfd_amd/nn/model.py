@@ -102,6 +102,11 @@ class GNN(nn.Module):
             self.to(self.device)
             self.load_state_dict(chk['weights'])
             self.num_fields = chk['arch']["decoder"][1][-1] if 'decoder' in chk['arch'].keys() else None
+        # names under which clipped fp16 values are reported (ops.f16_range_report)
+        from .blocks import MLP as _MLP
+        for name, m in self.named_modules():
+            if isinstance(m, _MLP):
+                m._site = f"{type(self).__name__}.{name}"
         return
 
     def to(self, *args, **kwargs):
@@ -221,6 +226,8 @@ class GNN(nn.Module):
             training_loss /= (iteration + 1)
             gradients_norm /= (iteration + 1)
             print(f"Epoch: {epoch:4d}, Training   loss: {training_loss:.4e}, Gradients: {gradients_norm:.4e}")
+            if ops.mlp_precision() == "f16x3":
+                ops.check_f16_range(self.device, f"fit(), epoch {epoch}")
             validation_loss = None
             if val_loader is not None:
                 validation_criterion = train_config['validation_loss']
@@ -296,6 +303,8 @@ class GNN(nn.Module):
             with Rollout(self, graph, n_out, capture=capture) as ro:
                 ro.run(n_out)
                 out = ro.result()
+            if ops.mlp_precision() == "f16x3":
+                ops.check_f16_range(out.device, "solve()")
             return out
 
     def invalidate_packed(self) -> None:

@@ -255,6 +255,60 @@ AGG_ON_LOAD = os.environ.get("G4C_AGG_ON_LOAD", "1") == "1"
 AGG_ON_LOAD_MIN_ROWS = int(os.environ.get("G4C_AGG_ON_LOAD_MIN_ROWS", "50000"))
 
 
+# ---- fp16 range of the "f16x3" arithmetic made observable (g4c_mlp_t.range_flag): every launch in that arithmetic carries a slot
+# of a per-device int32 array; a kernel that converted a value of magnitude >= 65504 to fp16 (it was clipped there) writes 1 into
+# its slot.  Slots are named after the MLP that launched ("NsThreeScaleGNN.mp112.edge_mlp"); f16_range_report() reads the array
+# (one device synchronisation), check_f16_range() turns a non-empty report into a RuntimeWarning.  Model.solve, Rollout.result,
+# DistributedRollout.gather_outputs and GNN.fit (per epoch) call it, so a clip is never silent on those paths; after a bare
+# model.forward() call gfd.check_f16_range() yourself.
+RANGE_SLOTS = 256
+_range_bufs = {}            # device -> int32 [RANGE_SLOTS]
+_range_sites: List[set] = [set() for _ in range(RANGE_SLOTS)]
+_range_slot_of = {}
+
+
+def _range_buffer(dev: torch.device) -> Tensor:
+    buf = _range_bufs.get(dev)
+    if buf is None:
+        buf = _range_bufs[dev] = torch.zeros(RANGE_SLOTS, dtype=torch.int32, device=dev)
+    return buf
+
+
+def _range_slot(site: str) -> int:
+    slot = _range_slot_of.get(site)
+    if slot is None:
+        slot = _range_slot_of[site] = len(_range_slot_of) % RANGE_SLOTS
+        _range_sites[slot].add(site)
+    return slot
+
+
+def f16_range_report(device: Optional[torch.device] = None, clear: bool = True) -> List[str]:
+    """Names of the MLPs whose launches clipped a value at the end of the fp16 range since the last report (all devices, or one).
+    Synchronises with the device(s)."""
+    hit: List[str] = []
+    for dev, buf in list(_range_bufs.items()):
+        if device is not None and torch.device(device) != dev:
+            continue
+        flags = buf.cpu()
+        for slot in torch.nonzero(flags).flatten().tolist():
+            hit += sorted(_range_sites[slot]) or [f"slot {slot}"]
+        if clear and len(hit):
+            buf.zero_()
+    return hit
+
+
+def check_f16_range(device: Optional[torch.device] = None, where: str = "") -> List[str]:
+    """RuntimeWarning when a launch in the "f16x3" arithmetic clipped an MLP input or hidden activation at +-65504 (the reference
+    computes these in fp32: nn/model.py:303-321).  Returns the offending MLPs' names."""
+    hit = f16_range_report(device)
+    if hit:
+        import warnings
+        warnings.warn(f"{where + ': ' if where else ''}the 'f16x3' MLP arithmetic clipped values at the end of the fp16 range (|x| >= 65504) in "
+                      f"{', '.join(hit[:8])}{' ...' if len(hit) > 8 else ''}: the result differs from an fp32 evaluation.  "
+                      "gfd.set_mlp_precision('bf16x6') keeps fp32's exponent range.", RuntimeWarning, stacklevel=2)
+    return hit
+
+
 _weights_epoch = 0
 
 
@@ -317,7 +371,7 @@ class PackedMLP:
 
     def __init__(self, weights: Sequence[Tensor], biases: Sequence[Tensor], ln: Optional[Tuple[Tensor, Tensor, float]],
                  seg_widths: Sequence[int], seg_negate: Sequence[bool], heads: Sequence[Tensor] = (),
-                 precision: str = "fp32", narrow: Optional[Sequence[bool]] = None):
+                 precision: str = "fp32", narrow: Optional[Sequence[bool]] = None, site: Optional[str] = None):
         """`heads`: bias-free [128, 128] weights applied to the MLP's final output row (g4c_mlp_forward_heads); their
         packed images continue the weight stream after the last layer.  `precision` "bf16": the bf16 stream of
         g4c_mlp_pack_layer_bx6 (every input block padded to 128 k; "bf16" uses the same stream, leading plane only).
@@ -350,6 +404,12 @@ class PackedMLP:
         self.desc = _lib.g4c_mlp_t()
         self.desc.n_layers = n_layers
         self.desc.w_format = 1 if self.split == "f16x2" else 0
+        # (`site`: the name a clipped value is reported under — f16_range_report)
+        self.site = site or "an MLP created outside a model"
+        if self.split == "f16x2":
+            self.desc.range_flag, self.desc.range_slot = _range_buffer(dev).data_ptr(), _range_slot(self.site)
+        else:
+            self.desc.range_flag, self.desc.range_slot = None, 0
         self._keep: List[Tensor] = []
         stream = _lib.stream_handle(dev)
         KC, NP = 32, 128                       # kernel constants: K chunk, computed layer width

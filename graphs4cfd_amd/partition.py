@@ -608,6 +608,8 @@ class DistributedRollout:
         full[self.mesh.owned_global[0]] = self.outputs
         if self.world > 1:
             dist.all_reduce(full)
+        if ops.mlp_precision() == "f16x3":
+            ops.check_f16_range(self.device, f"DistributedRollout (rank {self.rank})")
         if self._perm is not None:        # rows back in the caller's numbering
             out = torch.empty_like(full)
             out[self._perm] = full

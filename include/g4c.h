@@ -141,6 +141,12 @@ typedef struct {
     int32_t w_format;                /* 0: the format the entry point names (fp32 stream / three bf16 planes).  G4C_WFMT_F16X2: the
                                         stream was written by g4c_mlp_pack_layer_f16x3 — the g4c_mlp_forward_bx6* entry points then run
                                         their "f16x3" arithmetic (below). */
+    int32_t *range_flag;             /* NULL, or a device array of int32: a launch in the f16x3 arithmetic writes 1 into
+                                        range_flag[range_slot] when an MLP input or a hidden activation it converted to fp16 reached
+                                        the end of fp16's range (|x| >= 65504: the value was CLIPPED there) — never written otherwise,
+                                        never cleared by the library.  The reference computes in fp32 (nn/model.py:303-321), so a set
+                                        slot means the result may differ from it: rerun with the bf16x6 stream (fp32 exponent range). */
+    int32_t range_slot;
 } g4c_mlp_t;
 #define G4C_WFMT_F16X2 1
 
@@ -213,9 +219,9 @@ int g4c_mlp_bx6i_enable(int on);
  * keeps its 16-column slice of all three layers' weights in registers for the whole launch, the loop over tile pairs prefetches the
  * next pair's indices and rows): same envelope and the same per-element arithmetic as g4c_mlp_bx6i_enable's kernel (sums over k in a
  * different association: equal to it within fp32 rounding, the fused aggregation still bit-identical to g4c_segment_reduce of the
- * stored rows).  0 = never, 1 = launches with the fused aggregation of at least G4C_WS_MIN_ROWS rows (default 20 000; the default
- * mode, environment G4C_WS), 2 = every launch it can take (tests), 3 = like 1 plus the launches without aggregation; -1 only
- * queries.  Returns the previous setting.  Takes precedence over the dual-tile kernel. */
+ * stored rows).  0 = never, 1 = launches of at least G4C_WS_MIN_ROWS rows (default 20 000; the default mode, environment G4C_WS),
+ * 2 = every launch it can take (tests); -1 only queries.  Returns the previous setting.  The dual-tile kernel of
+ * g4c_mlp_bx6i_enable takes the bf16x6 stream only since round 3. */
 int g4c_mlp_ws_enable(int on);
 
 /* Rounded-bf16 variant (opt-in only; BASELINE config 3 "bf16 edge-MLP MFMA"): the same stream and kernel structure, but

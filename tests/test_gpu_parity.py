@@ -1170,3 +1170,40 @@ def test_ws_persistent_kernel_equals_tile_kernel(rows):
         if f"agg_{mean}" in got:
             assert torch.equal(got[f"agg_{mean}"], ops.segment_reduce(got[f"rows_{mean}"], csr, mean))
             assert torch.equal(got[f"agg_only_{mean}"], got[f"agg_{mean}"])
+
+
+# ------------------------------------------------------------------ the fp16 range of the default arithmetic is observable
+def test_f16_range_clip_is_reported_and_bf16x6_matches_the_oracle():
+    """Adversarial WEIGHTS, normal inputs: the LayerNorm gain of the first MP layer's message MLP x 3e4 puts its output latents
+    (|e'| up to ~1e5) beyond the fp16 range.  The reference computes in fp32 (nn/model.py:303-321).  In the default "f16x3" arithmetic
+    the launches that convert those latents clip them at 65504 — solve() must say so (RuntimeWarning naming the MLPs; nothing is
+    silent), and nothing may be reported for an ordinary model.  In "bf16x6" (fp32 exponent range) the result matches the oracle."""
+    import warnings
+    g = S.mus_graph(3000, levels=2, seed=3)
+    torch.manual_seed(4)
+    model = gfd.nn.NsTwoScaleGNN(arch=S.mus_arch("NsTwoScaleGNN", 128), device=DEV)
+    old = ops.set_mlp_precision("f16x3")
+    try:
+        ops.f16_range_report()                                  # (clear what earlier tests may have left)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)      # an ordinary model: no clip, no warning
+            model.solve(g.clone(), 2)
+        assert ops.f16_range_report() == []
+        with torch.no_grad():
+            model.mp111.edge_mlp.MLP.layer_norm.weight.mul_(3e4)
+        model.invalidate_packed()
+        w = {k: v.cpu() for k, v in model.state_dict().items()}
+        ref = O.mus_solve("NsTwoScaleGNN", g.to_dict(), w, 2, model.num_fields)
+        with pytest.warns(RuntimeWarning, match="clipped values at the end of the fp16 range") as rec:
+            out16 = model.solve(g.clone(), 2)
+        assert any("NsTwoScaleGNN.mp11" in str(r.message) for r in rec), [str(r.message) for r in rec]
+        assert torch.isfinite(out16).all()                      # clipped, not inf / NaN
+        assert ops.f16_range_report() == []                     # reported once, then cleared
+        ops.set_mlp_precision("bf16x6")
+        model.invalidate_packed()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)
+            out = model.solve(g.clone(), 2)
+        torch.testing.assert_close(out.cpu(), ref, rtol=2e-3, atol=2e-3)
+    finally:
+        ops.set_mlp_precision(old)
