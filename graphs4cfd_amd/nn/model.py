@@ -222,7 +222,8 @@ class GNN(nn.Module):
                     optimiser.step()
                     optimiser.zero_grad()
                     self.invalidate_packed()     # the step changed the weights, whatever path the gradients came from
-                plan.clear_caches()              # a fresh batch never reuses the previous one's plans: do not pin them in HBM
+                # (the plan caches are LRU- and byte-bounded (plan._Cache, G4C_PLAN_CACHE_MB): a loader whose graphs recur keeps its
+                # plans, a stream of fresh batches evicts the oldest — no global clear per iteration)
             training_loss /= (iteration + 1)
             gradients_norm /= (iteration + 1)
             print(f"Epoch: {epoch:4d}, Training   loss: {training_loss:.4e}, Gradients: {gradients_norm:.4e}")
@@ -418,8 +419,10 @@ class Rollout:
         if self.steps_done >= self.max_steps:
             raise RuntimeError(f"rollout buffer holds {self.max_steps} steps")
         with torch.no_grad():
-            if self._hipgraph is not None and ops.weights_epoch() != self._epoch:
-                self._hipgraph, self._epoch = None, -1    # the weights changed under the captured step: its images are stale
+            if self._epoch != -1 and ops.weights_epoch() != self._epoch:
+                # the weights changed since the last eager step (captured or not yet): the packed images are stale, and repacking
+                # (allocations + pack launches) must not happen inside a capture — one eager step first
+                self._hipgraph, self._epoch = None, -1
             if self.steps_done == 0 or not self.capture or self._epoch == -1:
                 self._one()                               # eager: builds the plans and the packed weight images
                 self._epoch = ops.weights_epoch()

@@ -262,10 +262,20 @@ class LocalMesh:
 # ------------------------------------------------------------------------------------- halo exchange
 class HaloExchanger:
     """v[n_own:] <- owned rows of the peers, one collective per call (`all_to_all_single` with split sizes:
-    RCCL grouped send/recv over xGMI on GPUs, gloo in the CPU tests).  world == 1: no-op."""
+    RCCL grouped send/recv over xGMI on GPUs, gloo in the CPU tests).  world == 1: no-op.
 
-    def __init__(self, mesh: LocalMesh, group=None):
-        self.mesh, self.group = mesh, group
+    A rank does not wait on peers it shares no edge with: with unequal splits torch's NCCL back-end issues the exchange as ONE
+    group of ncclSend / ncclRecv calls and skips every peer whose count is zero (torch/csrc/cuda/nccl.cpp,
+    all2all_single_unequal_split), i.e. it already is the neighbour-only point-to-point exchange — a hand-written
+    batch_isend_irecv would enqueue the same calls.  The pack launch in front of it (`g4c_copy_cols` through the concatenated send
+    lists) stays: a boundary row can go to two or three peers, the kernels' output index scatters a row to one place; where the
+    exchange is overlapped with the interior edges (HipImpl.mp) the pack runs on the side stream with the collective.
+
+    `force=True` (scripts/dist_check.py --force-exchange): enter the collective with world == 1 as well (zero-length splits) — on a
+    single-GPU box that is the only way to execute "hipGraph capture with an RCCL collective inside" at all."""
+
+    def __init__(self, mesh: LocalMesh, group=None, force: bool = False):
+        self.mesh, self.group, self.force = mesh, group, force
         self._send_buf: Dict[tuple, torch.Tensor] = {}
         self._send_cat: Dict[int, Optional[torch.Tensor]] = {}
         self._side = None
@@ -303,7 +313,7 @@ class HaloExchanger:
 
     def exchange(self, v: torch.Tensor, level: int) -> None:
         m = self.mesh
-        if m.world == 1:
+        if m.world == 1 and not self.force:
             return
         # (no per-rank shortcut for an empty halo: the exchange is a collective, every rank of the group has to enter it, with
         # zero-length splits if it has nothing to send or receive at this level)
@@ -543,7 +553,7 @@ class DistributedRollout:
         self.steps_done = 0
         self.capture = capture and device.type == "cuda"
         self.capture_error = None if self.capture else "capture not requested"
-        self._hipgraph = None
+        self._hipgraph, self._epoch = None, -1
 
     def _one(self) -> None:
         pred = self.fwd.forward()
@@ -555,8 +565,14 @@ class DistributedRollout:
         if self.steps_done >= self.max_steps:
             raise RuntimeError(f"rollout buffer holds {self.max_steps} steps")
         with torch.no_grad():
-            if self.steps_done == 0 or not self.capture:
+            if self._epoch != -1 and ops.weights_epoch() != self._epoch:
+                # (as nn.model.Rollout: the weights changed — load_state_dict, fit, invalidate_packed — so the captured step's packed
+                # images are stale or freed; one eager step repacks, then the step is captured again.  Every rank sees the same
+                # epoch sequence as long as every rank updates its replica of the model, which a partitioned rollout requires anyway)
+                self._hipgraph, self._epoch = None, -1
+            if self.steps_done == 0 or not self.capture or self._epoch == -1:
                 self._one()
+                self._epoch = ops.weights_epoch()
             elif self._hipgraph is None:
                 torch.cuda.synchronize(self.device)
                 hg, err = None, None
@@ -565,7 +581,9 @@ class DistributedRollout:
                     hg = torch.cuda.CUDAGraph()
                     # (thread_local: the process group's watchdog thread polls its events while this thread captures; under
                     # the default global mode a call from that thread can invalidate the capture)
-                    with torch.cuda.graph(hg, capture_error_mode="thread_local" if self.world > 1 else "global"):
+                    import torch.distributed as _dist
+                    pg_live = _dist.is_available() and _dist.is_initialized()
+                    with torch.cuda.graph(hg, capture_error_mode="thread_local" if (self.world > 1 or pg_live) else "global"):
                         self._one()
                 except Exception as exc:   # keep the rollout alive on stacks where the collective cannot be captured
                     hg, err = None, f"{type(exc).__name__}: {exc}"

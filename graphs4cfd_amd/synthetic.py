@@ -231,7 +231,12 @@ def guillard_coarsening(edge_index: torch.Tensor, num_nodes: int) -> torch.Tenso
     """Node-nested greedy coarsening (transforms/mugs.py:8-29): visit nodes in order; a node still
     marked coarse removes all its k senders.  Sequential by definition."""
     if edge_index.is_cuda:
-        return guillard_coarsening_rounds(edge_index, num_nodes)
+        # data-parallel rounds; on a numbering with long removal chains (a mesh numbered along a line: up to O(n) rounds) the bounded
+        # number of rounds runs out and the sequential visit below takes over on a host copy
+        mask = guillard_coarsening_rounds(edge_index, num_nodes, max_rounds=GUILLARD_MAX_ROUNDS, strict=False)
+        if mask is not None:
+            return mask
+        return guillard_coarsening(edge_index.cpu(), num_nodes).to(edge_index.device)
     row = edge_index[0].numpy()
     k = int((edge_index[1] == 0).sum())
     senders = row.reshape(-1, k)
@@ -242,13 +247,17 @@ def guillard_coarsening(edge_index: torch.Tensor, num_nodes: int) -> torch.Tenso
     return torch.from_numpy(coarse)
 
 
-def guillard_coarsening_rounds(edge_index: torch.Tensor, num_nodes: int, max_rounds: int = 100000) -> torch.Tensor:
+GUILLARD_MAX_ROUNDS = 256      # (random / Morton / spatially sorted numberings of 100k-node meshes need 20 - 60 rounds)
+
+
+def guillard_coarsening_rounds(edge_index: torch.Tensor, num_nodes: int, max_rounds: int = 100000, strict: bool = True):
     """The same mask as the sequential visit of `guillard_coarsening`, by rounds of data-parallel tensor ops (any device).
     Node l is *active* (still coarse when it is visited, so it removes its k senders) iff no active node visited before it
     lists l among its senders: a lexicographically-first recursion over the arcs l -> j (j a sender of l, l < j).  Each round
     decides every node all of whose earlier removers are decided — inactive as soon as one of them is active, active once
     all are inactive; the number of rounds is the longest chain of such arcs, not the number of nodes.  The final mask:
-    a node stays coarse iff no active node (earlier or later) removes it."""
+    a node stays coarse iff no active node (earlier or later) removes it.  `strict=False`: None instead of an error when
+    `max_rounds` rounds leave nodes undecided."""
     dev = edge_index.device
     k = int((edge_index[1] == 0).sum())
     remover = torch.arange(num_nodes, device=dev).repeat_interleave(k)        # node l, visited in index order ...
@@ -270,7 +279,10 @@ def guillard_coarsening_rounds(edge_index: torch.Tensor, num_nodes: int, max_rou
             break
         state = new_state
     if bool((state == UNDECIDED).any()):
-        raise RuntimeError("guillard_coarsening_rounds: undecided nodes left (cyclic arcs cannot occur: l < j)")
+        if not strict:
+            return None         # out of rounds (every round decides at least one node, so this is not a cycle): the caller falls back
+        raise RuntimeError(f"guillard_coarsening_rounds: {max_rounds} rounds were not enough (removal chains longer than that); "
+                           "raise max_rounds or use the sequential visit guillard_coarsening() on a host copy")
     hit = torch.zeros(num_nodes, dtype=torch.int32, device=dev).index_add_(0, removed, (state[remover] == ACTIVE).int())
     return hit == 0
 

@@ -10,6 +10,8 @@ ap = argparse.ArgumentParser(); ap.add_argument("--backend", default="nccl"); ap
 ap.add_argument("--nodes", type=int, default=20000); ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--model", default="NsThreeScaleGNN"); ap.add_argument("--dim", type=int, default=2); ap.add_argument("--hidden", type=int, default=128)
 ap.add_argument("--capture", type=int, default=-1, help="-1: capture the step in a hipGraph iff the transport is nccl")
+ap.add_argument("--force-exchange", action="store_true", help="enter every halo collective even with one rank (zero-length splits): executes "
+                "'hipGraph capture with an RCCL collective inside' on a single-GPU box")
 a = ap.parse_args()
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda", 0 if a.same_gpu else int(os.environ["LOCAL_RANK"]))
@@ -24,6 +26,8 @@ else:
     g = S.mus_graph(a.nodes, levels=levels, dim=a.dim, seed=1)
     model = getattr(gfd.nn, a.model)(arch=S.mus_arch(a.model, a.hidden, dim=a.dim), device=dev)
 dr = P.DistributedRollout(model, g, a.steps, rank, world, dev, capture=(a.backend == "nccl") if a.capture < 0 else bool(a.capture))
+if a.force_exchange:
+    dr.fwd.xch.force = True
 dr.run(a.steps)
 full = dr.gather_outputs()
 if rank == 0:
@@ -32,6 +36,8 @@ if rank == 0:
     x = dr.fwd.xch
     print(f"world={world} backend={a.backend} {a.model} dim={a.dim}: halo rows per level {dr.mesh.n_halo}, "
           f"{x.n_exchanges} exchanges, {x.bytes_sent} B sent, captured={dr.captured}, max|partitioned - single| = {err:.3e}", flush=True)
-    assert err < 2e-3, err
+    assert err < 5e-4, err          # (the full-forward parity bar of tests/test_gpu_parity.py; measured 1e-6 .. 3e-6)
+    if a.capture > 0:
+        assert dr.captured, f"the partitioned step was not captured: {dr.capture_error}"
 dist.barrier()
 dist.destroy_process_group()

@@ -1005,6 +1005,21 @@ def test_distributed_rollout_four_processes_one_gpu():
         assert "world=4" in out.stdout and "max|partitioned - single|" in out.stdout
 
 
+def test_distributed_rollout_rccl_capture_single_rank():
+    """The RCCL transport itself, as far as a one-GPU box can execute it: one process, backend nccl, every halo collective entered
+    with zero-length splits (--force-exchange), the partitioned step — collectives included — captured into a hipGraph and replayed
+    (the script asserts `captured`), against the single-process rollout at the 5e-4 forward tolerance."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29500 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "scripts", "dist_check.py"), "--backend", "nccl", "--capture", "1", "--force-exchange", "--nodes", "20000",
+           "--steps", "5"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "world=1 backend=nccl" in out.stdout and "captured=True" in out.stdout, out.stdout[-1000:]
+
+
 # ------------------------------------------------------------------ weights that change under cached images / captured steps
 def test_invalidate_packed_and_rollout_recapture():
     """An update that bypasses autograd's version counters (`p.data` arithmetic, EMA, a broadcast) is picked up after
