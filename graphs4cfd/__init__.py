@@ -17,7 +17,7 @@ for _name in ("graph", "loader", "nn", "transforms", "metrics", "datasets", "pla
     _mod = __import__(f"graphs4cfd_amd.{_name}", fromlist=["_"])
     _sys.modules[f"{__name__}.{_name}"] = _mod
     globals()[_name] = _mod
-for _name in ("blocks", "losses", "model", "mus_gnn", "mugs_gnn", "remus_gnn"):
+for _name in ("blocks", "losses", "model", "training", "mus_gnn", "mugs_gnn", "remus_gnn"):
     _sys.modules[f"{__name__}.nn.{_name}"] = __import__(f"graphs4cfd_amd.nn.{_name}", fromlist=["_"])
 
 

@@ -88,26 +88,27 @@ class GNN(nn.Module):
         self.load_model(arch, weights, checkpoint)
 
     def load_model(self, arch, weights, checkpoint):
-        """Architecture from an arch dict (+ optional weights file), or both from a `.chk` checkpoint
-        written by `save_checkpoint` (same file format as the reference)."""
-        if arch is not None and checkpoint is None:
-            self.load_arch(arch)
-            self.to(self.device)
-            if weights is not None:
-                self.load_state_dict(torch.load(weights, map_location=self.device))
-            self.num_fields = arch["decoder"][1][-1] if 'decoder' in arch.keys() else None
-        elif arch is None and weights is None and checkpoint is not None:
-            chk = torch.load(checkpoint, map_location=self.device, weights_only=False)
-            self.load_arch(chk['arch'])
-            self.to(self.device)
-            self.load_state_dict(chk['weights'])
-            self.num_fields = chk['arch']["decoder"][1][-1] if 'decoder' in chk['arch'].keys() else None
+        """Builds the modules and fills them: either from an arch dict (+ an optional state-dict file), or from a `.chk` written by
+        `save_checkpoint` (the reference's format, nn/model.py:112-150: 'arch', 'weights', optimiser state ...).  Any other
+        combination leaves the model without modules, like the reference does."""
+        source = None
+        if checkpoint is not None and arch is None and weights is None:
+            source = torch.load(checkpoint, map_location=self.device, weights_only=False)
+            arch, state = source['arch'], source['weights']
+        elif arch is not None and checkpoint is None:
+            state = torch.load(weights, map_location=self.device) if weights is not None else None
+        else:
+            return
+        self.load_arch(arch)
+        self.to(self.device)
+        if state is not None:
+            self.load_state_dict(state)
+        self.num_fields = arch["decoder"][1][-1] if 'decoder' in arch else None
         # names under which clipped fp16 values are reported (ops.f16_range_report)
         from .blocks import MLP as _MLP
         for name, m in self.named_modules():
             if isinstance(m, _MLP):
                 m._site = f"{type(self).__name__}.{name}"
-        return
 
     def to(self, *args, **kwargs):
         out = super().to(*args, **kwargs)
@@ -133,146 +134,17 @@ class GNN(nn.Module):
 
     # ---------------------------------------------------------------------------------- training
     def fit(self, train_config: TrainConfig, train_loader, val_loader=None):
-        """Trains the model (reference: nn/model.py:152-301 — same loop: Adam, optional ReduceLROnPlateau, gradient clipping,
-        one optimiser step per rollout step with the prediction fed back detached, validation over the longest rollout,
-        checkpoints in the reference's `.chk` format, rollout length advanced when the monitored loss passes the tolerance).
+        """Trains the model (the behaviour of the reference's nn/model.py:152-301: Adam, optional ReduceLROnPlateau, gradient
+        clipping, one optimiser step per rollout step with the prediction fed back detached, validation over the longest rollout,
+        `.chk` files in the reference's format, the rollout length advanced when the monitored loss passes the tolerance).  The
+        loop itself is nn/training.py (`Trainer`: a rollout curriculum, an optimiser factory, a checkpoint file, one method per pass).
 
         Differences, all deliberate: `scheduler=None` / `tensor_board=None` work (the reference dereferences both
         unconditionally, :279,:299); `mixed_precision` needs no loss scaling here — gradients and accumulations are fp32
-        whatever `ops.set_mlp_precision` says the MLP products run in — so the flag only prints a note."""
-        from torch import optim
-        if train_config['device'] is not None and torch.device(train_config['device']) != self.device:
-            self.to(train_config['device'])
-        criterion = train_config['training_loss']
-        steps_list = list(train_config['num_steps'])
-        max_n_out = steps_list[-1]
-        num_steps = iter(steps_list)
-        n_out = next(num_steps)
-        sch_cfg = train_config['scheduler']
-
-        def new_adam(lr):
-            """torch.optim.Adam as in the reference; on the GPU its single-launch (`fused`) form: 0.47 instead of 1.35 ms per
-            step for the 306 parameter tensors of a 3-scale model (same update rule)."""
-            if self.device.type == "cuda":
-                try:
-                    return optim.Adam(self.parameters(), lr=lr, fused=True)
-                except (TypeError, RuntimeError):
-                    pass
-            return optim.Adam(self.parameters(), lr=lr)
-
-        def new_scheduler(opt):
-            if sch_cfg is None or sch_cfg.get('patience') is None:
-                return None
-            return optim.lr_scheduler.ReduceLROnPlateau(opt, factor=sch_cfg['factor'], patience=sch_cfg['patience'], eps=0.)
-
-        checkpoint, scheduler = None, None
-        if train_config['checkpoint'] is not None and os.path.exists(train_config['checkpoint']):
-            print("Training from an existing check-point:", train_config['checkpoint'])
-            checkpoint = torch.load(train_config['checkpoint'], map_location=self.device, weights_only=False)
-            self.load_state_dict(checkpoint['weights'])
-            optimiser = new_adam(checkpoint['lr'])
-            optimiser.load_state_dict(checkpoint['optimiser'])
-            scheduler = new_scheduler(optimiser)
-            if scheduler is not None and 'scheduler' in checkpoint:
-                scheduler.load_state_dict(checkpoint['scheduler'])
-            while n_out < checkpoint['n_out']:
-                n_out = next(num_steps)
-            initial_epoch = checkpoint['epoch'] + 1
-        else:
-            if train_config['checkpoint'] is not None:
-                print("Not matching check-point file:", train_config['checkpoint'])
-            print('Training from randomly initialised weights')
-            optimiser = new_adam(train_config['lr'])
-            scheduler = new_scheduler(optimiser)
-            initial_epoch = 1
-        path = os.path.join(train_config["folder"], train_config["name"] + ".chk")
-        if os.path.exists(path):
-            print('Renaming', path, 'to:', path + '.bck')
-            os.rename(path, path + '.bck')
-        writer = None
-        if train_config['tensor_board'] is not None:
-            from torch.utils.tensorboard import SummaryWriter
-            writer = SummaryWriter(os.path.join(train_config["tensor_board"], train_config["name"]))
-        if train_config['mixed_precision']:
-            print(f"mixed_precision: MLP products run in ops.mlp_precision() = {ops.mlp_precision()!r}; gradients stay fp32, no loss scaling")
-        print(f'Training on device: {self.device}')
-        print(f'Number of trainable parameters: {self.num_params}')
-        self.history = []
-        for epoch in range(initial_epoch, train_config['epochs'] + 1):
-            if optimiser.param_groups[0]['lr'] < train_config['stopping']:
-                print(f"The learning rate is smaller than {train_config['stopping']}. Stopping training.")
-                self.save_checkpoint(path, n_out, epoch, optimiser, scheduler=scheduler)
-                break
-            print(f"Hyperparameters: n_out = {n_out}, lr = {optimiser.param_groups[0]['lr']}")
-            self.train()
-            training_loss, gradients_norm, iteration = 0., 0., -1
-            for iteration, data in enumerate(train_loader):
-                data = data.to(self.device)
-                pred = None
-                for t in range(n_out):
-                    if t > 0:
-                        data.field = self.shift_and_replace(data.field, pred.detach())
-                    pred = self.forward(data, t)
-                    loss = criterion(data, pred, data.target[:, self.num_fields * t:self.num_fields * (t + 1)])
-                    loss.backward()
-                    training_loss += loss.item() / n_out
-                    gradients_norm += self.grad_norm2() / n_out
-                    if train_config['grad_clip'] is not None and epoch > train_config['grad_clip']["epoch"]:
-                        nn.utils.clip_grad_norm_(self.parameters(), train_config['grad_clip']["limit"])
-                    optimiser.step()
-                    optimiser.zero_grad()
-                    self.invalidate_packed()     # the step changed the weights, whatever path the gradients came from
-                # (the plan caches are LRU- and byte-bounded (plan._Cache, G4C_PLAN_CACHE_MB): a loader whose graphs recur keeps its
-                # plans, a stream of fresh batches evicts the oldest — no global clear per iteration)
-            training_loss /= (iteration + 1)
-            gradients_norm /= (iteration + 1)
-            print(f"Epoch: {epoch:4d}, Training   loss: {training_loss:.4e}, Gradients: {gradients_norm:.4e}")
-            if ops.mlp_precision() == "f16x3":
-                ops.check_f16_range(self.device, f"fit(), epoch {epoch}")
-            validation_loss = None
-            if val_loader is not None:
-                validation_criterion = train_config['validation_loss']
-                self.eval()
-                with torch.no_grad():
-                    validation_loss = 0.
-                    for iteration, data in enumerate(val_loader):
-                        data = data.to(self.device)
-                        for t in range(max_n_out):
-                            if t > 0:
-                                data.field = self.shift_and_replace(data.field, pred)
-                            pred = self.forward(data, t)
-                            validation_loss += validation_criterion(
-                                data, pred, data.target[:, self.num_fields * t:self.num_fields * (t + 1)]).item() / max_n_out
-                    validation_loss /= (iteration + 1)
-                    print(f"Epoch: {epoch:4d}, Validation loss: {validation_loss:.4e}")
-            self.history.append({'epoch': epoch, 'n_out': n_out, 'training_loss': training_loss, 'validation_loss': validation_loss,
-                                 'gradients_norm': gradients_norm, 'lr': optimiser.param_groups[0]['lr']})
-            if writer is not None:
-                writer.add_scalar('Loss/train', training_loss, epoch)
-                if val_loader:
-                    writer.add_scalar('Loss/test', validation_loss, epoch)
-
-            def monitored(which: str):
-                if which[:2] == 'tr':
-                    return training_loss
-                if which[:3] == 'val':
-                    if validation_loss is None:
-                        raise ValueError("a validation loss is monitored but no val_loader was given")
-                    return validation_loss
-                raise NameError(f"Invalid loss selector {which!r} (expected 'training' or 'validation').")
-
-            if scheduler is not None:
-                scheduler.step(monitored(sch_cfg['loss']))
-            if not epoch % train_config["chk_interval"]:
-                print('Saving check-point in:', path)
-                self.save_checkpoint(path, n_out, epoch, optimiser, scheduler=scheduler)
-            if monitored(train_config['add_steps']['loss']) < train_config['add_steps']['tolerance'] and n_out < max_n_out:
-                n_out = next(num_steps)
-                optimiser = new_adam(train_config["lr"])
-                scheduler = new_scheduler(optimiser)
-        if writer is not None:
-            writer.close()
-        print("Finished training")
+        whatever `ops.set_mlp_precision` says the MLP products run in — so the flag only prints a note; a clip of the default
+        fp16-split arithmetic during an epoch is reported (ops.check_f16_range).  `self.history` holds one record per epoch."""
+        from .training import Trainer
+        Trainer(self, train_config, train_loader, val_loader).run()
         return
 
     def grad_norm2(self):
