@@ -196,6 +196,30 @@ def reference_flop_per_step(model, g):
     return total
 
 
+def pmc_pipe_util():
+    """MfmaUtil / VALUBusy of the shipped kernels in the default arithmetic, from the newest committed rocprofv3 --pmc summaries
+    (scripts/pmc_ws.sh via scripts/refresh_artifacts.sh: profiles/r*_pmc_mlp_ws.txt = the level-1 message launch on mlp_ws_kernel,
+    r*_pmc_mlp_bx6_node.txt = the level-1 node launch on mlp_bx6_kernel).  None when no file is committed."""
+    import glob
+    import re
+    out = {}
+    for key, pat in (("level1_message_mlp_ws_kernel", "r*_pmc_mlp_ws.txt"), ("level1_node_mlp_bx6_kernel", "r*_pmc_mlp_bx6_node.txt")):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+        if not files:
+            continue
+        txt = open(files[-1]).read()
+        ent = {"source": os.path.relpath(files[-1], ROOT)}
+        for name in ("MfmaUtil", "VALUBusy"):
+            m = re.search(name + r"\s+\d+\s+per-dispatch\s+(\d+)", txt)
+            if m:
+                ent[name + "_percent"] = int(m.group(1))
+        m1, m2 = re.search(r"SQ_LDS_BANK_CONFLICT\s+\d+\s+per-dispatch\s+(\d+)", txt), re.search(r"SQ_LDS_IDX_ACTIVE\s+\d+\s+per-dispatch\s+(\d+)", txt)
+        if m1 and m2 and int(m2.group(1)):
+            ent["lds_bank_conflict_share_of_lds_cycles"] = int(m1.group(1)) / int(m2.group(1))
+        out[key] = ent
+    return out or None
+
+
 def roofline_blocks(args, result, model, graph_cpu, dev, ops, Rollout):
     """Eager instrumented pass of the same step: HIP-event pair around every launch, on the launch stream."""
     eager = Rollout(model, graph_cpu.clone().to(dev), 12, capture=False)
@@ -248,7 +272,8 @@ def roofline_blocks(args, result, model, graph_cpu, dev, ops, Rollout):
     tot_t = sum(summ[k]["seconds"] for k in mlp_kinds)
     fallback = sum(summ[k]["launches"] // 3 for k in mlp_kinds if not k.startswith("mlp_bx6"))
     result["roofline"] = {
-        "bound": "mfma", "kernel": (dom + "<1, *, *> + mlp_bx6i_kernel for the message launches of >= 20k rows (bf16x6: 400k) (g4c_mlp_forward_bx6 / _heads_bx6 / _agg)") if dom.startswith("mlp_bx6")
+        "bound": "mfma", "kernel": (dom + "<1, *, *> (g4c_mlp_forward_bx6 / _heads_bx6 / _agg); the message launches of >= 20k rows run on mlp_ws_kernel "
+                                     "(f16x3 stream: weight-stationary persistent kernel) / mlp_bx6i_kernel (bf16x6 stream, >= 400k rows)") if dom.startswith("mlp_bx6")
         else dom.replace(">", ", *>") + " (g4c_mlp_forward)",
         "achieved": big["achieved"], "peak": big["peak"], "unit": "TFLOP/s", "frac": big["frac"], "mfma_dtype": big["mfma_dtype"],
         "algorithmic_tflops": big.get("algorithmic_tflops", big["achieved"]),
@@ -265,6 +290,8 @@ def roofline_blocks(args, result, model, graph_cpu, dev, ops, Rollout):
         "other_mlp_kernels": {k: mfma_entry(k) for k in mlp_kinds if k != dom}}
     if "algorithmic_vs_fp32_mfma_peak" in big:
         result["roofline"]["algorithmic_vs_fp32_mfma_peak"] = big["algorithmic_vs_fp32_mfma_peak"]
+    if args.workload == "headline" and args.precision == "f16x3":
+        result["roofline"]["mfma_util_pmc"] = pmc_pipe_util()
     # the same kernel against the HBM roofline: algorithmic bytes (every input block row read once, every output row written once:
     # 4 * (sum of input widths + output width [+ heads]) per row) / launch time.  Whichever fraction is larger is the bound the
     # kernel is closer to: MFMA for the 6-product fp32-accurate mode, HBM for the rounded-bf16 mode of config 3

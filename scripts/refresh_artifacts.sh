@@ -2,8 +2,8 @@
 # Round artifacts, produced on the GPU box into gpurun_out/artifacts_<tag>/ (copy them into profiles/ afterwards):
 #   pytest -m gpu tail, bench lines of every named workload, rocprofv3 kernel stats of the headline and REMuS benches, PMC HBM
 #   traffic of both, MFMA ceiling, training benches.
-# Usage: gpurun --timeout 3000 -- 'bash scripts/refresh_artifacts.sh r02'
-TAG=${1:-r02}
+# Usage: gpurun --timeout 3000 -- 'bash scripts/refresh_artifacts.sh r03'
+TAG=${1:-r03}
 cd "$GRAFT_REPO_ROOT"
 A=gpurun_out/artifacts_$TAG; rm -rf $A; mkdir -p $A
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $A/${TAG}_pytest_gpu.log
@@ -39,8 +39,17 @@ for wl in headline c3; do
 done
 timeout 300 python scripts/step_breakdown.py > $A/${TAG}_step_breakdown.log 2>&1
 timeout 300 python scripts/mlp_accuracy.py > $A/${TAG}_mlp_accuracy.log 2>&1
-timeout 300 python scripts/bx6i_check.py --time 2>&1 | tail -4 > $A/${TAG}_bx6i_check_and_ab.log
-G4C_MLP_PRECISION=bf16x6 timeout 300 python scripts/bx6i_check.py --time 2>&1 | tail -3 >> $A/${TAG}_bx6i_check_and_ab.log
+# the weight-stationary kernel (f16x3 stream): checks against the tile kernel + same-process A/B; the dual-tile kernel (bf16x6 stream)
+timeout 300 python scripts/ws_check.py --time 2>&1 | tail -4 > $A/${TAG}_ws_check_and_ab.log
+G4C_MLP_PRECISION=bf16x6 timeout 300 python scripts/bx6i_check.py --time 2>&1 | tail -3 > $A/${TAG}_bx6i_check_and_ab.log
+# cycle stamps of the weight-stationary kernel's pair loop (DESIGN.md 4.1 / 9 quote them)
+bash scripts/build_ws_timing.sh > /dev/null 2>&1 && timeout 120 python scripts/ws_stamps.py graphs4cfd_amd/lib/libg4c_ws_timing.so 2>&1 | grep -v amdgpu.ids > $A/${TAG}_ws_stamps.log
+# pipe-utilisation counters of the shipped kernels in the DEFAULT arithmetic: level-1 message launch (mlp_ws_kernel) and node launch (mlp_bx6_kernel)
+bash scripts/pmc_ws.sh ws ${TAG}_ws util sq3 lds sq2 tcc > $A/${TAG}_pmc_mlp_ws.txt 2>&1
+PMC_EXTRA_ARGS=--node bash scripts/pmc_ws.sh tile ${TAG}_node util sq3 lds sq2 tcc > $A/${TAG}_pmc_mlp_bx6_node.txt 2>&1
+# co-issue microbenchmark (how many vector instructions hide behind one MFMA, by shape and waves per SIMD)
+hipcc -w --offload-arch=gfx950 -O3 -o /tmp/mfma_fillers scripts/micro/mfma_fillers.hip 2>/dev/null && /tmp/mfma_fillers > $A/${TAG}_mfma_fillers.log 2>&1
+timeout 300 python scripts/bench_mugs.py 2>&1 | tail -3 > $A/${TAG}_bench_mugs.log
 # training path: step time + per-phase HIP-event times + the CPU leg
 timeout -k 10 900 python scripts/bench_train.py --steps 10 --cpu-steps 1 --phases 2> $A/train_stderr.log | tail -1 > $A/${TAG}_train_bench_100k.json
 ls -la $A

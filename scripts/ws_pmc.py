@@ -19,10 +19,12 @@ ep, csr = plan.edge_csr(ei, n)
 pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
 src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
 out, agg = torch.empty(rows, H, device=dev), torch.empty(n, H, device=dev)
-if "--node" in sys.argv:
+if "--node" in sys.argv:          # the level-1 node launch: [aggregate | v] -> MLP -> LayerNorm -> SELU, + the next layer's two first-layer products (heads)
     v = torch.randn(n, H, device=dev)
-    pkn = blk.node_mlp.packed([H, H], [False, False])
-    for _ in range(6): ops.mlp_forward(pkn, [ops.Source(agg), ops.Source(v)], n, _lib.ACT_SELU)
+    res = None
+    for _ in range(6):
+        res = blk.node_mlp.run_with_heads([ops.Source(agg), ops.Source(v)], n, _lib.ACT_SELU, blk.edge_mlp, H, [H, H])
+    assert res is not None
 else:
     for _ in range(6): ops.mlp_forward(pk, src, rows, 0, out=out, agg=(csr, agg, True))
 torch.cuda.synchronize()
