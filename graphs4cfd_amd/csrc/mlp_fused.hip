@@ -215,7 +215,8 @@ __device__ __forceinline__ void split_finish(const Params &p, float *sH, const f
             const int row = wave * RPW + r;
             const long long grow = row0 + row;
             if (grow < mlim) {
-                const f32x4 t = *reinterpret_cast<const f32x4 *>(sH + row * HS + 4 * i);
+                f32x4 t = *reinterpret_cast<const f32x4 *>(sH + row * HS + 4 * i);
+                if (p.out_bf16 == 2) t = selu4(t);          // (G4C_DTYPE_BF16_SELU: the reader's pending activation, applied before the one rounding)
                 bf16x4 b;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) b[u] = (__bf16)t[u];
@@ -1259,8 +1260,10 @@ extern "C" int g4c_mlp_forward_bf16_agg(const g4c_mlp_t *mlp, const g4c_src_t *s
                                         const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,
                                         float *agg, int32_t agg_ld, int32_t agg_mean, void *stream) {
     G4C_REQUIRE(tile_rows && tile_seg && seg_off && agg && n_tiles >= 0 && agg_ld >= NP, G4C_EINVAL, "g4c_mlp_forward_bf16_agg: bad aggregation plan");
-    G4C_REQUIRE(out_dtype == G4C_DTYPE_F32 || out_dtype == G4C_DTYPE_BF16, G4C_EINVAL, "g4c_mlp_forward_bf16_agg: unknown out_dtype %d", out_dtype);
-    const AggArgs a{tile_rows, tile_seg, seg_off, n_tiles, agg, agg_ld, agg_mean, out_dtype == G4C_DTYPE_BF16};
+    G4C_REQUIRE(out_dtype == G4C_DTYPE_F32 || out_dtype == G4C_DTYPE_BF16 || out_dtype == G4C_DTYPE_BF16_SELU, G4C_EINVAL,
+                "g4c_mlp_forward_bf16_agg: unknown out_dtype %d", out_dtype);
+    G4C_REQUIRE(out_dtype != G4C_DTYPE_BF16_SELU || act == G4C_ACT_NONE, G4C_EINVAL, "g4c_mlp_forward_bf16_agg: G4C_DTYPE_BF16_SELU with an output activation");
+    const AggArgs a{tile_rows, tile_seg, seg_off, n_tiles, agg, agg_ld, agg_mean, out_dtype};
     return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3216, (float *)out, out_ld, nullptr, act, nullptr, 0, 0,
                       nullptr, 0, nullptr, 0, stream, &a);
 }
@@ -1392,7 +1395,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         if (agg->rows_bf16) {
             G4C_REQUIRE(round1 && (!out || ((out_ld & 3) == 0 && ((uintptr_t)out & 7) == 0)), G4C_EUNSUPPORTED,
                         "g4c_mlp_forward_bf16_agg: bf16 output rows need the rounded-bf16 mode, out_ld a multiple of 4 and an 8-byte aligned out");
-            p.out_bf16 = 1;
+            p.out_bf16 = agg->rows_bf16;
         }
     }
     for (int l = 0; l < G4C_MAX_LAYERS; ++l) { p.save[l] = nullptr; p.mul[l] = nullptr; }

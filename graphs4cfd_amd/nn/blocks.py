@@ -306,10 +306,12 @@ def edgeScalarToNodeVector(edge_attr: Tensor, edge_index: Tensor, edgeUnitVector
 
 
 # ------------------------------------------------------------------------------------- MP
-# G4C_COMPACT_MESSAGES=1 (opt-in, rounded-bf16 mode only): EdgeMP's message rows are stored as bf16.  Measured on REMuS-GNN, 100k nodes:
-# 63.5 -> 67.4 steps/s; deviation from the fp32 reference forward at 20k nodes: mean unchanged (3.2e-3), max 3.6e-2 -> 6.5e-2 — outside the
-# margin the parity test of that mode allows, hence off by default.
-COMPACT_MESSAGES = __import__("os").environ.get("G4C_COMPACT_MESSAGES", "0") == "1"
+# Rounded-bf16 mode only (BASELINE config 3): EdgeMP's message rows — read again only by the next EdgeMP's message launch, which applies
+# SELU and rounds them to bf16 — are stored by the launch that fuses the aggregation as bf16(SELU(row)) (G4C_DTYPE_BF16_SELU): half the
+# bytes of the largest tensors of a REMuS-GNN step, and bit for bit the operand the reader would have formed from fp32 rows (the
+# aggregate still sees the un-activated fp32 rows).  Round 2 stored bf16(row) and let the reader apply SELU: two roundings, max
+# deviation from the fp32 reference 3.6e-2 -> 6.5e-2 at 20k nodes, which is why it was opt-in then.  G4C_COMPACT_MESSAGES=0 turns it off.
+COMPACT_MESSAGES = __import__("os").environ.get("G4C_COMPACT_MESSAGES", "1") == "1"
 
 
 def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, aggr: str, act_code: int,
@@ -327,8 +329,9 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
     multiplied them; `next_msg` = the message MLP of the MP layer that will consume v' on the SAME graph: the node
     launch then emits its products as well and a third value (those products, or None) is returned.
     `compact_messages` (EdgeMP: the returned e' is only ever read by the next EdgeMP's message launch): in the rounded-bf16 mode
-    the launch that fuses the aggregation stores e' as bf16 (ops.mlp_forward rows_dtype) — the consumer rounds it to bf16 anyway, and
-    REMuS-GNN's angle launches are HBM-bound on exactly these rows.
+    the launch that fuses the aggregation stores bf16(SELU(e')) (ops.mlp_forward rows_dtype / rows_act) — exactly the operand that
+    reader forms; REMuS-GNN's angle launches are HBM-bound on these rows.  A bf16 result is ALREADY ACTIVATED: its reader passes
+    `e_pre_act = ACT_NONE` (see `pending_act`).
     `n_targets` / `v_out` (partitioned sub-meshes, partition_remus.py): only the first `n_targets` rows of `v` are targets (the
     rows behind them are halo rows, read as senders only); v' for those rows is written into `v_out`."""
     if aggr not in ("mean", "sum", "add"):
@@ -347,7 +350,8 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
         agg = torch.empty((csr.n_seg, msg_mlp.output_size), dtype=torch.float32, device=v.device)
         e_new = msg_mlp.run_hoisted([e_src], [(senders, ep.row), (v, ep.col)], ep.n_edges,
                                     products=products, agg=(csr, agg, mean), store_rows=keep_e,
-                                    rows_dtype=torch.bfloat16 if compact_messages and COMPACT_MESSAGES else None)
+                                    rows_dtype=torch.bfloat16 if compact_messages and COMPACT_MESSAGES else None,
+                                    rows_act=_lib.ACT_SELU if compact_messages and COMPACT_MESSAGES else _lib.ACT_NONE)
         agg_src = Source(agg)
     elif ops.can_aggregate_on_load(csr, msg_mlp.output_size, [msg_mlp.output_size, int(v.size(1))]):
         # the node launch averages each target's messages while it gathers its input (g4c_src_t.seg_off): no separate
@@ -373,6 +377,12 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
         return nxt[0], e_new, nxt[1]
     v_new = upd_mlp.run_coded([agg_src, Source(v)], n_t, act_code, out=v_out)
     return v_new, e_new
+
+
+def pending_act(e: Optional[Tensor]) -> int:
+    """Activation still to be applied to the messages `_mp_step` returned: SELU for fp32 rows (stored raw, the aggregation needed them
+    so), none for compact bf16 rows (stored activated)."""
+    return _lib.ACT_NONE if (e is not None and torch.is_tensor(e) and e.dtype == torch.bfloat16) else _lib.ACT_SELU
 
 
 def _public_mp(msg_mlp: MLP, upd_mlp: MLP, v, e, index, aggr, activation, v_src=None):

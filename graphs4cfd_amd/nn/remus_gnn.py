@@ -14,6 +14,7 @@ import torch
 from .. import _lib, ops, plan
 from ..graph import Graph
 from ..ops import Source
+from . import blocks as _blocks
 from .blocks import MLP, EdgeMP, DownEdgeMP, UpEdgeMP, edgeScalarToNodeVector
 from .model import GNN
 
@@ -100,7 +101,7 @@ class NsRotEquiTreeScaleGNN(GNN):
                     e[lvl], a[lvl] = block.step(e[lvl], a[lvl], aidx[lvl], SELU, a_pre_act=a_pending[lvl], products=products[lvl],
                                                 keep_e=not last_use)
                     products[lvl] = None
-                a_pending[lvl] = SELU
+                a_pending[lvl] = _blocks.pending_act(a[lvl])       # (SELU; none when the rows came back compact and activated)
             elif op == "down":
                 a_x, idx_x = (a12, g.angle_index12) if lvl == 1 else (a23, g.angle_index23)
                 e[lvl + 1] = block(e[lvl], e[lvl + 1], a_x, idx_x, activation="selu")

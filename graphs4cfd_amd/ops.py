@@ -513,7 +513,7 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                 resid: Optional[Tensor] = None, resid_col0: int = 0, tile_mode: Optional[int] = None,
                 head_outs: Optional[Sequence[Tensor]] = None, agg: Optional[Tuple[CsrPlan, Tensor, bool]] = None,
                 save: Optional[Sequence[Optional[Tensor]]] = None, mul: Optional[Sequence[Optional[Tensor]]] = None,
-                store_rows: bool = True, rows_dtype: Optional[torch.dtype] = None) -> Optional[Tensor]:
+                store_rows: bool = True, rows_dtype: Optional[torch.dtype] = None, rows_act: int = _lib.ACT_NONE) -> Optional[Tensor]:
     """One fused MLP launch (g4c_mlp_forward).  `tile_mode` (tests / tuning) runs every row through
     g4c_mlp_forward_rows with that kernel variant instead of the library's own choice.
     `head_outs` ([n_rows, 128] tensors, one per head of `packed`): g4c_mlp_forward_heads.
@@ -524,6 +524,9 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
     result instead of bias + SELU (the backward chain of a block, see include/g4c.h).
     `rows_dtype=torch.bfloat16` (rounded-bf16 mode, with an aggregation the launch fuses; ignored otherwise): the output rows are
     stored as bf16 — their consumer rounds them to bf16 on load anyway, and the launch is HBM-bound on them; the aggregate stays fp32.
+    `rows_act=ACT_SELU` (only together with bf16 rows): the stored rows are bf16(SELU(row)) — the activation their reader would apply
+    on load, applied before the one rounding (G4C_DTYPE_BF16_SELU); the aggregate is taken from the un-activated fp32 rows.  Check
+    `out.dtype == torch.bfloat16` on the result to know whether the rows came back compact and activated.
     With gradients enabled and a differentiable input / parameter, the call is recorded for autograd (autograd.py)."""
     if torch.is_grad_enabled():
         from . import autograd as _ag
@@ -580,6 +583,10 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
             if out is not None and out.dtype not in (torch.float32, torch.bfloat16):
                 raise TypeError(f"out: expected float32 or bfloat16, got {out.dtype}")
             o_dt = 1 if (out is not None and out.dtype == torch.bfloat16) else 0
+            if o_dt and rows_act == _lib.ACT_SELU and rows16:
+                o_dt = 2
+            elif rows_act != _lib.ACT_NONE and rows16:
+                raise ValueError("rows_act: only ACT_SELU")
             call = lambda: _lib.check(lib.g4c_mlp_forward_bf16_agg(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out), o_ld, o_dt,
                                                                    act, *tail))
         if KernelTimer.active is None:

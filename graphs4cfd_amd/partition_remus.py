@@ -347,7 +347,8 @@ class RemusPartitionedForward:
             if op == "mp":
                 need_halo(lvl)
                 e[lvl], a[lvl] = impl.mp(name, e[lvl], a[lvl], a_pending[lvl], lvl)
-                a_pending[lvl], fresh[lvl] = SELU, False
+                from .nn.blocks import pending_act
+                a_pending[lvl], fresh[lvl] = pending_act(a[lvl]), False
             elif op == "down":
                 need_halo(lvl)
                 e[lvl + 1] = impl.down(name, e[lvl], e[lvl + 1], ax[lvl], lvl)

@@ -94,6 +94,7 @@ int g4c_weighted_segment_mean(const float *x, int32_t x_ld, const int32_t *x_idx
  * (nn/blocks.py:181,185,229,285,328,332,373,380,456; nn/mus_gnn.py:178-218). */
 #define G4C_DTYPE_F32 0
 #define G4C_DTYPE_BF16 1
+#define G4C_DTYPE_BF16_SELU 2   /* g4c_mlp_forward_bf16_agg out_dtype only: rows stored as bf16(SELU(row)) */
 
 typedef struct {
     const float *ptr;   /* [rows, ld] row-major */
@@ -248,7 +249,10 @@ int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs
 /* the same for the rounded-bf16 mode (g4c_mlp_forward_bf16: leading plane of the stream only).  out_dtype = G4C_DTYPE_BF16 stores
  * the rows as bf16 (out is then a bf16 pointer, out_ld in elements): in this mode the consumer of the rows rounds them to bf16 when
  * it loads them anyway, and the launch is HBM-bound on exactly these rows (REMuS-GNN's angle latents, BASELINE config 3); the
- * aggregate is computed from the fp32 tile and stays fp32. */
+ * aggregate is computed from the fp32 tile and stays fp32.  out_dtype = G4C_DTYPE_BF16_SELU stores bf16(SELU(row)) — the activation
+ * the model applies to the messages after the aggregation (nn/blocks.py:331-333, nn/remus_gnn.py:150-190), which their one reader
+ * would otherwise apply on load (g4c_src_t.pre_act) BEFORE rounding to bf16: stored this way the reader gets bit for bit the operand
+ * it would have formed from fp32 rows (one rounding, after the activation), the aggregate still sees the un-activated fp32 rows. */
 int g4c_mlp_forward_bf16_agg(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
                              int64_t n_rows, void *out, int32_t out_ld, int32_t out_dtype, int32_t act,
                              const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,

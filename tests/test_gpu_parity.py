@@ -1222,3 +1222,24 @@ def test_f16_range_clip_is_reported_and_bf16x6_matches_the_oracle():
         torch.testing.assert_close(out.cpu(), ref, rtol=2e-3, atol=2e-3)
     finally:
         ops.set_mlp_precision(old)
+
+
+def test_remus_bf16_compact_messages_are_bit_identical():
+    """Rounded-bf16 mode (BASELINE config 3): the angle messages stored as bf16(SELU(row)) by the launch that fuses the aggregation
+    (G4C_DTYPE_BF16_SELU, half the bytes) give bit for bit the forward of fp32 message rows — the reader forms the same operand (one
+    rounding, after the activation), the aggregate is taken from the fp32 rows either way."""
+    old = ops.set_mlp_precision("bf16")
+    was = B.COMPACT_MESSAGES
+    try:
+        g = S.remus_graph(20_000, k=5, seed=23).to(DEV)
+        torch.manual_seed(24)
+        model = gfd.nn.NsRotEquiTreeScaleGNN(arch=S.remus_arch(128), device=DEV)
+        outs = []
+        for on in (False, True):
+            B.COMPACT_MESSAGES = on
+            with torch.no_grad():
+                outs.append(model.forward(g).clone())
+        assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+    finally:
+        B.COMPACT_MESSAGES = was
+        ops.set_mlp_precision(old)
