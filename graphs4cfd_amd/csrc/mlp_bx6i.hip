@@ -117,9 +117,7 @@ __device__ __forceinline__ void other_slice(int s, const f32x16 &accE, const f32
 // mlp_bx6_kernel); REFILL (the second tile's phase): step s's fragments are replaced by the next layer's right after their last
 // use.  The phases of a pair are straight-line code (three layers, unrolled), so every refill is a plain redefinition.
 // SP == 2 (two-way fp16 split): two planes, W[step][2] (64 VGPRs), three products per step — the 2^-11 terms in acc1.
-#ifndef G4C_BX6I_VALU_PER_MFMA
-#define G4C_BX6I_VALU_PER_MFMA 8      // SP == 2: vector instructions interleaved after each of the step's three MFMAs
-#endif
+constexpr int BX6I_VALU_PER_MFMA = 8;      // (SP == 2 form only: vector instructions interleaved after each of the step's three MFMAs)
 template <int EK, bool REFILL, int SP>
 __device__ __forceinline__ void m_block(const __bf16 *pa, bf16x8 (&W)[8][SP], __amdgpu_buffer_rsrc_t rs, unsigned lo_b, unsigned wnext,
                                         f32x16 &acc, f32x16 &acc1, const f32x16 &accE, const f32x16 &accE1, const f32x4 (&xe)[4], const Other &o) {
@@ -151,7 +149,7 @@ __device__ __forceinline__ void m_block(const __bf16 *pa, bf16x8 (&W)[8][SP], __
 #pragma unroll
             for (int m = 0; m < (SP == 2 ? 3 : 6); ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, SP == 2 ? G4C_BX6I_VALU_PER_MFMA : 4, 0);              // VALU
+                __builtin_amdgcn_sched_group_barrier(0x002, SP == 2 ? BX6I_VALU_PER_MFMA : 4, 0);              // VALU
             }
             __builtin_amdgcn_sched_group_barrier(0x200, SP, 0);                 // DS write
         }
@@ -169,25 +167,14 @@ __device__ __forceinline__ void m_block(const __bf16 *pa, bf16x8 (&W)[8][SP], __
     }
 }
 
-#ifndef G4C_BX6I_F16_WGS
-#define G4C_BX6I_F16_WGS 3
-#endif
-#ifndef G4C_BX6I_ROW_STORES
-#define G4C_BX6I_ROW_STORES 1
-#endif
-#ifndef G4C_BX6I_ROW_STORES_PLAIN
-#define G4C_BX6I_ROW_STORES_PLAIN 1      // the same for the launches without aggregation (one more barrier)
-#endif
-#ifndef G4C_BX6I_LATE_W
-#define G4C_BX6I_LATE_W 1
-#endif
-#ifndef G4C_BX6I_DEFER_B
-#define G4C_BX6I_DEFER_B 0      // 1: tile B's additive rows are consumed after M(A,0) — 32 more live registers, 24-28 spilled: 469 us against 382
-#endif
+// (Round 3: this kernel takes the bf16x6 stream only — the two-way instantiation's knobs (workgroups per CU, late first-layer weight
+// fetch, deferred additive rows of tile B: 24 - 28 spilled registers, 469 us against 382) went with it.  Finished rows are stored
+// from their LDS copy, whole rows per store instruction, with and without the fused aggregation: -20 us on the level-1 launch.)
+constexpr bool BX6I_ROW_STORES = true;
 // DIRECT: the weighted block's rows are the tile's own rows (no gather index: the MP layers' edge latents) — their loads do not wait
 // for the index round trip.
 template <bool AGG, int SP, bool DIRECT>
-__global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_kernel(const Params p) {
+__global__ __launch_bounds__(256, 2) void mlp_bx6i_kernel(const Params p) {
     // two tiles' operand planes + gather indices: 52 992 B; 96 stationary weight registers -> two workgroups per CU
     // (SP == 2: 35 584 B, 64 weight registers, 168 VGPRs -> three workgroups per CU: 385 us against 412 us at two, level-1 launch)
     constexpr int TILE_BF16 = SP * PLN;
@@ -262,7 +249,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
     };
     // LATE_W: the first layer's weights (L2 hits) are fetched after tile A's additive rows are consumed, which leaves the registers
     // for BOTH tiles' additive gathers to be in flight together — one round trip instead of two in front of the first matrix phase
-    constexpr bool LATE_W = G4C_BX6I_LATE_W && SP == 2;
+    constexpr bool LATE_W = false;          // (the two-way instantiation fetched its first layer's weights after tile A's additive rows)
     if (!LATE_W) load_w();
     if (tid < 192) sIdx[0][0][tid] = idx_val;          // [t][k][r] = [tid / 96][(tid % 96) / 32][tid % 32]
     __syncthreads();
@@ -324,7 +311,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
         if (adds) take_adds(accB, b0, b1);
     } else {
         if (adds) { take_adds(accA, a0, a1); issue_adds(1, a0, a1); }
-        if (adds && !G4C_BX6I_DEFER_B) take_adds(accB, a0, a1);
+        if (adds) take_adds(accB, a0, a1);
     }
     __syncthreads();
     BI_STAMP(3);
@@ -347,7 +334,6 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
     constexpr unsigned WB = 2u * BLOCK6;        // bytes of one layer's block of the stream
     // layer 0
     m_block<2, false, SP>(paA, W, rs, lo_b, 0u, accA, accA1, accB, accB1, xB, oB);             // for B: park
-    if (adds && G4C_BX6I_DEFER_B && !LATE_W) take_adds(accB, a0, a1);
     BI_STAMP(4);
     __syncthreads();
     BI_STAMP(5);
@@ -429,7 +415,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
 #pragma unroll
             for (int c = 0; c < 16; ++c) x[c] = g4c::tanh_f(x[c]);
         }
-        if (AGG || G4C_BX6I_ROW_STORES_PLAIN) {
+        if (AGG || BX6I_ROW_STORES) {
 #pragma unroll
             for (int c = 0; c < 16; c += 4) {
                 f32x4 v;
@@ -437,7 +423,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
                 *reinterpret_cast<f32x4 *>(rowp + c) = v;
             }
         }
-        if (!(AGG ? G4C_BX6I_ROW_STORES : G4C_BX6I_ROW_STORES_PLAIN) && p.out && myrow < nrow[t]) {
+        if (!BX6I_ROW_STORES && p.out && myrow < nrow[t]) {
             const long long orow = (!AGG && p.out_idx) ? p.out_idx[row0[t] + myrow] : row0[t] + myrow;      // (g4c_mlp_forward's out_idx)
             float *op = p.out + orow * p.out_ld + cb;
 #pragma unroll
@@ -449,7 +435,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
         }
     }
     BI_STAMP(21);
-    if (!AGG && G4C_BX6I_ROW_STORES_PLAIN && p.out) {
+    if (!AGG && BX6I_ROW_STORES && p.out) {
         // whole rows per store instruction from the LDS copy (as with AGG below); out_idx scatters them (g4c_mlp_forward's out_idx)
         __syncthreads();
 #pragma unroll
@@ -470,7 +456,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_BX6I_F16_WGS : 2) void mlp_bx6i_
         // aggregation of the targets whose messages the tiles hold (rows in CSR order): same summation order and the same mean
         // formula as segment_reduce_kernel, so the result is bit-identical to the separate launch
         __syncthreads();
-        if (G4C_BX6I_ROW_STORES && p.out) {
+        if (BX6I_ROW_STORES && p.out) {
             // the finished rows are in LDS for the reduction anyway: store them from there, 32 lanes along a row (every store
             // instruction of a wave writes two complete 512-byte rows instead of a 16-byte piece of each 64-byte chunk of 8 rows)
 #pragma unroll

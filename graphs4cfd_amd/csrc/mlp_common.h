@@ -166,17 +166,10 @@ __device__ __forceinline__ unsigned pack_f16(f32x2 x, f32x2 &back) {
 // h's), so the fused multiply-add returns exactly (y - h) * 2^11 and the only rounding is the final one to fp16 — as before.
 // (Written as inline assembly: hipcc widens the halves with v_cvt_f32_f16 instead of folding them into the fma.)
 #ifndef G4C_SPLIT_MIX
-#define G4C_SPLIT_MIX 1
+#define G4C_SPLIT_MIX 1      // (0: the conversion form, kept for scripts/split_mix_check.py's bitwise comparison of the two builds)
 #endif
-// Packed-f32 vector instructions (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32) issued beside MFMAs cost ~4 ns each instead of ~0.5
-// in isolation (scripts/micro/mfma_fillers.hip: two v_pk_fma_f32 per 32x32x16 MFMA, two waves per SIMD: 22.4 ns per MFMA against 15.0
-// with two v_fma_f32).  G4C_NO_PK = 1 keeps the epilogue math of the matrix phases on plain instructions (the empty asm stops hipcc's
-// SLP vectoriser from re-packing them) — in the kernels here that is 16 more instructions per phase and measured no faster (a phase
-// of mlp_ws_kernel: 1868 against 1736 cycles), because every vector instruction beyond ~2 per 16x16x32 MFMA is exposed anyway: off.
-#ifndef G4C_NO_PK
-#define G4C_NO_PK 0
-#endif
-__device__ __forceinline__ float opaque_f32(float x) { asm volatile("" : "+v"(x)); return x; }
+// (Packed-f32 vector instructions beside MFMAs cost ~4 ns each in isolation — scripts/micro/mfma_fillers.hip — but replacing the three
+// this split and the SELU use by plain instructions made a phase of mlp_ws_kernel no faster: 1868 against 1736 cycles)
 // Range tracking of the f16x3 arithmetic: every value that is converted to fp16 (MLP inputs when they are parked, hidden
 // activations in the epilogues) is also compared with the end of the fp16 range; a wave that saw a clipped value writes the flag word
 // once, at the end of the kernel (a plain store of 1: nothing is written on the fast path).  Two trackers:
@@ -210,9 +203,7 @@ __device__ __forceinline__ void split_pair_f16(f32x2 y, unsigned &hu, unsigned &
     b[0] = (_Float16)y[0]; b[1] = (_Float16)y[1];
     hu = __builtin_bit_cast(unsigned, b);
     if (G4C_SPLIT_MIX) {
-        f32x2 ys;
-        if (G4C_NO_PK) { ys[0] = opaque_f32(y[0] * F16_LO_SCALE); ys[1] = opaque_f32(y[1] * F16_LO_SCALE); }
-        else ys = y * F16_LO_SCALE;
+        const f32x2 ys = y * F16_LO_SCALE;
         const float c = -F16_LO_SCALE;
         asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lu) : "v"(hu), "s"(c), "v"(ys[0]));
         asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu) : "v"(hu), "s"(c), "v"(ys[1]));

@@ -105,9 +105,10 @@ template <int NCT> struct RingN { typename BVec<NCT>::type s0, s1, s2, s3, s4, s
 __device__ __forceinline__ float bget(const f32x4 &b, int k) { return b[k]; }
 __device__ __forceinline__ float bget(const float2 &b, int k) { return k ? b.y : b.x; }
 
-#ifndef G4C_SPLIT_PRIO
-#define G4C_SPLIT_PRIO 0
-#endif
+// (tried on this kernel and measured neutral or worse in round 1, now constants: s_setprio around the MFMAs, LayerNorm parameters
+// from global memory at 8 workgroups per CU ("slim"), 7 waves per SIMD)
+constexpr int G4C_SPLIT_PRIO = 0;
+constexpr int G4C_SPLIT_SLIM = 0;
 template <int NCT>
 __device__ __forceinline__ void mma_chunk_n(const float *pa, RingN<NCT> &g, const float *wnext, unsigned lo, AccN<NCT> &acc) {
     float2 a = *reinterpret_cast<const float2 *>(pa);
@@ -132,9 +133,6 @@ __device__ __forceinline__ void mma_chunk_n(const float *pa, RingN<NCT> &g, cons
 #undef G4C_STEP
 }
 
-#ifndef G4C_SPLIT_SLIM
-#define G4C_SPLIT_SLIM 0
-#endif
 // LayerNorm / activation / store of a finished 32-row tile held in sH; rows split over the NW waves of the workgroup.
 // Shared by the column-split kernels.  Needs: all waves' last-layer columns visible in sH (barrier done by the caller).
 template <int NW, int ROWS = 32>
@@ -249,9 +247,7 @@ __device__ __forceinline__ void split_finish(const Params &p, float *sH, const f
     }
 }
 
-#ifndef G4C_SPLIT_B4
-#define G4C_SPLIT_B4 1
-#endif
+constexpr int G4C_SPLIT_B4 = 1;        // 16-byte weight ring slots (two steps per load)
 // ring of four 16-byte slots, each holding this lane's B operands of TWO consecutive steps (NCT == 1)
 struct Ring4 { f32x4 p0, p1, p2, p3; };
 __device__ __forceinline__ void ring4_fill(Ring4 &g, const float *w, unsigned lo4) {
@@ -278,12 +274,7 @@ __device__ __forceinline__ void mma_chunk_4(const float *pa, Ring4 &g, const flo
 #undef G4C_PAIR
 }
 
-#ifndef G4C_SPLIT_SLIM
-#define G4C_SPLIT_SLIM 0
-#endif
-#ifndef G4C_SPLIT_MINW
-#define G4C_SPLIT_MINW 1
-#endif
+constexpr int G4C_SPLIT_MINW = 1;
 template <int NW, bool VEC>
 __global__ __launch_bounds__(64 * NW, G4C_SPLIT_MINW) void mlp_split_kernel(const Params p) {
     constexpr int ROWS = 32, NCT = 4 / NW, NPIECE = 4 / NW;   // pieces (8 rows x 32 cols) of a chunk gathered per wave
@@ -557,10 +548,7 @@ __global__ void pack_layer_kernel(const float *__restrict__ W, int n_out, int k_
 // (g4c_mlp_pack_layer_bx6: [128-k block][column tile][16-k step][plane][lane][8], 6 bytes per weight).
 // Template parameter SP = 3: the above.  SP = 1: only the leading terms (operands ROUNDED to bf16, one product) — the
 // opt-in "bf16" mode of BASELINE config 3 ("bf16 edge-MLP MFMA", ~1e-2 deviation) on the same stream and structure.
-#ifndef G4C_BX6_RING
-#define G4C_BX6_RING 2
-#endif
-constexpr int RD6 = G4C_BX6_RING;              // ring depth in 16-k steps (2 or 4)
+constexpr int RD6 = 2;              // weight ring depth in 16-k steps (4 / 8 measured slower: 483 / 563 us against 446 on the level-1 launch)
 struct Ring6 { bf16x8 h[RD6], m[RD6], l[RD6]; };
 
 // one 128-k block for RT row tiles of 32: per 16-k step and row tile 6 MFMAs from the three LDS planes (plane stride
@@ -568,9 +556,7 @@ struct Ring6 { bf16x8 h[RD6], m[RD6], l[RD6]; };
 // refilled RD6 steps ahead.  A fragments are double-buffered per (step, row tile) item: the next item's three
 // ds_read_b128 are issued before this item's MFMAs.
 
-#ifndef G4C_BX6_TUNE
-#define G4C_BX6_TUNE 0      // tuning bits: 1 = s_setprio around the MFMAs, 2 = no sched_barriers in the MFMA loop
-#endif
+constexpr int G4C_BX6_TUNE = 0;      // (1 = s_setprio around the MFMAs, 2 = no sched_barriers in the MFMA loop: both measured neutral)
 // SP == 2 (two-way fp16 split, mlp_common.h): planes h / l, three products per step — (Wh, xl) and (Wl, xh) into acc1 (the terms
 // that carry the factor 2^-11), (Wh, xh) into acc.
 template <int RT, int SP>
@@ -629,28 +615,19 @@ __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6
 }
 
 
-#ifndef G4C_SEG_CHUNKS
-#define G4C_SEG_CHUNKS 1
-#endif
-#ifndef G4C_SEG_INFLIGHT
-#define G4C_SEG_INFLIGHT 6       // rows of a segment in flight per column chunk when a source is aggregated on load
-#endif
-#ifndef G4C_BX6_MINW
-#define G4C_BX6_MINW 4
-#endif
-#ifndef G4C_F16_RT2_MINW
-#define G4C_F16_RT2_MINW 2      // (RT = 2, SP = 2: 44 registers spilled at three workgroups per CU)
-#endif
-#ifndef G4C_F16_MINW
-#define G4C_F16_MINW 4          // workgroups per CU the SP == 2 instantiations are register-limited for
-#endif
+constexpr int G4C_SEG_CHUNKS = 1;
+constexpr int G4C_SEG_INFLIGHT = 6;     // rows of a segment in flight per column chunk when a source is aggregated on load
+constexpr int G4C_BX6_MINW = 4;         // workgroups per CU the instantiations are register-limited for (launch_bounds)
+constexpr int G4C_F16_MINW = 4;
 // RT = 1: 32-row tile.  RT = 2: 64-row tile — every weight fragment feeds two row tiles (half the L2 -> register weight
 // traffic per row, which is what this kernel stalls on) and every memory round trip of the tile's critical path serves
 // twice the rows.
 // FULL: every weighted input block and every additive block is exactly 128 wide and 16-byte aligned (the MP layers):
 // no column masks anywhere.
 template <int RT, bool VEC, bool FULL, int SP, bool SAVE = false>
-__global__ __launch_bounds__(256, RT == 1 ? (SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) : (SP == 2 ? G4C_F16_RT2_MINW : 3)) void mlp_bx6_kernel(const Params p) {
+__global__ __launch_bounds__(256, SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) void mlp_bx6_kernel(const Params p) {
+    static_assert(RT == 1, "64-row tiles (RT = 2) measured slower in every arithmetic (480 against 446 us, two / three workgroups per CU) and cannot "
+                           "take the fused aggregation: not instantiated since round 3");
     constexpr int ROWS = 32 * RT, NW = 4;
     constexpr int PLN = ROWS * HB;              // one bf16 operand plane [ROWS][136]
     // three operand planes; the fp32 final tile [ROWS][132] aliases them
@@ -1444,14 +1421,12 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
         return bx6i_launch(p, agg != nullptr, f16x2, st);
     } else if (bx6) {
-        static const int64_t rt2_rows = getenv("G4C_BX6_RT2_ROWS") ? atoll(getenv("G4C_BX6_RT2_ROWS")) : (1LL << 40);   // measured slower (2 waves per SIMD): off
         bool full = all_vec;
         for (int s2 = 0; s2 < p.n_src; ++s2) full = full && p.src[s2].width == NP;
         for (int a = 0; a < p.n_add; ++a)
             full = full && p.add[a].width == NP && (p.add[a].ld & 3) == 0 && ((uintptr_t)p.add[a].ptr & 15) == 0;
         const dim3 blk(256);
-        const bool rt2 = !agg && !save && row_count >= rt2_rows && p.n_src <= 2 && p.n_add <= 2;      // 64-row tiles (tuning only)
-        p.n_tiles = agg ? agg->n_tiles : (int)((row_count + (rt2 ? 63 : 31)) / (rt2 ? 64 : 32));
+        p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
         if (p.n_tiles == 0) return G4C_OK;
         const dim3 grid(p.n_tiles);
 #define G4C_BX6_LAUNCH(RT, SP)                                                                         \
@@ -1469,9 +1444,9 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
             else if (all_vec) mlp_bx6_kernel<1, true, false, 3, true><<<grid, blk, 0, st>>>(p);
             else mlp_bx6_kernel<1, false, false, 3, true><<<grid, blk, 0, st>>>(p);
         }
-        else if (f16x2) { if (rt2) G4C_BX6_LAUNCH(2, 2); else G4C_BX6_LAUNCH(1, 2); }
-        else if (round1) { if (rt2) G4C_BX6_LAUNCH(2, 1); else G4C_BX6_LAUNCH(1, 1); }
-        else { if (rt2) G4C_BX6_LAUNCH(2, 3); else G4C_BX6_LAUNCH(1, 3); }
+        else if (f16x2) G4C_BX6_LAUNCH(1, 2);
+        else if (round1) G4C_BX6_LAUNCH(1, 1);
+        else G4C_BX6_LAUNCH(1, 3);
 #undef G4C_BX6_LAUNCH
     } else {
         p.n_tiles = (int)((row_count + 31) / 32);

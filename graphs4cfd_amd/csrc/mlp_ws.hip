@@ -32,9 +32,9 @@ extern "C" int g4c_ws_read_stamps(unsigned long long *host, int n) {
 #define WS_STAMP(k) do {} while (0)
 #endif
 
-// timing-only ablations (wrong results): 1 no epilogue work inside the matrix phases, 2 no MFMAs, 4 no B-fragment reads,
-// 8 no plane writes, 16 no SELU (identity), 32 no fp16 split (h only), 64 plane writes of constant zeros, 128 plane writes to
-// lane-linear (conflict-free) addresses
+// timing-only ablations (wrong results; scripts/build_ws_timing.sh <suffix> -DG4C_WS_ABLATE=<bits>, scripts/ws_stamps.py): 2 no MFMAs,
+// 4 no B-fragment reads beyond the first two slices, 16 no SELU (identity), 32 no fp16 split (l = h).  (Removing the plane WRITES is
+// not a valid ablation: hipcc then treats the never-written planes as undefined and drops half of the MFMAs with them.)
 #ifndef G4C_WS_ABLATE
 #define G4C_WS_ABLATE 0
 #endif
@@ -67,25 +67,12 @@ struct Other {
     __bf16 *plane_acc;        // EK 1: this lane's element (row n, feature fcol) of the other tile's planes (swizzled address)
     __bf16 *plane_park;       // EK 2: (row prow, column pc) (swizzled address)
     float *fin;               // EK 3: (row n, feature fcol) of the other tile's fp32 rows
-    int lin_off;              // (timing ablation 128: element offset of plane_acc inside its tile)
 };
 
-#define G4C_WS_SCALAR_MATH G4C_NO_PK      // no packed-f32 vector ALU instructions in the epilogue (mlp_common.h)
-__device__ __forceinline__ float opaque(float x) { return opaque_f32(x); }
 __device__ __forceinline__ f32x2 selu2w(f32x2 x) {
     if (G4C_WS_ABLATE & 16) return x;
     const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f;
     const float scale = 1.0507009873554804934193349852946f;
-    if (G4C_WS_SCALAR_MATH) {
-        f32x2 y;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float m = fmaxf(x[e], 0.f);
-            const float t = __builtin_amdgcn_exp2f(opaque(fminf(x[e], 0.f) * 1.4426950408889634f));
-            y[e] = fmaf(m, scale, opaque(fmaf(t, sa, -sa)));
-        }
-        return y;
-    }
     f32x2 t, m;
 #pragma unroll
     for (int e = 0; e < 2; ++e) { m[e] = fmaxf(x[e], 0.f); t[e] = fminf(x[e], 0.f); }
@@ -95,11 +82,11 @@ __device__ __forceinline__ f32x2 selu2w(f32x2 x) {
     return m * scale + (t * sa - sa);
 }
 
-// two-way fp16 split of a pair -> one packed pair per plane (split_pair_f16, mlp_common.h: four vector instructions)
+// two-way fp16 split of a pair -> one packed pair per plane (split_pair_f16, mlp_common.h: four vector instructions + the range tracker)
 __device__ __forceinline__ void put_pair_f16(__bf16 *d, f32x2 y, RangeV &rng) {
     unsigned hu, lu;
     split_pair_f16(y, hu, lu, rng);
-    if (G4C_WS_ABLATE & 8) { asm volatile("" :: "v"(hu), "v"(lu)); return; }
+    if (G4C_WS_ABLATE & 32) lu = hu;
     *reinterpret_cast<unsigned *>(d) = hu;
     *reinterpret_cast<unsigned *>(d + PLN) = lu;
 }
@@ -113,119 +100,25 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-// plane writes: 0 = one ds_write2st64_b32 per pair as soon as it is split; 1 = two ds_write_b64 per unit (after its second pair);
-// 2 = all four ds_write_b64 of the block after its last MFMA.  Measured per-pair period: 15 706 / 15 714 / 15 950 cycles.
-#ifndef G4C_WS_WRITE_MODE
-#define G4C_WS_WRITE_MODE 0
-#endif
-struct Pend { unsigned h[2][2], l[2][2]; };       // [unit][pair] packed fp16 pairs waiting to be written
-
-template <int EK>
-__device__ __forceinline__ void flush_unit(int u, const Other &o, const Pend &w) {
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    __bf16 *d = (EK == 1 ? o.plane_acc : o.plane_park) + u * 16 * PS;
-    u32x2 hh, ll;
-    hh[0] = w.h[u][0]; hh[1] = w.h[u][1]; ll[0] = w.l[u][0]; ll[1] = w.l[u][1];
-    if (G4C_WS_ABLATE & 8) { asm volatile("" :: "v"(hh), "v"(ll)); return; }
-    if (G4C_WS_ABLATE & 64) { asm volatile("" :: "v"(hh), "v"(ll)); hh[0] = 0; hh[1] = 0; ll = hh; }            // constant data: no dependency on the VALU chain
-    if (G4C_WS_ABLATE & 128) d = const_cast<__bf16 *>(o.plane_acc) - o.lin_off + 4 * (threadIdx.x & 63) + u * 1024 + (EK == 1 ? 0 : 256);   // lane-linear addresses: conflict-free
-    *reinterpret_cast<u32x2 *>(d) = hh;
-    *reinterpret_cast<u32x2 *>(d + PLN) = ll;
-}
-
-// Stage-per-slice form of the hidden-layer epilogue / the park (EK 1 / 2): every slice of the block applies ONE stage to all
-// eight values of the phase, so the vector instructions of a slice are independent of each other.  A wave issues in order: in the
-// pair-at-a-time form below every instruction waits for the one before it (fold -> min -> mul -> exp -> fma -> fma -> cvt -> mul ->
-// mix: ten levels, two values wide), and a stalled vector instruction also holds back the wave's next MFMA.
-#ifndef G4C_WS_STAGED
-#define G4C_WS_STAGED 0          // (measured the same as the pair-at-a-time form: 1784 against 1736 cycles per phase)
-#endif
-struct Stage8 { float x[8], m[8]; };
 template <int EK, bool PACT>
-__device__ __forceinline__ void other_stage(int s, const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, Stage8 &q, Pend &w, RangeV &rng) {
-    const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f;
-    const float scale = 1.0507009873554804934193349852946f;
-    const bool act = EK == 1 || PACT;
-    if (s == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q.x[i] = EK == 1 ? fmaf(accE1[i >> 2][i & 3], F16_LO_UNSCALE, accE[i >> 2][i & 3]) : xe[i >> 2][i & 3];
-    } else if (s == 1) {
-        if (act) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { if (G4C_WS_ABLATE & 512) { q.m[i] = q.x[i]; continue; } q.m[i] = fmaxf(q.x[i], 0.f); q.x[i] = fminf(q.x[i], 0.f); }
-        }
-    } else if (s == 2) {
-        if (act) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) q.x[i] = (G4C_WS_ABLATE & 1024) ? q.x[i] : opaque(q.x[i] * 1.4426950408889634f);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) q.x[i] = (G4C_WS_ABLATE & 256) ? opaque(q.x[i] + 1.f) : __builtin_amdgcn_exp2f(q.x[i]);
-        }
-    } else if (s == 3) {
-        if (act) {
-#pragma unroll
-            for (int i = 4; i < 8; ++i) q.x[i] = (G4C_WS_ABLATE & 256) ? opaque(q.x[i] + 1.f) : __builtin_amdgcn_exp2f(q.x[i]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) q.x[i] = (G4C_WS_ABLATE & 1024) ? q.x[i] : opaque(fmaf(q.x[i], sa, -sa));
-        }
-    } else if (s == 4) {
-        if (act) {
-#pragma unroll
-            for (int i = 4; i < 8; ++i) q.x[i] = (G4C_WS_ABLATE & 1024) ? q.x[i] : opaque(fmaf(q.x[i], sa, -sa));
-#pragma unroll
-            for (int i = 0; i < 8; ++i) q.x[i] = (G4C_WS_ABLATE & 1024) ? q.x[i] + q.m[i] : fmaf(q.m[i], scale, q.x[i]);
-        }
-    } else if (s == 5) {
-        // h = fp16(y) for the four pairs; m <- y * 2^11
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f16x2 b;
-            b[0] = (_Float16)q.x[2 * j]; b[1] = (_Float16)q.x[2 * j + 1];
-            { f32x2 yy; yy[0] = q.x[2 * j]; yy[1] = q.x[2 * j + 1]; range_track(rng, yy); }
-            w.h[j >> 1][j & 1] = __builtin_bit_cast(unsigned, b);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) q.m[i] = opaque(q.x[i] * F16_LO_SCALE);
-    } else if (s == 6) {
-        const float c = -F16_LO_SCALE;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(w.l[j >> 1][j & 1]) : "v"(w.h[j >> 1][j & 1]), "s"(c), "v"(q.m[2 * j]));
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(w.l[j >> 1][j & 1]) : "v"(w.h[j >> 1][j & 1]), "s"(c), "v"(q.m[2 * j + 1]));
-    } else if (s == 7) {
-        flush_unit<EK>(0, o, w); flush_unit<EK>(1, o, w);
-    }
-}
-
-template <int EK, bool PACT>
-__device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, f32x2 &hold, Pend &w, RangeV &rng) {
+__device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, f32x2 &hold, RangeV &rng) {
     const int u = s >> 2, pc4 = s & 3, pr = pc4 >> 1;
     if (EK == 1) {
         if ((pc4 & 1) == 0) {
             f32x2 x, x1;
             x[0] = accE[u][2 * pr]; x[1] = accE[u][2 * pr + 1];
             x1[0] = accE1[u][2 * pr]; x1[1] = accE1[u][2 * pr + 1];
-            if (G4C_NO_PK) { x[0] = fmaf(x1[0], F16_LO_UNSCALE, x[0]); x[1] = fmaf(x1[1], F16_LO_UNSCALE, x[1]); }
-            else x = x1 * F16_LO_UNSCALE + x;
-            hold = selu2w(x);
-        } else if (G4C_WS_WRITE_MODE == 0) {
-            put_pair_f16(o.plane_acc + u * 16 * PS + 2 * pr, hold, rng);
+            hold = selu2w(x1 * F16_LO_UNSCALE + x);         // (the fold is one v_pk_fma_f32)
         } else {
-            split_pair_f16(hold, w.h[u][pr], w.l[u][pr], rng);
-            if (G4C_WS_WRITE_MODE == 1 && pr == 1) flush_unit<EK>(u, o, w);
+            put_pair_f16(o.plane_acc + u * 16 * PS + 2 * pr, hold, rng);
         }
     } else if (EK == 2) {
         if ((pc4 & 1) == 0) {
             f32x2 x;
             x[0] = xe[u][2 * pr]; x[1] = xe[u][2 * pr + 1];
             hold = PACT ? selu2w(x) : x;
-        } else if (G4C_WS_WRITE_MODE == 0) {
-            put_pair_f16(o.plane_park + u * 16 * PS + 2 * pr, hold, rng);
         } else {
-            split_pair_f16(hold, w.h[u][pr], w.l[u][pr], rng);
-            if (G4C_WS_WRITE_MODE == 1 && pr == 1) flush_unit<EK>(u, o, w);
+            put_pair_f16(o.plane_park + u * 16 * PS + 2 * pr, hold, rng);
         }
     } else if (EK == 3) {
         if (pc4 == 0) {
@@ -237,13 +130,9 @@ __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const
     }
 }
 
-#ifndef G4C_WS_VALU_PER_MFMA
-#define G4C_WS_VALU_PER_MFMA 4
-#endif
-#ifndef G4C_WS_CLUSTER
-#define G4C_WS_CLUSTER 0          // 0: one MFMA, a few vector instructions, ...; 1 / 2: the MFMAs of one / two slices back to back, then the vector work
-#endif
-
+// vector instructions scheduled behind each MFMA of a slice (measured: 3, 4, 6 and MFMAs in bursts of 3 / 6 with the vector work behind
+// them all within 3 % of each other — DESIGN.md 4.1 "What bounds it")
+constexpr int WS_VALU_PER_MFMA = 4;
 // One 128-k block for one tile: acc += W(layer) x planes, 8 slices (k-step ks = s / 2, sample row block rb = s % 2) of three
 // products each: (Wh, xl) and (Wl, xh) into acc1 (the 2^-11 terms), (Wh, xh) into acc.  pa[ks]: this lane's B-operand address
 // (row n, granule (4 ks + g) ^ n) in the tile's h plane.
@@ -258,9 +147,6 @@ __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16
         fh[s] = *reinterpret_cast<const bf16x8 *>(pn); fl[s] = *reinterpret_cast<const bf16x8 *>(pn + PLN);
     }
     f32x2 hold = {0.f, 0.f};
-    Pend w;
-    Stage8 q;
-    constexpr bool STAGED = G4C_WS_STAGED && (EK == 1 || EK == 2);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int ks = s >> 1, rb = s & 1;
@@ -270,7 +156,7 @@ __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16
             fl[(s + 2) % 3] = *reinterpret_cast<const bf16x8 *>(pn + PLN);
         }
         if (!EK) __builtin_amdgcn_sched_barrier(0);
-        if (!(G4C_WS_ABLATE & 1)) { if (STAGED) other_stage<EK, PACT>(s, accE, accE1, xe, o, q, w, rng); else other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, w, rng); }
+        other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, rng);
         const bf16x8 ch = fh[s % 3], cl = fl[s % 3];
         if (G4C_WS_ABLATE & 2) {
             asm volatile("" :: "v"(ch), "v"(cl));
@@ -279,37 +165,25 @@ __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16
         acc[rb] = mfma16(W[ks][0], ch, acc[rb]);
         acc1[rb] = mfma16(W[ks][1], ch, acc1[rb]);
         }
-        if (EK && G4C_WS_CLUSTER == 0) {
+        if (EK) {
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                  // DS read (fragments two slices ahead)
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, G4C_WS_VALU_PER_MFMA, 0);      // VALU
+                __builtin_amdgcn_sched_group_barrier(0x002, WS_VALU_PER_MFMA, 0);      // VALU
             }
             __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                  // DS write
-        } else if (EK && (G4C_WS_CLUSTER == 1 || (s & 1))) {
-            // MFMAs in bursts (one or two slices' worth), the vector work behind them: the two waves of a SIMD then run in anti-phase,
-            // one in its matrix burst while the other is in its vector burst
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * G4C_WS_CLUSTER, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * G4C_WS_CLUSTER, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 40, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
         }
-        if (G4C_WS_CLUSTER < 2 || (s & 1)) __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    if (!STAGED && (EK == 1 || EK == 2) && G4C_WS_WRITE_MODE == 2 && !(G4C_WS_ABLATE & 1)) { flush_unit<EK>(0, o, w); flush_unit<EK>(1, o, w); }
 }
 
 // a whole unit outside a matrix phase (the first tile of a pair is parked with nothing to overlap with; B's last rows)
 template <int EK, bool PACT>
 __device__ __forceinline__ void other_all(const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, RangeV &rng) {
     f32x2 hold = {0.f, 0.f};
-    Pend w;
-    Stage8 q;
-    constexpr bool STAGED = G4C_WS_STAGED && (EK == 1 || EK == 2);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { if (STAGED) other_stage<EK, PACT>(s, accE, accE1, xe, o, q, w, rng); else other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, w, rng); }
-    if (!STAGED && (EK == 1 || EK == 2) && G4C_WS_WRITE_MODE == 2) { flush_unit<EK>(0, o, w); flush_unit<EK>(1, o, w); }
+    for (int s = 0; s < 8; ++s) other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, rng);
 }
 
 template <bool AGG, bool DIRECT, bool ADDS>
@@ -459,8 +333,8 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         const int l32 = tid & 31;
         const int acc_off = n * PS + 8 * ((2 * wave + (g >> 1)) ^ n) + 4 * (g & 1);            // features fcol .. fcol + 3 of row n
         const int park_off = prow * PS + 8 * ((l32 >> 1) ^ prow) + 4 * (l32 & 1);               // columns pc .. pc + 3 of row prow
-        oA.plane_acc = sA + acc_off; oA.plane_park = sA + park_off; oA.fin = fA + n * HS + fcol; oA.lin_off = acc_off;
-        oB.plane_acc = sB + acc_off; oB.plane_park = sB + park_off; oB.fin = fB + n * HS + fcol; oB.lin_off = acc_off;
+        oA.plane_acc = sA + acc_off; oA.plane_park = sA + park_off; oA.fin = fA + n * HS + fcol;
+        oB.plane_acc = sB + acc_off; oB.plane_park = sB + park_off; oB.fin = fB + n * HS + fcol;
     }
     const __bf16 *paA[4], *paB[4];
 #pragma unroll
