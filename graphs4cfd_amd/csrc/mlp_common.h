@@ -285,6 +285,6 @@ int bx6i_launch(const Params &p, bool agg, bool f16x2, hipStream_t st);
 // weight-stationary persistent kernel (mlp_ws.hip): f16x3 stream only
 int ws_enable(int on);
 bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count);
-int ws_launch(const Params &p, bool agg, hipStream_t st);
+int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st);
 
 }  // namespace g4cm

@@ -1222,6 +1222,14 @@ extern "C" int g4c_mlp_forward_heads_bx6(const g4c_mlp_t *mlp, const g4c_src_t *
                       (const float *)head_w, n_heads, head_out, head_ld, stream);
 }
 
+extern "C" int g4c_mlp_forward_heads_bf16(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                                          float *out, int32_t out_ld, int32_t act,
+                                          const void *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream) {
+    G4C_REQUIRE(n_heads >= 1 && n_heads <= G4C_MAX_HEADS && head_w && head_out, G4C_EINVAL, "g4c_mlp_forward_heads_bf16: bad heads (n=%d)", n_heads);
+    return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3216, out, out_ld, nullptr, act, nullptr, 0, 0,
+                      (const float *)head_w, n_heads, head_out, head_ld, stream);
+}
+
 extern "C" int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                        float *out, int32_t out_ld, int32_t act,
                                        const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,
@@ -1399,7 +1407,6 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     p.n_heads = n_heads; p.head_ld = head_ld;
     for (int hd = 0; hd < G4C_MAX_HEADS; ++hd) p.head_out[hd] = hd < n_heads ? head_out[hd] : nullptr;
     if (n_heads) {
-        G4C_REQUIRE(!round1, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads: no rounded-bf16 variant");
         G4C_REQUIRE((head_ld & 3) == 0 || !bx6, G4C_EINVAL, "g4c_mlp_forward_heads: head outputs need a leading dimension that is a multiple of 4");
         G4C_REQUIRE(p.n_out == NP && !resid && !out_idx && head_ld >= NP, G4C_EINVAL,
                     "g4c_mlp_forward_heads: heads need a 128-wide output without residual / output index (n_out=%d)", p.n_out);
@@ -1415,7 +1422,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     if (bx6 && !force_tiles && ws_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
         // weight-stationary persistent kernel (mlp_ws.hip): pairs of 32-row tiles (whole segments with aggregation), one workgroup per CU
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
-        return ws_launch(p, agg != nullptr, st);
+        return ws_launch(p, agg != nullptr, round1, st);
     } else if (bx6 && !force_tiles && bx6i_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
         // dual-tile software-pipelined kernel (mlp_bx6i.hip): pairs of 32-row tiles (whole segments with aggregation)
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);

@@ -15,9 +15,12 @@
 //     LayerNorm / store / aggregation tail, so no dependent memory round trip is left on a pair's critical path;
 //   * inside a pair the two tiles alternate layer by layer as in mlp_bx6i_kernel: while a wave issues the MFMAs of one tile its
 //     vector ALUs run the other tile's epilogue (bias is the accumulator start value; SELU, fp16 split, planes).
-// Envelope (everything else keeps mlp_bx6_kernel / mlp_bx6i_kernel): f16x3 stream, ONE weighted 128-wide 16-byte aligned input block
-// (rows direct or through an index, optional SELU on load), 0 or 2 additive 128-wide blocks, three layers, 128-wide output rows
-// without residual / heads; an output index only without the fused aggregation.
+// Envelope (everything else keeps mlp_bx6_kernel / mlp_bx6i_kernel): f16x3 stream (SP = 2) or the rounded-bf16 mode (SP = 1: one
+// v_mfma_f32_16x16x32_bf16 per multiply-add on the leading plane of the bf16x6 stream, operands rounded to bf16 exactly where
+// mlp_bx6_kernel<.., SP = 1> rounds them; there the rows of the weighted block may be bf16 and the output rows may be stored as bf16 /
+// bf16(SELU) — g4c_mlp_forward_bf16_agg), ONE weighted 128-wide aligned input block (rows direct or through an index, optional SELU on
+// load), 0 or 2 additive 128-wide blocks (SP = 1: 2), two or three layers, 128-wide output rows without residual / heads; an output
+// index only without the fused aggregation.
 #include "mlp_common.h"
 #include <cstdlib>
 using namespace g4cm;
@@ -51,8 +54,10 @@ constexpr int TILE_BF16 = 2 * PLN;      // two planes (h, l * 2^11)
 constexpr int FIN = 32 * HS;            // floats of a tile's fp32 final rows [32][132]
 constexpr int SEGCAP = 64;              // segment offsets of a tile staged in LDS (more segments: read from global memory)
 
+template <int SP>
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    if constexpr (SP == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
 // rows [r0, r0 + n) and segments [s0, s1) of the two tiles of a pair (wave-uniform)
@@ -83,12 +88,21 @@ __device__ __forceinline__ f32x2 selu2w(f32x2 x) {
 }
 
 // two-way fp16 split of a pair -> one packed pair per plane (split_pair_f16, mlp_common.h: four vector instructions + the range tracker)
-__device__ __forceinline__ void put_pair_f16(__bf16 *d, f32x2 y, RangeV &rng) {
-    unsigned hu, lu;
-    split_pair_f16(y, hu, lu, rng);
-    if (G4C_WS_ABLATE & 32) lu = hu;
-    *reinterpret_cast<unsigned *>(d) = hu;
-    *reinterpret_cast<unsigned *>(d + PLN) = lu;
+// (SP = 1: the pair rounded to bf16, one plane)
+template <int SP>
+__device__ __forceinline__ void put_pair(__bf16 *d, f32x2 y, RangeV &rng) {
+    if constexpr (SP == 1) {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        bf16x2 b;
+        b[0] = (__bf16)y[0]; b[1] = (__bf16)y[1];
+        *reinterpret_cast<bf16x2 *>(d) = b;
+    } else {
+        unsigned hu, lu;
+        split_pair_f16(y, hu, lu, rng);
+        if (G4C_WS_ABLATE & 32) lu = hu;
+        *reinterpret_cast<unsigned *>(d) = hu;
+        *reinterpret_cast<unsigned *>(d + PLN) = lu;
+    }
 }
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row
@@ -100,7 +114,7 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-template <int EK, bool PACT>
+template <int SP, int EK, bool PACT>
 __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, f32x2 &hold, RangeV &rng) {
     const int u = s >> 2, pc4 = s & 3, pr = pc4 >> 1;
     if (EK == 1) {
@@ -108,9 +122,9 @@ __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const
             f32x2 x, x1;
             x[0] = accE[u][2 * pr]; x[1] = accE[u][2 * pr + 1];
             x1[0] = accE1[u][2 * pr]; x1[1] = accE1[u][2 * pr + 1];
-            hold = selu2w(x1 * F16_LO_UNSCALE + x);         // (the fold is one v_pk_fma_f32)
+            hold = SP == 1 ? selu2w(x) : selu2w(x1 * F16_LO_UNSCALE + x);         // (the fold is one v_pk_fma_f32)
         } else {
-            put_pair_f16(o.plane_acc + u * 16 * PS + 2 * pr, hold, rng);
+            put_pair<SP>(o.plane_acc + u * 16 * PS + 2 * pr, hold, rng);
         }
     } else if (EK == 2) {
         if ((pc4 & 1) == 0) {
@@ -118,13 +132,13 @@ __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const
             x[0] = xe[u][2 * pr]; x[1] = xe[u][2 * pr + 1];
             hold = PACT ? selu2w(x) : x;
         } else {
-            put_pair_f16(o.plane_park + u * 16 * PS + 2 * pr, hold, rng);
+            put_pair<SP>(o.plane_park + u * 16 * PS + 2 * pr, hold, rng);
         }
     } else if (EK == 3) {
         if (pc4 == 0) {
             f32x4 x;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = fmaf(accE1[u][e], F16_LO_UNSCALE, accE[u][e]);
+            for (int e = 0; e < 4; ++e) x[e] = SP == 1 ? accE[u][e] : fmaf(accE1[u][e], F16_LO_UNSCALE, accE[u][e]);
             *reinterpret_cast<f32x4 *>(o.fin + u * 16 * HS) = x;
         }
     }
@@ -136,15 +150,17 @@ constexpr int WS_VALU_PER_MFMA = 4;
 // One 128-k block for one tile: acc += W(layer) x planes, 8 slices (k-step ks = s / 2, sample row block rb = s % 2) of three
 // products each: (Wh, xl) and (Wl, xh) into acc1 (the 2^-11 terms), (Wh, xh) into acc.  pa[ks]: this lane's B-operand address
 // (row n, granule (4 ks + g) ^ n) in the tile's h plane.
-template <int EK, bool PACT = false>
-__device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16x8 (&W)[4][2], f32x4 (&acc)[2], f32x4 (&acc1)[2],
+// (SP = 1: the one product (W, x) of the leading planes, no acc1.)
+template <int SP, int EK, bool PACT = false>
+__device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16x8 (&W)[4][SP], f32x4 (&acc)[2], f32x4 (&acc1)[2],
                                         const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, RangeV &rng) {
     // B fragments (h, l planes) of slice s: row block s % 2, k-step s / 2; fetched two slices ahead of their MFMAs
     bf16x8 fh[3], fl[3];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const __bf16 *pn = pa[s >> 1] + (s & 1) * 16 * PS;
-        fh[s] = *reinterpret_cast<const bf16x8 *>(pn); fl[s] = *reinterpret_cast<const bf16x8 *>(pn + PLN);
+        fh[s] = *reinterpret_cast<const bf16x8 *>(pn);
+        if (SP == 2) fl[s] = *reinterpret_cast<const bf16x8 *>(pn + PLN);
     }
     f32x2 hold = {0.f, 0.f};
 #pragma unroll
@@ -153,41 +169,48 @@ __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16
         if (s + 2 < 8 && !(G4C_WS_ABLATE & 4)) {
             const __bf16 *pn = pa[(s + 2) >> 1] + ((s + 2) & 1) * 16 * PS;
             fh[(s + 2) % 3] = *reinterpret_cast<const bf16x8 *>(pn);
-            fl[(s + 2) % 3] = *reinterpret_cast<const bf16x8 *>(pn + PLN);
+            if (SP == 2) fl[(s + 2) % 3] = *reinterpret_cast<const bf16x8 *>(pn + PLN);
         }
         if (!EK) __builtin_amdgcn_sched_barrier(0);
-        other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, rng);
-        const bf16x8 ch = fh[s % 3], cl = fl[s % 3];
-        if (G4C_WS_ABLATE & 2) {
-            asm volatile("" :: "v"(ch), "v"(cl));
+        other_piece<SP, EK, PACT>(s, accE, accE1, xe, o, hold, rng);
+        const bf16x8 ch = fh[s % 3];
+        if constexpr (SP == 1) {
+            acc[rb] = mfma16<1>(W[ks][0], ch, acc[rb]);
         } else {
-        acc1[rb] = mfma16(W[ks][0], cl, acc1[rb]);
-        acc[rb] = mfma16(W[ks][0], ch, acc[rb]);
-        acc1[rb] = mfma16(W[ks][1], ch, acc1[rb]);
+            const bf16x8 cl = fl[s % 3];
+            if (G4C_WS_ABLATE & 2) {
+                asm volatile("" :: "v"(ch), "v"(cl));
+            } else {
+                acc1[rb] = mfma16<2>(W[ks][0], cl, acc1[rb]);
+                acc[rb] = mfma16<2>(W[ks][0], ch, acc[rb]);
+                acc1[rb] = mfma16<2>(W[ks][1], ch, acc1[rb]);
+            }
         }
         if (EK) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                  // DS read (fragments two slices ahead)
+            __builtin_amdgcn_sched_group_barrier(0x100, SP, 0);                 // DS read (fragments two slices ahead)
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
+            for (int m = 0; m < (SP == 2 ? 3 : 1); ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, WS_VALU_PER_MFMA, 0);      // VALU
+                __builtin_amdgcn_sched_group_barrier(0x002, SP == 2 ? WS_VALU_PER_MFMA : 3 * WS_VALU_PER_MFMA, 0);      // VALU
             }
-            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                  // DS write
+            __builtin_amdgcn_sched_group_barrier(0x200, SP, 0);                 // DS write
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // a whole unit outside a matrix phase (the first tile of a pair is parked with nothing to overlap with; B's last rows)
-template <int EK, bool PACT>
+template <int SP, int EK, bool PACT>
 __device__ __forceinline__ void other_all(const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, RangeV &rng) {
     f32x2 hold = {0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 8; ++s) other_piece<EK, PACT>(s, accE, accE1, xe, o, hold, rng);
+    for (int s = 0; s < 8; ++s) other_piece<SP, EK, PACT>(s, accE, accE1, xe, o, hold, rng);
 }
 
-template <bool AGG, bool DIRECT, bool ADDS>
+// SP: 2 the f16x3 stream, 1 the rounded-bf16 mode;  NL: layers (2 or 3);  XB16 (SP = 1): the weighted block's rows are bf16
+template <bool AGG, bool DIRECT, bool ADDS, int SP, int NL, bool XB16>
 __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const int n_pairs) {
+    static_assert((SP == 1 || SP == 2) && (NL == 2 || NL == 3) && (SP == 1 || !XB16), "mlp_ws_kernel: unsupported instantiation");
     __shared__ __attribute__((aligned(16))) __bf16 sP[2 * TILE_BF16];      // operand planes of tiles A, B (34 816 B)
     __shared__ __attribute__((aligned(16))) float sF[2 * FIN];             // fp32 final rows of tiles A, B (33 792 B)
     __shared__ int sIdx[2][2 * 3 * 32];          // ring of 2: [tile][weighted block, additive 0, additive 1][row]
@@ -285,6 +308,12 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
             for (int hh = 0; hh < 2; ++hh) {
                 const int r = prow + 16 * hh;
                 const int gr = DIRECT ? m.r0[t] + (r < nn ? r : nn - 1) : sIdx[ring][t * 96 + r];
+                if constexpr (XB16) {       // bf16 rows (8-byte aligned: the launcher checks): widened by a shift / a mask — exact
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 w = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const __bf16 *>(p.src[0].ptr) + (long long)gr * p.src[0].ld + p.src[0].col0 + pc);
+                    xr[t][hh][0] = __builtin_bit_cast(float, w[0] << 16); xr[t][hh][1] = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+                    xr[t][hh][2] = __builtin_bit_cast(float, w[1] << 16); xr[t][hh][3] = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+                } else
                 xr[t][hh] = *reinterpret_cast<const f32x4 *>(p.src[0].ptr + (long long)gr * p.src[0].ld + p.src[0].col0 + pc);
             }
         }
@@ -305,8 +334,8 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
     // (pack_layer_bx6_kernel: [column tile][16-k step][plane][(k / 8 % 2) * 32 + feature % 32][k % 8]) one 16-byte piece per (ks, plane)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, 0x7fffffff, 0x00020000);
     const unsigned lo_b = 2u * (unsigned)((wave >> 1) * 8 * STEP6 + (g >> 1) * STEP6 + ((g & 1) * 32 + 16 * (wave & 1) + n) * 8);
-    bf16x8 W[3][4][2];
-    f16_range_mode();
+    bf16x8 W[NL][4][SP];
+    if (SP == 2) f16_range_mode();
     RangeV rng;                       // running max |value converted to fp16| (mlp_common.h range_track)
 
     Meta m0 = fix_meta(load_meta(p_begin)), m1 = fix_meta(load_meta(p_begin + 1)), m2 = fix_meta(load_meta(p_begin + 2));
@@ -316,12 +345,12 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         store_tables(v1, 1);
     }
 #pragma unroll
-    for (int l = 0; l < 3; ++l)
+    for (int l = 0; l < NL; ++l)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) W[l][ks][pl] = ldw(rs, lo_b + 1024u * pl, (unsigned)l * 2u * BLOCK6 + (unsigned)ks * 4u * STEP6);
-    if (tid < 3 * NP) sBias[tid] = p.b[tid];
+            for (int pl = 0; pl < SP; ++pl) W[l][ks][pl] = ldw(rs, lo_b + 1024u * pl, (unsigned)l * 2u * BLOCK6 + (unsigned)ks * 4u * STEP6);
+    if (tid < NL * NP) sBias[tid] = p.b[tid];
     if (tid < 2 * NP) sGB[tid] = p.gamma ? (tid < NP ? p.gamma[tid] : p.beta[tid - NP]) : 0.f;
     __syncthreads();
 
@@ -349,8 +378,8 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
     };
     // start of a pair: tile A's input rows -> planes (nothing to overlap with yet), both tiles' start values = bias + additive rows
     auto open_pair = [&](const f32x4 (&x)[2][2], const f32x4 (&a)[2][2][2]) __attribute__((always_inline)) {
-        if (pact) other_all<2, true>(accA, accA1, x[0], oA, rng);
-        else other_all<2, false>(accA, accA1, x[0], oA, rng);
+        if (pact) other_all<SP, 2, true>(accA, accA1, x[0], oA, rng);
+        else other_all<SP, 2, false>(accA, accA1, x[0], oA, rng);
         bias_init(accA, accA1, 0);
         bias_init(accB, accB1, 0);
         if (ADDS) {
@@ -377,33 +406,35 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         // (no barrier here: tile A's planes were written by open_pair in front of the previous iteration's LayerNorm barrier — the
         // one before the loop for the first pair — and nothing the stragglers of the previous tail still read is written in this phase)
         WS_STAMP(1);
-        if (pact) m_block<2, true>(paA, W[0], accA, accA1, accB, accB1, xr[1], oB, rng);                 // for B: park
-        else m_block<2, false>(paA, W[0], accA, accA1, accB, accB1, xr[1], oB, rng);
+        if (pact) m_block<SP, 2, true>(paA, W[0], accA, accA1, accB, accB1, xr[1], oB, rng);                 // for B: park
+        else m_block<SP, 2, false>(paA, W[0], accA, accA1, accB, accB1, xr[1], oB, rng);
         __syncthreads();
         WS_STAMP(2);
         // ---- rows one pair ahead (indices in LDS since the previous iteration)
         f32x4 nxr[2][2], nad[2][2][2];
         gather_x(m1, (it + 1) & 1, nxr);
-        m_block<1>(paB, W[0], accB, accB1, accA, accA1, xr[1], oA, rng);                 // for A: epilogue of layer 0
+        m_block<SP, 1>(paB, W[0], accB, accB1, accA, accA1, xr[1], oA, rng);                 // for A: epilogue of layer 0
         bias_init(accA, accA1, 1);
         __syncthreads();
         WS_STAMP(3);
         gather_adds(0, (it + 1) & 1, nad[0]);
-        m_block<1>(paA, W[1], accA, accA1, accB, accB1, xr[1], oB, rng);                 // for B: epilogue of layer 0
+        m_block<SP, 1>(paA, W[1], accA, accA1, accB, accB1, xr[1], oB, rng);                 // for B: epilogue of layer 0
         bias_init(accB, accB1, 1);
         __syncthreads();
         WS_STAMP(4);
         gather_adds(1, (it + 1) & 1, nad[1]);
-        m_block<1>(paB, W[1], accB, accB1, accA, accA1, xr[1], oA, rng);                 // for A: epilogue of layer 1
-        bias_init(accA, accA1, 2);
-        __syncthreads();
-        WS_STAMP(5);
-        m_block<1>(paA, W[2], accA, accA1, accB, accB1, xr[1], oB, rng);                 // for B: epilogue of layer 1
-        bias_init(accB, accB1, 2);
-        __syncthreads();
-        WS_STAMP(6);
-        m_block<3>(paB, W[2], accB, accB1, accA, accA1, xr[1], oA, rng);                 // for A: last layer's fp32 rows
-        other_all<3, false>(accB, accB1, xr[1], oB, rng);                                // B's last layer -> fp32 rows
+        if constexpr (NL == 3) {
+            m_block<SP, 1>(paB, W[1], accB, accB1, accA, accA1, xr[1], oA, rng);             // for A: epilogue of layer 1
+            bias_init(accA, accA1, 2);
+            __syncthreads();
+            WS_STAMP(5);
+            m_block<SP, 1>(paA, W[2], accA, accA1, accB, accB1, xr[1], oB, rng);             // for B: epilogue of layer 1
+            bias_init(accB, accB1, 2);
+            __syncthreads();
+            WS_STAMP(6);
+        }
+        m_block<SP, 3>(paB, W[NL - 1], accB, accB1, accA, accA1, xr[1], oA, rng);            // for A: last layer's fp32 rows
+        other_all<SP, 3, false>(accB, accB1, xr[1], oB, rng);                                // B's last layer -> fp32 rows
         __syncthreads();
         WS_STAMP(7);
         // ---- the next pair opens BEFORE this pair's tail: its rows were gathered four phases ago, and the tail's stores are then
@@ -460,8 +491,19 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
             if (AGG) { *reinterpret_cast<f32x4 *>(rowp) = v0; *reinterpret_cast<f32x4 *>(rowp + 4) = v1; }
             if (p.out && row < m0.n[t]) {
                 const long long orow = (!AGG && p.out_idx) ? p.out_idx[m0.r0[t] + row] : m0.r0[t] + row;
-                float *op = p.out + orow * p.out_ld + n * 8;
-                *reinterpret_cast<f32x4 *>(op) = v0; *reinterpret_cast<f32x4 *>(op + 4) = v1;
+                if (SP == 1 && p.out_bf16) {
+                    // rows kept in bf16 (g4c_mlp_forward_bf16_agg out_dtype; == 2: the reader's pending SELU applied before the one
+                    // rounding — the aggregation below still sees the fp32 rows without it), 16 bytes per lane
+                    f32x4 w0 = v0, w1 = v1;
+                    if (p.out_bf16 == 2) { w0 = selu4(v0); w1 = selu4(v1); }         // (the formula the reader's SELU on load uses)
+                    bf16x8 b;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { b[c] = (__bf16)w0[c]; b[4 + c] = (__bf16)w1[c]; }
+                    *reinterpret_cast<bf16x8 *>(reinterpret_cast<__bf16 *>(p.out) + orow * p.out_ld + n * 8) = b;
+                } else {
+                    float *op = p.out + orow * p.out_ld + n * 8;
+                    *reinterpret_cast<f32x4 *>(op) = v0; *reinterpret_cast<f32x4 *>(op + 4) = v1;
+                }
             }
         }
         WS_STAMP(9);
@@ -513,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         WS_STAMP(10);
         m0 = m1; m1 = m2; m2 = fix_meta(m3raw);
     }
-    range_report(p, rng);
+    if (SP == 2) range_report(p, rng);
 }
 
 }  // namespace
@@ -535,23 +577,25 @@ bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, 
     static const long long min_env = getenv("G4C_WS_MIN_ROWS") ? atoll(getenv("G4C_WS_MIN_ROWS")) : -1;
     const long long min_rows = min_env >= 0 ? min_env : 20000;
     const int mode = ws_enable(-1);
-    if (!mode || round1 || save || !f16x2) return false;
+    if (!mode || save || !(f16x2 || round1)) return false;          // (the bf16x6 stream keeps mlp_bx6i_kernel / mlp_bx6_kernel)
     if (mode == 1 && row_count < min_rows) return false;
     if (p.n_src != 1 || p.n_nar != 0 || (p.n_add != 0 && p.n_add != 2) || p.n_heads) return false;
-    if (p.n_layers != 3 || p.n_out != NP || p.resid || p.out_bf16) return false;
+    if (round1 && p.n_add != 2) return false;
+    if ((p.n_layers != 3 && p.n_layers != 2) || p.n_out != NP || p.resid) return false;
+    if (p.out_bf16 && (!round1 || (p.out_ld & 7) || ((uintptr_t)p.out & 15))) return false;
     if (p.out_idx && (agg || !p.out)) return false;          // (scattered output rows: the plain launch only)
     const Src &s = p.src[0];
-    if (s.width != NP || !s.vec || s.seg_off || s.bf16) return false;
+    if (s.width != NP || !s.vec || s.seg_off || (s.bf16 && !round1)) return false;
     for (int a = 0; a < p.n_add; ++a)
         if (p.add[a].width != NP || (p.add[a].ld & 3) || ((uintptr_t)p.add[a].ptr & 15)) return false;
-    if (p.out && ((p.out_ld & 3) || ((uintptr_t)p.out & 15))) return false;
+    if (p.out && !p.out_bf16 && ((p.out_ld & 3) || ((uintptr_t)p.out & 15))) return false;
     if (p.gamma && (((uintptr_t)p.gamma & 15) || ((uintptr_t)p.beta & 15))) return false;
     if (((uintptr_t)p.b & 15)) return false;
     if (p.M >= (1LL << 31)) return false;
     return true;
 }
 
-int ws_launch(const Params &p, bool agg, hipStream_t st) {
+int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st) {
     const int n_pairs = (p.n_tiles + 1) / 2;
     if (n_pairs == 0) return G4C_OK;
     static int n_cu = 0;
@@ -560,15 +604,23 @@ int ws_launch(const Params &p, bool agg, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
     }
     const dim3 grid(n_pairs < n_cu ? n_pairs : n_cu), blk(512);
-    const bool direct = p.src[0].idx == nullptr, adds = p.n_add == 2;
-#define G4C_WS_LAUNCH(AGG, DIRECT)                                                                   \
+    const bool direct = p.src[0].idx == nullptr, adds = p.n_add == 2, two = p.n_layers == 2, xb16 = p.src[0].bf16 != 0;
+#define G4C_WS_GO(AGG, DIRECT, ADDS, SP, NL, XB16) mlp_ws_kernel<AGG, DIRECT, ADDS, SP, NL, XB16><<<grid, blk, 0, st>>>(p, n_pairs)
+#define G4C_WS_SHAPE(AGG, DIRECT)                                                                    \
     do {                                                                                             \
-        if (adds) mlp_ws_kernel<AGG, DIRECT, true><<<grid, blk, 0, st>>>(p, n_pairs);                \
-        else mlp_ws_kernel<AGG, DIRECT, false><<<grid, blk, 0, st>>>(p, n_pairs);                    \
+        if (round1) {                                                                                \
+            if (two) { if (xb16) G4C_WS_GO(AGG, DIRECT, true, 1, 2, true); else G4C_WS_GO(AGG, DIRECT, true, 1, 2, false); }      \
+            else { if (xb16) G4C_WS_GO(AGG, DIRECT, true, 1, 3, true); else G4C_WS_GO(AGG, DIRECT, true, 1, 3, false); }          \
+        } else if (two) {                                                                            \
+            if (adds) G4C_WS_GO(AGG, DIRECT, true, 2, 2, false); else G4C_WS_GO(AGG, DIRECT, false, 2, 2, false);                 \
+        } else {                                                                                     \
+            if (adds) G4C_WS_GO(AGG, DIRECT, true, 2, 3, false); else G4C_WS_GO(AGG, DIRECT, false, 2, 3, false);                 \
+        }                                                                                            \
     } while (0)
-    if (agg) { if (direct) G4C_WS_LAUNCH(true, true); else G4C_WS_LAUNCH(true, false); }
-    else { if (direct) G4C_WS_LAUNCH(false, true); else G4C_WS_LAUNCH(false, false); }
-#undef G4C_WS_LAUNCH
+    if (agg) { if (direct) G4C_WS_SHAPE(true, true); else G4C_WS_SHAPE(true, false); }
+    else { if (direct) G4C_WS_SHAPE(false, true); else G4C_WS_SHAPE(false, false); }
+#undef G4C_WS_SHAPE
+#undef G4C_WS_GO
     return g4c::check_launch("g4c_mlp_forward (ws)");
 }
 

@@ -148,7 +148,7 @@ class MLP(nn.Module):
             return None
         sources = _split_wide(sources)
         prec = ops.effective_precision([s.width for s in sources])
-        if prec == "bf16":
+        if prec == "bf16" and not HOIST_BF16:
             return None
         narrow = tuple(_narrow_flags(sources)) if prec != "fp32" else (False,) * len(sources)
         key = ("heads", id(consumer), k_cols, tuple(widths), tuple(s.width for s in sources), tuple(s.negate for s in sources), prec, narrow)
@@ -212,7 +212,7 @@ class MLP(nn.Module):
         # up-sampling — is hoisted at any size: its products are formed from 128-wide chunks, the launch itself keeps one block)
         too_many = (sum((s.width + 127) // 128 for s in plain) > _lib.MAX_SRC and any(s.width > 128 for s in plain)
                     and ops.mlp_precision() in ("bf16x6", "f16x3") and not ops.grad_mode())
-        if (n_rows < HOIST_MIN_ROWS or ops.mlp_precision() == "bf16" or ops.grad_mode()) and products is None and not too_many:   # (plain bf16 MFMAs are ~free: never hoist)
+        if (n_rows < HOIST_MIN_ROWS or (ops.mlp_precision() == "bf16" and not HOIST_BF16) or ops.grad_mode()) and products is None and not too_many:
             return self.run_coded(plain, n_rows, act_code, **kw)
         kw_widths = [s.width for s in k_sources]
         off = sum(kw_widths)
@@ -312,6 +312,12 @@ def edgeScalarToNodeVector(edge_attr: Tensor, edge_index: Tensor, edgeUnitVector
 # aggregate still sees the un-activated fp32 rows).  Round 2 stored bf16(row) and let the reader apply SELU: two roundings, max
 # deviation from the fp32 reference 3.6e-2 -> 6.5e-2 at 20k nodes, which is why it was opt-in then.  G4C_COMPACT_MESSAGES=0 turns it off.
 COMPACT_MESSAGES = __import__("os").environ.get("G4C_COMPACT_MESSAGES", "1") == "1"
+# Rounded-bf16 mode: the first layer of a message MLP is hoisted as in the other arithmetics (products of the bf16-rounded node rows
+# with the bf16-rounded weights, fp32 accumulate: the operands the unhoisted launch forms, added in another order).  Measured on
+# config 3 (REMuS-GNN, 100k nodes): the level-1 angle launch is not HBM-bound on its gathers (reading them from bf16 copies of the
+# sender rows: 1160 -> 1130 us) but on per-tile latency and vector work; hoisted, with the products from the producer's launch
+# (g4c_mlp_forward_heads_bf16) and the message launch on mlp_ws_kernel<SP = 1>, it takes 1160 -> 800 us.  G4C_HOIST_BF16=0: as before.
+HOIST_BF16 = __import__("os").environ.get("G4C_HOIST_BF16", "1") == "1"
 
 
 def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, aggr: str, act_code: int,

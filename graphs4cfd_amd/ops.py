@@ -393,8 +393,6 @@ class PackedMLP:
             raise ValueError(f"a narrow input block has more than {_lib.NARROW_MAX} columns")
         self.narrow = narrow       # three-plane bf16 weight stream, 128-k input blocks ("bf16" reads plane 0 only)
         planes = 3
-        if precision == "bf16" and heads:
-            raise NotImplementedError("heads in plain bf16")
         dev = _lib.require_hip(*weights, *[b for b in biases if b is not None], *heads)
         n_layers = len(weights)
         if not 1 <= n_layers <= _lib.MAX_LAYERS:
@@ -620,8 +618,8 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
         else:
             _timed("mlp_bx6_kernel", packed.flops_per_row * n_rows, 4.0 * (sum(packed.seg_widths) + packed.n_out + 128 * len(live)) * n_rows, call)
     elif packed.precision != "fp32":
-        if tile_mode is not None or (head_outs is not None and packed.precision == "bf16"):
-            raise NotImplementedError("bf16 MLP with a forced tile mode / plain bf16 with heads")
+        if tile_mode is not None:
+            raise NotImplementedError("bf16 MLP with a forced tile mode")
         if head_outs is not None:
             if len(head_outs) != packed.n_heads or packed.n_heads == 0:
                 raise ValueError(f"{len(head_outs)} head outputs for a packing with {packed.n_heads} heads")
@@ -629,9 +627,10 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                 raise NotImplementedError("heads with an output index / residual")
             _lib.require_hip(*head_outs)
             ho = (C.c_void_p * len(head_outs))(*[h.data_ptr() for h in head_outs])
-            call = lambda: _lib.check(lib.g4c_mlp_forward_heads_bx6(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out),
-                                                                    _ld(out), act, packed.head_w, len(head_outs), ho,
-                                                                    _ld(head_outs[0]), _lib.stream_handle(dev)))
+            heads_fn = lib.g4c_mlp_forward_heads_bf16 if packed.precision == "bf16" else lib.g4c_mlp_forward_heads_bx6
+            call = lambda: _lib.check(heads_fn(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out),
+                                               _ld(out), act, packed.head_w, len(head_outs), ho,
+                                               _ld(head_outs[0]), _lib.stream_handle(dev)))
         else:
             fwd = lib.g4c_mlp_forward_bf16 if packed.precision == "bf16" else lib.g4c_mlp_forward_bx6
             call = lambda: _lib.check(fwd(C.byref(packed.desc), arr, len(sources), n_rows, *args))

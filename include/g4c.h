@@ -263,6 +263,14 @@ int g4c_mlp_forward_heads_bx6(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *sr
                               const void *head_w, int32_t n_heads, float *const *head_out /*host*/, int32_t head_ld,
                               void *stream);
 
+/* the same in the rounded-bf16 mode (stream of g4c_mlp_forward_bf16): head j = bf16(act(y)) x bf16(head weights j), fp32 accumulate —
+ * the operands the consumer's own first layer would form from the gathered rows of y, so its hoisted first layer
+ * (g4c_src_t.additive) adds the same products in another order. */
+int g4c_mlp_forward_heads_bf16(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
+                               int64_t n_rows, float *out, int32_t out_ld, int32_t act,
+                               const void *head_w, int32_t n_heads, float *const *head_out /*host*/, int32_t head_ld,
+                               void *stream);
+
 /* ---------------------------------------------------------------- REMuS helpers (HBM-bound)
  * out[e, f] = v[node[e], 2f]*U[e,0] + v[node[e], 2f+1]*U[e,1]
  * (nn/remus_gnn.py:124-126, nn/blocks.py:454). node == NULL reads row e. */

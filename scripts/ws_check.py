@@ -15,8 +15,6 @@ enable = getattr(lib, f"g4c_mlp_{a.kernel}_enable")
 lib.g4c_mlp_bx6i_enable(0)
 lib.g4c_mlp_ws_enable(0)
 dev = torch.device("cuda", 0); H = 128
-torch.manual_seed(0)
-blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(dev)
 bad = []
 
 
@@ -30,56 +28,89 @@ def both(fn):
     return ref, got
 
 
-def cmp(name, ref, got, tol):
-    d = (ref - got).abs().max().item() if ref.numel() else 0.0
-    ok = d <= tol and bool(torch.isfinite(got).all())
-    print(f"{'ok  ' if ok else 'FAIL'} {name:58s} max|{a.kernel} - tile| = {d:.2e} (tol {tol:g})")
+def cmp(name, ref, got, tol, mean_tol=None):
+    ref, got = ref.float(), got.float()
+    d = (ref - got).abs()
+    dmax = d.max().item() if ref.numel() else 0.0
+    dmean = d.mean().item() if ref.numel() else 0.0
+    ok = dmax <= tol and bool(torch.isfinite(got).all()) and (mean_tol is None or dmean <= mean_tol)
+    print(f"{'ok  ' if ok else 'FAIL'} {name:70s} max|{a.kernel} - tile| = {dmax:.2e} (tol {tol:g})" + (f" mean {dmean:.1e}" if mean_tol is not None else ""))
     if not ok: bad.append(name)
 
 
-for rows in (600000, 100000, 6001, 999, 65, 64, 33, 32, 7, 1):
-    n = max(rows // 6, 2)
-    e, v = torch.randn(rows, H, device=dev), torch.randn(n, H, device=dev)
-    row = torch.randint(0, n, (rows,), device=dev, dtype=torch.int32)
-    col = (torch.arange(rows, device=dev) // 6).clamp(max=n - 1).to(torch.int32)
+def check_variant(prec, layers):
+    """One arithmetic (f16x3 stream / rounded-bf16 mode) and depth (3 = MuS-GNN's MLPs, 2 = REMuS-GNN's).  In the rounded-bf16 mode the
+    two kernels add the products of a row in different orders (16x16x32 against 32x32x16 MFMAs), and a last-bit difference of a hidden
+    pre-activation can flip its rounding to bf16: a few elements differ by ~1e-3, the mean difference stays at round-off level."""
+    ops.set_mlp_precision(prec)
+    torch.manual_seed(0)
+    hid = (H,) * layers
+    blk = B.GNBlock((3 * H, hid, True), (2 * H, hid, True)).to(dev)
+    tol, mtol = (2e-5, None) if prec != "bf16" else (3e-2, 2e-5)
+    tag = f"[{prec}, {layers} layers] "
     W1 = blk.edge_mlp.state_dict()["MLP.linear_1.weight"]
-    pr, pc = (v @ W1[:, H:2 * H].T).contiguous(), (v @ W1[:, 2 * H:].T).contiguous()
     pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
-    src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=row, additive=True), ops.Source(pc, index=col, additive=True)]
-    cmp(f"edge hoisted rows={rows}", *both(lambda: ops.mlp_forward(pk, src, rows)), 2e-5)
-    idx = torch.randint(0, rows, (rows,), device=dev, dtype=torch.int32)
-    cmp(f"one block through an index, SELU out rows={rows}", *both(lambda: ops.mlp_forward(pk, [ops.Source(e, index=idx)], rows, _lib.ACT_SELU)), 2e-5)
-    oidx = torch.randperm(rows, device=dev).to(torch.int32)
-    cmp(f"edge hoisted, scattered output rows={rows}", *both(lambda: ops.mlp_forward(pk, src, rows, out=torch.zeros(rows, H, device=dev), out_idx32=oidx)), 2e-5)
-for rows, ragged in ((600000, False), (19972, True), (116, True)):
-    n = rows // 6
-    if ragged:
-        deg = torch.randint(0, 10, (n,)); deg[0] = 0; deg[-1] = 0
-        colh = torch.arange(n).repeat_interleave(deg)
-    else:
-        colh = torch.arange(n).repeat_interleave(6)
-    E = int(colh.numel())
-    ei = torch.stack([torch.randint(0, n, (E,)), colh]).to(dev)
-    ep, csr = plan.edge_csr(ei, n)
-    e, v = torch.randn(E, H, device=dev), torch.randn(n, H, device=dev)
-    W1 = blk.edge_mlp.state_dict()["MLP.linear_1.weight"]
-    pr, pc = (v @ W1[:, H:2 * H].T).contiguous(), (v @ W1[:, 2 * H:].T).contiguous()
-    pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
-    src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
-    for mean in (True, False):
-        def run():
-            agg = torch.full((n, H), float("nan"), device=dev)
-            y = ops.mlp_forward(pk, src, E, agg=(csr, agg, mean))
-            return y, agg
-        (y0, a0), (y1, a1) = both(run)
-        cmp(f"fused agg rows={E} ragged={ragged} mean={mean}: e'", y0, y1, 2e-5)
-        cmp(f"fused agg rows={E} ragged={ragged} mean={mean}: agg == reduce(e') bit-exact", ops.segment_reduce(y1, csr, mean), a1, 0.0)
-        def run_noe():
-            agg = torch.full((n, H), float("nan"), device=dev)
-            ops.mlp_forward(pk, src, E, agg=(csr, agg, mean), store_rows=False)
-            return agg
-        enable(2); a2 = run_noe(); enable(0)
-        cmp(f"fused agg rows={E} ragged={ragged} mean={mean}: rows not stored, same aggregate", a1, a2, 0.0)
+    for rows in (600000, 100000, 6001, 999, 65, 64, 33, 32, 7, 1):
+        n = max(rows // 6, 2)
+        e, v = torch.randn(rows, H, device=dev), torch.randn(n, H, device=dev)
+        row = torch.randint(0, n, (rows,), device=dev, dtype=torch.int32)
+        col = (torch.arange(rows, device=dev) // 6).clamp(max=n - 1).to(torch.int32)
+        pr, pc = (v @ W1[:, H:2 * H].T).contiguous(), (v @ W1[:, 2 * H:].T).contiguous()
+        src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=row, additive=True), ops.Source(pc, index=col, additive=True)]
+        cmp(tag + f"edge hoisted rows={rows}", *both(lambda: ops.mlp_forward(pk, src, rows)), tol, mtol)
+        idx = torch.randint(0, rows, (rows,), device=dev, dtype=torch.int32)
+        cmp(tag + f"one block through an index, SELU out rows={rows}", *both(lambda: ops.mlp_forward(pk, [ops.Source(e, index=idx)], rows, _lib.ACT_SELU)), tol, mtol)
+        srci = [ops.Source(e, index=idx)] + src[1:]
+        cmp(tag + f"edge hoisted, weighted block through an index rows={rows}", *both(lambda: ops.mlp_forward(pk, srci, rows)), tol, mtol)
+        oidx = torch.randperm(rows, device=dev).to(torch.int32)
+        cmp(tag + f"edge hoisted, scattered output rows={rows}", *both(lambda: ops.mlp_forward(pk, src, rows, out=torch.zeros(rows, H, device=dev), out_idx32=oidx)), tol, mtol)
+    for rows, ragged in ((600000, False), (19972, True), (116, True)):
+        n = rows // 6
+        if ragged:
+            deg = torch.randint(0, 10, (n,)); deg[0] = 0; deg[-1] = 0
+            colh = torch.arange(n).repeat_interleave(deg)
+        else:
+            colh = torch.arange(n).repeat_interleave(6)
+        E = int(colh.numel())
+        ei = torch.stack([torch.randint(0, n, (E,)), colh]).to(dev)
+        ep, csr = plan.edge_csr(ei, n)
+        e, v = torch.randn(E, H, device=dev), torch.randn(n, H, device=dev)
+        pr, pc = (v @ W1[:, H:2 * H].T).contiguous(), (v @ W1[:, 2 * H:].T).contiguous()
+        src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+        for mean in (True, False):
+            def run():
+                agg = torch.full((n, H), float("nan"), device=dev)
+                y = ops.mlp_forward(pk, src, E, agg=(csr, agg, mean))
+                return y, agg
+            (y0, a0), (y1, a1) = both(run)
+            cmp(tag + f"fused agg rows={E} ragged={ragged} mean={mean}: e'", y0, y1, tol, mtol)
+            cmp(tag + f"fused agg rows={E} ragged={ragged} mean={mean}: agg == reduce(e') bit-exact", ops.segment_reduce(y1, csr, mean), a1, 0.0)
+            def run_noe():
+                agg = torch.full((n, H), float("nan"), device=dev)
+                ops.mlp_forward(pk, src, E, agg=(csr, agg, mean), store_rows=False)
+                return agg
+            enable(2); a2 = run_noe(); enable(0)
+            cmp(tag + f"fused agg rows={E} ragged={ragged} mean={mean}: rows not stored, same aggregate", a1, a2, 0.0)
+        if prec == "bf16":
+            # REMuS-GNN's angle launch in this mode: bf16 rows in (stored activated by the previous launch), bf16(SELU(row)) rows out
+            e16 = torch.nn.functional.selu(e).to(torch.bfloat16)
+            src16 = [ops.Source(e16)] + src[1:]
+            for dt, act in ((torch.bfloat16, _lib.ACT_SELU), (torch.bfloat16, _lib.ACT_NONE), (None, _lib.ACT_NONE)):
+                def run16():
+                    agg = torch.full((n, H), float("nan"), device=dev)
+                    y = ops.mlp_forward(pk, src16, E, agg=(csr, agg, True), rows_dtype=dt, rows_act=act)
+                    return y, agg
+                (y0, a0), (y1, a1) = both(run16)
+                assert y1.dtype == (dt or torch.float32)
+                cmp(tag + f"bf16 rows in, out {dt} act {act} rows={E} ragged={ragged}: e'", y0, y1, 6e-2 if dt else tol, 1e-4 if dt else mtol)
+                cmp(tag + f"bf16 rows in, out {dt} act {act} rows={E} ragged={ragged}: aggregate", a0, a1, tol, mtol)
+    ops.set_mlp_precision("f16x3")
+
+
+for prec, layers in (("f16x3", 3), ("f16x3", 2), ("bf16", 2), ("bf16", 3)):
+    check_variant(prec, layers)
+torch.manual_seed(0)
+blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(dev)
 print(f"all {a.kernel} checks passed" if not bad else "FAILED: " + ", ".join(bad))
 if a.time:
     rows = a.rows; n = rows // 6
@@ -108,3 +139,36 @@ if a.time:
                 times[k].append(s_.elapsed_time(t_) / 3 * 1e3)
         setk("tile")
         print(f"{cname:20s} " + "   ".join(f"{k} median {statistics.median(v):8.1f} us (min {min(v):8.1f})" for k, v in times.items()))
+    # REMuS-GNN's level-1 angle launch (config 3): rounded-bf16 mode, 2 layers, 5 angles per edge, bf16 rows in and out, fused aggregation
+    ops.set_mlp_precision("bf16")
+    rows = 2_500_000; n = rows // 5
+    blk2 = B.GNBlock((3 * H, (H, H), True), (2 * H, (H, H), True)).to(dev)
+    e16 = torch.randn(rows, H, device=dev).to(torch.bfloat16)
+    colh = torch.arange(n).repeat_interleave(5)
+    # (senders with the locality of a mesh: a neighbour within +-64 edges)
+    rowh = (colh + torch.randint(-64, 65, (rows,))).clamp(0, n - 1)
+    ei = torch.stack([rowh, colh]).to(dev)
+    ep, csr = plan.edge_csr(ei, n)
+    pr, pc = torch.randn(n, H, device=dev), torch.randn(n, H, device=dev)
+    pk2 = blk2.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+    src2 = [ops.Source(e16), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+    agg2 = torch.empty(n, H, device=dev)
+    src2f = [ops.Source(e16.float())] + src2[1:]
+    cases2 = {"angle(bf16 mode, 2 layers, bf16 rows in / out)+agg": lambda: ops.mlp_forward(pk2, src2, rows, agg=(csr, agg2, True), rows_dtype=torch.bfloat16, rows_act=_lib.ACT_SELU),
+              "angle(bf16 mode, 2 layers, fp32 rows in, bf16 out)+agg": lambda: ops.mlp_forward(pk2, src2f, rows, agg=(csr, agg2, True), rows_dtype=torch.bfloat16, rows_act=_lib.ACT_SELU),
+              "angle(bf16 mode, 2 layers, fp32 rows in / out)+agg": lambda: ops.mlp_forward(pk2, src2f, rows, agg=(csr, agg2, True)),
+              "angle(bf16 mode, 2 layers, bf16 rows in, none out)+agg": lambda: ops.mlp_forward(pk2, src2, rows, agg=(csr, agg2, True), store_rows=False)}
+    for cname, fn in cases2.items():
+        times = {"tile": [], "ws": []}
+        for k in times:
+            setk(k); fn(); fn()
+        torch.cuda.synchronize()
+        for r in range(10):
+            for k in times:
+                setk(k)
+                s_, t_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record(); fn(); fn(); t_.record(); torch.cuda.synchronize()
+                times[k].append(s_.elapsed_time(t_) / 2 * 1e3)
+        setk("tile")
+        print(f"{cname:56s} " + "   ".join(f"{k} median {statistics.median(v):8.1f} us (min {min(v):8.1f})" for k, v in times.items()))
+    ops.set_mlp_precision("f16x3")
