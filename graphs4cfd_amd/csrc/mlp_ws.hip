@@ -31,8 +31,10 @@ extern "C" int g4c_ws_read_stamps(unsigned long long *host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4c_ws_stamps), sizeof(unsigned long long) * n);
 }
 #define WS_STAMP(k) do { if (it == 1 && tid == 0 && blockIdx.x < 256) g4c_ws_stamps[blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define WS_STAMP_ONCE(k, v) do { if (tid == 0 && blockIdx.x < 256) g4c_ws_stamps[blockIdx.x * 32 + (k)] = (v); } while (0)      // 12 kernel start, 13 end, 14 pairs
 #else
 #define WS_STAMP(k) do {} while (0)
+#define WS_STAMP_ONCE(k, v) do {} while (0)
 #endif
 
 // timing-only ablations (wrong results; scripts/build_ws_timing.sh <suffix> -DG4C_WS_ABLATE=<bits>, scripts/ws_stamps.py): 2 no MFMAs,
@@ -235,6 +237,8 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         p_end = __builtin_amdgcn_readfirstlane((int)(((long long)(slot + 1) * n_pairs) / G));
     }
     if (p_begin >= p_end) return;
+    WS_STAMP_ONCE(12, __builtin_readcyclecounter());
+    WS_STAMP_ONCE(14, (unsigned long long)(p_end - p_begin));
 
     // (the loads are issued where load_meta is called; fix_meta — the v_readfirstlanes that wait for them — an iteration later)
     auto load_meta = [&](int pair) __attribute__((always_inline)) {
@@ -555,6 +559,7 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         WS_STAMP(10);
         m0 = m1; m1 = m2; m2 = fix_meta(m3raw);
     }
+    WS_STAMP_ONCE(13, __builtin_readcyclecounter());
     if (SP == 2) range_report(p, rng);
 }
 

@@ -12,7 +12,8 @@ for name, (res, args) in _lib._SIGNATURES.items():
     fn = getattr(lib, name); fn.restype, fn.argtypes = res, args
 _lib._lib = lib
 torch.set_grad_enabled(False)
-bf16 = len(sys.argv) > 2 and sys.argv[2] == "bf16"
+bf16 = len(sys.argv) > 2 and sys.argv[2].startswith("bf16")
+f32in = len(sys.argv) > 2 and sys.argv[2] == "bf16-f32in"
 dev = torch.device("cuda", 0); H = 128
 deg = 5 if bf16 else 6
 rows = 2_500_000 if bf16 else 600000; n = rows // deg
@@ -26,7 +27,7 @@ rowh = (colh + torch.randint(-64, 65, (rows,))).clamp(0, n - 1) if bf16 else tor
 ei = torch.stack([rowh, colh]).to(dev)
 ep, csr = plan.edge_csr(ei, n)
 pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
-src = [ops.Source(e.to(torch.bfloat16)) if bf16 else ops.Source(e, pre_act=_lib.ACT_SELU),
+src = [ops.Source(e) if f32in else ops.Source(e.to(torch.bfloat16)) if bf16 else ops.Source(e, pre_act=_lib.ACT_SELU),
        ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
 out, agg = torch.empty(rows, H, device=dev), torch.empty(n, H, device=dev)
 lib.g4c_mlp_ws_enable(2)
@@ -52,3 +53,6 @@ for k in keys[1:]:
     print(f"{names[k]:62s} median {int(np.median(d)):7d}  (p10 {int(np.percentile(d, 10)):7d}, p90 {int(np.percentile(d, 90)):7d})")
     prev = k
 print("pair period (loop top -> end of tail) median", int(np.median(st[:, 10] - st[:, 0])))
+per = (st[:, 13] - st[:, 12]) / np.maximum(st[:, 14], 1)
+print(f"whole launch, ticks per pair and workgroup: median {np.median(per):.0f}, p10 {np.percentile(per, 10):.0f}, p90 {np.percentile(per, 90):.0f}, max {per.max():.0f};"
+      f" launch span {int(st[:, 13].max() - st[:, 12].min())} ticks, latest start {int(st[:, 12].max() - st[:, 12].min())}")

@@ -1135,52 +1135,75 @@ def test_bx6i_dual_tile_kernel_equals_tile_kernel(rows, kernel, prec, monkeypatc
 
 
 # ------------------------------------------------------------------ the weight-stationary persistent kernel (mlp_ws.hip)
+@pytest.mark.parametrize("variant", [("f16x3", 3), ("f16x3", 2), ("bf16", 2), ("bf16", 3)], ids=lambda v: f"{v[0]}-{v[1]}layers")
 @pytest.mark.parametrize("rows", [1, 33, 6000, 70000])
-def test_ws_persistent_kernel_equals_tile_kernel(rows):
-    """g4c_mlp_ws_enable(2): the weight-stationary persistent f16x3 kernel against the 32-row-tile kernel on the message form (first
+def test_ws_persistent_kernel_equals_tile_kernel(rows, variant):
+    """g4c_mlp_ws_enable(2): the weight-stationary persistent kernel against the 32-row-tile kernel on the message form (first
     layer hoisted, rows direct / through an index / scattered through an output index), with the fused per-target aggregation on
-    regular and ragged segments (bit-exact reduction of the rows it stores, same aggregate when the rows are not stored)."""
+    regular and ragged segments (bit-exact reduction of the rows it stores, same aggregate when the rows are not stored) — in the
+    f16x3 stream and in the rounded-bf16 mode, for three-layer (MuS-GNN) and two-layer (REMuS-GNN) MLPs; in the rounded-bf16 mode
+    also with bf16 rows in and bf16 / bf16(SELU) rows out (g4c_mlp_forward_bf16_agg: REMuS-GNN's angle launches).
+    Rounded-bf16 tolerance: the kernels add a row's products in different orders, and a last-bit difference of a hidden
+    pre-activation can flip its rounding to bf16 (single elements differ by ~1e-3, the mean difference is round-off)."""
+    prec, layers = variant
     if ops.mlp_precision() != "f16x3":
-        pytest.skip("the weight-stationary kernel takes the f16x3 stream only")
+        pytest.skip("runs under the default arithmetic only (it sets the mode itself)")
     lib = _lib.load()
     H, n = 128, max(rows // 6, 2)
-    torch.manual_seed(rows)
-    blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
-    v = torch.randn(n, H, device=DEV)
-    deg = torch.full((n,), 6, dtype=torch.long) if rows != 6000 else torch.randint(0, 10, (n,))
-    col = torch.arange(n).repeat_interleave(deg)
-    E = int(col.numel())
-    edge_index = torch.stack([torch.randint(0, n, (E,)), col]).to(DEV)
-    e = torch.randn(E, H, device=DEV)
-    ep, csr = plan.edge_csr(edge_index, n)
-    W1 = blk.edge_mlp.state_dict()["MLP.linear_1.weight"]
-    pr, pc = (v @ W1[:, H:2 * H].T).contiguous(), (v @ W1[:, 2 * H:].T).contiguous()
-    pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
-    src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
-    idx = torch.randint(0, E, (E,), device=DEV, dtype=torch.int32)
-    oidx = torch.randperm(E, device=DEV).to(torch.int32)
-
-    def run():
-        out = {"edge": ops.mlp_forward(pk, src, E), "indexed": ops.mlp_forward(pk, [ops.Source(e, index=idx)], E, _lib.ACT_SELU),
-               "scattered": ops.mlp_forward(pk, src, E, out=torch.zeros(E, H, device=DEV), out_idx32=oidx)}
-        if csr.tiles() is not None:
-            for mean in (True, False):
-                a = torch.full((n, H), float("nan"), device=DEV)
-                out[f"rows_{mean}"] = ops.mlp_forward(pk, src, E, agg=(csr, a, mean))
-                out[f"agg_{mean}"] = a
-                a2 = torch.full((n, H), float("nan"), device=DEV)
-                ops.mlp_forward(pk, src, E, agg=(csr, a2, mean), store_rows=False)
-                out[f"agg_only_{mean}"] = a2
-        return out
+    old_prec = ops.set_mlp_precision(prec)
     old_ws, old_i = lib.g4c_mlp_ws_enable(0), lib.g4c_mlp_bx6i_enable(0)
     try:
+        torch.manual_seed(rows)
+        hid = (H,) * layers
+        blk = B.GNBlock((3 * H, hid, True), (2 * H, hid, True)).to(DEV)
+        v = torch.randn(n, H, device=DEV)
+        deg = torch.full((n,), 6, dtype=torch.long) if rows != 6000 else torch.randint(0, 10, (n,))
+        col = torch.arange(n).repeat_interleave(deg)
+        E = int(col.numel())
+        edge_index = torch.stack([torch.randint(0, n, (E,)), col]).to(DEV)
+        e = torch.randn(E, H, device=DEV)
+        ep, csr = plan.edge_csr(edge_index, n)
+        W1 = blk.edge_mlp.state_dict()["MLP.linear_1.weight"]
+        pr, pc = (v @ W1[:, H:2 * H].T).contiguous(), (v @ W1[:, 2 * H:].T).contiguous()
+        pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+        adds = [ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+        src = [ops.Source(e, pre_act=_lib.ACT_SELU)] + adds
+        idx = torch.randint(0, E, (E,), device=DEV, dtype=torch.int32)
+        oidx = torch.randperm(E, device=DEV).to(torch.int32)
+        e16 = torch.nn.functional.selu(e).to(torch.bfloat16)
+
+        def run():
+            out = {"edge": ops.mlp_forward(pk, src, E), "indexed": ops.mlp_forward(pk, [ops.Source(e, index=idx)] + adds, E, _lib.ACT_SELU),
+                   "indexed_no_adds": ops.mlp_forward(pk, [ops.Source(e, index=idx)], E, _lib.ACT_SELU),
+                   "scattered": ops.mlp_forward(pk, src, E, out=torch.zeros(E, H, device=DEV), out_idx32=oidx)}
+            if csr.tiles() is not None:
+                for mean in (True, False):
+                    a = torch.full((n, H), float("nan"), device=DEV)
+                    out[f"rows_{mean}"] = ops.mlp_forward(pk, src, E, agg=(csr, a, mean))
+                    out[f"agg_{mean}"] = a
+                    a2 = torch.full((n, H), float("nan"), device=DEV)
+                    ops.mlp_forward(pk, src, E, agg=(csr, a2, mean), store_rows=False)
+                    out[f"agg_only_{mean}"] = a2
+                if prec == "bf16":
+                    for name, act in (("selu", _lib.ACT_SELU), ("plain", _lib.ACT_NONE)):
+                        a = torch.full((n, H), float("nan"), device=DEV)
+                        y = ops.mlp_forward(pk, [ops.Source(e16)] + adds, E, agg=(csr, a, True), rows_dtype=torch.bfloat16, rows_act=act)
+                        assert y.dtype == torch.bfloat16
+                        out[f"rows16_{name}"], out[f"agg16_{name}"] = y.float(), a
+            return out
         ref = run()
         lib.g4c_mlp_ws_enable(2)
         got = run()
     finally:
         lib.g4c_mlp_ws_enable(old_ws); lib.g4c_mlp_bx6i_enable(old_i)
+        ops.set_mlp_precision(old_prec)
     for k in ref:
-        torch.testing.assert_close(got[k], ref[k], rtol=2e-5, atol=2e-5, msg=lambda m: f"{k}: {m}")
+        if prec != "bf16":
+            torch.testing.assert_close(got[k], ref[k], rtol=2e-5, atol=2e-5, msg=lambda m: f"{k}: {m}")
+        else:
+            d = (got[k] - ref[k]).abs()
+            lim, mlim = (6e-2, 2e-4) if k.startswith("rows16") else (3e-2, 5e-5)        # (rows16: one bf16 ulp of an O(1) value is 8e-3)
+            assert torch.isfinite(got[k]).all() and d.max().item() <= lim and d.mean().item() <= mlim, (k, d.max().item(), d.mean().item())
     for mean in (True, False):
         if f"agg_{mean}" in got:
             assert torch.equal(got[f"agg_{mean}"], ops.segment_reduce(got[f"rows_{mean}"], csr, mean))
