@@ -70,6 +70,37 @@ def test_segment_reduce_sorted_bit_exact_and_activations():
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("permuted", [False, True])
+def test_segment_reduce_large_ragged_bit_exact(permuted):
+    """40k ragged segments: bit-identical to a sequential index_add_ in plan order — empty segments at both ends and in long runs,
+    segments longer than one batch of rows (8), with and without the plan's permutation; a tensor without any row."""
+    torch.manual_seed(5)
+    n_seg = 40_003
+    deg = torch.randint(0, 12, (n_seg,))
+    deg[:40] = 0; deg[-23:] = 0; deg[1000:1100] = 0; deg[5000] = 77; deg[5001] = 9; deg[5002] = 8
+    idx = torch.arange(n_seg).repeat_interleave(deg)
+    m = int(idx.numel())
+    if permuted:
+        idx = idx[torch.randperm(m)]
+    src = torch.randn(m, 128)
+    csr = plan.build_csr(idx, n_seg, DEV)
+    assert (csr.perm is not None) == permuted
+    out = ops.segment_reduce(src.to(DEV), csr, False)
+    ref = torch.zeros(n_seg, 128).index_add_(0, idx, src)
+    if not permuted:
+        assert torch.equal(out.cpu(), ref)
+    else:           # (index_add_ adds in index order = the stable plan's order per segment)
+        assert torch.equal(out.cpu(), ref)
+    mean = ops.segment_reduce(src.to(DEV), csr, True, act=_lib.ACT_TANH, src_act=_lib.ACT_SELU)
+    cnt = torch.bincount(idx, minlength=n_seg).clamp(min=1).float()[:, None]
+    ref_m = torch.tanh(torch.zeros(n_seg, 128).index_add_(0, idx, torch.nn.functional.selu(src)) / cnt)
+    torch.testing.assert_close(mean.cpu(), ref_m, rtol=1e-5, atol=1e-6)
+    # no rows at all
+    empty = plan.build_csr(torch.zeros(0, dtype=torch.long), 20_000, DEV)
+    z = ops.segment_reduce(torch.zeros(0, 128, device=DEV), empty, True)
+    assert z.shape == (20_000, 128) and torch.all(z == 0)
+
+
 def test_scatter_dropin(golden):
     c = golden("blocks.pt")["scatter"]
     src, idx = c["src"].to(DEV), c["index"].to(DEV)
