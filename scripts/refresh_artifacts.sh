@@ -38,12 +38,15 @@ for wl in headline c3; do
       bench.py --gpus 2 --workload $wl --steps 20 --warmup 3 2> $A/bench_${wl}_2rank_stderr.log | tail -1 > $A/${TAG}_bench_${wl}_2rank_samegpu.json
 done
 timeout 300 python scripts/step_breakdown.py > $A/${TAG}_step_breakdown.log 2>&1
+timeout 300 python scripts/step_breakdown.py --workload c3 > $A/${TAG}_step_breakdown_c3.log 2>&1
+timeout 300 python scripts/bench_segment_reduce.py 2>&1 | grep -v amdgpu.ids > $A/${TAG}_segment_reduce_rotating.log
 timeout 300 python scripts/mlp_accuracy.py > $A/${TAG}_mlp_accuracy.log 2>&1
-# the weight-stationary kernel (f16x3 stream): checks against the tile kernel + same-process A/B; the dual-tile kernel (bf16x6 stream)
-timeout 300 python scripts/ws_check.py --time 2>&1 | tail -4 > $A/${TAG}_ws_check_and_ab.log
+# the weight-stationary kernel (f16x3 stream and rounded-bf16 mode, 2 / 3 layers): checks against the tile kernel + same-process A/B; the dual-tile kernel (bf16x6 stream)
+timeout 600 python scripts/ws_check.py --time 2>&1 | grep -v "^ok\|amdgpu.ids" > $A/${TAG}_ws_check_and_ab.log
 G4C_MLP_PRECISION=bf16x6 timeout 300 python scripts/bx6i_check.py --time 2>&1 | tail -3 > $A/${TAG}_bx6i_check_and_ab.log
 # cycle stamps of the weight-stationary kernel's pair loop (DESIGN.md 4.1 / 9 quote them)
 bash scripts/build_ws_timing.sh > /dev/null 2>&1 && timeout 120 python scripts/ws_stamps.py graphs4cfd_amd/lib/libg4c_ws_timing.so 2>&1 | grep -v amdgpu.ids > $A/${TAG}_ws_stamps.log
+timeout 120 python scripts/ws_stamps.py graphs4cfd_amd/lib/libg4c_ws_timing.so bf16 2>&1 | grep -v amdgpu.ids > $A/${TAG}_ws_stamps_bf16_mode.log
 # pipe-utilisation counters of the shipped kernels in the DEFAULT arithmetic: level-1 message launch (mlp_ws_kernel) and node launch (mlp_bx6_kernel)
 bash scripts/pmc_ws.sh ws ${TAG}_ws util sq3 lds sq2 tcc > $A/${TAG}_pmc_mlp_ws.txt 2>&1
 PMC_EXTRA_ARGS=--node bash scripts/pmc_ws.sh tile ${TAG}_node util sq3 lds sq2 tcc > $A/${TAG}_pmc_mlp_bx6_node.txt 2>&1

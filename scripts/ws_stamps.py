@@ -53,6 +53,6 @@ for k in keys[1:]:
     print(f"{names[k]:62s} median {int(np.median(d)):7d}  (p10 {int(np.percentile(d, 10)):7d}, p90 {int(np.percentile(d, 90)):7d})")
     prev = k
 print("pair period (loop top -> end of tail) median", int(np.median(st[:, 10] - st[:, 0])))
-per = (st[:, 13] - st[:, 12]) / np.maximum(st[:, 14], 1)
-print(f"whole launch, ticks per pair and workgroup: median {np.median(per):.0f}, p10 {np.percentile(per, 10):.0f}, p90 {np.percentile(per, 90):.0f}, max {per.max():.0f};"
-      f" launch span {int(st[:, 13].max() - st[:, 12].min())} ticks, latest start {int(st[:, 12].max() - st[:, 12].min())}")
+live = st[:, 14] > 0
+per = (st[live, 13] - st[live, 12]) / st[live, 14]
+print(f"whole launch, ticks per pair and workgroup: median {np.median(per):.0f}, p10 {np.percentile(per, 10):.0f}, p90 {np.percentile(per, 90):.0f}, max {per.max():.0f}")
