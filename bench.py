@@ -273,7 +273,7 @@ def roofline_blocks(args, result, model, graph_cpu, dev, ops, Rollout):
     fallback = sum(summ[k]["launches"] // 3 for k in mlp_kinds if not k.startswith("mlp_bx6"))
     result["roofline"] = {
         "bound": "mfma", "kernel": (dom + "<1, *, *> (g4c_mlp_forward_bx6 / _heads_bx6 / _agg); the message launches of >= 20k rows run on mlp_ws_kernel "
-                                     "(f16x3 stream: weight-stationary persistent kernel) / mlp_bx6i_kernel (bf16x6 stream, >= 400k rows)") if dom.startswith("mlp_bx6")
+                                     "(f16x3 stream and rounded-bf16 mode: weight-stationary persistent kernel) / mlp_bx6i_kernel (bf16x6 stream, >= 400k rows)") if dom.startswith("mlp_bx6")
         else dom.replace(">", ", *>") + " (g4c_mlp_forward)",
         "achieved": big["achieved"], "peak": big["peak"], "unit": "TFLOP/s", "frac": big["frac"], "mfma_dtype": big["mfma_dtype"],
         "algorithmic_tflops": big.get("algorithmic_tflops", big["achieved"]),
