@@ -277,7 +277,8 @@ def roofline_blocks(args, result, model, graph_cpu, dev, ops, Rollout):
         else dom.replace(">", ", *>") + " (g4c_mlp_forward)",
         "achieved": big["achieved"], "peak": big["peak"], "unit": "TFLOP/s", "frac": big["frac"], "mfma_dtype": big["mfma_dtype"],
         "algorithmic_tflops": big.get("algorithmic_tflops", big["achieved"]),
-        "traffic": traffic["avg"]("mlp_bx6" if dom.startswith("mlp_bx6") else dom.rstrip(">")) if traffic else None, "traffic_source": traffic_src if traffic else None,
+        # (the timer's "mlp_bx6_kernel" class = every launch of the split-operand family: tile kernel, dual-tile kernel, weight-stationary kernel)
+        "traffic": traffic["avg"](("mlp_bx6", "mlp_ws") if dom.startswith("mlp_bx6") else dom.rstrip(">")) if traffic else None, "traffic_source": traffic_src if traffic else None,
         "launches_per_step": big["launches_per_step"], "avg_launch_us": big["avg_launch_us"], "flop_per_launch": big["flop_per_launch"],
         "ms_per_step_in_kernel": big["ms_per_step"],
         # (precision "bf16x6" / "bf16": MLPs with an input block wider than 128 columns run on the fp32-MFMA kernels)

@@ -407,8 +407,9 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         // ---- tables two pairs ahead (their meta was loaded an iteration ago), meta three pairs ahead
         const Meta m3raw = load_meta(pair + 3);
         const int tv = load_tables(m2);
-        // (no barrier here: tile A's planes were written by open_pair in front of the previous iteration's LayerNorm barrier — the
-        // one before the loop for the first pair — and nothing the stragglers of the previous tail still read is written in this phase)
+        // (tile A's planes were written by open_pair in the previous iteration's tail — before the loop for the first pair — and a
+        // barrier lies between: the aggregation's, or the one that closes a tail without aggregation; nothing the stragglers of
+        // the previous tail still read is written in this phase)
         WS_STAMP(1);
         if (pact) m_block<SP, 2, true>(paA, W[0], accA, accA1, accB, accB1, xr[1], oB, rng);                 // for B: park
         else m_block<SP, 2, false>(paA, W[0], accA, accA1, accB, accB1, xr[1], oB, rng);
@@ -511,6 +512,9 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
             }
         }
         WS_STAMP(9);
+        // without the aggregation nothing else separates open_pair's plane writes from the next iteration's M(A,0), which reads the
+        // rows every OTHER wave parked (a wave that ran ahead through its LayerNorm read stale rows: seen once in 600k-row launches)
+        if (!AGG) __syncthreads();
         if (AGG) {
             __syncthreads();
             // aggregation of the targets whose messages the tiles hold (rows in CSR order): the rows of a segment are added in order

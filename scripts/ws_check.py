@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graphs4cfd_amd import _lib, ops, plan
 from graphs4cfd_amd.nn import blocks as B
 ap = argparse.ArgumentParser(); ap.add_argument("--time", action="store_true"); ap.add_argument("--rows", type=int, default=600000); ap.add_argument("--kernel", default="ws", choices=["ws"])
+ap.add_argument("--stress", type=int, default=0, help="repeat the large launches this many times against one tile-kernel result (races show up as rare mismatches)")
 a = ap.parse_args()
 torch.set_grad_enabled(False)
 lib = _lib.load()
@@ -109,6 +110,37 @@ def check_variant(prec, layers):
 
 for prec, layers in (("f16x3", 3), ("f16x3", 2), ("bf16", 2), ("bf16", 3)):
     check_variant(prec, layers)
+if a.stress:
+    for prec, layers in (("f16x3", 3), ("f16x3", 2), ("bf16", 2)):
+        ops.set_mlp_precision(prec)
+        torch.manual_seed(1)
+        hid = (H,) * layers
+        blk = B.GNBlock((3 * H, hid, True), (2 * H, hid, True)).to(dev)
+        rows = 600000; n = rows // 6
+        e, v = torch.randn(rows, H, device=dev), torch.randn(n, H, device=dev)
+        W1 = blk.edge_mlp.state_dict()["MLP.linear_1.weight"]
+        pr, pc = (v @ W1[:, H:2 * H].T).contiguous(), (v @ W1[:, 2 * H:].T).contiguous()
+        pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+        idx = torch.randint(0, rows, (rows,), device=dev, dtype=torch.int32)
+        col = (torch.arange(rows, device=dev) // 6).to(torch.int32)
+        ei = torch.stack([torch.randint(0, n, (rows,), device=dev), col.long()])
+        ep, csr = plan.edge_csr(ei, n)
+        adds = [ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+        agg = torch.empty(n, H, device=dev)
+        cases = {"indexed + adds, no aggregation": lambda: ops.mlp_forward(pk, [ops.Source(e, index=idx)] + adds, rows, _lib.ACT_SELU),
+                 "direct + adds, no aggregation": lambda: ops.mlp_forward(pk, [ops.Source(e, pre_act=_lib.ACT_SELU)] + adds, rows),
+                 "direct + adds + aggregation": lambda: ops.mlp_forward(pk, [ops.Source(e, pre_act=_lib.ACT_SELU)] + adds, rows, agg=(csr, agg, True))}
+        if prec != "bf16":
+            cases["indexed, no adds, no aggregation"] = lambda: ops.mlp_forward(pk, [ops.Source(e, index=idx)], rows, _lib.ACT_SELU)
+        for cname, fn in cases.items():
+            enable(2); first = fn().clone(); worst = 0.0
+            for r in range(a.stress):
+                worst = max(worst, (fn() - first).abs().max().item())
+            enable(0)
+            ok = worst == 0.0
+            print(f"{'ok  ' if ok else 'FAIL'} [{prec}, {layers} layers] stress x{a.stress}: {cname:40s} max difference between repeated launches {worst:.2e}")
+            if not ok: bad.append(f"stress {prec} {layers} {cname}")
+    ops.set_mlp_precision("f16x3")
 torch.manual_seed(0)
 blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(dev)
 print(f"all {a.kernel} checks passed" if not bad else "FAILED: " + ", ".join(bad))

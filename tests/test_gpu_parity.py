@@ -1241,6 +1241,47 @@ def test_ws_persistent_kernel_equals_tile_kernel(rows, variant):
             assert torch.equal(got[f"agg_only_{mean}"], got[f"agg_{mean}"])
 
 
+@pytest.mark.parametrize("variant", [("f16x3", 3), ("f16x3", 2), ("bf16", 2)], ids=lambda v: f"{v[0]}-{v[1]}layers")
+def test_ws_persistent_kernel_repeated_launches_are_identical(variant):
+    """The persistent kernel hands tiles from wave to wave through LDS; a missing barrier shows up as a rare difference between two
+    launches on the same inputs (round 3: the tail of a launch WITHOUT the fused aggregation lacked the one between the next pair's
+    parked rows and their first use — seen as one mismatch in a 600k-row launch).  60 launches of each large shape must be
+    bit-identical to the first."""
+    prec, layers = variant
+    if ops.mlp_precision() != "f16x3":
+        pytest.skip("runs under the default arithmetic only (it sets the mode itself)")
+    lib = _lib.load()
+    H, rows = 128, 300_000
+    n = rows // 6
+    old_prec = ops.set_mlp_precision(prec)
+    old_ws, old_i = lib.g4c_mlp_ws_enable(2), lib.g4c_mlp_bx6i_enable(0)
+    try:
+        torch.manual_seed(7)
+        hid = (H,) * layers
+        blk = B.GNBlock((3 * H, hid, True), (2 * H, hid, True)).to(DEV)
+        e, v = torch.randn(rows, H, device=DEV), torch.randn(n, H, device=DEV)
+        W1 = blk.edge_mlp.state_dict()["MLP.linear_1.weight"]
+        pr, pc = (v @ W1[:, H:2 * H].T).contiguous(), (v @ W1[:, 2 * H:].T).contiguous()
+        pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+        idx = torch.randint(0, rows, (rows,), device=DEV, dtype=torch.int32)
+        col = torch.arange(rows, device=DEV) // 6
+        ep, csr = plan.edge_csr(torch.stack([torch.randint(0, n, (rows,), device=DEV), col]), n)
+        adds = [ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+        agg = torch.empty(n, H, device=DEV)
+        cases = {"indexed + adds": lambda: ops.mlp_forward(pk, [ops.Source(e, index=idx)] + adds, rows, _lib.ACT_SELU),
+                 "direct + adds": lambda: ops.mlp_forward(pk, [ops.Source(e, pre_act=_lib.ACT_SELU)] + adds, rows),
+                 "direct + adds + aggregation": lambda: ops.mlp_forward(pk, [ops.Source(e, pre_act=_lib.ACT_SELU)] + adds, rows, agg=(csr, agg, True))}
+        if prec != "bf16":
+            cases["indexed, no adds"] = lambda: ops.mlp_forward(pk, [ops.Source(e, index=idx)], rows, _lib.ACT_SELU)
+        for name, fn in cases.items():
+            first = fn().clone()
+            for _ in range(60):
+                assert torch.equal(fn(), first), name
+    finally:
+        lib.g4c_mlp_ws_enable(old_ws); lib.g4c_mlp_bx6i_enable(old_i)
+        ops.set_mlp_precision(old_prec)
+
+
 # ------------------------------------------------------------------ the fp16 range of the default arithmetic is observable
 def test_f16_range_clip_is_reported_and_bf16x6_matches_the_oracle():
     """Adversarial WEIGHTS, normal inputs: the LayerNorm gain of the first MP layer's message MLP x 3e4 puts its output latents
