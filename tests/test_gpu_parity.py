@@ -1241,20 +1241,21 @@ def test_ws_persistent_kernel_equals_tile_kernel(rows, variant):
             assert torch.equal(got[f"agg_only_{mean}"], got[f"agg_{mean}"])
 
 
-@pytest.mark.parametrize("variant", [("f16x3", 3), ("f16x3", 2), ("bf16", 2)], ids=lambda v: f"{v[0]}-{v[1]}layers")
+@pytest.mark.parametrize("variant", [("f16x3", 3, "ws"), ("f16x3", 2, "ws"), ("bf16", 2, "ws"), ("bf16x6", 3, "bx6i")],
+                         ids=lambda v: f"{v[2]}-{v[0]}-{v[1]}layers")
 def test_ws_persistent_kernel_repeated_launches_are_identical(variant):
     """The persistent kernel hands tiles from wave to wave through LDS; a missing barrier shows up as a rare difference between two
     launches on the same inputs (round 3: the tail of a launch WITHOUT the fused aggregation lacked the one between the next pair's
     parked rows and their first use — seen as one mismatch in a 600k-row launch).  60 launches of each large shape must be
-    bit-identical to the first."""
-    prec, layers = variant
+    bit-identical to the first.  (Also the dual-tile kernel of the bf16x6 stream, which pipelines pairs of tiles the same way.)"""
+    prec, layers, kernel = variant
     if ops.mlp_precision() != "f16x3":
         pytest.skip("runs under the default arithmetic only (it sets the mode itself)")
     lib = _lib.load()
     H, rows = 128, 300_000
     n = rows // 6
     old_prec = ops.set_mlp_precision(prec)
-    old_ws, old_i = lib.g4c_mlp_ws_enable(2), lib.g4c_mlp_bx6i_enable(0)
+    old_ws, old_i = lib.g4c_mlp_ws_enable(2 if kernel == "ws" else 0), lib.g4c_mlp_bx6i_enable(2 if kernel == "bx6i" else 0)
     try:
         torch.manual_seed(7)
         hid = (H,) * layers
