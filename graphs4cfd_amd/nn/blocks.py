@@ -117,18 +117,88 @@ class MLP(nn.Module):
             hit = self._packed[key]
         return hit[1]
 
+    # -- MLPs outside the one-launch envelope ---------------------------------------------
+    def fits_one_launch(self) -> bool:
+        """The fused kernels take up to _lib.MAX_LAYERS Linear layers of at most 128 outputs each (every published graphs4cfd
+        architecture).  The reference's MLP (nn/blocks.py:129-141) accepts any widths and depth: such an MLP runs as a chain of
+        launches (`_run_stages`)."""
+        lin = self._linears()
+        return len(lin) <= _lib.MAX_LAYERS and all(l.out_features <= 128 for l in lin)
+
+    def _stage(self, key, weights, biases, ln, sources: Sequence[Source]) -> ops.PackedMLP:
+        prec = ops.effective_precision([s.width for s in sources])
+        narrow = tuple(_narrow_flags(sources)) if prec != "fp32" else (False,) * len(sources)
+        key = ("stage",) + key + (tuple(s.width for s in sources), tuple(s.negate for s in sources), prec, narrow)
+        sig = self._signature()
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != sig:
+            pk = ops.PackedMLP(weights, biases, ln, key[-4], key[-3], precision=prec, narrow=narrow, site=self._site)
+            self._packed[key] = (sig, pk)
+            hit = self._packed[key]
+        return hit[1]
+
+    def _run_stages(self, sources: Sequence[Source], n_rows: int, act_code: int, **kw) -> Tensor:
+        """Any widths / depth as a chain of fused launches: consecutive layers of <= 128 outputs share a launch (at most
+        _lib.MAX_LAYERS of them, SELU between them as always); a layer with more than 128 outputs is a launch per 128-column
+        chunk of its output (rows [c, c + 128) of its weight), whose results enter the next layer as its input blocks — so a layer
+        may be up to 128 * _lib.MAX_SRC wide.  LayerNorm and the caller's activation / residual / output index belong to the last
+        launch; a LayerNorm over more than 128 columns has no kernel here."""
+        if ops.grad_mode():
+            raise NotImplementedError("training an MLP with a layer wider than 128 or more than 4 Linear layers")
+        lin = self._linears()
+        ln = getattr(self.MLP, "layer_norm", None)
+        if ln is not None and lin[-1].out_features > 128:
+            raise NotImplementedError("LayerNorm over more than 128 columns is outside the fused-MLP kernel envelope")
+        dev = sources[0].tensor.device
+        cur, i, n = list(_split_wide(sources)), 0, len(lin)
+        while i < n:
+            if lin[i].out_features > 128:
+                w_out = lin[i].out_features
+                if (w_out + 127) // 128 > _lib.MAX_SRC and i + 1 < n:
+                    raise NotImplementedError(f"hidden layer width {w_out} > {128 * _lib.MAX_SRC} is outside the fused-MLP kernel envelope")
+                last = i == n - 1
+                if last and any(kw.get(k) is not None for k in ("out_idx32", "resid", "agg", "head_outs")):
+                    raise NotImplementedError("output index / residual / aggregation / heads on an output wider than 128 columns")
+                wide = kw.get("out") if (last and kw.get("out") is not None) else torch.empty((n_rows, w_out), dtype=torch.float32, device=dev)
+                for c in range(0, w_out, 128):
+                    c1 = min(c + 128, w_out)
+                    pk = self._stage((i, c), [lin[i].weight[c:c1]], [lin[i].bias[c:c1] if lin[i].bias is not None else None], None, cur)
+                    ops.mlp_forward(pk, cur, n_rows, act_code if last else _lib.ACT_SELU, out=wide[:, c:c1])
+                if last:
+                    return wide
+                cur = [Source(wide, col0=c, width=min(128, w_out - c)) for c in range(0, w_out, 128)]
+                i += 1
+                continue
+            j = i
+            while j < n and j - i < _lib.MAX_LAYERS and lin[j].out_features <= 128:
+                j += 1
+            last = j == n
+            pk = self._stage((i, j), [l.weight for l in lin[i:j]], [l.bias for l in lin[i:j]],
+                             (ln.weight, ln.bias, ln.eps) if (last and ln is not None) else None, cur)
+            if last:
+                return ops.mlp_forward(pk, cur, n_rows, act_code, **kw)
+            cur = [Source(ops.mlp_forward(pk, cur, n_rows, _lib.ACT_SELU))]
+            i = j
+        raise AssertionError("unreachable")
+
     def run(self, sources: Sequence[Source], n_rows: int, activation=None, out: Optional[Tensor] = None,
             out_idx32: Optional[Tensor] = None, resid: Optional[Tensor] = None, resid_col0: int = 0) -> Tensor:
         """cat(sources) -> MLP -> activation (+ resid), one fused launch."""
         code = _lib.act_code(activation)
         if code is None and resid is not None:
             raise NotImplementedError("a residual after a non-fusable activation")
+        if not self.fits_one_launch():
+            y = self._run_stages(sources, n_rows, _lib.ACT_NONE if code is None else code, out=out, out_idx32=out_idx32, resid=resid,
+                                 resid_col0=resid_col0)
+            return _finish(y, activation, code)
         sources = _split_wide(sources)
         pk = self.packed([s.width for s in sources], [s.negate for s in sources], _narrow_flags(sources))
         y = ops.mlp_forward(pk, sources, n_rows, _lib.ACT_NONE if code is None else code, out, out_idx32, resid, resid_col0)
         return _finish(y, activation, code)
 
     def run_coded(self, sources: Sequence[Source], n_rows: int, act_code: int = _lib.ACT_NONE, **kw) -> Tensor:
+        if not self.fits_one_launch():
+            return self._run_stages(sources, n_rows, act_code, **kw)
         sources = _split_wide(sources)
         pk = self.packed([s.width for s in sources], [s.negate for s in sources], _narrow_flags(sources))
         return ops.mlp_forward(pk, sources, n_rows, act_code, **kw)
@@ -143,6 +213,8 @@ class MLP(nn.Module):
         consumer compute its products itself.  `out` / `head_outs` (entries may be None): caller-provided [n_rows, 128]
         destinations (row-sliced views of wider buffers are fine)."""
         if self.output_size != 128 or any(int(w) != 128 for w in widths) or not 1 <= len(widths) <= _lib.MAX_HEADS:
+            return None
+        if not self.fits_one_launch():
             return None
         if ops.grad_mode():          # recorded for autograd: the plain launches are the differentiable ones
             return None
@@ -208,6 +280,8 @@ class MLP(nn.Module):
         work they save (measured crossover ~25k rows, scripts/sweep_tile_modes.py): one plain fused launch then.
         `products` (from the producer's launch, MLP.run_with_heads): the per-node terms, already multiplied."""
         plain = list(k_sources) + [Source(t, index=idx) for t, idx in gathered]
+        if not self.fits_one_launch():          # (a chain of launches: nothing to hoist into)
+            return self.run_coded(plain, n_rows, act_code, **kw)
         # (a gathered block wider than 128 whose chunks would exceed the kernels' block count — gMuS-GNN's 2H-wide latents after an
         # up-sampling — is hoisted at any size: its products are formed from 128-wide chunks, the launch itself keeps one block)
         too_many = (sum((s.width + 127) // 128 for s in plain) > _lib.MAX_SRC and any(s.width > 128 for s in plain)

@@ -818,14 +818,42 @@ def test_full_size_properties():
 
 
 # ------------------------------------------------------------------ error behaviour
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x6", "fp32"])
+@pytest.mark.parametrize("shape", [(8, (256, 16), False), (300, (200, 300, 64), True), (128, (128,) * 6, True), (64, (64, 300), False),
+                                   (40, (512, 96, 96, 96, 96, 33), True), (128, (130, 128), True)],
+                         ids=["wide-hidden", "wide-in-and-hidden", "six-layers", "wide-out", "wide-then-deep", "just-over"])
+def test_mlp_any_widths_and_depth(shape, prec):
+    """The reference's MLP takes any widths and depth (nn/blocks.py:129-141); the fused kernels take <= 4 layers of <= 128 outputs per
+    launch.  Outside that envelope the module runs a chain of launches (MLP._run_stages: a wide layer as one launch per 128-column
+    chunk of its output, deep MLPs as consecutive launches) — same result as torch's nn.Sequential on the same weights."""
+    k_in, widths, ln = shape
+    old = ops.set_mlp_precision(prec)
+    try:
+        torch.manual_seed(sum(widths))
+        mlp = B.MLP(k_in, widths, ln).to(DEV)
+        assert not mlp.fits_one_launch()
+        x = torch.randn(777, k_in, device=DEV)
+        with torch.no_grad():
+            got = mlp(x)
+            ref = mlp.MLP.double()(x.double()).float()
+            mlp.MLP.float()
+            got_act = mlp.run([ops.Source(x)], 777, activation="selu")
+        torch.testing.assert_close(got, ref, **BLOCK)
+        torch.testing.assert_close(got_act, torch.nn.functional.selu(ref), **BLOCK)
+    finally:
+        ops.set_mlp_precision(old)
+
+
 def test_errors():
     mlp = B.MLP(8, (16, 16), True).to(DEV)
     with pytest.raises(RuntimeError, match="HIP"):
         mlp(torch.randn(4, 8))
     with pytest.raises(ValueError):
         mlp(torch.randn(4, 9, device=DEV))
-    with pytest.raises(NotImplementedError):
-        B.MLP(8, (256, 16)).to(DEV)(torch.randn(4, 8, device=DEV))
+    with pytest.raises(NotImplementedError):          # LayerNorm over more than 128 columns
+        B.MLP(8, (16, 256), True).to(DEV)(torch.randn(4, 8, device=DEV))
+    with pytest.raises(NotImplementedError):          # a hidden layer wider than 4 x 128
+        B.MLP(8, (1024, 16)).to(DEV)(torch.randn(4, 8, device=DEV))
     with pytest.raises(ValueError):
         gfd.nn.NsOneScaleGNN(model="no-such-model")
 
