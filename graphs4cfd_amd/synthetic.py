@@ -113,6 +113,29 @@ def connect_knn(pos: torch.Tensor, k: int, period=None) -> Tuple[torch.Tensor, t
         row = knn_neighbours_device(pos, k).reshape(-1)
         col = torch.arange(n, device=pos.device).repeat_interleave(k)
         return torch.stack([row, col], 0), pos[col] - pos[row]
+    if pos.is_cuda and dim == 2 and sum(d is not None for d in per) == 1:
+        # positions on the GPU, ONE periodic axis of a 2-D cloud: its embedding (cos, sin, other coordinate) is 3-D, which the cell-grid
+        # search takes.  The grid works in fp32, the reference path in the embedded float64 coordinates: 2k + 2 candidates per
+        # centre come from the grid, their float64 distances order them (stable: the grid's order for equal distances), the nearest
+        # k stay — the host path's neighbours unless more than k + 2 points tie within fp32 resolution at the k-th distance.
+        # (two periodic axes embed in 4-D, periodic 3-D clouds in >= 4-D: host path below)
+        n = int(pos.size(0))
+        ax = 0 if per[0] is not None else 1
+        x = pos[:, ax].detach().double()
+        d = float(x.max() - x.min()) if isinstance(per[ax], str) and per[ax] == "auto" else float(per[ax])
+        circ = torch.stack((torch.cos(2 * np.pi / d * x), torch.sin(2 * np.pi / d * x)), 1)
+        other = pos[:, 1 - ax].detach().double().unsqueeze(1)
+        emb = torch.cat((circ, other), 1) if ax == 0 else torch.cat((other, circ), 1)          # (the reference's column order: x part, y part)
+        kc = min(n - 1, 2 * k + 2)
+        cand = knn_neighbours_device(emb.float(), kc)                                           # [n, kc], nearest first in fp32
+        d2 = ((emb[cand] - emb[:, None, :]) ** 2).sum(-1)
+        pick = torch.sort(d2, dim=1, stable=True)[1][:, :k]
+        row = torch.gather(cand, 1, pick).reshape(-1)
+        col = torch.arange(n, device=pos.device).repeat_interleave(k)
+        edge_attr = pos[col] - pos[row]
+        c = edge_attr[:, ax]
+        edge_attr[:, ax] = torch.where(c < -d / 2, c + d, torch.where(c > d / 2, c - d, c))
+        return torch.stack([row, col], 0), edge_attr
     lengths, cols = [], []
     for ax in range(dim):
         x = pos[:, ax].detach().cpu().double()

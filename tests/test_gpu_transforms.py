@@ -74,6 +74,22 @@ def test_connect_knn_on_device_equals_host_path(n, dim, k):
     assert torch.equal(ea_d.cpu(), ea_h)
 
 
+@pytest.mark.parametrize("n,k,period", [(50_000, 6, (None, "auto")), (50_000, 6, ("auto", None)), (8_000, 5, (2.5, None)), (300, 6, (None, 1.0))])
+def test_connect_knn_periodic_axis_on_device_equals_host_path(n, k, period):
+    """One periodic axis of a 2-D cloud (transforms/connect.py:38-71: the axis enters the search as a point on a circle; its edge
+    components are wrapped): the device path (3-D cell grid on the embedding + float64 re-ranking of 2k + 2 candidates) gives the host
+    path's edges — which tests/test_synthetic.py pins to the reference's outputs — and the same wrapped edge attributes."""
+    pos = torch.rand(n, 2, generator=torch.Generator().manual_seed(n + k)) * torch.tensor([2.5, 1.0])
+    ei_h, ea_h = S.connect_knn(pos.clone(), k, period=period)
+    ei_d, ea_d = S.connect_knn(pos.to(DEV), k, period=period)
+    assert ei_d.device.type == "cuda" and ei_d.shape == (2, n * k)
+    assert torch.equal(ei_d.cpu(), ei_h)
+    torch.testing.assert_close(ea_d.cpu(), ea_h, rtol=0, atol=1e-6)
+    ax = 0 if period[0] is not None else 1
+    d = float(pos[:, ax].max() - pos[:, ax].min()) if period[ax] == "auto" else float(period[ax])
+    assert float(ea_d[:, ax].abs().max()) <= d / 2 + 1e-6             # wrapped
+
+
 def test_connect_knn_on_device_clustered_cloud():
     """A strongly non-uniform cloud (most cells empty, a few crowded: the ring search has to widen): still exact."""
     g = torch.Generator().manual_seed(3)
