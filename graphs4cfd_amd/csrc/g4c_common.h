@@ -58,9 +58,11 @@ struct DeviceGuard {
 __device__ __forceinline__ float selu_f(float x) {
     const float alpha = 1.6732632423543772848170429916717f;   // torch's SELU constants
     const float scale = 1.0507009873554804934193349852946f;
-    const float e = __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.4426950408889634f);
-    const float neg = fmaf(scale * alpha, e, -scale * alpha);
-    return x > 0.f ? scale * x : neg;
+    // exp(min(x, 0)) as v_exp_f32 with the clamp modifier (the median folds into the instruction: no v_min), then
+    // scale * max(x, 0) + (scale * alpha * e - scale * alpha), whose second term is exactly 0 for x >= 0: four vector
+    // instructions + the exponential, and the same bits as the select form (x > 0 ? scale * x : scale * alpha * (e - 1))
+    const float e = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x * 1.4426950408889634f), 0.f, 1.f);
+    return fmaf(fmaxf(x, 0.f), scale, fmaf(scale * alpha, e, -scale * alpha));
 }
 
 __device__ __forceinline__ float tanh_f(float x) {

@@ -38,17 +38,7 @@ namespace {
 constexpr int PLN = 32 * HB;                 // bf16 elements of one operand plane of a tile [32][136]
 // one tile: SP planes (the fp32 final rows [32][132] alias them: 16 896 B <= 2 planes = 17 408 B)
 
-__device__ __forceinline__ f32x2 selu2i(f32x2 x) {
-    const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f;
-    const float scale = 1.0507009873554804934193349852946f;
-    f32x2 t, m;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) { m[e] = fmaxf(x[e], 0.f); t[e] = fminf(x[e], 0.f); }
-    t = t * 1.4426950408889634f;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) t[e] = __builtin_amdgcn_exp2f(t[e]);
-    return m * scale + (t * sa - sa);
-}
+__device__ __forceinline__ f32x2 selu2i(f32x2 x) { return selu2(x); }
 
 // exact three-way split of a pair -> one packed pair per plane (planes PLN elements apart); SP == 2: the two-way fp16 split
 template <int SP>

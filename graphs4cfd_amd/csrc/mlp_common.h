@@ -19,6 +19,7 @@ constexpr int CHUNK_FLOATS = KC * NP;   // packed weights per chunk: [16 kpairs]
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct Src {
     const float *ptr;
@@ -106,24 +107,23 @@ __device__ __forceinline__ bf16x8 ldw(__amdgpu_buffer_rsrc_t rs, unsigned voff_b
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// SELU of four values with the multiplies / fused multiply-adds written as vector math (v_pk_mul_f32 / v_pk_fma_f32):
-// scale*max(x,0) + scale*alpha*(exp(min(x,0)) - 1); the second term is exactly 0 for x >= 0.
+// SELU of four values: scale*max(x,0) + scale*alpha*(exp(min(x,0)) - 1); the second term is exactly 0 for x >= 0
+// (g4c::selu_f: the clamp modifier of v_exp_f32 stands in for min(x, 0)).
 __device__ __forceinline__ f32x4 selu4(f32x4 x) {
-    const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f;
-    const float scale = 1.0507009873554804934193349852946f;
-    f32x4 t, m;
+    f32x4 y;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { t[e] = fminf(x[e], 0.f); m[e] = fmaxf(x[e], 0.f); }
-    t = t * 1.4426950408889634f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_exp2f(t[e]);
-    return m * scale + (t * sa - sa);
+    for (int e = 0; e < 4; ++e) y[e] = g4c::selu_f(x[e]);
+    return y;
+}
+__device__ __forceinline__ f32x2 selu2(f32x2 x) {
+    f32x2 y;
+    y[0] = g4c::selu_f(x[0]); y[1] = g4c::selu_f(x[1]);
+    return y;
 }
 
 // exact three-way bf16 split of four fp32 values.  Two values at a time: ONE v_cvt_pk_bf16_f32 gives both bf16 terms, and
 // their fp32 values come back with a shift / a mask of that packed word (instead of one extra conversion per element);
 // the remainders are vector subtractions (v_pk_add_f32).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16(f32x2 x, f32x2 &back) {
     bf16x2 b;

@@ -78,15 +78,7 @@ struct Other {
 
 __device__ __forceinline__ f32x2 selu2w(f32x2 x) {
     if (G4C_WS_ABLATE & 16) return x;
-    const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f;
-    const float scale = 1.0507009873554804934193349852946f;
-    f32x2 t, m;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) { m[e] = fmaxf(x[e], 0.f); t[e] = fminf(x[e], 0.f); }
-    t = t * 1.4426950408889634f;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) t[e] = __builtin_amdgcn_exp2f(t[e]);
-    return m * scale + (t * sa - sa);
+    return selu2(x);
 }
 
 // two-way fp16 split of a pair -> one packed pair per plane (split_pair_f16, mlp_common.h: four vector instructions + the range tracker)
