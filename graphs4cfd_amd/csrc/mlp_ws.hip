@@ -11,8 +11,9 @@
 //     first tile, and — because the weights are loop-invariant — the pair loop is an ordinary loop (the single-layer stationary form
 //     of mlp_bx6i_kernel redefines its weight registers per layer, which hipcc duplicates across a back edge);
 //   * the loop is software-pipelined over pairs: gather indices and segment offsets are fetched two pairs ahead (into LDS), input rows
-//     and additive rows one pair ahead (into registers), the next pair's first tile is parked before the current pair's
-//     LayerNorm / store / aggregation tail, so no dependent memory round trip is left on a pair's critical path;
+//     and additive rows one pair ahead (into registers: tile A's in the matrix phases, tile B's — needed a phase later — in the
+//     tail, so that they are not live across the phases), the next pair's first tile is parked inside the current pair's last
+//     matrix phase, so no dependent memory round trip is left on a pair's critical path;
 //   * inside a pair the two tiles alternate layer by layer as in mlp_bx6i_kernel: while a wave issues the MFMAs of one tile its
 //     vector ALUs run the other tile's epilogue (bias is the accumulator start value; SELU, fp16 split, planes).
 // Envelope (everything else keeps mlp_bx6_kernel / mlp_bx6i_kernel): f16x3 stream (SP = 2) or the rounded-bf16 mode (SP = 1: one
@@ -68,7 +69,8 @@ struct Meta { int r0[2], n[2], s0[2], s1[2]; };
 // What the vector ALUs do for the OTHER tile while this tile's MFMAs issue, one piece per slice s = 0..7 (unit u = s / 4 = sample
 // row block / row half, piece s % 4):
 //   EK 0 nothing;  1 hidden-layer epilogue of accE[u] (sample rows 16 u + n);  2 park rows prow + 16 u of the gathered input
-//   (PACT: SELU pending on the stored rows);  3 last layer: fp32 rows of accE[u] into the tile's final buffer.
+//   (PACT: SELU pending on the stored rows);  3 last layer: fp32 rows of accE[u] into the tile's final buffer;  4 (m_block) = 3, then 2
+//   with the next pair's rows.
 // EK 1 / 2 work on one PAIR of values at a time: pieces 0 / 2 = [fold,] SELU of pair 0 / 1, pieces 1 / 3 = fp16 split + plane writes.
 struct Other {
     __bf16 *plane_acc;        // EK 1: this lane's element (row n, feature fcol) of the other tile's planes (swizzled address)
@@ -166,7 +168,12 @@ __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16
             if (SP == 2) fl[(s + 2) % 3] = *reinterpret_cast<const bf16x8 *>(pn + PLN);
         }
         if (!EK) __builtin_amdgcn_sched_barrier(0);
-        other_piece<SP, EK, PACT>(s, accE, accE1, xe, o, hold, rng);
+        if constexpr (EK == 4) {          // last layer's fp32 rows of accE, then the NEXT pair's first tile parked into the same tile's planes
+            other_piece<SP, 3, false>(s, accE, accE1, xe, o, hold, rng);
+            other_piece<SP, 2, PACT>(s, accE, accE1, xe, o, hold, rng);
+        } else {
+            other_piece<SP, EK, PACT>(s, accE, accE1, xe, o, hold, rng);
+        }
         const bf16x8 ch = fh[s % 3];
         if constexpr (SP == 1) {
             acc[rb] = mfma16<1>(W[ks][0], ch, acc[rb]);
@@ -296,9 +303,8 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
     // Three batches of four 16-byte loads per lane, issued in three different phases: a CU's share of the HBM bandwidth is ~13 bytes
     // per clock, and all eight waves firing twelve loads at once fill the memory pipeline's queue and block the waves' instruction
     // issue for ~4 k cycles (measured: the phase behind the burst took 5.8 k cycles instead of 1.7 k)
-    auto gather_x = [&](const Meta &m, int ring, f32x4 (&xr)[2][2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
+    auto gather_x = [&](const Meta &m, int ring, int t, f32x4 (&xt)[2], unsigned (&raw)[2][2]) __attribute__((always_inline)) {
+        {
             const int nn = m.n[t] > 0 ? m.n[t] : m.n[0];
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
@@ -307,10 +313,19 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
                 if constexpr (XB16) {       // bf16 rows (8-byte aligned: the launcher checks): widened by a shift / a mask — exact
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                     const u32x2 w = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const __bf16 *>(p.src[0].ptr) + (long long)gr * p.src[0].ld + p.src[0].col0 + pc);
-                    xr[t][hh][0] = __builtin_bit_cast(float, w[0] << 16); xr[t][hh][1] = __builtin_bit_cast(float, w[0] & 0xffff0000u);
-                    xr[t][hh][2] = __builtin_bit_cast(float, w[1] << 16); xr[t][hh][3] = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+                    raw[hh][0] = w[0]; raw[hh][1] = w[1];      // (widen_x before use)
                 } else
-                xr[t][hh] = *reinterpret_cast<const f32x4 *>(p.src[0].ptr + (long long)gr * p.src[0].ld + p.src[0].col0 + pc);
+                xt[hh] = *reinterpret_cast<const f32x4 *>(p.src[0].ptr + (long long)gr * p.src[0].ld + p.src[0].col0 + pc);
+            }
+        }
+    };
+    // (bf16 rows stay packed in two registers until they are used: the shift / mask would wait for the load where it was issued)
+    auto widen_x = [&](f32x4 (&xt)[2], const unsigned (&raw)[2][2]) __attribute__((always_inline)) {
+        if constexpr (XB16) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                xt[hh][0] = __builtin_bit_cast(float, raw[hh][0] << 16); xt[hh][1] = __builtin_bit_cast(float, raw[hh][0] & 0xffff0000u);
+                xt[hh][2] = __builtin_bit_cast(float, raw[hh][1] << 16); xt[hh][3] = __builtin_bit_cast(float, raw[hh][1] & 0xffff0000u);
             }
         }
     };
@@ -366,32 +381,40 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
     for (int ks = 0; ks < 4; ++ks) { paA[ks] = sA + n * PS + 8 * ((4 * ks + g) ^ n); paB[ks] = paA[ks] + TILE_BF16; }
 
     f32x4 accA[2], accB[2], accA1[2], accB1[2];
-    f32x4 xr[2][2], ad[2][2][2];
+    f32x4 xr[2][2];
     auto bias_init = [&](f32x4 (&acc)[2], f32x4 (&acc1)[2], int l) __attribute__((always_inline)) {
         const f32x4 b4 = *reinterpret_cast<const f32x4 *>(sBias + l * NP + fcol);
         acc[0] = b4; acc[1] = b4;
         acc1[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    // start of a pair: tile A's input rows -> planes (nothing to overlap with yet), both tiles' start values = bias + additive rows
-    auto open_pair = [&](const f32x4 (&x)[2][2], const f32x4 (&a)[2][2][2]) __attribute__((always_inline)) {
-        if (pact) other_all<SP, 2, true>(accA, accA1, x[0], oA, rng);
-        else other_all<SP, 2, false>(accA, accA1, x[0], oA, rng);
-        bias_init(accA, accA1, 0);
-        bias_init(accB, accB1, 0);
+    // start of the FIRST pair: tile A's input rows -> planes (nothing to overlap with yet), both tiles' start values = bias + additive
+    // rows (the later pairs: inside / after the previous pair's last matrix phase)
+    // start values of a tile = bias + additive rows (in this order: what the tile kernels add)
+    auto start_values = [&](f32x4 (&acc)[2], f32x4 (&acc1)[2], const f32x4 (&a)[2][2]) __attribute__((always_inline)) {
+        bias_init(acc, acc1, 0);
         if (ADDS) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    accA[rb][e] = (accA[rb][e] + a[0][rb][0][e]) + a[0][rb][1][e];
-                    accB[rb][e] = (accB[rb][e] + a[1][rb][0][e]) + a[1][rb][1][e];
-                }
+                for (int e = 0; e < 4; ++e) acc[rb][e] = (acc[rb][e] + a[rb][0][e]) + a[rb][1][e];
         }
     };
-    gather_x(m0, 0, xr);
-    gather_adds(0, 0, ad[0]);
-    gather_adds(1, 0, ad[1]);
-    open_pair(xr, ad);
+    // Loop-carried: xr[1] / adB = input rows / additive rows of the CURRENT pair's tile B (gathered in the previous tail: parked /
+    // added in and after the first matrix phase), accA = tile A's start values, tile A's rows in its planes.
+    f32x4 adB[2][2];
+    unsigned rawB[2][2] = {{0u, 0u}, {0u, 0u}};        // (XB16: tile B's bf16 rows as loaded)
+    {
+        f32x4 adA[2][2];
+        unsigned rawA[2][2] = {{0u, 0u}, {0u, 0u}};
+        gather_x(m0, 0, 0, xr[0], rawA);
+        gather_x(m0, 0, 1, xr[1], rawB);
+        gather_adds(0, 0, adA);
+        gather_adds(1, 0, adB);
+        widen_x(xr[0], rawA);
+        if (pact) other_all<SP, 2, true>(accA, accA1, xr[0], oA, rng);
+        else other_all<SP, 2, false>(accA, accA1, xr[0], oA, rng);
+        start_values(accA, accA1, adA);
+    }
     __syncthreads();                                       // tile A's planes of the first pair visible
 
     for (int it = 0, pair = p_begin; pair < p_end; ++pair, ++it) {
@@ -399,27 +422,28 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         // ---- tables two pairs ahead (their meta was loaded an iteration ago), meta three pairs ahead
         const Meta m3raw = load_meta(pair + 3);
         const int tv = load_tables(m2);
-        // (tile A's planes were written by open_pair in the previous iteration's tail — before the loop for the first pair — and a
-        // barrier lies between: the aggregation's, or the one that closes a tail without aggregation; nothing the stragglers of
-        // the previous tail still read is written in this phase)
+        // (tile A's planes were written in the previous iteration's last matrix phase — before the loop for the first pair — and
+        // that phase's barrier lies between; nothing the stragglers of the previous tail still read is written in this phase)
         WS_STAMP(1);
-        if (pact) m_block<SP, 2, true>(paA, W[0], accA, accA1, accB, accB1, xr[1], oB, rng);                 // for B: park
-        else m_block<SP, 2, false>(paA, W[0], accA, accA1, accB, accB1, xr[1], oB, rng);
+        widen_x(xr[1], rawB);
+        if (pact) m_block<SP, 2, true>(paA, W[0], accA, accA1, accA, accA1, xr[1], oB, rng);                 // for B: park
+        else m_block<SP, 2, false>(paA, W[0], accA, accA1, accA, accA1, xr[1], oB, rng);
+        start_values(accB, accB1, adB);
         __syncthreads();
         WS_STAMP(2);
-        // ---- rows one pair ahead (indices in LDS since the previous iteration)
-        f32x4 nxr[2][2], nad[2][2][2];
-        gather_x(m1, (it + 1) & 1, nxr);
+        // ---- tile A's rows one pair ahead (indices in LDS since the previous iteration); tile B's: in the tail
+        f32x4 nxa[2], nadA[2][2];
+        unsigned nraw[2][2] = {{0u, 0u}, {0u, 0u}};
+        gather_x(m1, (it + 1) & 1, 0, nxa, nraw);
         m_block<SP, 1>(paB, W[0], accB, accB1, accA, accA1, xr[1], oA, rng);                 // for A: epilogue of layer 0
         bias_init(accA, accA1, 1);
         __syncthreads();
         WS_STAMP(3);
-        gather_adds(0, (it + 1) & 1, nad[0]);
+        gather_adds(0, (it + 1) & 1, nadA);
         m_block<SP, 1>(paA, W[1], accA, accA1, accB, accB1, xr[1], oB, rng);                 // for B: epilogue of layer 0
         bias_init(accB, accB1, 1);
         __syncthreads();
         WS_STAMP(4);
-        gather_adds(1, (it + 1) & 1, nad[1]);
         if constexpr (NL == 3) {
             m_block<SP, 1>(paB, W[1], accB, accB1, accA, accA1, xr[1], oA, rng);             // for A: epilogue of layer 1
             bias_init(accA, accA1, 2);
@@ -430,15 +454,19 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
             __syncthreads();
             WS_STAMP(6);
         }
-        m_block<SP, 3>(paB, W[NL - 1], accB, accB1, accA, accA1, xr[1], oA, rng);            // for A: last layer's fp32 rows
+        // for A: last layer's fp32 rows — and the NEXT pair's tile A parked into A's planes (their last readers, M(A, NL - 1), are
+        // behind the previous barrier; the rows were gathered four phases ago): this phase has next to no vector work of its own
+        widen_x(nxa, nraw);
+        if (pact) m_block<SP, 4, true>(paB, W[NL - 1], accB, accB1, accA, accA1, nxa, oA, rng);
+        else m_block<SP, 4, false>(paB, W[NL - 1], accB, accB1, accA, accA1, nxa, oA, rng);
         other_all<SP, 3, false>(accB, accB1, xr[1], oB, rng);                                // B's last layer -> fp32 rows
         __syncthreads();
         WS_STAMP(7);
-        // ---- the next pair opens BEFORE this pair's tail: its rows were gathered four phases ago, and the tail's stores are then
-        // not in front of any load the next iteration waits for
-        open_pair(nxr, nad);
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) xr[1][hh] = nxr[1][hh];
+        // ---- the next pair's tile A start values; then its tile B rows (parked under its M(A', 0)) are gathered: in front of this
+        // tail's stores (memory returns in order per wave), a tail and a phase ahead of their use, so that they are not live across
+        // this pair's matrix phases (tile B's additive rows: at the end of the tail)
+        start_values(accA, accA1, nadA);
+        gather_x(m1, (it + 1) & 1, 1, xr[1], rawB);
         // the tables fetched at the top of this iteration (older than every other load in flight) go to the ring slot of the pair
         // whose rows were gathered in the previous iteration; the next iteration's top barrier publishes them
         store_tables(tv, it + 2);
@@ -504,9 +532,8 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
             }
         }
         WS_STAMP(9);
-        // without the aggregation nothing else separates open_pair's plane writes from the next iteration's M(A,0), which reads the
-        // rows every OTHER wave parked (a wave that ran ahead through its LayerNorm read stale rows: seen once in 600k-row launches)
-        if (!AGG) __syncthreads();
+        // (no barrier at the end of a tail without the aggregation: the next pair's parked rows — what a wave that runs ahead into
+        // M(A', 0) reads — were written before the barrier that closed the last matrix phase)
         if (AGG) {
             __syncthreads();
             // aggregation of the targets whose messages the tiles hold (rows in CSR order): the rows of a segment are added in order
@@ -552,6 +579,9 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
                 }
             }
         }
+        // the next pair's tile B additive rows (added after its M(A', 0)): behind this tail's stores — issued together with tile B's
+        // rows at the top of the tail, the six loads per lane held up the LayerNorm's stores (tail 3.4 k -> 6.6 k ticks)
+        gather_adds(1, (it + 1) & 1, adB);
         WS_STAMP(10);
         m0 = m1; m1 = m2; m2 = fix_meta(m3raw);
     }
