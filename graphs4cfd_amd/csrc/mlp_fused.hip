@@ -855,11 +855,20 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) void ml
     // holds sample row i (= lane & 31, + 32 per row tile) and the 16 output features 32*ct0 + 8*(q>>2) + 4*h + (q&3):
     // four runs of four consecutive features -> 16-byte gathers / LDS accesses instead of 16 scalar ones.
     f32x16 acc[RT], acc1[RT];       // acc1: the 2^-11 terms of the two-way fp16 split (SP == 2 only)
-#pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { acc[t][q] = 0.f; acc1[t][q] = 0.f; }
     const int fbase = ct0 * 32 + 4 * h;
+    // a layer's accumulators start at its bias (then the additive rows, then the products — the order mlp_ws_kernel adds them in):
+    // no bias add in the epilogues
+    auto bias_start = [&](int l) __attribute__((always_inline)) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>((LDS_BIAS ? sBias : p.b) + l * NP + fbase + 8 * gq);
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[t][4 * gq + e] = b4[e]; acc1[t][4 * gq + e] = 0.f; }
+        }
+    };
+    bias_start(0);
     for (int a = 0; a < p.n_add; ++a) {
         const int width = p.add[a].width;
         const bool vec = FULL || (((p.add[a].ld & 3) == 0) && ((width & 3) == 0) && (((uintptr_t)p.add[a].ptr & 15) == 0));
@@ -940,10 +949,9 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) void ml
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>((LDS_BIAS ? sBias : p.b) + l * NP + fbase + 8 * gq);
                     f32x4 x;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[e] = (SP == 2 ? fmaf(acc1[t][4 * gq + e], F16_LO_UNSCALE, acc[t][4 * gq + e]) : acc[t][4 * gq + e]) + b4[e];
+                    for (int e = 0; e < 4; ++e) x[e] = SP == 2 ? fmaf(acc1[t][4 * gq + e], F16_LO_UNSCALE, acc[t][4 * gq + e]) : acc[t][4 * gq + e];
                     *reinterpret_cast<f32x4 *>(sH + (i + 32 * t) * HS + fbase + 8 * gq) = x;
                     if (SAVE) {
                         const long long gr = row0 + i + 32 * t;
@@ -959,7 +967,6 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) void ml
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>((LDS_BIAS ? sBias : p.b) + l * NP + fbase + 8 * gq);
                 f32x4 x;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) x[e] = SP == 2 ? fmaf(acc1[t][4 * gq + e], F16_LO_UNSCALE, acc[t][4 * gq + e]) : acc[t][4 * gq + e];
@@ -970,9 +977,9 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) void ml
                     const f32x4 r = *reinterpret_cast<const f32x4 *>(p.mul[l] + (gr < mlim ? gr : mlim - 1) * p.mul_ld + fbase + 8 * gq);
                     const float sc = 1.0507009873554804934193349852946f, sa = 1.7580993408473768599402175208123f;   // scale, scale * alpha
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = (x[e] + b4[e]) * (r[e] > 0.f ? sc : r[e] + sa);
+                    for (int e = 0; e < 4; ++e) y[e] = x[e] * (r[e] > 0.f ? sc : r[e] + sa);
                 } else {
-                    y = selu4(x + b4);
+                    y = selu4(x);
                 }
                 if (SAVE) {
                     const long long gr = row0 + i + 32 * t;
@@ -987,10 +994,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) void ml
             }
         __syncthreads();
         G4C_STAMPW(5 + 2 * l);
-#pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { acc[t][q] = 0.f; acc1[t][q] = 0.f; }
+        bias_start(l + 1);
         mma_block_bx6<RT, SP>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
         wofs += 2u * BLOCK6;
         __syncthreads();
