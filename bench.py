@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--no-strict-range", action="store_true", help="skip the bf16x6 (fp32 exponent range) rollout beside an f16x3 headline")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-partition-check", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=45.0)
+    ap.add_argument("--cpu-budget-s", type=float, default=75.0)
     a = ap.parse_args()
     w = WORKLOADS[a.workload]
     a.custom = a.nodes is not None or a.model is not None or (a.precision is not None and a.precision != w["precision"])
