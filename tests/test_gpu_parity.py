@@ -1114,7 +1114,9 @@ def test_invalidate_packed_and_rollout_recapture():
         ro.close()
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs")
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs: the gpurun boxes and the driver's GPU-test tier expose "
+                    "one, and HIP_VISIBLE_DEVICES cannot make one device appear twice — g4c::DeviceGuard's device switch has run on "
+                    "device 0 only (a no-op there); run this test on a multi-GPU node")
 def test_model_on_a_non_current_device():
     """`device=cuda:1` while the process's current device stays 0 (the reference API's usage): the C entry points switch to
     the device that owns their buffers."""
