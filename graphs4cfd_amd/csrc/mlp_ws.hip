@@ -83,6 +83,37 @@ __device__ __forceinline__ f32x2 selu2w(f32x2 x) {
     return selu2(x);
 }
 
+// G4C_WS_SCALED (f16x3 stream): the values that are about to be split are carried as S = y * 2^11 — the SELU forms them with its two
+// FMAs' constants scaled (the same bits as y * 2^11: a power of two commutes with both roundings), a row that is parked without an
+// activation is multiplied once, as before — and the split reads S twice: h = fp16(S * 2^-11) by v_fma_mixlo/hi_f16 (the product is
+// exactly y, one rounding: the bits of v_cvt_pk_f16_f32), l = fp16(fma(h, -2^11, S)) as before.  One vector instruction less per pair
+// (no y * 2^11), the same planes bit for bit; the range tracker compares S with 65504 * 2^11.
+#ifndef G4C_WS_SCALED
+#define G4C_WS_SCALED 1
+#endif
+__device__ __forceinline__ f32x2 selu2w_scaled(f32x2 x) {
+    const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f * F16_LO_SCALE;
+    const float scale = 1.0507009873554804934193349852946f * F16_LO_SCALE;
+    f32x2 r;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float ex = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x[e] * 1.4426950408889634f), 0.f, 1.f);
+        r[e] = fmaf(fmaxf(x[e], 0.f), scale, fmaf(sa, ex, -sa));
+    }
+    return r;
+}
+__device__ __forceinline__ void put_pair_scaled(__bf16 *d, f32x2 S, RangeV &rng) {
+    rng.m = fmaxf(fmaxf(rng.m, fabsf(S[0])), fabsf(S[1]));          // (v_max3_f32; in units of 2^-11: range_report_scaled)
+    unsigned hu, lu;
+    const float up = F16_LO_UNSCALE, dn = -F16_LO_SCALE;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hu) : "v"(S[0]), "s"(up));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hu) : "v"(S[1]), "s"(up));
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lu) : "v"(hu), "s"(dn), "v"(S[0]));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu) : "v"(hu), "s"(dn), "v"(S[1]));
+    *reinterpret_cast<unsigned *>(d) = hu;
+    *reinterpret_cast<unsigned *>(d + PLN) = lu;
+}
+
 // two-way fp16 split of a pair -> one packed pair per plane (split_pair_f16, mlp_common.h: four vector instructions + the range tracker)
 // (SP = 1: the pair rounded to bf16, one plane)
 template <int SP>
@@ -118,17 +149,21 @@ __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const
             f32x2 x, x1;
             x[0] = accE[u][2 * pr]; x[1] = accE[u][2 * pr + 1];
             x1[0] = accE1[u][2 * pr]; x1[1] = accE1[u][2 * pr + 1];
-            hold = SP == 1 ? selu2w(x) : selu2w(x1 * F16_LO_UNSCALE + x);         // (the fold is one v_pk_fma_f32)
+            if (SP == 2 && G4C_WS_SCALED && !(G4C_WS_ABLATE & 48)) hold = selu2w_scaled(x1 * F16_LO_UNSCALE + x);
+            else hold = SP == 1 ? selu2w(x) : selu2w(x1 * F16_LO_UNSCALE + x);         // (the fold is one v_pk_fma_f32)
         } else {
-            put_pair<SP>(o.plane_acc + u * 16 * PS + 2 * pr, hold, rng);
+            if (SP == 2 && G4C_WS_SCALED && !(G4C_WS_ABLATE & 48)) put_pair_scaled(o.plane_acc + u * 16 * PS + 2 * pr, hold, rng);
+            else put_pair<SP>(o.plane_acc + u * 16 * PS + 2 * pr, hold, rng);
         }
     } else if (EK == 2) {
         if ((pc4 & 1) == 0) {
             f32x2 x;
             x[0] = xe[u][2 * pr]; x[1] = xe[u][2 * pr + 1];
-            hold = PACT ? selu2w(x) : x;
+            if (SP == 2 && G4C_WS_SCALED && !(G4C_WS_ABLATE & 48)) hold = PACT ? selu2w_scaled(x) : x * F16_LO_SCALE;
+            else hold = PACT ? selu2w(x) : x;
         } else {
-            put_pair<SP>(o.plane_park + u * 16 * PS + 2 * pr, hold, rng);
+            if (SP == 2 && G4C_WS_SCALED && !(G4C_WS_ABLATE & 48)) put_pair_scaled(o.plane_park + u * 16 * PS + 2 * pr, hold, rng);
+            else put_pair<SP>(o.plane_park + u * 16 * PS + 2 * pr, hold, rng);
         }
     } else if (EK == 3) {
         if (pc4 == 0) {
@@ -586,7 +621,10 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         m0 = m1; m1 = m2; m2 = fix_meta(m3raw);
     }
     WS_STAMP_ONCE(13, __builtin_readcyclecounter());
-    if (SP == 2) range_report(p, rng);
+    if (SP == 2) {
+        if (G4C_WS_SCALED && !(G4C_WS_ABLATE & 48)) rng.m *= F16_LO_UNSCALE;       // (tracked in units of 2^-11)
+        range_report(p, rng);
+    }
 }
 
 }  // namespace
