@@ -78,9 +78,23 @@ struct Other {
     float *fin;               // EK 3: (row n, feature fcol) of the other tile's fp32 rows
 };
 
+// LOADED: x comes straight from memory — fmaxf would first canonicalise it (v_max_f32 x, x: one more instruction per value), the
+// instruction itself does not need that (same value: g4c::selu_f's formula)
+template <bool LOADED = false>
 __device__ __forceinline__ f32x2 selu2w(f32x2 x) {
     if (G4C_WS_ABLATE & 16) return x;
-    return selu2(x);
+    if constexpr (!LOADED) return selu2(x);
+    const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f;
+    const float scale = 1.0507009873554804934193349852946f;
+    f32x2 r;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float ex = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x[e] * 1.4426950408889634f), 0.f, 1.f);
+        float m;
+        asm("v_max_f32 %0, 0, %1" : "=v"(m) : "v"(x[e]));
+        r[e] = fmaf(m, scale, fmaf(sa, ex, -sa));
+    }
+    return r;
 }
 
 // G4C_WS_SCALED (f16x3 stream): the values that are about to be split are carried as S = y * 2^11 — the SELU forms them with its two
@@ -91,6 +105,7 @@ __device__ __forceinline__ f32x2 selu2w(f32x2 x) {
 #ifndef G4C_WS_SCALED
 #define G4C_WS_SCALED 1
 #endif
+template <bool LOADED = false>
 __device__ __forceinline__ f32x2 selu2w_scaled(f32x2 x) {
     const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f * F16_LO_SCALE;
     const float scale = 1.0507009873554804934193349852946f * F16_LO_SCALE;
@@ -98,7 +113,10 @@ __device__ __forceinline__ f32x2 selu2w_scaled(f32x2 x) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const float ex = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x[e] * 1.4426950408889634f), 0.f, 1.f);
-        r[e] = fmaf(fmaxf(x[e], 0.f), scale, fmaf(sa, ex, -sa));
+        float m;
+        if constexpr (LOADED) asm("v_max_f32 %0, 0, %1" : "=v"(m) : "v"(x[e]));
+        else m = fmaxf(x[e], 0.f);
+        r[e] = fmaf(m, scale, fmaf(sa, ex, -sa));
     }
     return r;
 }
@@ -159,8 +177,8 @@ __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const
         if ((pc4 & 1) == 0) {
             f32x2 x;
             x[0] = xe[u][2 * pr]; x[1] = xe[u][2 * pr + 1];
-            if (SP == 2 && G4C_WS_SCALED && !(G4C_WS_ABLATE & 48)) hold = PACT ? selu2w_scaled(x) : x * F16_LO_SCALE;
-            else hold = PACT ? selu2w(x) : x;
+            if (SP == 2 && G4C_WS_SCALED && !(G4C_WS_ABLATE & 48)) hold = PACT ? selu2w_scaled<true>(x) : x * F16_LO_SCALE;
+            else hold = PACT ? selu2w<true>(x) : x;
         } else {
             if (SP == 2 && G4C_WS_SCALED && !(G4C_WS_ABLATE & 48)) put_pair_scaled(o.plane_park + u * 16 * PS + 2 * pr, hold, rng);
             else put_pair<SP>(o.plane_park + u * 16 * PS + 2 * pr, hold, rng);
