@@ -159,6 +159,16 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// (two independent sums at once: each step's DPP adds alternate, so neither waits for its own previous step)
+__device__ __forceinline__ void row16_sum2(float &a, float &b) {
+#define G4C_DPP_ADD(v, ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false))
+    G4C_DPP_ADD(a, 0xB1); G4C_DPP_ADD(b, 0xB1);
+    G4C_DPP_ADD(a, 0x4E); G4C_DPP_ADD(b, 0x4E);
+    G4C_DPP_ADD(a, 0x141); G4C_DPP_ADD(b, 0x141);
+    G4C_DPP_ADD(a, 0x140); G4C_DPP_ADD(b, 0x140);
+#undef G4C_DPP_ADD
+}
+
 template <int SP, int EK, bool PACT>
 __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, f32x2 &hold, RangeV &rng) {
     const int u = s >> 2, pc4 = s & 3, pr = pc4 >> 1;
@@ -529,58 +539,78 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         // reduced inside a 16-lane DPP row (quad_perm, row_half_mirror, row_mirror: no LDS round trips); a wave takes 4 rows per
         // pass, the workgroup a whole tile per pass.  The finished rows are stored straight from the registers (16 lanes = one
         // 512-byte row); only the aggregation needs them back in LDS.
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        // Stage by stage over BOTH tiles (one basic block per stage: the uniform branches on gamma / the activation are outside the
+        // per-tile work), so that one tile's LDS reads, DPP reductions and rsqrt hide under the other tile's arithmetic.
+        {
             const int row = wave * 4 + g;
-            float *rowp = (t == 0 ? fA : fB) + row * HS + n * 8;
-            float x[8];
+            float *const rowp[2] = {fA + row * HS + n * 8, fB + row * HS + n * 8};
+            float x[2][8];
 #pragma unroll
-            for (int c = 0; c < 8; c += 4) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp + c);
-                x[c] = v[0]; x[c + 1] = v[1]; x[c + 2] = v[2]; x[c + 3] = v[3];
-            }
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 8; c += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp[t] + c);
+                    x[t][c] = v[0]; x[t][c + 1] = v[1]; x[t][c + 2] = v[2]; x[t][c + 3] = v[3];
+                }
             if (p.gamma) {
-                float sum = 0.f;
+                float sum[2], mean[2], var[2], rstd[2];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) sum += x[c];
-                sum = row16_sum(sum);
-                const float mean = sum * (1.0f / NP);
-                float var = 0.f;
+                for (int t = 0; t < 2; ++t) {
+                    sum[t] = 0.f;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) { const float dl = x[c] - mean; var += dl * dl; }
-                var = row16_sum(var);
-                const float rstd = rsqrtf(var * (1.0f / NP) + p.eps);
+                    for (int c = 0; c < 8; ++c) sum[t] += x[t][c];
+                }
+                row16_sum2(sum[0], sum[1]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    mean[t] = sum[t] * (1.0f / NP);
+                    var[t] = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { const float dl = x[t][c] - mean[t]; var[t] += dl * dl; }
+                }
+                row16_sum2(var[0], var[1]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) rstd[t] = rsqrtf(var[t] * (1.0f / NP) + p.eps);
 #pragma unroll
                 for (int c = 0; c < 8; c += 4) {
                     const f32x4 g4 = *reinterpret_cast<const f32x4 *>(sGB + n * 8 + c), b4 = *reinterpret_cast<const f32x4 *>(sGB + NP + n * 8 + c);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) x[c + u] = fmaf((x[c + u] - mean) * rstd, g4[u], b4[u]);
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) x[t][c + u] = fmaf((x[t][c + u] - mean[t]) * rstd[t], g4[u], b4[u]);
                 }
             }
             if (p.act == G4C_ACT_SELU) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) x[c] = g4c::selu_f(x[c]);
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) x[t][c] = g4c::selu_f(x[t][c]);
             } else if (p.act == G4C_ACT_TANH) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) x[c] = g4c::tanh_f(x[c]);
-            }
-            f32x4 v0, v1;
-            v0[0] = x[0]; v0[1] = x[1]; v0[2] = x[2]; v0[3] = x[3]; v1[0] = x[4]; v1[1] = x[5]; v1[2] = x[6]; v1[3] = x[7];
-            if (AGG) { *reinterpret_cast<f32x4 *>(rowp) = v0; *reinterpret_cast<f32x4 *>(rowp + 4) = v1; }
-            if (p.out && row < m0.n[t]) {
-                const long long orow = (!AGG && p.out_idx) ? p.out_idx[m0.r0[t] + row] : m0.r0[t] + row;
-                if (SP == 1 && p.out_bf16) {
-                    // rows kept in bf16 (g4c_mlp_forward_bf16_agg out_dtype; == 2: the reader's pending SELU applied before the one
-                    // rounding — the aggregation below still sees the fp32 rows without it), 16 bytes per lane
-                    f32x4 w0 = v0, w1 = v1;
-                    if (p.out_bf16 == 2) { w0 = selu4(v0); w1 = selu4(v1); }         // (the formula the reader's SELU on load uses)
-                    bf16x8 b;
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { b[c] = (__bf16)w0[c]; b[4 + c] = (__bf16)w1[c]; }
-                    *reinterpret_cast<bf16x8 *>(reinterpret_cast<__bf16 *>(p.out) + orow * p.out_ld + n * 8) = b;
-                } else {
-                    float *op = p.out + orow * p.out_ld + n * 8;
-                    *reinterpret_cast<f32x4 *>(op) = v0; *reinterpret_cast<f32x4 *>(op + 4) = v1;
+                    for (int c = 0; c < 8; ++c) x[t][c] = g4c::tanh_f(x[t][c]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 v0, v1;
+                v0[0] = x[t][0]; v0[1] = x[t][1]; v0[2] = x[t][2]; v0[3] = x[t][3]; v1[0] = x[t][4]; v1[1] = x[t][5]; v1[2] = x[t][6]; v1[3] = x[t][7];
+                if (AGG) { *reinterpret_cast<f32x4 *>(rowp[t]) = v0; *reinterpret_cast<f32x4 *>(rowp[t] + 4) = v1; }
+                if (p.out && row < m0.n[t]) {
+                    const long long orow = (!AGG && p.out_idx) ? p.out_idx[m0.r0[t] + row] : m0.r0[t] + row;
+                    if (SP == 1 && p.out_bf16) {
+                        // rows kept in bf16 (g4c_mlp_forward_bf16_agg out_dtype; == 2: the reader's pending SELU applied before the one
+                        // rounding — the aggregation below still sees the fp32 rows without it), 16 bytes per lane
+                        f32x4 w0 = v0, w1 = v1;
+                        if (p.out_bf16 == 2) { w0 = selu4(v0); w1 = selu4(v1); }         // (the formula the reader's SELU on load uses)
+                        bf16x8 b;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { b[c] = (__bf16)w0[c]; b[4 + c] = (__bf16)w1[c]; }
+                        *reinterpret_cast<bf16x8 *>(reinterpret_cast<__bf16 *>(p.out) + orow * p.out_ld + n * 8) = b;
+                    } else {
+                        float *op = p.out + orow * p.out_ld + n * 8;
+                        *reinterpret_cast<f32x4 *>(op) = v0; *reinterpret_cast<f32x4 *>(op + 4) = v1;
+                    }
                 }
             }
         }
