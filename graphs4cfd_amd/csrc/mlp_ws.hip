@@ -543,13 +543,19 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         // per-tile work), so that one tile's LDS reads, DPP reductions and rsqrt hide under the other tile's arithmetic.
         {
             const int row = wave * 4 + g;
-            float *const rowp[2] = {fA + row * HS + n * 8, fB + row * HS + n * 8};
+            // this lane's eight columns of a row: fp32 rows out — [4 n, 4 n + 4) and [64 + 4 n, 64 + 4 n + 4), so that each of the two
+            // 16-byte stores of the 16 lanes of a row writes 256 contiguous bytes (whole 128-byte lines; with eight consecutive
+            // columns per lane each store instruction wrote every other 16 bytes of all four lines of the row); bf16 rows out —
+            // [8 n, 8 n + 8): one 16-byte store per lane, 256 contiguous bytes per row
+            const bool rows16 = SP == 1 && p.out_bf16;
+            const int cq[2] = {rows16 ? n * 8 : n * 4, rows16 ? n * 8 + 4 : 64 + n * 4};
+            float *const rowp[2] = {fA + row * HS, fB + row * HS};
             float x[2][8];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int c = 0; c < 8; c += 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp[t] + c);
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp[t] + cq[c >> 2]);
                     x[t][c] = v[0]; x[t][c + 1] = v[1]; x[t][c + 2] = v[2]; x[t][c + 3] = v[3];
                 }
             if (p.gamma) {
@@ -573,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
                 for (int t = 0; t < 2; ++t) rstd[t] = rsqrtf(var[t] * (1.0f / NP) + p.eps);
 #pragma unroll
                 for (int c = 0; c < 8; c += 4) {
-                    const f32x4 g4 = *reinterpret_cast<const f32x4 *>(sGB + n * 8 + c), b4 = *reinterpret_cast<const f32x4 *>(sGB + NP + n * 8 + c);
+                    const f32x4 g4 = *reinterpret_cast<const f32x4 *>(sGB + cq[c >> 2]), b4 = *reinterpret_cast<const f32x4 *>(sGB + NP + cq[c >> 2]);
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -595,7 +601,7 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
             for (int t = 0; t < 2; ++t) {
                 f32x4 v0, v1;
                 v0[0] = x[t][0]; v0[1] = x[t][1]; v0[2] = x[t][2]; v0[3] = x[t][3]; v1[0] = x[t][4]; v1[1] = x[t][5]; v1[2] = x[t][6]; v1[3] = x[t][7];
-                if (AGG) { *reinterpret_cast<f32x4 *>(rowp[t]) = v0; *reinterpret_cast<f32x4 *>(rowp[t] + 4) = v1; }
+                if (AGG) { *reinterpret_cast<f32x4 *>(rowp[t] + cq[0]) = v0; *reinterpret_cast<f32x4 *>(rowp[t] + cq[1]) = v1; }
                 if (p.out && row < m0.n[t]) {
                     const long long orow = (!AGG && p.out_idx) ? p.out_idx[m0.r0[t] + row] : m0.r0[t] + row;
                     if (SP == 1 && p.out_bf16) {
@@ -608,8 +614,8 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
                         for (int c = 0; c < 4; ++c) { b[c] = (__bf16)w0[c]; b[4 + c] = (__bf16)w1[c]; }
                         *reinterpret_cast<bf16x8 *>(reinterpret_cast<__bf16 *>(p.out) + orow * p.out_ld + n * 8) = b;
                     } else {
-                        float *op = p.out + orow * p.out_ld + n * 8;
-                        *reinterpret_cast<f32x4 *>(op) = v0; *reinterpret_cast<f32x4 *>(op + 4) = v1;
+                        float *op = p.out + orow * p.out_ld;
+                        *reinterpret_cast<f32x4 *>(op + cq[0]) = v0; *reinterpret_cast<f32x4 *>(op + cq[1]) = v1;
                     }
                 }
             }
