@@ -559,7 +559,10 @@ struct Ring6 { bf16x8 h[RD6], m[RD6], l[RD6]; };
 constexpr int G4C_BX6_TUNE = 0;      // (1 = s_setprio around the MFMAs, 2 = no sched_barriers in the MFMA loop: both measured neutral)
 // SP == 2 (two-way fp16 split, mlp_common.h): planes h / l, three products per step — (Wh, xl) and (Wl, xh) into acc1 (the terms
 // that carry the factor 2^-11), (Wh, xh) into acc.
-template <int RT, int SP>
+// SWAP (the heads): the two MFMA operands trade places, so the accumulator comes out untransposed — a lane holds ONE output feature
+// (lane & 31 of the wave's 32-column slice) of the 16 sample rows 8 (q / 4) + 4 (lane / 32) + q % 4 — and a store instruction writes
+// 128 contiguous bytes of each of two rows (same products, same order of k inside the MFMA).
+template <int RT, int SP, bool SWAP = false>
 __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6 &g, __amdgpu_buffer_rsrc_t rs, unsigned wofs, unsigned lo_b,
                                               f32x16 (&acc)[RT], f32x16 (&acc1)[RT]) {
     bf16x8 ah = *reinterpret_cast<const bf16x8 *>(pa), am = ah, al = ah;
@@ -585,20 +588,34 @@ __device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6
                 if (!(G4C_BX6_TUNE & 2)) __builtin_amdgcn_sched_barrier(0);
                 if (G4C_BX6_TUNE & 1) __builtin_amdgcn_s_setprio(1);
                 if (SP == 3 && !(G4C_ABLATE & 128)) {
+                if (SWAP) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, g.h[r], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, g.l[r], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, g.m[r], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, g.h[r], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, g.m[r], acc[t], 0, 0, 0);
+                } else {
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], al, acc[t], 0, 0, 0);     // small terms first
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.l[r], ah, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.m[r], am, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], am, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.m[r], ah, acc[t], 0, 0, 0);
+                }
                 } else if (SP == 3) {      // (ablation) keep every operand live with one cheap VALU op instead of five MFMAs
                     acc[t][0] += (float)al[0] + (float)am[0] + (float)g.l[r][0] + (float)g.m[r][0];
                 }
                 if (SP == 2) {
-                    acc1[t] = mfma_f16(g.h[r], am, acc1[t]);
-                    acc1[t] = mfma_f16(g.m[r], ah, acc1[t]);
-                    acc[t] = mfma_f16(g.h[r], ah, acc[t]);
+                    if (SWAP) {
+                        acc1[t] = mfma_f16(am, g.h[r], acc1[t]);
+                        acc1[t] = mfma_f16(ah, g.m[r], acc1[t]);
+                        acc[t] = mfma_f16(ah, g.h[r], acc[t]);
+                    } else {
+                        acc1[t] = mfma_f16(g.h[r], am, acc1[t]);
+                        acc1[t] = mfma_f16(g.m[r], ah, acc1[t]);
+                        acc[t] = mfma_f16(g.h[r], ah, acc[t]);
+                    }
                 } else
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], ah, acc[t], 0, 0, 0);
+                acc[t] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, g.h[r], acc[t], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(g.h[r], ah, acc[t], 0, 0, 0);
                 if (G4C_BX6_TUNE & 1) __builtin_amdgcn_s_setprio(0);
                 if (t + 1 == RT && !(G4C_ABLATE & 32)) {
                     const unsigned sx = (G4C_ABLATE & 1024) ? 0u : so + 2u * r * STEP6;     // (1024: always the same 3 KB -> L1 hits)
@@ -1044,22 +1061,25 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) void ml
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { acc[t][q] = 0.f; acc1[t][q] = 0.f; }
-            mma_block_bx6<RT, SP>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
+            mma_block_bx6<RT, SP, true>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
             wofs += 2u * BLOCK6;
-            float *ho = p.head_out[hd];
+            // untransposed accumulator (SWAP): lane (i, h) holds column ct0 * 32 + i of the rows 32 t + 8 gq + 4 h + e; one dword
+            // store per value, 32 lanes = one 128-byte line of a row.  The rows of the tile past mlim fall outside the buffer
+            // descriptor's range (num_records) and are dropped by the hardware.
+            const long long left = mlim - row0;
+            const int nrows = left >= ROWS ? ROWS : (left > 0 ? (int)left : 0);
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(p.head_out[hd] + row0 * p.head_ld, 0, nrows * p.head_ld * 4, 0x00020000);
+            const unsigned vo = (unsigned)(4 * h * p.head_ld + ct0 * 32 + i) * 4u;
 #pragma unroll
-            for (int t = 0; t < RT; ++t) {
-                const long long grow = row0 + i + 32 * t;
-                if (grow < mlim) {
+            for (int t = 0; t < RT; ++t)
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        f32x4 x;
+                for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) x[e] = SP == 2 ? fmaf(acc1[t][4 * gq + e], F16_LO_UNSCALE, acc[t][4 * gq + e]) : acc[t][4 * gq + e];
-                        *reinterpret_cast<f32x4 *>(ho + grow * p.head_ld + fbase + 8 * gq) = x;
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = SP == 2 ? fmaf(acc1[t][4 * gq + e], F16_LO_UNSCALE, acc[t][4 * gq + e]) : acc[t][4 * gq + e];
+                        // (the row offset is part of the VECTOR offset: the scalar offset is not range-checked)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rh, vo + (unsigned)((32 * t + 8 * gq + e) * p.head_ld) * 4u, 0, 0);
                     }
-                }
-            }
         }
     }
     if (SP == 2) range_report(p, rng);

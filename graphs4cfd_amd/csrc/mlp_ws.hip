@@ -545,9 +545,11 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
             const int row = wave * 4 + g;
             // this lane's eight columns of a row: fp32 rows out — [4 n, 4 n + 4) and [64 + 4 n, 64 + 4 n + 4), so that each of the two
             // 16-byte stores of the 16 lanes of a row writes 256 contiguous bytes (whole 128-byte lines; with eight consecutive
-            // columns per lane each store instruction wrote every other 16 bytes of all four lines of the row); bf16 rows out —
-            // [8 n, 8 n + 8): one 16-byte store per lane, 256 contiguous bytes per row
-            const bool rows16 = SP == 1 && p.out_bf16;
+            // columns per lane each store instruction wrote every other 16 bytes of all four lines of the row); rounded-bf16 mode —
+            // [8 n, 8 n + 8): its rows usually go out as bf16, one 16-byte store per lane, 256 contiguous bytes per row (and the
+            // LayerNorm's sums are formed in the same order whichever way its rows are stored: the compact message rows must give
+            // bit for bit the forward of fp32 rows, test_remus_bf16_compact_messages_are_bit_identical)
+            constexpr bool rows16 = SP == 1;
             const int cq[2] = {rows16 ? n * 8 : n * 4, rows16 ? n * 8 + 4 : 64 + n * 4};
             float *const rowp[2] = {fA + row * HS, fB + row * HS};
             float x[2][8];
