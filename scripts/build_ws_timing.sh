@@ -2,7 +2,7 @@
 # libg4c variant whose weight-stationary kernel writes cycle stamps (scripts/ws_stamps.py): graphs4cfd_amd/lib/libg4c_ws_timing.so
 set -e
 cd "$(dirname "$0")/../graphs4cfd_amd/csrc"
-make -j8 >/dev/null
+make -j8 >/dev/null      # (NOTE: this also rebuilds ../lib/libg4c.so from the CURRENT sources: run make again after a git stash pop)
 # usage: build_ws_timing.sh [suffix [extra -D flags...]]   (e.g. build_ws_timing.sh _a1 -DG4C_WS_ABLATE=1)
 SFX=$1; [ $# -gt 0 ] && shift
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DG4C_WS_TIMING "$@" -c mlp_ws.hip -o build/mlp_ws_timing$SFX.o
