@@ -630,6 +630,7 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         // M(A', 0) reads — were written before the barrier that closed the last matrix phase)
         if (AGG) {
             __syncthreads();
+            WS_STAMP(15);
             // aggregation of the targets whose messages the tiles hold (rows in CSR order): the rows of a segment are added in order
             // (clamped loads, predicated adds) and divided by max(count, 1) like segment_reduce_kernel does, so the result is
             // bit-identical to the separate launch.  32 lanes per target (16 bytes each), 16 targets per pass over both tiles.
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         }
         // the next pair's tile B additive rows (added after its M(A', 0)): behind this tail's stores — issued together with tile B's
         // rows at the top of the tail, the six loads per lane held up the LayerNorm's stores (tail 3.4 k -> 6.6 k ticks)
+        WS_STAMP(16);
         if constexpr (SP != 1) gather_adds(1, (it + 1) & 1, adB);
         WS_STAMP(10);
         m0 = m1; m1 = m2; m2 = fix_meta(m3raw);

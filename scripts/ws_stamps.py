@@ -52,6 +52,10 @@ for k in keys[1:]:
     d = st[:, k] - st[:, prev]
     print(f"{names[k]:62s} median {int(np.median(d)):7d}  (p10 {int(np.percentile(d, 10)):7d}, p90 {int(np.percentile(d, 90)):7d})")
     prev = k
+for a_, b_, nm in ((9, 15, "  of which: wait at the aggregation barrier"), (15, 16, "  of which: aggregation"), (16, 10, "  of which: tile B additive gathers issued")):
+    if st[:, 15].any():
+        d = st[:, b_] - st[:, a_]
+        print(f"{nm:62s} median {int(np.median(d)):7d}  (p10 {int(np.percentile(d, 10)):7d}, p90 {int(np.percentile(d, 90)):7d})")
 print("pair period (loop top -> end of tail) median", int(np.median(st[:, 10] - st[:, 0])))
 live = st[:, 14] > 0
 per = (st[live, 13] - st[live, 12]) / st[live, 14]
