@@ -1,4 +1,5 @@
 #include "g4c_common.h"
+#include <atomic>
 
 namespace g4c {
 static thread_local char g_err[512] = "";
@@ -16,6 +17,18 @@ int visible_devices() {
         if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); c = 0; }
         return c;
     }();
+    return n;
+}
+
+int cu_count() {
+    constexpr int MAXD = 64;
+    static std::atomic<int> cached[MAXD];          // zero-initialised; a benign race stores the same value twice
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    int n = (dev >= 0 && dev < MAXD) ? cached[dev].load(std::memory_order_relaxed) : 0;
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    if (dev >= 0 && dev < MAXD) cached[dev].store(n, std::memory_order_relaxed);
     return n;
 }
 }  // namespace g4c

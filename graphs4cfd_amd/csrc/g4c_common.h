@@ -24,6 +24,8 @@ inline int check_launch(const char *what) {
 // API takes `device=cuda:N`; the stream argument alone cannot say which device — torch's default stream of any device is the
 // null handle).  With one visible device (one process per GPU, the normal deployment) the guard costs nothing.
 int visible_devices();
+// compute units of the CURRENT device (the one a launch that follows goes to); cached per device ordinal, thread-safe
+int cu_count();
 struct DeviceGuard {
     int prev = -1;
     explicit DeviceGuard(const void *device_ptr) {

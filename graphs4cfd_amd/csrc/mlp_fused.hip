@@ -1294,12 +1294,16 @@ extern "C" int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp, const g4c_src_t *srcs, 
                       nullptr, 0, nullptr, 0, stream);
 }
 
+static thread_local int g_last_kernel = G4C_KERNEL_NONE;
+extern "C" int g4c_mlp_last_kernel(void) { return g_last_kernel; }
+
 static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                       int64_t row_begin, int64_t row_count, int32_t tile_rows,
                       float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                       const float *resid, int32_t resid_ld, int32_t resid_col0,
                       const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream,
                       const AggArgs *agg, const SaveArgs *save) {
+    g_last_kernel = G4C_KERNEL_NONE;
     const bool force_tiles = (tile_rows == 3249) || (tile_rows == 3217);     // 3248 / 3216 on the 32-row-tile kernel only (tests, A/B)
     if (force_tiles) tile_rows -= 1;
     const bool round1 = (tile_rows == 3216);     // operands rounded to bf16: only the leading plane of the stream is used
@@ -1446,10 +1450,12 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     if (bx6 && !force_tiles && ws_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
         // weight-stationary persistent kernel (mlp_ws.hip): pairs of 32-row tiles (whole segments with aggregation), one workgroup per CU
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
+        g_last_kernel = G4C_KERNEL_MLP_WS;
         return ws_launch(p, agg != nullptr, round1, st);
     } else if (bx6 && !force_tiles && bx6i_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
         // dual-tile software-pipelined kernel (mlp_bx6i.hip): pairs of 32-row tiles (whole segments with aggregation)
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
+        g_last_kernel = G4C_KERNEL_MLP_BX6I;
         return bx6i_launch(p, agg != nullptr, f16x2, st);
     } else if (bx6) {
         bool full = all_vec;
@@ -1459,6 +1465,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         const dim3 blk(256);
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
         if (p.n_tiles == 0) return G4C_OK;
+        g_last_kernel = G4C_KERNEL_MLP_BX6;
         const dim3 grid(p.n_tiles);
 #define G4C_BX6_LAUNCH(RT, SP)                                                                         \
         do {                                                                                           \
@@ -1481,6 +1488,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
 #undef G4C_BX6_LAUNCH
     } else {
         p.n_tiles = (int)((row_count + 31) / 32);
+        g_last_kernel = G4C_KERNEL_MLP_SPLIT;
         if (all_vec) mlp_split_kernel<4, true><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
         else mlp_split_kernel<4, false><<<dim3(p.n_tiles), dim3(256), 0, st>>>(p);
     }

@@ -742,11 +742,7 @@ bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, 
 int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st) {
     const int n_pairs = (p.n_tiles + 1) / 2;
     if (n_pairs == 0) return G4C_OK;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = g4c::cu_count();
     const dim3 grid(n_pairs < n_cu ? n_pairs : n_cu), blk(512);
     const bool direct = p.src[0].idx == nullptr, adds = p.n_add == 2, two = p.n_layers == 2, xb16 = p.src[0].bf16 != 0;
 #define G4C_WS_GO(AGG, DIRECT, ADDS, SP, NL, XB16) mlp_ws_kernel<AGG, DIRECT, ADDS, SP, NL, XB16><<<grid, blk, 0, st>>>(p, n_pairs)

@@ -106,9 +106,12 @@ class GNN(nn.Module):
         self.num_fields = arch["decoder"][1][-1] if 'decoder' in arch else None
         # names under which clipped fp16 values are reported (ops.f16_range_report)
         from .blocks import MLP as _MLP
+        sites = []
         for name, m in self.named_modules():
             if isinstance(m, _MLP):
                 m._site = f"{type(self).__name__}.{name}"
+                sites.append(m._site)
+        self._range_sites = frozenset(sites)     # what a rollout of THIS model clears on entry and reports (ops.check_f16_range(sites=))
 
     def to(self, *args, **kwargs):
         out = super().to(*args, **kwargs)
@@ -173,12 +176,9 @@ class GNN(nn.Module):
                 capture = n_out >= 4 and os.environ.get("G4C_HIPGRAPH", "1") != "0"
             if ops.mlp_precision() == "f16x3":
                 _warn_f16_range(graph)
-            with Rollout(self, graph, n_out, capture=capture) as ro:
+            with Rollout(self, graph, n_out, capture=capture, label="solve()") as ro:
                 ro.run(n_out)
-                out = ro.result()
-            if ops.mlp_precision() == "f16x3":
-                ops.check_f16_range(out.device, "solve()")
-            return out
+                return ro.result()       # (reports a clip of the default arithmetic in this model's own launches)
 
     def invalidate_packed(self) -> None:
         """Declare every packed weight image stale (they are rebuilt on the next launch).  The images are keyed on the parameters'
@@ -258,7 +258,8 @@ class Rollout:
     every later step is a replay: no host synchronisation, no per-kernel launch cost.
     The caller's `graph.field` is swapped for a private working copy and restored on close()."""
 
-    def __init__(self, model: "GNN", graph: Graph, max_steps: int, capture: bool = True, reorder: Optional[bool] = None):
+    def __init__(self, model: "GNN", graph: Graph, max_steps: int, capture: bool = True, reorder: Optional[bool] = None,
+                 label: str = "Rollout"):
         """`reorder` (default: meshes of >= REORDER_MIN_NODES nodes, unless G4C_REORDER=0): run on a copy of the Graph whose level-1
         nodes are numbered along a Morton curve (reorder.py: the senders an edge tile gathers are then rows its neighbours
         just touched) and map the output rows back in `result()`; Graph layouts the renumbering does not know run as they are."""
@@ -282,9 +283,17 @@ class Rollout:
         self.steps_done = 0
         self._hipgraph, self._epoch, self._pins = None, -1, None
         graph.field = self.field
+        # per-mesh constants (the encoders of edge_attr / angle_attr*): computed by the first eager step, read by every later one
+        self.static = ops.StaticCache()
+        # fp16 range flags: this rollout answers for its own model's launches only — whatever an earlier launch of these MLPs
+        # left behind is dropped here, other models' flags are left alone
+        self.label, self._sites = label, getattr(model, "_range_sites", None)
+        if ops.mlp_precision() == "f16x3":
+            ops.f16_range_clear(dev, self._sites)
 
     def _one(self):
-        pred = self.model.forward(self.graph, self.steps_done)
+        with self.static:
+            pred = self.model.forward(self.graph, self.steps_done)
         ops.rollout_advance(self.field, pred, self.outputs, self.step_counter, self.nf)
 
     def step(self) -> None:
@@ -321,7 +330,10 @@ class Rollout:
             self.step_counter.fill_(1)
 
     def result(self) -> torch.Tensor:
-        """`outputs` with its rows in the caller's node numbering."""
+        """`outputs` with its rows in the caller's node numbering.  In the default "f16x3" arithmetic a value this rollout's
+        launches clipped at the end of the fp16 range is reported here (RuntimeWarning naming the MLPs; one synchronisation)."""
+        if ops.mlp_precision() == "f16x3":
+            ops.check_f16_range(self.outputs.device, self.label, sites=self._sites)
         if self._perm is None:
             return self.outputs
         out = torch.empty_like(self.outputs)

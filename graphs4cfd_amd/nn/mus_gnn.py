@@ -21,7 +21,7 @@ from typing import Optional
 
 import torch
 
-from .. import _lib
+from .. import _lib, ops
 from ..graph import Graph
 from ..ops import Source
 from . import blocks as _blocks
@@ -74,7 +74,10 @@ class _MuSGNN(GNN):
         n = int(field0.size(0))
         inputs = [Source(getattr(graph, k)) for k in ('field', 'loc', 'glob', 'omega') if hasattr(graph, k)]
         edge_index = graph.edge_index
-        e = self.edge_encoder.run_coded([Source(graph.edge_attr)], int(graph.edge_attr.size(0)), SELU)
+        # (edge_attr never changes inside a rollout — nn/model.py:316-320 replaces graph.field only — so a Rollout computes this
+        # launch once per mesh and weights: ops.StaticCache; a bare forward() launches it every time, like the reference :73,178)
+        e = ops.static_launch("edge_encoder", [graph.edge_attr],
+                              lambda: self.edge_encoder.run_coded([Source(graph.edge_attr)], int(graph.edge_attr.size(0)), SELU))
         # `products`: first-layer node-side terms of the next MP layer, when the launch producing its `v` made them
         v, products = self._launch_for(self.node_encoder, inputs, n, SELU, 0, int(edge_index.size(1)))
         e_pending = NONE          # activation not yet applied to `e` (deferred to its readers)

@@ -67,6 +67,10 @@ class NsRotEquiTreeScaleGNN(GNN):
         self.edge_decoder = MLP(*arch["decoder"])
         self.to(self.device)
 
+    def _angle_latents(self, name: str, att: torch.Tensor) -> torch.Tensor:
+        enc = getattr(self, name)
+        return ops.static_launch(name, [att], lambda: enc.run_coded([Source(att)], int(att.size(0)), SELU))
+
     def forward(self, graph: Graph, t: Optional[int] = None) -> torch.Tensor:
         g = graph
         sfx = {1: "", 2: "2", 3: "3"}
@@ -78,11 +82,13 @@ class NsRotEquiTreeScaleGNN(GNN):
             proj = ops.project_to_edges(g.field, ep.col, getattr(g, f"edgeUnitVector{s}"), ep.n_edges, nfeat)
             e[lvl] = getattr(self, f"edge_encoder{s}").run_coded(
                 [Source(proj), Source(g.glob, ep.col), Source(g.omega, ep.col)], ep.n_edges, SELU)
-            att = getattr(g, f"angle_attr{s}")
-            a[lvl] = getattr(self, f"angle_encoder{s}").run_coded([Source(att)], int(att.size(0)), SELU)
+            # (the angle attributes are static inside a rollout — nn/model.py:316-320 replaces graph.field only — so a Rollout
+            # runs the five angle encoders once per mesh and weights, ops.StaticCache; a bare forward() launches them, like the
+            # reference nn/remus_gnn.py:136-140)
+            a[lvl] = self._angle_latents(f"angle_encoder{s}", getattr(g, f"angle_attr{s}"))
             aidx[lvl] = getattr(g, f"angle_index{s}")
-        a12 = self.angle_encoder12.run_coded([Source(g.angle_attr12)], int(g.angle_attr12.size(0)), SELU)
-        a23 = self.angle_encoder23.run_coded([Source(g.angle_attr23)], int(g.angle_attr23.size(0)), SELU)
+        a12 = self._angle_latents("angle_encoder12", g.angle_attr12)
+        a23 = self._angle_latents("angle_encoder23", g.angle_attr23)
         a_pending = {1: NONE, 2: NONE, 3: NONE}
         products = {1: None, 2: None, 3: None}   # first-layer edge-side terms of the next EdgeMP of a level, if already made
         prog = self._PROGRAM

@@ -37,6 +37,9 @@ class KernelTimer:
         a.record()
         out = fn()
         b.record()
+        if kind.startswith("mlp_"):
+            # the library picks the kernel family per launch (arithmetic, shape, row count): label the record by what ran
+            kind = _lib.KERNEL_NAMES.get(int(_lib.load().g4c_mlp_last_kernel()), kind)
         self.records.append((kind, flops, nbytes, a, b))
         return out
 
@@ -54,6 +57,49 @@ class KernelTimer:
 def _timed(kind: str, flops: float, nbytes: float, fn):
     kt = KernelTimer.active
     return fn() if kt is None else kt.launch(kind, flops, nbytes, fn)
+
+
+class StaticCache:
+    """Results of launches whose inputs cannot change between the steps of one rollout (reference: nn/model.py:316-320 — `solve`
+    only ever replaces `graph.field`): `selu(edge_encoder(edge_attr))` of the MuS-GNN models (nn/mus_gnn.py:73,178 of the reference)
+    and REMuS-GNN's five angle encoders (nn/remus_gnn.py:136-140).  A `Rollout` / `DistributedRollout` activates its cache around
+    every step; the first (eager) step fills it, the captured step finds the entries and therefore contains neither the launches
+    nor the tensors in its write set.  A bare `model.forward()` has no active cache and recomputes, like the reference.
+
+    An entry is valid for one (weights epoch, arithmetic, identity + version + shape of every input tensor): an in-place edit of
+    `edge_attr`, new weights or `set_mlp_precision` recompute it — the same bits either way, the cached tensor is what the launch
+    would have produced again."""
+    active: Optional["StaticCache"] = None
+
+    def __init__(self):
+        self.store = {}
+        self.hits = self.misses = 0
+        self._prev = None
+
+    def __enter__(self):
+        self._prev, StaticCache.active = StaticCache.active, self
+        return self
+
+    def __exit__(self, *exc):
+        StaticCache.active = self._prev
+        return False
+
+    def get(self, name: str, inputs: Sequence[Tensor], fn):
+        key = (weights_epoch(), mlp_precision()) + tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in inputs)
+        hit = self.store.get(name)
+        if hit is not None and hit[0] == key:
+            self.hits += 1
+            return hit[1]
+        self.misses += 1
+        val = fn()
+        self.store[name] = (key, val, tuple(inputs))      # (the inputs are kept alive: the key holds their addresses)
+        return val
+
+
+def static_launch(name: str, inputs: Sequence[Tensor], fn):
+    """`fn()` — or its cached result when a rollout's StaticCache is active (never while a call is recorded for autograd)."""
+    c = StaticCache.active
+    return fn() if (c is None or torch.is_grad_enabled()) else c.get(name, inputs, fn)
 
 
 def _f32_2d(t: Tensor, name: str) -> Tensor:
@@ -258,13 +304,15 @@ AGG_ON_LOAD_MIN_ROWS = int(os.environ.get("G4C_AGG_ON_LOAD_MIN_ROWS", "50000"))
 # ---- fp16 range of the "f16x3" arithmetic made observable (g4c_mlp_t.range_flag): every launch in that arithmetic carries a slot
 # of a per-device int32 array; a kernel that converted a value of magnitude >= 65504 to fp16 (it was clipped there) writes 1 into
 # its slot.  Slots are named after the MLP that launched ("NsThreeScaleGNN.mp112.edge_mlp"); f16_range_report() reads the array
-# (one device synchronisation), check_f16_range() turns a non-empty report into a RuntimeWarning.  Model.solve, Rollout.result,
-# DistributedRollout.gather_outputs and GNN.fit (per epoch) call it, so a clip is never silent on those paths; after a bare
-# model.forward() call gfd.check_f16_range() yourself.
-RANGE_SLOTS = 256
+# (one device synchronisation), check_f16_range() turns a non-empty report into a RuntimeWarning.  Rollout.result (hence
+# Model.solve), DistributedRollout.gather_outputs and GNN.fit (per epoch) call it, so a clip is never silent on those paths; a
+# rollout clears its own model's slots on entry and reports only those, so a clip is attributed to the model that launched it.
+# After a bare model.forward() call gfd.check_f16_range() yourself.
+RANGE_SLOTS = 4096
 _range_bufs = {}            # device -> int32 [RANGE_SLOTS]
 _range_sites: List[set] = [set() for _ in range(RANGE_SLOTS)]
 _range_slot_of = {}
+_range_wrapped = False
 
 
 def _range_buffer(dev: torch.device) -> Tensor:
@@ -275,32 +323,81 @@ def _range_buffer(dev: torch.device) -> Tensor:
 
 
 def _range_slot(site: str) -> int:
+    global _range_wrapped
     slot = _range_slot_of.get(site)
     if slot is None:
-        slot = _range_slot_of[site] = len(_range_slot_of) % RANGE_SLOTS
+        n = len(_range_slot_of)
+        if n >= RANGE_SLOTS and not _range_wrapped:
+            _range_wrapped = True
+            import warnings
+            warnings.warn(f"more than {RANGE_SLOTS} named MLP sites: fp16 range flags are shared between sites from here on "
+                          "(a clip is then reported under every name that shares its slot)", RuntimeWarning)
+        slot = _range_slot_of[site] = n % RANGE_SLOTS
         _range_sites[slot].add(site)
     return slot
 
 
-def f16_range_report(device: Optional[torch.device] = None, clear: bool = True) -> List[str]:
-    """Names of the MLPs whose launches clipped a value at the end of the fp16 range since the last report (all devices, or one).
-    Synchronises with the device(s)."""
-    hit: List[str] = []
+def _indexed(device) -> Optional[torch.device]:
+    """torch.device('cuda') / 'cuda' name the CURRENT device: the flag buffers are keyed by indexed devices."""
+    if device is None:
+        return None
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def range_slots_of(sites) -> List[int]:
+    """Flag slots of the named MLP sites that have launched in the f16x3 arithmetic so far (others have no slot yet)."""
+    return sorted({_range_slot_of[s] for s in sites if s in _range_slot_of})
+
+
+def f16_range_clear(device: Optional[torch.device] = None, sites=None) -> None:
+    """Forget recorded clips: every slot, or only those of `sites` (names as in f16_range_report) — what a rollout does on entry so
+    that it reports its own launches only.  Enqueued on the current stream (no synchronisation)."""
+    device = _indexed(device)
     for dev, buf in list(_range_bufs.items()):
-        if device is not None and torch.device(device) != dev:
+        if device is not None and device != dev:
+            continue
+        if sites is None:
+            buf.zero_()
+        else:
+            slots = range_slots_of(sites)
+            if slots:
+                buf[torch.tensor(slots, dtype=torch.long, device=dev)] = 0
+
+
+def f16_range_report(device: Optional[torch.device] = None, clear: bool = True, sites=None) -> List[str]:
+    """Names of the MLPs whose launches clipped a value at the end of the fp16 range since the last report / clear (all devices, or
+    one; `sites`: only these names — a model's own MLPs — are looked at and cleared).  Synchronises with the device(s)."""
+    hit: List[str] = []
+    device = _indexed(device)
+    only = None if sites is None else set(sites)
+    for dev, buf in list(_range_bufs.items()):
+        if device is not None and device != dev:
             continue
         flags = buf.cpu()
+        mine = []
         for slot in torch.nonzero(flags).flatten().tolist():
-            hit += sorted(_range_sites[slot]) or [f"slot {slot}"]
-        if clear and len(hit):
-            buf.zero_()
+            names = sorted(_range_sites[slot]) or [f"slot {slot}"]
+            if only is not None:
+                names = [n for n in names if n in only]
+                if not names:
+                    continue
+            mine.append(slot)
+            hit += names
+        if clear and mine:
+            if only is None:
+                buf.zero_()
+            else:
+                buf[torch.tensor(mine, dtype=torch.long, device=dev)] = 0
     return hit
 
 
-def check_f16_range(device: Optional[torch.device] = None, where: str = "") -> List[str]:
+def check_f16_range(device: Optional[torch.device] = None, where: str = "", sites=None) -> List[str]:
     """RuntimeWarning when a launch in the "f16x3" arithmetic clipped an MLP input or hidden activation at +-65504 (the reference
-    computes these in fp32: nn/model.py:303-321).  Returns the offending MLPs' names."""
-    hit = f16_range_report(device)
+    computes these in fp32: nn/model.py:303-321).  Returns the offending MLPs' names.  `sites`: see f16_range_report."""
+    hit = f16_range_report(device, sites=sites)
     if hit:
         import warnings
         warnings.warn(f"{where + ': ' if where else ''}the 'f16x3' MLP arithmetic clipped values at the end of the fp16 range (|x| >= 65504) in "

@@ -377,7 +377,8 @@ class HipImpl:
 
     def encode(self, mesh: LocalMesh, v_out: torch.Tensor, next_name: Optional[str] = None, pr_out: Optional[torch.Tensor] = None):
         m = self.m
-        e = m.edge_encoder.run_coded([Source(mesh.edge_attr)], int(mesh.edge_attr.size(0)), SELU)
+        e = ops.static_launch("edge_encoder", [mesh.edge_attr],       # (static inside a rollout: ops.StaticCache)
+                              lambda: m.edge_encoder.run_coded([Source(mesh.edge_attr)], int(mesh.edge_attr.size(0)), SELU))
         srcs = [Source(mesh.inputs[k]) for k in ("field", "loc", "glob", "omega") if k in mesh.inputs]
         return e, self._node_launch(m.node_encoder, srcs, mesh.n_own[0], SELU, v_out, next_name, pr_out)
 
@@ -554,9 +555,14 @@ class DistributedRollout:
         self.capture = capture and device.type == "cuda"
         self.capture_error = None if self.capture else "capture not requested"
         self._hipgraph, self._epoch = None, -1
+        self.static = ops.StaticCache()        # per-mesh constants (edge / angle encoders), as nn.model.Rollout
+        self._sites = getattr(model, "_range_sites", None)
+        if ops.mlp_precision() == "f16x3" and device.type == "cuda":
+            ops.f16_range_clear(device, self._sites)
 
     def _one(self) -> None:
-        pred = self.fwd.forward()
+        with self.static:
+            pred = self.fwd.forward()
         ops.rollout_advance(self.field, pred, self.outputs, self.step_counter, self.nf)
 
     def step(self) -> None:
@@ -627,7 +633,7 @@ class DistributedRollout:
         if self.world > 1:
             dist.all_reduce(full)
         if ops.mlp_precision() == "f16x3":
-            ops.check_f16_range(self.device, f"DistributedRollout (rank {self.rank})")
+            ops.check_f16_range(self.device, f"DistributedRollout (rank {self.rank})", sites=self._sites)
         if self._perm is not None:        # rows back in the caller's numbering
             out = torch.empty_like(full)
             out[self._perm] = full

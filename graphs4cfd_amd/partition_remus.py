@@ -275,10 +275,14 @@ class RemusHipImpl:
             e[l] = self.buf("e", l)
             getattr(m, f"edge_encoder{s}").run_coded([Source(proj), Source(mesh.inputs["glob"], mesh.col32[l]), Source(mesh.inputs["omega"], mesh.col32[l])],
                                                      mesh.n_edges[l], SELU, out=e[l][: mesh.n_edges[l]])
-            a[l] = getattr(m, f"angle_encoder{s}").run_coded([Source(mesh.angle_attr[l])], int(mesh.angle_attr[l].size(0)), SELU)
-        ax = {1: m.angle_encoder12.run_coded([Source(mesh.down_attr[1])], int(mesh.down_attr[1].size(0)), SELU),
-              2: m.angle_encoder23.run_coded([Source(mesh.down_attr[2])], int(mesh.down_attr[2].size(0)), SELU)}
+            a[l] = self._angle_latents(f"angle_encoder{s}", mesh.angle_attr[l])
+        ax = {1: self._angle_latents("angle_encoder12", mesh.down_attr[1]), 2: self._angle_latents("angle_encoder23", mesh.down_attr[2])}
         return e, a, ax
+
+    def _angle_latents(self, name: str, att: torch.Tensor) -> torch.Tensor:
+        """(static inside a rollout: ops.StaticCache, as NsRotEquiTreeScaleGNN._angle_latents)"""
+        enc = getattr(self.m, name)
+        return ops.static_launch(name, [att], lambda: enc.run_coded([Source(att)], int(att.size(0)), SELU))
 
     def mp(self, name: str, e: torch.Tensor, a: torch.Tensor, a_pending: int, lvl: int):
         from .nn.blocks import _mp_step

@@ -225,6 +225,18 @@ int g4c_mlp_bx6i_enable(int on);
  * g4c_mlp_bx6i_enable takes the bf16x6 stream only since round 3. */
 int g4c_mlp_ws_enable(int on);
 
+/* Which kernel family the calling thread's most recent fused-MLP launch (any g4c_mlp_forward* entry point) ran on — the library
+ * picks it per launch (arithmetic, shape, row count), so a profiler-free caller that times launches with events (bench.py's
+ * roofline leg) can label them by the kernel that executed instead of by the entry point: G4C_KERNEL_NONE (no launch yet, or the
+ * last call launched nothing), _MLP_SPLIT (mlp_split_kernel: fp32 MFMA), _MLP_BX6 (mlp_bx6_kernel: split-operand tile kernel),
+ * _MLP_BX6I (mlp_bx6i_kernel: dual-tile), _MLP_WS (mlp_ws_kernel: weight-stationary persistent). */
+#define G4C_KERNEL_NONE 0
+#define G4C_KERNEL_MLP_SPLIT 1
+#define G4C_KERNEL_MLP_BX6 2
+#define G4C_KERNEL_MLP_BX6I 3
+#define G4C_KERNEL_MLP_WS 4
+int g4c_mlp_last_kernel(void);
+
 /* Rounded-bf16 variant (opt-in only; BASELINE config 3 "bf16 edge-MLP MFMA"): the same stream and kernel structure, but
  * only the LEADING bf16 term of every operand is used (one product per multiply-add): weights and the activations
  * entering each Linear are rounded to bf16, accumulation / bias / SELU / LayerNorm / additive sources / residual stay

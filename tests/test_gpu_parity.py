@@ -1369,3 +1369,101 @@ def test_remus_bf16_compact_messages_are_bit_identical():
     finally:
         B.COMPACT_MESSAGES = was
         ops.set_mlp_precision(old)
+
+
+# ------------------------------------------------------------------ per-mesh constants are cached across rollout steps (round 4)
+def _manual_rollout(model, g, field, n_out):
+    """solve() spelled out with bare forward() calls (which never use the cache); n_in = 1: the next input is the prediction.
+    Returns ([N, nf * n_out], last prediction)."""
+    outs = []
+    with torch.no_grad():
+        for _ in range(n_out):
+            g.field = field
+            field = model.forward(g).clone()
+            outs.append(field)
+    return torch.cat(outs, dim=1), field
+
+
+@pytest.mark.parametrize("family", ["mus", "remus"])
+def test_static_encoder_cache_is_bit_identical_and_invalidates(family):
+    """Rollout computes selu(edge_encoder(edge_attr)) (MuS-GNN; reference nn/mus_gnn.py:73,178) / the five angle encoders (REMuS-GNN;
+    nn/remus_gnn.py:136-140) ONCE: nn/model.py:316-320 replaces graph.field only.  Same bits as launching them every step; an
+    in-place edit of the static input or new weights recompute; a bare forward() never touches the cache."""
+    from graphs4cfd_amd.nn.model import Rollout
+    if family == "mus":
+        g = S.mus_graph(4000, levels=2, seed=71).to(DEV)
+        torch.manual_seed(72)
+        model = gfd.nn.NsTwoScaleGNN(arch=S.mus_arch("NsTwoScaleGNN", 128), device=DEV)
+        static_attr, n_static = "edge_attr", 1
+    else:
+        g = S.remus_graph(3000, k=5, seed=73).to(DEV)
+        torch.manual_seed(74)
+        model = gfd.nn.NsRotEquiTreeScaleGNN(arch=S.remus_arch(128), device=DEV)
+        static_attr, n_static = "angle_attr", 5
+    g.batch = torch.zeros(g.num_nodes, dtype=torch.long, device=DEV)
+    f0 = g.field.clone()
+    assert f0.size(1) == model.num_fields
+    ref, _ = _manual_rollout(model, g, f0.clone(), 4)
+    for capture in (False, True):
+        g.field = f0.clone()
+        with Rollout(model, g, 4, capture=capture, reorder=False) as ro:
+            ro.run(4)
+            assert ro.static.misses == n_static and ro.static.hits == n_static * (1 if capture else 3), (ro.static.misses, ro.static.hits)
+            assert torch.equal(ro.result(), ref), (ro.result() - ref).abs().max().item()
+    assert ops.StaticCache.active is None
+    # an in-place edit of the static input between two steps of ONE rollout is seen (version counter), as are new weights
+    att = getattr(g, static_attr)
+    g.field = f0.clone()
+    with Rollout(model, g, 4, capture=False, reorder=False) as ro:
+        ro.run(2)
+        att.mul_(1.5)
+        ro.run(1)
+        assert ro.static.misses == n_static + 1
+        model.invalidate_packed()
+        ro.run(1)
+        assert ro.static.misses == 2 * n_static + 1
+        got = ro.result().clone()
+    # (the same edit at the same step with every launch executed)
+    att.div_(1.5)
+    a, last = _manual_rollout(model, g, f0.clone(), 2)
+    att.mul_(1.5)
+    b, _ = _manual_rollout(model, g, last, 2)
+    assert torch.equal(got, torch.cat([a, b], dim=1))
+
+
+def test_f16_range_report_is_scoped_to_the_model_that_clipped():
+    """A clip in model A's launches must not be reported by model B's solve() (the flags are per device, not per model: a rollout
+    clears its own model's slots on entry and reports only those), and it must still be reported when A is asked."""
+    import warnings
+    old = ops.set_mlp_precision("f16x3")
+    try:
+        g = S.mus_graph(2500, levels=2, seed=81)
+        torch.manual_seed(82)
+        a = gfd.nn.NsTwoScaleGNN(arch=S.mus_arch("NsTwoScaleGNN", 128), device=DEV)
+        b = gfd.nn.NsOneScaleGNN(arch=S.mus_arch("NsOneScaleGNN", 128), device=DEV)
+        g1 = S.mus_graph(2500, levels=1, seed=83)
+        with torch.no_grad():
+            a.mp111.edge_mlp.MLP.layer_norm.weight.mul_(3e4)
+        a.invalidate_packed()
+        ga = g.clone().to(DEV)
+        ga.batch = torch.zeros(ga.num_nodes, dtype=torch.long, device=DEV)
+        with torch.no_grad():
+            a.forward(ga)                                   # bare forward: sets A's flags, nobody asked yet
+        # a clip of an MLP that belongs to no model at all (the stale flag GPUTEST_r03 showed in an unrelated test's warnings)
+        mlp = B.MLP(128, (128, 128), True).to(DEV)
+        mlp(torch.full((64, 128), 1e5, device=DEV))
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)
+            b.solve(g1.clone(), 2)                          # B did not clip: silent
+        hit = ops.f16_range_report(DEV, clear=False)
+        assert any(h.startswith("NsTwoScaleGNN.mp11") for h in hit) and any("outside a model" in h for h in hit), hit
+        with pytest.warns(RuntimeWarning, match="NsTwoScaleGNN.mp11"):
+            gfd.check_f16_range(torch.device("cuda"), sites=a._range_sites)        # (un-indexed device = the current one)
+        # A's own solve(): the stale flags of its earlier forward are dropped on entry, its own clip is reported, nothing else
+        with pytest.warns(RuntimeWarning) as rec:
+            a.solve(g.clone(), 2)
+        msgs = [str(r.message) for r in rec if "fp16 range" in str(r.message)]
+        assert msgs and all("outside a model" not in m and "NsOneScaleGNN" not in m for m in msgs), msgs
+        assert ops.f16_range_report(DEV) == ["an MLP created outside a model"]
+    finally:
+        ops.set_mlp_precision(old)
