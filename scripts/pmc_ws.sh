@@ -5,6 +5,9 @@ K=$1; TAG=$2; shift 2
 PASSES=${@:-"util sq3 lds sq2 tcc"}
 EXTRA=${PMC_EXTRA_ARGS:-}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+# which kernel sources the counters below were collected from (bench.py compares this with the sources it runs: roofline.mfma_util_pmc_imported)
+KERN=mlp_ws_kernel; [ "$K" = "tile" ] && KERN=mlp_bx6_kernel; [ "$K" = "bx6i" ] && KERN=mlp_bx6i_kernel
+echo "# kernel: $KERN  source_sha16: $(python -c "import bench; print(bench.source_sha16('$KERN'))")"
 declare -A C
 C[util]="MfmaUtil VALUBusy MemUnitStalled"
 C[sq3]="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES"
