@@ -24,5 +24,5 @@ with torch.no_grad(), ops.KernelTimer() as kt:
 torch.cuda.synchronize()
 summ = kt.summary()
 kinds = {k: v["launches"] for k, v in summ.items() if k.startswith("mlp_")}
-print("mlp launches per step:", kinds, " fp32_mfma_fallback =", sum(n for k, n in kinds.items() if not k.startswith("mlp_bx6")))
+print("mlp launches per step:", kinds, " fp32_mfma_fallback =", kinds.get("mlp_split_kernel", 0))
 print(f"{a.model}, {a.nodes} nodes: {a.steps / dt:.2f} steps/s ({1e3 * dt / a.steps:.2f} ms/step), finite={bool(torch.isfinite(ro.outputs).all())}")
