@@ -288,9 +288,4 @@ bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, 
 int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st);
 
 
-// four-wave weight-stationary persistent kernel on v_mfma_f32_32x32x16 (mlp_w4.hip): f16x3 stream only
-int w4_enable(int on);
-bool w4_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count);
-int w4_launch(const Params &p, bool agg, hipStream_t st);
-
 }  // namespace g4cm

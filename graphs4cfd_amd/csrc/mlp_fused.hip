@@ -1447,12 +1447,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     if (row_count == 0) return G4C_OK;
     p.row_base = row_begin;
     p.M = row_begin + row_count;          // rows past the range are neither gathered nor stored
-    if (bx6 && !force_tiles && w4_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
-        // four-wave weight-stationary persistent kernel on 32x32x16 MFMAs (mlp_w4.hip): the large message launches of the f16x3 stream
-        p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
-        g_last_kernel = G4C_KERNEL_MLP_W4;
-        return w4_launch(p, agg != nullptr, st);
-    } else if (bx6 && !force_tiles && ws_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
+    if (bx6 && !force_tiles && ws_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
         // weight-stationary persistent kernel (mlp_ws.hip): pairs of 32-row tiles (whole segments with aggregation), one workgroup per CU
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
         g_last_kernel = G4C_KERNEL_MLP_WS;

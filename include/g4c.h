@@ -225,26 +225,16 @@ int g4c_mlp_bx6i_enable(int on);
  * g4c_mlp_bx6i_enable takes the bf16x6 stream only since round 3. */
 int g4c_mlp_ws_enable(int on);
 
-/* The same launches of the f16x3 stream on FOUR waves, one per SIMD with the SIMD's whole register file (mlp_w4.hip: every wave keeps
- * its 32-column slice of all layers' weights in 192 registers, products on v_mfma_f32_32x32x16_f16 — half the MFMA issues and half
- * the LDS operand traffic per flop of g4c_mlp_ws_enable's kernel, ~5 vector instructions hidden behind each MFMA).  Same envelope
- * (fp32 rows only) and the same per-element arithmetic; the fused aggregation bit-identical to g4c_segment_reduce of the stored rows.
- * 0 = never, 1 = launches of at least G4C_W4_MIN_ROWS rows (default 200 000; the default mode, environment G4C_W4), 2 = every launch
- * it can take (tests); -1 only queries.  Returns the previous setting. */
-int g4c_mlp_w4_enable(int on);
-
 /* Which kernel family the calling thread's most recent fused-MLP launch (any g4c_mlp_forward* entry point) ran on — the library
  * picks it per launch (arithmetic, shape, row count), so a profiler-free caller that times launches with events (bench.py's
  * roofline leg) can label them by the kernel that executed instead of by the entry point: G4C_KERNEL_NONE (no launch yet, or the
  * last call launched nothing), _MLP_SPLIT (mlp_split_kernel: fp32 MFMA), _MLP_BX6 (mlp_bx6_kernel: split-operand tile kernel),
- * _MLP_BX6I (mlp_bx6i_kernel: dual-tile), _MLP_WS (mlp_ws_kernel: weight-stationary persistent, 8 waves, 16x16x32 MFMAs),
- * _MLP_W4 (mlp_w4_kernel: weight-stationary persistent, 4 waves of 512 registers, 32x32x16 MFMAs). */
+ * _MLP_BX6I (mlp_bx6i_kernel: dual-tile), _MLP_WS (mlp_ws_kernel: weight-stationary persistent). */
 #define G4C_KERNEL_NONE 0
 #define G4C_KERNEL_MLP_SPLIT 1
 #define G4C_KERNEL_MLP_BX6 2
 #define G4C_KERNEL_MLP_BX6I 3
 #define G4C_KERNEL_MLP_WS 4
-#define G4C_KERNEL_MLP_W4 5
 int g4c_mlp_last_kernel(void);
 
 /* Rounded-bf16 variant (opt-in only; BASELINE config 3 "bf16 edge-MLP MFMA"): the same stream and kernel structure, but

@@ -4,11 +4,6 @@ set -e
 cd "$(dirname "$0")/../graphs4cfd_amd/csrc"
 make -j8 >/dev/null      # (NOTE: this also rebuilds ../lib/libg4c.so from the CURRENT sources: run make again after a git stash pop)
 # usage: build_ws_timing.sh [suffix [extra -D flags...]]   (e.g. build_ws_timing.sh _a1 -DG4C_WS_ABLATE=1)
-# (G4C_TIMING_KERNEL=w4: the four-wave kernel mlp_w4.hip instead -> libg4c_w4_timing<suffix>.so, scripts/ws_stamps.py ... w4)
 SFX=$1; [ $# -gt 0 ] && shift
-K=${G4C_TIMING_KERNEL:-ws}
-OTHER=mlp_w4; EXTRA=""
-if [ "$K" = "w4" ]; then OTHER=mlp_ws; EXTRA="-fno-slp-vectorize"; fi
-UP=$(echo $K | tr a-z A-Z)
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $EXTRA -DG4C_${UP}_TIMING "$@" -c mlp_$K.hip -o build/mlp_${K}_timing$SFX.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libg4c_${K}_timing$SFX.so build/error.o build/plan.o build/segment_reduce.o build/mlp_fused.o build/mlp_bx6i.o build/$OTHER.o build/mlp_${K}_timing$SFX.o build/remus_ops.o build/train_ops.o build/knn_grid.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DG4C_WS_TIMING "$@" -c mlp_ws.hip -o build/mlp_ws_timing$SFX.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libg4c_ws_timing$SFX.so build/error.o build/plan.o build/segment_reduce.o build/mlp_fused.o build/mlp_bx6i.o build/mlp_ws_timing$SFX.o build/remus_ops.o build/train_ops.o build/knn_grid.o

@@ -7,7 +7,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from graphs4cfd_amd import _lib, ops, plan
 from graphs4cfd_amd.nn import blocks as B
-ap = argparse.ArgumentParser(); ap.add_argument("--time", action="store_true"); ap.add_argument("--rows", type=int, default=600000); ap.add_argument("--kernel", default="ws", choices=["ws", "w4"], help="ws: mlp_ws_kernel (8 waves, 16x16x32 MFMAs); w4: mlp_w4_kernel (4 waves, 32x32x16 MFMAs; f16x3 stream only)")
+ap = argparse.ArgumentParser(); ap.add_argument("--time", action="store_true"); ap.add_argument("--rows", type=int, default=600000); ap.add_argument("--kernel", default="ws", choices=["ws"])
 ap.add_argument("--stress", type=int, default=0, help="repeat the large launches this many times against one tile-kernel result (races show up as rare mismatches)")
 a = ap.parse_args()
 torch.set_grad_enabled(False)
@@ -15,7 +15,6 @@ lib = _lib.load()
 enable = getattr(lib, f"g4c_mlp_{a.kernel}_enable")
 lib.g4c_mlp_bx6i_enable(0)
 lib.g4c_mlp_ws_enable(0)
-lib.g4c_mlp_w4_enable(0)
 dev = torch.device("cuda", 0); H = 128
 bad = []
 
@@ -109,7 +108,7 @@ def check_variant(prec, layers):
     ops.set_mlp_precision("f16x3")
 
 
-VARIANTS = (("f16x3", 3), ("f16x3", 2)) + ((("bf16", 2), ("bf16", 3)) if a.kernel == "ws" else ())
+VARIANTS = (("f16x3", 3), ("f16x3", 2), ("bf16", 2), ("bf16", 3))
 for prec, layers in VARIANTS:
     check_variant(prec, layers)
 if a.stress:
@@ -159,9 +158,9 @@ if a.time:
     cases = {"edge(hoisted)": lambda: ops.mlp_forward(pk, src, rows, 0, out=out),
              "edge(hoisted)+agg": lambda: ops.mlp_forward(pk, src, rows, 0, out=out, agg=(csr, agg, True))}
     def setk(k):
-        lib.g4c_mlp_ws_enable(2 if k == "ws" else 0); lib.g4c_mlp_bx6i_enable(2 if k == "bx6i" else 0); lib.g4c_mlp_w4_enable(2 if k == "w4" else 0)
+        lib.g4c_mlp_ws_enable(2 if k == "ws" else 0); lib.g4c_mlp_bx6i_enable(2 if k == "bx6i" else 0)
     for cname, fn in cases.items():
-        times = {"tile": [], "ws": [], "w4": []}
+        times = {"tile": [], "bx6i": [], "ws": []}
         for k in times:
             setk(k); fn(); fn()
         torch.cuda.synchronize()
@@ -173,8 +172,6 @@ if a.time:
                 times[k].append(s_.elapsed_time(t_) / 3 * 1e3)
         setk("tile")
         print(f"{cname:20s} " + "   ".join(f"{k} median {statistics.median(v):8.1f} us (min {min(v):8.1f})" for k, v in times.items()))
-    if a.kernel == "w4":
-        sys.exit(1 if bad else 0)
     # REMuS-GNN's level-1 angle launch (config 3): rounded-bf16 mode, 2 layers, 5 angles per edge, bf16 rows in and out, fused aggregation
     ops.set_mlp_precision("bf16")
     rows = 2_500_000; n = rows // 5

@@ -12,7 +12,6 @@ for name, (res, args) in _lib._SIGNATURES.items():
     fn = getattr(lib, name); fn.restype, fn.argtypes = res, args
 _lib._lib = lib
 torch.set_grad_enabled(False)
-w4 = "w4" in sys.argv[2:]          # the four-wave kernel (mlp_w4.hip; G4C_TIMING_KERNEL=w4 bash scripts/build_ws_timing.sh)
 bf16 = len(sys.argv) > 2 and sys.argv[2].startswith("bf16")
 f32in = len(sys.argv) > 2 and sys.argv[2] == "bf16-f32in"
 dev = torch.device("cuda", 0); H = 128
@@ -31,15 +30,14 @@ pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
 src = [ops.Source(e) if f32in else ops.Source(e.to(torch.bfloat16)) if bf16 else ops.Source(e, pre_act=_lib.ACT_SELU),
        ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
 out, agg = torch.empty(rows, H, device=dev), torch.empty(n, H, device=dev)
-lib.g4c_mlp_ws_enable(0 if w4 else 2); lib.g4c_mlp_w4_enable(2 if w4 else 0)
+lib.g4c_mlp_ws_enable(2)
 for _ in range(3):
     if bf16: ops.mlp_forward(pk, src, rows, 0, agg=(csr, agg, True), rows_dtype=torch.bfloat16, rows_act=_lib.ACT_SELU)
     else: ops.mlp_forward(pk, src, rows, 0, out=out, agg=(csr, agg, True))
 torch.cuda.synchronize()
 buf = np.zeros(256 * 32, dtype=np.uint64)
-read = lib.g4c_w4_read_stamps if w4 else lib.g4c_ws_read_stamps
-read.argtypes = [C.c_void_p, C.c_int]
-read(buf.ctypes.data, buf.size)
+lib.g4c_ws_read_stamps.argtypes = [C.c_void_p, C.c_int]
+lib.g4c_ws_read_stamps(buf.ctypes.data, buf.size)
 st = buf.reshape(256, 32).astype(np.int64)
 names = {0: "loop top", 1: "meta + table loads issued", 2: "M(A,0) + park B, barrier", 3: "tables -> LDS, gathers issued, M(B,0) + E(A,0), barrier",
          4: "M(A,1) + E(B,0), barrier", 5: "M(B,1) + E(A,1), barrier", 6: "M(A,2) + E(B,1), barrier", 7: "M(B,2) + F(A), F(B), barrier",
