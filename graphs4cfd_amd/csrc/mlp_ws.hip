@@ -105,6 +105,7 @@ __device__ __forceinline__ f32x2 selu2w(f32x2 x) {
 #ifndef G4C_WS_SCALED
 #define G4C_WS_SCALED 1
 #endif
+
 template <bool LOADED = false>
 __device__ __forceinline__ f32x2 selu2w_scaled(f32x2 x) {
     const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f * F16_LO_SCALE;
@@ -124,10 +125,12 @@ __device__ __forceinline__ void put_pair_scaled(__bf16 *d, f32x2 S, RangeV &rng)
     rng.m = fmaxf(fmaxf(rng.m, fabsf(S[0])), fabsf(S[1]));          // (v_max3_f32; in units of 2^-11: range_report_scaled)
     unsigned hu, lu;
     const float up = F16_LO_UNSCALE, dn = -F16_LO_SCALE;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hu) : "v"(S[0]), "s"(up));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hu) : "v"(S[1]), "s"(up));
-    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lu) : "v"(hu), "s"(dn), "v"(S[0]));
-    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lu) : "v"(hu), "s"(dn), "v"(S[1]));
+    // (one statement: hipcc pads an s_nop behind every asm statement whose output the next instruction reads — three per pair before)
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %0, %5, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %0, %5, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(hu), "=&v"(lu) : "v"(S[0]), "v"(S[1]), "s"(up), "s"(dn));
     *reinterpret_cast<unsigned *>(d) = hu;
     *reinterpret_cast<unsigned *>(d + PLN) = lu;
 }

@@ -12,6 +12,8 @@ ap.add_argument("--model", default="NsThreeScaleGNN"); ap.add_argument("--dim", 
 ap.add_argument("--capture", type=int, default=-1, help="-1: capture the step in a hipGraph iff the transport is nccl")
 ap.add_argument("--force-exchange", action="store_true", help="enter every halo collective even with one rank (zero-length splits): executes "
                 "'hipGraph capture with an RCCL collective inside' on a single-GPU box")
+ap.add_argument("--time", type=int, default=0, help="after the check: time this many steps of the captured (hipGraph-replayed) and of the uncaptured "
+                "(eager launches + eager collectives) partitioned step — what a capture failure on the first real RCCL run would cost per rank")
 a = ap.parse_args()
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda", 0 if a.same_gpu else int(os.environ["LOCAL_RANK"]))
@@ -39,5 +41,27 @@ if rank == 0:
     assert err < 5e-4, err          # (the full-forward parity bar of tests/test_gpu_parity.py; measured 1e-6 .. 3e-6)
     if a.capture > 0:
         assert dr.captured, f"the partitioned step was not captured: {dr.capture_error}"
+if a.time:
+    import time
+    res = {}
+    for name, cap in (("captured (hipGraph replay)", True), ("uncaptured (eager launches and collectives)", False)):
+        r = P.DistributedRollout(model, g, a.time + 4, rank, world, dev, capture=cap)
+        if a.force_exchange:
+            r.fwd.xch.force = True
+        r.run(3)                                   # eager step, capture step, one replay
+        dist.barrier(); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        r.run(a.time)
+        dist.barrier(); torch.cuda.synchronize(dev)
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        res[name] = (1e3 * float(el.item()) / a.time, r.captured, r.capture_error)
+        del r
+    if rank == 0:
+        for name, (ms, captured, note) in res.items():
+            print(f"world={world} backend={a.backend} {a.model} {a.nodes} nodes, {x.n_exchanges // max(a.steps, 1)} exchanges per step: {name}: {ms:.3f} ms/step "
+                  f"(captured={captured}{'' if note is None else ', ' + str(note)})", flush=True)
+        c, u = res["captured (hipGraph replay)"][0], res["uncaptured (eager launches and collectives)"][0]
+        print(f"eager fallback / captured = {u / c:.2f}x", flush=True)
 dist.barrier()
 dist.destroy_process_group()
