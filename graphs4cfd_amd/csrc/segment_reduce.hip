@@ -16,6 +16,9 @@
 namespace {
 
 constexpr int UNROLL = 8;
+#ifndef G4C_SEG_SPLIT_BATCH
+#define G4C_SEG_SPLIT_BATCH 1
+#endif
 
 template <int LPR>
 __global__ __launch_bounds__(256) void segment_reduce_kernel(
@@ -34,21 +37,41 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(
         // would serialise them); only the adds are predicated.
         for (int p = beg; p < end; p += UNROLL) {
             float4 v[UNROLL];
+            // the second half of a batch only when one of its rows exists (coarse edges pool ~4 fine edges: half the row requests)
+            const bool more = G4C_SEG_SPLIT_BATCH && (p + UNROLL / 2 >= end);
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
+            for (int u = 0; u < UNROLL / 2; ++u) {
                 const int pp = (p + u < end) ? (p + u) : (end - 1);
                 const long long r = perm ? perm[pp] : pp;
                 v[u] = *reinterpret_cast<const float4 *>(src + r * src_ld + c);
             }
+            if (!more) {
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const bool on = (p + u < end);
-                if (src_act) {   // wave-uniform
-                    v[u].x = g4c::apply_act(v[u].x, src_act); v[u].y = g4c::apply_act(v[u].y, src_act);
-                    v[u].z = g4c::apply_act(v[u].z, src_act); v[u].w = g4c::apply_act(v[u].w, src_act);
+                for (int u = UNROLL / 2; u < UNROLL; ++u) {
+                    const int pp = (p + u < end) ? (p + u) : (end - 1);
+                    const long long r = perm ? perm[pp] : pp;
+                    v[u] = *reinterpret_cast<const float4 *>(src + r * src_ld + c);
                 }
-                acc.x += on ? v[u].x : 0.f; acc.y += on ? v[u].y : 0.f;
-                acc.z += on ? v[u].z : 0.f; acc.w += on ? v[u].w : 0.f;
+            } else {
+#pragma unroll
+                for (int u = UNROLL / 2; u < UNROLL; ++u) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (src_act) {   // wave-uniform: the activation only on rows that exist (a coarse edge pools ~3 fine edges: a SELU on all
+                             // eight slots of the batch was a third of this launch's time); same additions in the same order
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    if (p + u < end) {
+                        acc.x += g4c::apply_act(v[u].x, src_act); acc.y += g4c::apply_act(v[u].y, src_act);
+                        acc.z += g4c::apply_act(v[u].z, src_act); acc.w += g4c::apply_act(v[u].w, src_act);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const bool on = (p + u < end);
+                    acc.x += on ? v[u].x : 0.f; acc.y += on ? v[u].y : 0.f;
+                    acc.z += on ? v[u].z : 0.f; acc.w += on ? v[u].w : 0.f;
+                }
             }
         }
         if (mean) { acc.x /= cnt; acc.y /= cnt; acc.z /= cnt; acc.w /= cnt; }
