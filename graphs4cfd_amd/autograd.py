@@ -7,7 +7,7 @@ the passes (per MP layer at 100k nodes: the [E, 3H] concatenation, three [E, H] 
 Here the forward of a block stays ONE fused launch, recorded by a `torch.autograd.Function`:
 
   * forward: g4c_mlp_forward_bx6_save — the fused kernel also writes each layer's output rows (SELU(hidden), pre-LayerNorm
-    rows), so the backward recomputes no product (SAVE_ACTIVATIONS; `G4C_TRAIN_SAVE=0` keeps only block inputs / outputs and
+    rows), so the backward recomputes no product (SAVE_ACTIVATIONS; False keeps only block inputs / outputs and
     re-forms the hidden layers in the backward with single-layer launches of the same kernel);
   * weight + bias gradients of the 128-wide layers: g4c_weight_grad (one pass over dZ and A, fp32 MFMA, partial tiles added in a
     fixed order); other widths: a split-row strided-batched rocBLAS GEMM + g4c_colsum;
@@ -120,9 +120,9 @@ def segment_broadcast(dout: Tensor, csr, mean: bool, n_src_rows: int) -> Tensor:
 
 # keep the hidden activations of every fused MLP from the forward launch (g4c_mlp_forward_bx6_save) instead of recomputing them
 # in the backward pass: ~3 x [rows, 128] fp32 more per MLP between the passes (100k nodes, 3-scale: 7.3 -> 27.5 GB peak), no recompute
-# GEMMs.  G4C_TRAIN_SAVE=0: the memory-light recompute path.
-SAVE_ACTIVATIONS = __import__("os").environ.get("G4C_TRAIN_SAVE", "1") != "0"
-FUSED_LINEAR = __import__("os").environ.get("G4C_TRAIN_FUSED_LINEAR", "1") != "0"
+# GEMMs.  SAVE_ACTIVATIONS = False: the memory-light recompute path.
+SAVE_ACTIVATIONS = True
+FUSED_LINEAR = True
 HOIST_MIN_ROWS = 32768             # below: the step is host-bound, and hoisting a block costs five more launches than it saves
 FUSED_LINEAR_MIN_ROWS = 65536      # below: packing the weights for one launch costs more host time than the fusion saves
 
@@ -148,7 +148,7 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int = _lib.AC
     return ops.mlp_forward(pk, [Source(x, col0=128 * j, width=128) for j in range(blocks)], int(x.size(0)), act)
 
 
-FUSED_CHAIN = __import__("os").environ.get("G4C_TRAIN_FUSED_CHAIN", "1") != "0"
+FUSED_CHAIN = True
 
 
 def backward_chain(g: Tensor, weights: Sequence[Tensor], acts: Sequence[Tensor], w_dense: Tensor):

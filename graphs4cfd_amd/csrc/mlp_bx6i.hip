@@ -482,11 +482,11 @@ __global__ __launch_bounds__(256, 2) void mlp_bx6i_kernel(const Params p) {
 
 namespace g4cm {
 
-// 0 off, 1 (default; environment G4C_BX6I) launches of at least G4C_BX6I_MIN_ROWS rows (default 20 000 in f16x3 mode, 400 000 in bf16x6
-// mode: the kernel needs a full machine of its larger workgroups), 2 every launch it can take (tests)
+// 0 off, 1 (default) launches of at least BX6I_MIN_ROWS rows (the kernel needs a full machine of its two workgroups per CU: same-box
+// crossover against the tile kernel ~300 k rows), 2 every launch it can take (tests)
 static int g_bx6i = -1;
 int bx6i_enable(int on) {
-    if (g_bx6i < 0) g_bx6i = getenv("G4C_BX6I") ? atoi(getenv("G4C_BX6I")) : 1;
+    if (g_bx6i < 0) g_bx6i = 1;
     const int old = g_bx6i;
     if (on >= 0) g_bx6i = on > 2 ? 2 : on;
     return old;
@@ -495,8 +495,8 @@ int bx6i_enable(int on) {
 bool bx6i_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count) {
     // f16x3 mode (three workgroups per CU, shorter pairs): the kernel is ahead from ~20 k rows (6k-node mesh +1 %, 12.5k-node mesh and 2-scale 10k-node mesh +5 %, 25k / 50k-node meshes +6 / +10 %, level-2 launches of the 100k mesh +0.5 %
     // of the step; the interior launches of a 2- / 4-way partition); bf16x6 mode (two workgroups per CU): from ~300 k
-    static const long long min_env = getenv("G4C_BX6I_MIN_ROWS") ? atoll(getenv("G4C_BX6I_MIN_ROWS")) : -1;
-    const long long min_rows = min_env >= 0 ? min_env : (f16x2 ? 20000 : 400000);
+    constexpr long long BX6I_MIN_ROWS = 400000;
+    const long long min_rows = BX6I_MIN_ROWS;
     const int mode = bx6i_enable(-1);
     // (the f16x3 stream goes to the weight-stationary kernel, mlp_ws.hip, which also tracks the fp16 range; this kernel's two-way
     // instantiation sits at its register limit — one more live register and it spills a hundred — and is no longer launched)

@@ -709,20 +709,19 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
 
 namespace g4cm {
 
-// 0 off, 1 (default; environment G4C_WS) launches of at least G4C_WS_MIN_ROWS rows (measured on the level-1 message launch against
+// 0 off, 1 (default) launches of at least 20 000 rows (measured on the level-1 message launch against
 // the two-way instantiation of mlp_bx6i_kernel, which it replaces: 322 us against 339 us with the fused aggregation, 288 against 292
 // without), 2 every launch it can take (tests)
 static int g_ws = -1;
 int ws_enable(int on) {
-    if (g_ws < 0) g_ws = getenv("G4C_WS") ? atoi(getenv("G4C_WS")) : 1;
+    if (g_ws < 0) g_ws = 1;
     const int old = g_ws;
     if (on >= 0) g_ws = on > 2 ? 2 : on;
     return old;
 }
 
 bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count) {
-    static const long long min_env = getenv("G4C_WS_MIN_ROWS") ? atoll(getenv("G4C_WS_MIN_ROWS")) : -1;
-    const long long min_rows = min_env >= 0 ? min_env : 20000;
+    constexpr long long min_rows = 20000;          // (same-box sweeps of round 3: ahead of the tile kernel from ~20 k rows)
     const int mode = ws_enable(-1);
     if (!mode || save || !(f16x2 || round1)) return false;          // (the bf16x6 stream keeps mlp_bx6i_kernel / mlp_bx6_kernel)
     if (mode == 1 && row_count < min_rows) return false;

@@ -140,10 +140,8 @@ extern "C" int g4c_segment_reduce(const float *src, int32_t src_ld, const int32_
             src, src_ld, perm, off, n_seg, width, mean, src_act, act, out, out_ld);
         return g4c::check_launch("g4c_segment_reduce");
     }
-    static const int force_lpr = getenv("G4C_SEG_LPR") ? atoi(getenv("G4C_SEG_LPR")) : 0;     // tuning only
-    int q = width / 4;
-    if (force_lpr == 16 && q > 16) q = 16;
-    if (force_lpr == 8 && q > 8) q = 8;
+    // (32 lanes per 128-wide row: 16 / 8 lanes with two / four pieces each measured 15 / 45 % slower on pool_edge's short segments)
+    const int q = width / 4;
     if (q > 16) {
         const long long total = (long long)n_seg * 32;
         segment_reduce_kernel<32><<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s>>>(

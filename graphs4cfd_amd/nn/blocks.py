@@ -24,7 +24,7 @@ from ..ops import Source
 
 import os
 # first-layer hoisting (MLP.run_hoisted) pays off only when the launch is throughput-bound
-HOIST_MIN_ROWS = int(os.environ.get("G4C_HOIST_MIN_ROWS", 24576))
+HOIST_MIN_ROWS = 24576
 
 Tensor = torch.Tensor
 
@@ -384,14 +384,14 @@ def edgeScalarToNodeVector(edge_attr: Tensor, edge_index: Tensor, edgeUnitVector
 # SELU and rounds them to bf16 — are stored by the launch that fuses the aggregation as bf16(SELU(row)) (G4C_DTYPE_BF16_SELU): half the
 # bytes of the largest tensors of a REMuS-GNN step, and bit for bit the operand the reader would have formed from fp32 rows (the
 # aggregate still sees the un-activated fp32 rows).  Round 2 stored bf16(row) and let the reader apply SELU: two roundings, max
-# deviation from the fp32 reference 3.6e-2 -> 6.5e-2 at 20k nodes, which is why it was opt-in then.  G4C_COMPACT_MESSAGES=0 turns it off.
-COMPACT_MESSAGES = __import__("os").environ.get("G4C_COMPACT_MESSAGES", "1") == "1"
+# deviation from the fp32 reference 3.6e-2 -> 6.5e-2 at 20k nodes, which is why it was opt-in then.
+COMPACT_MESSAGES = True
 # Rounded-bf16 mode: the first layer of a message MLP is hoisted as in the other arithmetics (products of the bf16-rounded node rows
 # with the bf16-rounded weights, fp32 accumulate: the operands the unhoisted launch forms, added in another order).  Measured on
 # config 3 (REMuS-GNN, 100k nodes): the level-1 angle launch is not HBM-bound on its gathers (reading them from bf16 copies of the
 # sender rows: 1160 -> 1130 us) but on per-tile latency and vector work; hoisted, with the products from the producer's launch
-# (g4c_mlp_forward_heads_bf16) and the message launch on mlp_ws_kernel<SP = 1>, it takes 1160 -> 800 us.  G4C_HOIST_BF16=0: as before.
-HOIST_BF16 = __import__("os").environ.get("G4C_HOIST_BF16", "1") == "1"
+# (g4c_mlp_forward_heads_bf16) and the message launch on mlp_ws_kernel<SP = 1>, it takes 1160 -> 800 us.
+HOIST_BF16 = True
 
 
 def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, aggr: str, act_code: int,
@@ -422,7 +422,7 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
     ep, csr = plan.edge_csr(index, n_t)
     senders = v if v_src is None else v_src
     mean = aggr == "mean"
-    e_src = e if isinstance(e, Source) else Source(e, pre_act=e_pre_act)      # (a Source: DownMP.pool(lazy_edges=True))
+    e_src = e if isinstance(e, Source) else Source(e, pre_act=e_pre_act)
     if ops.can_fuse_aggregation(csr, msg_mlp.output_size):
         # the edge launch reduces the rows it has just computed (whole CSR segments per row tile, g4c_mlp_forward_bx6_agg):
         # no second pass over the messages; with keep_e=False (the model discards e', nn/mus_gnn.py:199-200) they are not
@@ -534,7 +534,7 @@ class DownMP(nn.Module):
                 item.reset_parameters()
 
     def pool(self, graph: Graph, field: Tensor, edge_index: Tensor, edge_attr: Tensor, activation=None,
-             e_pre_act: int = _lib.ACT_NONE, target_major: bool = False, lazy_edges: bool = False):
+             e_pre_act: int = _lib.ACT_NONE, target_major: bool = False):
         """Functional core: returns (field_l, edge_index_l, edge_attr_l) without touching the Graph.
         `e_pre_act`: activation still pending on `edge_attr` (applied while pooling)."""
         h, l = self.hr_graph_idx, self.lr_graph_idx
@@ -546,11 +546,6 @@ class DownMP(nn.Module):
         pooled = _finish(pooled, activation, code)
         # (target_major: the models' internal coarse edge order, see plan.pool_edge_plan; the public forward keeps `coalesce` order)
         pp = plan.pool_edge_plan(getattr(graph, f'idx{h}_to_idx{l}'), edge_index, target_major)
-        if lazy_edges and ops.AGG_ON_LOAD and ops.effective_precision([int(edge_attr.size(1))]) != "fp32" and int(edge_attr.size(1)) == 128:
-            # (optional, G4C_LAZY_POOL=1; off by default: measured neutral at 100k nodes and -0.7 % at 12.5k in a same-box A/B) the
-            # pooled coarse edge latents are not materialised: the first coarse edge MLP forms them while it gathers its
-            # input (a Source that _mp_step takes in place of the tensor)
-            return pooled, pp.edge_index, Source(edge_attr, pre_act=e_pre_act, segments=pp.csr, seg_mean=True)
         ea_l = ops.segment_reduce(edge_attr, pp.csr, True, src_act=e_pre_act)
         return pooled, pp.edge_index, ea_l
 

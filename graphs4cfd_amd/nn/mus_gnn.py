@@ -29,7 +29,6 @@ from .blocks import MLP, MP, DownMP, UpMP
 from .model import GNN
 
 SELU, TANH, NONE = _lib.ACT_SELU, _lib.ACT_TANH, _lib.ACT_NONE
-_LAZY_POOL = __import__("os").environ.get("G4C_LAZY_POOL", "0") == "1"    # pooled coarse edge latents formed on load (DownMP.pool)
 
 
 class _MuSGNN(GNN):
@@ -87,7 +86,7 @@ class _MuSGNN(GNN):
             block = getattr(self, name)
             if name.startswith("down_mp"):
                 stash.append((v, edge_index, e, e_pending))
-                v, edge_index, e = block.pool(graph, v, edge_index, e, torch.tanh, e_pre_act=e_pending, target_major=True, lazy_edges=_LAZY_POOL)
+                v, edge_index, e = block.pool(graph, v, edge_index, e, torch.tanh, e_pre_act=e_pending, target_major=True)
                 e_pending, products = NONE, None
             elif name.startswith("up_mp"):
                 v_old, edge_index, e, e_pending = stash.pop()

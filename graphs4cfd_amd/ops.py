@@ -289,16 +289,17 @@ _PRECISION = os.environ.get("G4C_MLP_PRECISION", "f16x3")
 # node launch no longer re-reads the 307 MB of messages (the largest single stream of a level-1 MP layer after the messages'
 # own write).  The launch then runs on tiles of WHOLE segments: with in-degree 6 (or 5) a 32-row tile holds 30 rows, i.e.
 # 6.7 % more tiles — speed-neutral on the 100k rollout (+0.8 %), 2.5 GB less traffic per step.  On from FUSE_AGG_MIN_ROWS
-# rows (below, launches are latency-bound and the row tiles of whole segments only cost); G4C_FUSE_AGG=0 switches it off.
-FUSE_AGG = os.environ.get("G4C_FUSE_AGG", "1") == "1"
-FUSE_AGG_MIN_ROWS = int(os.environ.get("G4C_FUSE_AGG_MIN_ROWS", "50000"))
+# rows (below, launches are latency-bound and the row tiles of whole segments only cost).  (Module attributes, not environment
+# switches: the A/B runs that fixed them are in DESIGN.md / HISTORY.md; tests flip them directly.)
+FUSE_AGG = True
+FUSE_AGG_MIN_ROWS = 50000
 # Aggregation on load (g4c_src_t.seg_off): the node-MLP launch averages each target's messages while it gathers its input,
 # instead of a separate g4c_segment_reduce pass (bit-identical values; no tile-alignment constraint, unlike FUSE_AGG).
-AGG_ON_LOAD = os.environ.get("G4C_AGG_ON_LOAD", "1") == "1"
+AGG_ON_LOAD = True
 # below this many rows to aggregate, the launch that gathers them is latency-bound and a separate g4c_segment_reduce is quicker
 # (same-box sweep: 12.5k-node 3-scale mesh 789 -> 822 steps/s, 2-scale 10k nodes 1079 -> 1110, 25k nodes 503 -> 516 with the
 # threshold at 50k rows; neutral at 100k nodes)
-AGG_ON_LOAD_MIN_ROWS = int(os.environ.get("G4C_AGG_ON_LOAD_MIN_ROWS", "50000"))
+AGG_ON_LOAD_MIN_ROWS = 50000
 
 
 # ---- fp16 range of the "f16x3" arithmetic made observable (g4c_mlp_t.range_flag): every launch in that arithmetic carries a slot

@@ -188,7 +188,7 @@ class _Cache:
 
 _edge_plans = _Cache()
 _host_copies = _Cache(capacity=256)
-_REMEMBER_HOST = __import__("os").environ.get("G4C_HOST_COPIES", "1") != "0"      # (0: always read index tensors back; A/B only)
+_REMEMBER_HOST = True      # (False: always read index tensors back; A/B only — scripts/bench_fit_batches.py flips it)
 _pool_plans = _Cache()
 _index_plans = _Cache()
 _cluster_plans = _Cache()

@@ -432,7 +432,15 @@ def pinv_k2(u: torch.Tensor) -> torch.Tensor:
     unit vectors stays far inside float64; one rounding to the input dtype at the end).  Rank one (all k vectors collinear — the
     SVD drops the second singular value below rcond * sigma_1, torch's default rcond = 1e-15 * max(k, 2)): U^T / ||U||_F^2; zero block: 0.
     Elementwise tensor ops only: no host round trip, no per-block LAPACK call (the host SVD was what was left of the device
-    build of a REMuS graph: 237 ms at 100k nodes)."""
+    build of a REMuS graph: 237 ms at 100k nodes).
+
+    How close to the reference's stored inverses (tests/test_synthetic.py): rtol 1e-5 / atol 1e-6 on the golden REMuS graph's
+    blocks (well conditioned); 2e-3 relative on nearly collinear blocks (angles within 1e-3 rad, condition ~1e3) — that is the
+    float32 SVD's own error there, this routine works in float64; and NOT equal on exactly rank-deficient blocks: the reference's
+    rcond = 1e-15 lies below float32 resolution, so its float32 SVD keeps a noise-level second singular value (~1e-7 sigma_1) and
+    inverts it, while this returns the minimum-norm pseudo-inverse (the rank is decided on the exact float64 singular values).  A
+    degenerate stencil (all k neighbours on one line through the node) therefore gives a different — finite, meaningful — matrix
+    than the reference's arbitrary one."""
     if u.dim() != 3 or u.size(2) != 2:
         raise ValueError(f"pinv_k2 expects [n, k, 2], got {tuple(u.shape)}")
     x, y = u[..., 0].double(), u[..., 1].double()

@@ -211,16 +211,15 @@ int g4c_mlp_pack_layer_f16x3(const float *W, int32_t n_out, int32_t k_in, const 
 /* The dual-tile software-pipelined form of the exact-split kernel (mlp_bx6i.hip: a workgroup alternates between two 32-row tiles,
  * the vector work of one running under the MFMAs of the other, the layer's weights stationary in registers for both) takes the
  * launches of the MP layers' message MLP (one weighted 128-wide block + 0 or 2 additive blocks, three layers, plain 128-wide output
- * rows — through out_idx too — with or without the fused aggregation): 0 = never, 1 = launches of at least G4C_BX6I_MIN_ROWS rows
- * (default 20 000 for the f16x3 stream, 400 000 for the bf16x6 stream; the
- * default mode, environment G4C_BX6I), 2 = every launch it can take (tests); -1 only queries.  Returns the previous setting. */
+ * rows — through out_idx too — with or without the fused aggregation) in the bf16x6 stream: 0 = never, 1 = launches of at least
+ * 400 000 rows (the default mode), 2 = every launch it can take (tests); -1 only queries.  Returns the previous setting. */
 int g4c_mlp_bx6i_enable(int on);
 
 /* Weight-stationary persistent form of the same launches for the f16x3 stream (mlp_ws.hip: one 8-wave workgroup per CU, every wave
  * keeps its 16-column slice of all three layers' weights in registers for the whole launch, the loop over tile pairs prefetches the
  * next pair's indices and rows): same envelope and the same per-element arithmetic as g4c_mlp_bx6i_enable's kernel (sums over k in a
  * different association: equal to it within fp32 rounding, the fused aggregation still bit-identical to g4c_segment_reduce of the
- * stored rows).  0 = never, 1 = launches of at least G4C_WS_MIN_ROWS rows (default 20 000; the default mode, environment G4C_WS),
+ * stored rows).  0 = never, 1 = launches of at least 20 000 rows (the default mode),
  * 2 = every launch it can take (tests); -1 only queries.  Returns the previous setting.  The dual-tile kernel of
  * g4c_mlp_bx6i_enable takes the bf16x6 stream only since round 3. */
 int g4c_mlp_ws_enable(int on);

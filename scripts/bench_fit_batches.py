@@ -1,10 +1,12 @@
 """Training iterations over FRESH batches (every batch a new collated graph, as in GNN.fit with a DataLoader): the static-plan
 builders run once per batch on the host, so what matters is that they never read index tensors back from the device
-(plan.remember_host) and are O(n).  A/B: G4C_HOST_COPIES=0 python scripts/bench_fit_batches.py"""
+(plan.remember_host) and are O(n).  A/B: python scripts/bench_fit_batches.py --no-host-copies"""
 import sys, time, torch
 sys.path.insert(0, "/root/repo")
 import graphs4cfd_amd as gfd
-from graphs4cfd_amd import synthetic as S
+from graphs4cfd_amd import plan, synthetic as S
+if "--no-host-copies" in sys.argv:
+    plan._REMEMBER_HOST = False
 dev = torch.device("cuda", 0)
 n = 7000
 h = 2.0 * n ** -0.5

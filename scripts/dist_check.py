@@ -12,9 +12,14 @@ ap.add_argument("--model", default="NsThreeScaleGNN"); ap.add_argument("--dim", 
 ap.add_argument("--capture", type=int, default=-1, help="-1: capture the step in a hipGraph iff the transport is nccl")
 ap.add_argument("--force-exchange", action="store_true", help="enter every halo collective even with one rank (zero-length splits): executes "
                 "'hipGraph capture with an RCCL collective inside' on a single-GPU box")
+ap.add_argument("--hoist-min-rows", type=int, default=None, help="blocks.HOIST_MIN_ROWS for this run (0: every MP layer hoists, i.e. every halo "
+                "exchange carries first-layer products)")
 ap.add_argument("--time", type=int, default=0, help="after the check: time this many steps of the captured (hipGraph-replayed) and of the uncaptured "
                 "(eager launches + eager collectives) partitioned step — what a capture failure on the first real RCCL run would cost per rank")
 a = ap.parse_args()
+if a.hoist_min_rows is not None:
+    from graphs4cfd_amd.nn import blocks as _B
+    _B.HOIST_MIN_ROWS = a.hoist_min_rows
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda", 0 if a.same_gpu else int(os.environ["LOCAL_RANK"]))
 torch.cuda.set_device(dev)
@@ -43,7 +48,7 @@ if rank == 0:
         assert dr.captured, f"the partitioned step was not captured: {dr.capture_error}"
 if a.time:
     import time
-    res = {}
+    res, per_step = {}, 0
     for name, cap in (("captured (hipGraph replay)", True), ("uncaptured (eager launches and collectives)", False)):
         r = P.DistributedRollout(model, g, a.time + 4, rank, world, dev, capture=cap)
         if a.force_exchange:
@@ -56,10 +61,12 @@ if a.time:
         el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         res[name] = (1e3 * float(el.item()) / a.time, r.captured, r.capture_error)
+        if not cap:
+            per_step = r.fwd.xch.n_exchanges // (a.time + 3)          # (every step of the eager runner enters its collectives from Python)
         del r
     if rank == 0:
         for name, (ms, captured, note) in res.items():
-            print(f"world={world} backend={a.backend} {a.model} {a.nodes} nodes, {x.n_exchanges // max(a.steps, 1)} exchanges per step: {name}: {ms:.3f} ms/step "
+            print(f"world={world} backend={a.backend} {a.model} {a.nodes} nodes, {per_step} exchanges per step: {name}: {ms:.3f} ms/step "
                   f"(captured={captured}{'' if note is None else ', ' + str(note)})", flush=True)
         c, u = res["captured (hipGraph replay)"][0], res["uncaptured (eager launches and collectives)"][0]
         print(f"eager fallback / captured = {u / c:.2f}x", flush=True)

@@ -10,6 +10,6 @@ rm -rf $A/prof_train
     python scripts/bench_train.py --steps 3 --cpu-steps 0 > $A/prof_train_stdout.log 2> $A/prof_train_stderr.log )
 cp $(find $A/prof_train -name '*kernel_stats.csv' | head -1) $A/${TAG}_train_rocprofv3_kernel_stats.csv 2>/dev/null
 rm -rf $A/prof_train
-for v in 1 0; do echo "G4C_HOST_COPIES=$v"; G4C_HOST_COPIES=$v timeout -k 5 300 python scripts/bench_fit_batches.py 2>&1 | grep -i "fresh\|same"; done > $A/${TAG}_fit_fresh_batches.log
+for v in "" "--no-host-copies"; do echo "host copies of index tensors: ${v:-kept}"; timeout -k 5 300 python scripts/bench_fit_batches.py $v 2>&1 | grep -i "fresh\|same"; done > $A/${TAG}_fit_fresh_batches.log
 timeout -k 5 300 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $A/${TAG}_pytest_gpu.log
 ls -la $A

@@ -1038,9 +1038,9 @@ def test_distributed_rollout_two_processes_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "scripts", "dist_check.py"), "--backend", "gloo", "--same-gpu",
            "--nodes", "12000", "--steps", "3"]
-    # G4C_HOIST_MIN_ROWS=0: every MP layer hoists, i.e. the halo exchange carries the first-layer products (partition.py)
-    for env in (dict(os.environ), dict(os.environ, G4C_HOIST_MIN_ROWS="0")):
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    # --hoist-min-rows 0: every MP layer hoists, i.e. the halo exchange carries the first-layer products (partition.py)
+    for extra in ([], ["--hoist-min-rows", "0"]):
+        out = subprocess.run(cmd + extra, capture_output=True, text=True, timeout=600, env=dict(os.environ))
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
         assert "max|partitioned - single|" in out.stdout
 
@@ -1055,7 +1055,7 @@ def test_distributed_rollout_four_processes_one_gpu():
     base = [sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
             "--master-port", str(port), os.path.join(root, "scripts", "dist_check.py"), "--backend", "gloo", "--same-gpu"]
     runs = [(base + ["--nodes", "100000", "--steps", "2"], dict(os.environ)),
-            (base + ["--nodes", "30000", "--steps", "2"], dict(os.environ, G4C_HOIST_MIN_ROWS="0")),
+            (base + ["--nodes", "30000", "--steps", "2", "--hoist-min-rows", "0"], dict(os.environ)),
             (base + ["--nodes", "20000", "--steps", "2", "--model", "NsFourScaleGNN", "--dim", "3"], dict(os.environ)),
             (base + ["--nodes", "20000", "--steps", "2", "--model", "NsRotEquiTreeScaleGNN"], dict(os.environ))]
     for cmd, env in runs:
