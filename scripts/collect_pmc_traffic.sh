@@ -6,15 +6,15 @@
 # (B) the bench without it (only rollout steps run: total bytes / steps executed = HBM traffic per rollout step).
 # Usage (on the GPU box): bash scripts/collect_pmc_traffic.sh <round-tag> [workload]   -> profiles/<tag>_pmc_traffic[_<workload>].json
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 WL=${2:-headline}
 SFX=""; [ "$WL" != "headline" ] && SFX="_$WL"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_traffic_$TAG$SFX
 rm -rf $OUT; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/A_$c -o p -- python bench.py --workload $WL --steps 4 --warmup 1 --no-cpu-baseline --no-strict-range > $OUT/A_$c.log 2>&1
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/B_$c -o p -- python bench.py --workload $WL --steps 6 --warmup 1 --no-cpu-baseline --no-roofline --no-strict-range > $OUT/B_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/A_$c -o p -- python bench.py --workload $WL --steps 4 --warmup 1 --no-cpu-baseline --no-strict-range --no-side-configs > $OUT/A_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/B_$c -o p -- python bench.py --workload $WL --steps 6 --warmup 1 --no-cpu-baseline --no-roofline --no-strict-range --no-side-configs > $OUT/B_$c.log 2>&1
 done
 python - "$OUT" "$TAG" "$SFX" "$WL" <<'PY'
 import csv, glob, collections, json, sys

@@ -2,8 +2,8 @@
 # Round artifacts, produced on the GPU box into gpurun_out/artifacts_<tag>/ (copy them into profiles/ afterwards):
 #   pytest -m gpu tail, bench lines of every named workload, rocprofv3 kernel stats of the headline and REMuS benches, PMC HBM
 #   traffic of both, MFMA ceiling, training benches.
-# Usage: gpurun --timeout 3000 -- 'bash scripts/refresh_artifacts.sh r03'
-TAG=${1:-r03}
+# Usage: gpurun --timeout 3000 -- 'bash scripts/refresh_artifacts.sh r04'
+TAG=${1:-r04}
 cd "$GRAFT_REPO_ROOT"
 A=gpurun_out/artifacts_$TAG; rm -rf $A; mkdir -p $A
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $A/${TAG}_pytest_gpu.log
@@ -16,7 +16,7 @@ for wl in c2 c3 c5-1gpu; do
 done
 for wl in headline c3; do
   ( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $A/prof_$wl -o p -- \
-      python bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --no-strict-range > $A/prof_${wl}_stdout.log 2> $A/prof_${wl}_stderr.log )
+      python bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --no-strict-range --no-side-configs > $A/prof_${wl}_stdout.log 2> $A/prof_${wl}_stderr.log )
   tail -1 $A/prof_${wl}_stdout.log > $A/${TAG}_bench_${wl}_under_rocprofv3.json
   cp $(find $A/prof_$wl -name '*kernel_stats.csv' | head -1) $A/${TAG}_rocprofv3_kernel_stats_${wl}.csv
   rm -rf $A/prof_$wl
@@ -40,6 +40,9 @@ done
 timeout 300 python scripts/step_breakdown.py > $A/${TAG}_step_breakdown.log 2>&1
 timeout 300 python scripts/step_breakdown.py --workload c3 > $A/${TAG}_step_breakdown_c3.log 2>&1
 timeout 300 python scripts/bench_segment_reduce.py 2>&1 | grep -v amdgpu.ids > $A/${TAG}_segment_reduce_rotating.log
+timeout 300 python scripts/bench_pool_edge.py 2>&1 | grep -v amdgpu.ids > $A/${TAG}_pool_edge_reductions.log
+timeout 300 python scripts/step_breakdown.py --nodes 12500 2>&1 | grep -v amdgpu.ids > $A/${TAG}_step_breakdown_12k5.log
+timeout 300 python scripts/step_breakdown.py --workload c2 2>&1 | grep -v amdgpu.ids > $A/${TAG}_step_breakdown_c2.log
 timeout 300 python scripts/mlp_accuracy.py > $A/${TAG}_mlp_accuracy.log 2>&1
 # the weight-stationary kernel (f16x3 stream and rounded-bf16 mode, 2 / 3 layers): checks against the tile kernel + same-process A/B; the dual-tile kernel (bf16x6 stream)
 timeout 600 python scripts/ws_check.py --time 2>&1 | grep -v "^ok\|amdgpu.ids" > $A/${TAG}_ws_check_and_ab.log
@@ -50,8 +53,14 @@ timeout 120 python scripts/ws_stamps.py graphs4cfd_amd/lib/libg4c_ws_timing.so b
 # pipe-utilisation counters of the shipped kernels in the DEFAULT arithmetic: level-1 message launch (mlp_ws_kernel) and node launch (mlp_bx6_kernel)
 bash scripts/pmc_ws.sh ws ${TAG}_ws util sq3 lds sq2 tcc > $A/${TAG}_pmc_mlp_ws.txt 2>&1
 PMC_EXTRA_ARGS=--node bash scripts/pmc_ws.sh tile ${TAG}_node util sq3 lds sq2 tcc > $A/${TAG}_pmc_mlp_bx6_node.txt 2>&1
-# co-issue microbenchmark (how many vector instructions hide behind one MFMA, by shape and waves per SIMD)
+# co-issue microbenchmarks (what hides behind one MFMA, by shape, waves per SIMD and instruction kind)
 hipcc -w --offload-arch=gfx950 -O3 -o /tmp/mfma_fillers scripts/micro/mfma_fillers.hip 2>/dev/null && /tmp/mfma_fillers > $A/${TAG}_mfma_fillers.log 2>&1
+for m in mfma_gap_patterns mfma_chain_probe mfma_lds_probe; do
+  hipcc -w --offload-arch=gfx950 -O3 -o /tmp/$m scripts/micro/$m.hip 2>/dev/null && /tmp/$m > $A/${TAG}_$m.log 2>&1
+done
+# what a hipGraph-capture failure on the first real RCCL run would cost: captured against eager partitioned step, world size 1, collectives entered
+{ for n in 12500 100000; do timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 2954$((n % 7)) scripts/dist_check.py \
+    --backend nccl --capture 1 --force-exchange --nodes $n --time 50 2>&1 | grep "world=\|eager fallback"; done; } > $A/${TAG}_dist_single.log
 timeout 300 python scripts/bench_mugs.py 2>&1 | tail -3 > $A/${TAG}_bench_mugs.log
 # training path: step time + per-phase HIP-event times + the CPU leg
 timeout -k 10 900 python scripts/bench_train.py --steps 10 --cpu-steps 1 --phases 2> $A/train_stderr.log | tail -1 > $A/${TAG}_train_bench_100k.json
