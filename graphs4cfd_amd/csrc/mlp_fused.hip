@@ -22,6 +22,7 @@
 //
 // MFMA-bound in fp32: 2*K*128 FLOP per row per layer against ~(K_in + N_out)*4 bytes per row.
 #include "mlp_common.h"
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 using namespace g4cm;
@@ -548,8 +549,12 @@ __global__ void pack_layer_kernel(const float *__restrict__ W, int n_out, int k_
 // (g4c_mlp_pack_layer_bx6: [128-k block][column tile][16-k step][plane][lane][8], 6 bytes per weight).
 // Template parameter SP = 3: the above.  SP = 1: only the leading terms (operands ROUNDED to bf16, one product) — the
 // opt-in "bf16" mode of BASELINE config 3 ("bf16 edge-MLP MFMA", ~1e-2 deviation) on the same stream and structure.
-constexpr int RD6 = 2;              // weight ring depth in 16-k steps (4 / 8 measured slower: 483 / 563 us against 446 on the level-1 launch)
-struct Ring6 { bf16x8 h[RD6], m[RD6], l[RD6]; };
+// weight ring depth in 16-k steps.  2 where the launch fills the chip (4 / 8 measured slower: 483 / 563 us against 446 on the level-1
+// launch — registers, i.e. waves per SIMD, are what hides the L2 latency there).  8 (a whole 128-k block in flight: the NEXT block's
+// weights are requested while this block multiplies) for SMALL launches, <= g_bx6_deep_tiles tiles: with one wave per SIMD nothing else
+// covers the L2 round trip, and a ring of 2 exposes it four times per block (2 800 cycles per block against 770 of MFMAs;
+// scripts/small_launch_stamps.py)
+template <int RD6> struct Ring6 { bf16x8 h[RD6], m[RD6], l[RD6]; };
 
 // one 128-k block for RT row tiles of 32: per 16-k step and row tile 6 MFMAs from the three LDS planes (plane stride
 // `plane`, row-tile stride 32*HB); the weight fragments of a step are shared by the row tiles; ring slot s % RD6 is
@@ -562,8 +567,8 @@ constexpr int G4C_BX6_TUNE = 0;      // (1 = s_setprio around the MFMAs, 2 = no 
 // SWAP (the heads): the two MFMA operands trade places, so the accumulator comes out untransposed — a lane holds ONE output feature
 // (lane & 31 of the wave's 32-column slice) of the 16 sample rows 8 (q / 4) + 4 (lane / 32) + q % 4 — and a store instruction writes
 // 128 contiguous bytes of each of two rows (same products, same order of k inside the MFMA).
-template <int RT, int SP, bool SWAP = false>
-__device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6 &g, __amdgpu_buffer_rsrc_t rs, unsigned wofs, unsigned lo_b,
+template <int RT, int SP, bool SWAP = false, int RD6 = 2>
+__device__ __forceinline__ void mma_block_bx6(const __bf16 *pa, int plane, Ring6<RD6> &g, __amdgpu_buffer_rsrc_t rs, unsigned wofs, unsigned lo_b,
                                               f32x16 (&acc)[RT], f32x16 (&acc1)[RT]) {
     bf16x8 ah = *reinterpret_cast<const bf16x8 *>(pa), am = ah, al = ah;
     if (SP >= 2) am = *reinterpret_cast<const bf16x8 *>(pa + plane);
@@ -641,8 +646,8 @@ constexpr int G4C_F16_MINW = 4;
 // twice the rows.
 // FULL: every weighted input block and every additive block is exactly 128 wide and 16-byte aligned (the MP layers):
 // no column masks anywhere.
-template <int RT, bool VEC, bool FULL, int SP, bool SAVE = false>
-__global__ __launch_bounds__(256, SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) void mlp_bx6_kernel(const Params p) {
+template <int RT, bool VEC, bool FULL, int SP, bool SAVE = false, int RD6 = 2>
+__global__ __launch_bounds__(256, RD6 > 2 ? 2 : (SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW)) void mlp_bx6_kernel(const Params p) {
     static_assert(RT == 1, "64-row tiles (RT = 2) measured slower in every arithmetic (480 against 446 us, two / three workgroups per CU) and cannot "
                            "take the fused aggregation: not instantiated since round 3");
     constexpr int ROWS = 32 * RT, NW = 4;
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) void ml
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, 0x7fffffff, 0x00020000);
     const unsigned lo_b = 2u * (unsigned)(ct0 * 8 * STEP6 + lane * 8);    // this lane's byte offset inside a block of the stream
     unsigned wofs = 0;                                                     // byte offset of the current block (wave-uniform)
-    Ring6 ring;
+    Ring6<RD6> ring;
 
     // this wave's rows of an input block: lane -> row (lane>>3) + 8*wave (+ 32 per row tile), 4 floats at column
     // 4*(lane&7) of each 32-k chunk.  A block whose rows are not gathered through an index can start right away.
@@ -947,7 +952,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) void ml
         const bool more = s + 1 < p.n_src;
         if (more && RT == 1) gather(s + 1, false);          // (RT = 2: 32 more live registers would cost a wave per SIMD)
         __builtin_amdgcn_sched_barrier(0);
-        mma_block_bx6<RT, SP>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
+        mma_block_bx6<RT, SP, false, RD6>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
         wofs += 2u * BLOCK6;
         __syncthreads();                   // everybody is done reading the planes
         if (more) {
@@ -1012,7 +1017,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) void ml
         __syncthreads();
         G4C_STAMPW(5 + 2 * l);
         bias_start(l + 1);
-        mma_block_bx6<RT, SP>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
+        mma_block_bx6<RT, SP, false, RD6>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
         wofs += 2u * BLOCK6;
         __syncthreads();
         G4C_STAMPW(6 + 2 * l);
@@ -1056,12 +1061,13 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) void ml
                 if (SP == 3) *reinterpret_cast<bf16x4 *>(d + 2 * PLN) = vl;
             }
         __syncthreads();
+        G4C_STAMPW(14);
         for (int hd = 0; hd < p.n_heads; ++hd) {
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { acc[t][q] = 0.f; acc1[t][q] = 0.f; }
-            mma_block_bx6<RT, SP, true>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
+            mma_block_bx6<RT, SP, true, RD6>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
             wofs += 2u * BLOCK6;
             // untransposed accumulator (SWAP): lane (i, h) holds column ct0 * 32 + i of the rows 32 t + 8 gq + 4 h + e; one dword
             // store per value, 32 lanes = one 128-byte line of a row.  The rows of the tile past mlim fall outside the buffer
@@ -1082,6 +1088,7 @@ __global__ __launch_bounds__(256, SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW) void ml
                     }
         }
     }
+    G4C_STAMPW(15);
     if (SP == 2) range_report(p, rng);
 }
 
@@ -1297,6 +1304,14 @@ extern "C" int g4c_mlp_forward_bx6(const g4c_mlp_t *mlp, const g4c_src_t *srcs, 
 static thread_local int g_last_kernel = G4C_KERNEL_NONE;
 extern "C" int g4c_mlp_last_kernel(void) { return g_last_kernel; }
 
+// launches of at most this many 32-row tiles run the tile kernel's deep-ring instantiation (Ring6)
+static std::atomic<int> g_bx6_deep_tiles{512};
+extern "C" int g4c_mlp_small_launch_tiles(int n_tiles) {
+    const int prev = g_bx6_deep_tiles.load(std::memory_order_relaxed);
+    if (n_tiles >= 0) g_bx6_deep_tiles.store(n_tiles, std::memory_order_relaxed);
+    return prev;
+}
+
 static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                       int64_t row_begin, int64_t row_count, int32_t tile_rows,
                       float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
@@ -1467,9 +1482,14 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         if (p.n_tiles == 0) return G4C_OK;
         g_last_kernel = G4C_KERNEL_MLP_BX6;
         const dim3 grid(p.n_tiles);
+        const bool deep = p.n_tiles <= g_bx6_deep_tiles;          // (small launch: whole-block weight ring, see Ring6)
 #define G4C_BX6_LAUNCH(RT, SP)                                                                         \
         do {                                                                                           \
-            if (full) mlp_bx6_kernel<RT, true, true, SP><<<grid, blk, 0, st>>>(p);                     \
+            if (deep) {                                                                                \
+                if (full) mlp_bx6_kernel<RT, true, true, SP, false, 8><<<grid, blk, 0, st>>>(p);       \
+                else if (all_vec) mlp_bx6_kernel<RT, true, false, SP, false, 8><<<grid, blk, 0, st>>>(p); \
+                else mlp_bx6_kernel<RT, false, false, SP, false, 8><<<grid, blk, 0, st>>>(p);          \
+            } else if (full) mlp_bx6_kernel<RT, true, true, SP><<<grid, blk, 0, st>>>(p);              \
             else if (all_vec) mlp_bx6_kernel<RT, true, false, SP><<<grid, blk, 0, st>>>(p);            \
             else mlp_bx6_kernel<RT, false, false, SP><<<grid, blk, 0, st>>>(p);                        \
         } while (0)

@@ -224,6 +224,12 @@ int g4c_mlp_bx6i_enable(int on);
  * g4c_mlp_bx6i_enable takes the bf16x6 stream only since round 3. */
 int g4c_mlp_ws_enable(int on);
 
+/* Small launches of the tile kernel (at most n_tiles 32-row tiles; default 512 = two workgroups per CU) run an instantiation that
+ * keeps a whole 128-k block of weights in flight per wave — the next block's weights are requested while this block multiplies —
+ * instead of the two-step ring the chip-filling launches use: with one or two waves per SIMD nothing else hides the L2 round trip.
+ * Same arithmetic, bit-identical results.  n_tiles >= 0 sets the limit (0 = never), -1 only queries.  Returns the previous limit. */
+int g4c_mlp_small_launch_tiles(int n_tiles);
+
 /* Which kernel family the calling thread's most recent fused-MLP launch (any g4c_mlp_forward* entry point) ran on — the library
  * picks it per launch (arithmetic, shape, row count), so a profiler-free caller that times launches with events (bench.py's
  * roofline leg) can label them by the kernel that executed instead of by the entry point: G4C_KERNEL_NONE (no launch yet, or the

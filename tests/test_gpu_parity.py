@@ -1195,6 +1195,61 @@ def test_bx6i_dual_tile_kernel_equals_tile_kernel(rows, kernel, prec, monkeypatc
             assert torch.equal(got[f"agg_only_{mean}"], got[f"agg_{mean}"])
 
 
+# ------------------------------------------------------------------ the tile kernel's small-launch instantiation (deep weight ring)
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x6", "bf16"])
+@pytest.mark.parametrize("rows", [1, 33, 700, 5000])
+def test_small_launch_deep_ring_is_bit_identical(rows, prec):
+    """g4c_mlp_small_launch_tiles: launches of few tiles run mlp_bx6_kernel with a whole 128-k block of weights in flight per wave
+    instead of the two-step ring.  Only the order of the weight LOADS changes — every result must be bit for bit the ring-of-two
+    kernel's: node launch with heads (two direct blocks), message launch with additive rows / an index / the fused aggregation,
+    an encoder with a narrow input, in the three split arithmetics."""
+    if ops.mlp_precision() != "f16x3":
+        pytest.skip("runs under the default arithmetic only (it sets the mode itself)")
+    lib = _lib.load()
+    H, n = 128, max(rows // 6, 2)
+    old_prec = ops.set_mlp_precision(prec)
+    old_ws, old_i = lib.g4c_mlp_ws_enable(0), lib.g4c_mlp_bx6i_enable(0)
+    old_lim = lib.g4c_mlp_small_launch_tiles(-1)
+    try:
+        torch.manual_seed(rows + 7)
+        blk = B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(DEV)
+        enc = B.MLP(5, (H, H, H), True).to(DEV)
+        v, aggr = torch.randn(n, H, device=DEV), torch.randn(n, H, device=DEV)
+        col = torch.arange(n).repeat_interleave(6)
+        E = int(col.numel())
+        edge_index = torch.stack([torch.randint(0, n, (E,)), col]).to(DEV)
+        e, ea = torch.randn(E, H, device=DEV), torch.randn(E, 5, device=DEV)
+        ep, csr = plan.edge_csr(edge_index, n)
+        W1 = blk.edge_mlp.state_dict()["MLP.linear_1.weight"]
+        pr, pc = (v @ W1[:, H:2 * H].T).contiguous(), (v @ W1[:, 2 * H:].T).contiguous()
+        pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+        adds = [ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+        idx = torch.randint(0, E, (E,), device=DEV, dtype=torch.int32)
+
+        def run():
+            out = {}
+            y, heads = blk.node_mlp.run_with_heads([ops.Source(aggr), ops.Source(v)], n, _lib.ACT_SELU, blk.edge_mlp, H, [H, H])
+            out["node"], out["head0"], out["head1"] = y, heads[0].float(), heads[1].float()
+            out["edge"] = ops.mlp_forward(pk, [ops.Source(e, pre_act=_lib.ACT_SELU)] + adds, E)
+            out["indexed"] = ops.mlp_forward(pk, [ops.Source(e, index=idx)] + adds, E, _lib.ACT_SELU)
+            out["encoder"] = enc(ea)
+            if csr.tiles() is not None:
+                a = torch.full((n, H), float("nan"), device=DEV)
+                out["rows"] = ops.mlp_forward(pk, [ops.Source(e)] + adds, E, agg=(csr, a, True))
+                out["agg"] = a
+            return {k: t.clone() for k, t in out.items()}
+        lib.g4c_mlp_small_launch_tiles(0)
+        ref = run()
+        lib.g4c_mlp_small_launch_tiles(1 << 30)
+        got = run()
+    finally:
+        lib.g4c_mlp_small_launch_tiles(old_lim)
+        lib.g4c_mlp_ws_enable(old_ws); lib.g4c_mlp_bx6i_enable(old_i)
+        ops.set_mlp_precision(old_prec)
+    for k in ref:
+        assert torch.isfinite(got[k]).all() and torch.equal(got[k], ref[k]), k
+
+
 # ------------------------------------------------------------------ the weight-stationary persistent kernel (mlp_ws.hip)
 @pytest.mark.parametrize("variant", [("f16x3", 3), ("f16x3", 2), ("bf16", 2), ("bf16", 3)], ids=lambda v: f"{v[0]}-{v[1]}layers")
 @pytest.mark.parametrize("rows", [1, 33, 6000, 70000])
