@@ -660,8 +660,13 @@ __global__ __launch_bounds__(256, RD6 > 2 ? 2 : (SP == 2 ? G4C_F16_MINW : G4C_BX
     constexpr int NSLOT = RT == 2 ? 2 : G4C_MAX_SRC;
     constexpr bool LDS_BIAS = RT == 1;
     constexpr int BIAS_FLOATS = LDS_BIAS ? G4C_MAX_LAYERS * NP : 0;
-    __shared__ __attribute__((aligned(16))) float lds[BUF_FLOATS + 2 * NSLOT * ROWS + BIAS_FLOATS + 2 * NP];
-    float *sH = lds;
+    // SMALL (the deep-ring instantiation of launches of few tiles: one or two workgroups per CU, LDS to spare): the fp32 final tile
+    // has its own buffer instead of aliasing the planes — one barrier less in front of the heads — and both heads' MFMA blocks run
+    // back to back on separate accumulators, all head stores behind them
+    constexpr bool SMALL = RD6 > 2;
+    constexpr int FIN_FLOATS = SMALL ? ROWS * HS : 0;
+    __shared__ __attribute__((aligned(16))) float lds[BUF_FLOATS + 2 * NSLOT * ROWS + BIAS_FLOATS + 2 * NP + FIN_FLOATS];
+    float *sH = SMALL ? lds + BUF_FLOATS + 2 * NSLOT * ROWS + BIAS_FLOATS + 2 * NP : lds;
     __bf16 *sB = reinterpret_cast<__bf16 *>(lds);
     int *sRow = reinterpret_cast<int *>(lds + BUF_FLOATS);
     int *sRowAdd = sRow + NSLOT * ROWS;
@@ -1048,7 +1053,7 @@ __global__ __launch_bounds__(256, RD6 > 2 ? 2 : (SP == 2 ? G4C_F16_MINW : G4C_BX
         for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[t][q] = *reinterpret_cast<const f32x4 *>(sH + (grow_l + 32 * t) * HS + q * KC + c4);
-        __syncthreads();
+        if (!SMALL) __syncthreads();          // (SMALL: the planes do not alias the tile; their last readers are behind older barriers)
 #pragma unroll
         for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -1062,30 +1067,53 @@ __global__ __launch_bounds__(256, RD6 > 2 ? 2 : (SP == 2 ? G4C_F16_MINW : G4C_BX
             }
         __syncthreads();
         G4C_STAMPW(14);
-        for (int hd = 0; hd < p.n_heads; ++hd) {
-#pragma unroll
-            for (int t = 0; t < RT; ++t)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) { acc[t][q] = 0.f; acc1[t][q] = 0.f; }
-            mma_block_bx6<RT, SP, true, RD6>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
-            wofs += 2u * BLOCK6;
-            // untransposed accumulator (SWAP): lane (i, h) holds column ct0 * 32 + i of the rows 32 t + 8 gq + 4 h + e; one dword
-            // store per value, 32 lanes = one 128-byte line of a row.  The rows of the tile past mlim fall outside the buffer
-            // descriptor's range (num_records) and are dropped by the hardware.
-            const long long left = mlim - row0;
-            const int nrows = left >= ROWS ? ROWS : (left > 0 ? (int)left : 0);
-            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(p.head_out[hd] + row0 * p.head_ld, 0, nrows * p.head_ld * 4, 0x00020000);
-            const unsigned vo = (unsigned)(4 * h * p.head_ld + ct0 * 32 + i) * 4u;
+        // untransposed accumulator (SWAP): lane (i, h) holds column ct0 * 32 + i of the rows 32 t + 8 gq + 4 h + e; one dword
+        // store per value, 32 lanes = one 128-byte line of a row.  The rows of the tile past mlim fall outside the buffer
+        // descriptor's range (num_records) and are dropped by the hardware.
+        const long long left = mlim - row0;
+        // (wave-uniform by construction, but a value the vector ALU produced — the clamp below is a v_med3 — lives in a vector register,
+        // and a buffer descriptor built from vector registers makes hipcc wrap EVERY store in a readfirstlane "waterfall" loop: twelve
+        // instructions per stored dword, 1 450 cycles per head of a tile.  Explicitly scalar:)
+        const int nrows = __builtin_amdgcn_readfirstlane(left >= ROWS ? ROWS : (left > 0 ? (int)left : 0));
+        const unsigned vo = (unsigned)(4 * h * p.head_ld + ct0 * 32 + i) * 4u;
+        auto head_store = [&](int hd, const f32x16 (&a)[RT], const f32x16 (&a1)[RT]) __attribute__((always_inline)) {
+            const unsigned long long hb = reinterpret_cast<unsigned long long>(p.head_out[hd] + row0 * p.head_ld);
+            float *const hbase = reinterpret_cast<float *>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(hb >> 32)) << 32) |
+                                                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)hb));
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(hbase, 0, nrows * p.head_ld * 4, 0x00020000);
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float x = SP == 2 ? fmaf(acc1[t][4 * gq + e], F16_LO_UNSCALE, acc[t][4 * gq + e]) : acc[t][4 * gq + e];
+                        const float x = SP == 2 ? fmaf(a1[t][4 * gq + e], F16_LO_UNSCALE, a[t][4 * gq + e]) : a[t][4 * gq + e];
                         // (the row offset is part of the VECTOR offset: the scalar offset is not range-checked)
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rh, vo + (unsigned)((32 * t + 8 * gq + e) * p.head_ld) * 4u, 0, 0);
                     }
+        };
+        auto head_zero = [&](f32x16 (&a)[RT], f32x16 (&a1)[RT]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { a[t][q] = 0.f; a1[t][q] = 0.f; }
+        };
+        if constexpr (SMALL) {
+            static_assert(G4C_MAX_HEADS == 2, "the small-launch head path multiplies both heads before it stores either");
+            f32x16 acc2[RT], acc21[RT];
+            head_zero(acc, acc1); head_zero(acc2, acc21);
+            mma_block_bx6<RT, SP, true, RD6>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
+            wofs += 2u * BLOCK6;
+            if (p.n_heads > 1) mma_block_bx6<RT, SP, true, RD6>(pa, PLN, ring, rs, wofs, lo_b, acc2, acc21);
+            head_store(0, acc, acc1);
+            if (p.n_heads > 1) head_store(1, acc2, acc21);
+        } else {
+            for (int hd = 0; hd < p.n_heads; ++hd) {
+                head_zero(acc, acc1);
+                mma_block_bx6<RT, SP, true, RD6>(pa, PLN, ring, rs, wofs, lo_b, acc, acc1);
+                wofs += 2u * BLOCK6;
+                head_store(hd, acc, acc1);
+            }
         }
     }
     G4C_STAMPW(15);
