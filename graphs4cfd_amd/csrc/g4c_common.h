@@ -53,6 +53,35 @@ struct DeviceGuard {
         }                                 \
     } while (0)
 
+// a / count for the mean of a segment (count >= 1), BIT FOR BIT the IEEE quotient `a / (float)count`, in 4 vector instructions per
+// value + 3 per count instead of the ~11 of the compiler's division (v_div_scale x2, v_rcp, five FMAs, v_div_fmas, v_div_fixup), of
+// which only the reciprocal is shared between the values of a count.  y = the correctly rounded 1 / count (v_rcp_f32 + one Newton
+// step: checked against the exact reciprocal for every count up to MEAN_DIV_MAX_COUNT by test_mean_div_is_the_ieee_quotient);
+// q0 = a y, r = a - count q0 exactly (FMA), q1 = q0 + r y rounded once: the correctly rounded quotient (Markstein's theorem — y
+// correctly rounded, q0 within an ulp) as long as nothing underflows.  Everything else — larger counts, quotients below 2^-100 (the
+// residual could underflow), zeros, infinities, NaNs — takes the division itself, for the whole wave (a wave-uniform branch that
+// data of O(1) never takes).
+constexpr int MEAN_DIV_MAX_COUNT = 4096;
+typedef float mean_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mean_f32x4 mean_div4(mean_f32x4 a, int count) {
+    const float c = (float)count;
+    const float y0 = __builtin_amdgcn_rcpf(c);
+    const float y = fmaf(fmaf(-c, y0, 1.f), y0, y0);
+    mean_f32x4 q;
+    bool rare = count > MEAN_DIV_MAX_COUNT;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float q0 = a[e] * y;
+        q[e] = fmaf(fmaf(-c, q0, a[e]), y, q0);
+        rare |= !(fabsf(q[e]) >= 0x1p-100f);            // (true for NaN as well)
+    }
+    if (__builtin_amdgcn_ballot_w64(rare) != 0ull) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q[e] = a[e] / c;
+    }
+    return q;
+}
+
 // Branch-free activations on the hardware transcendental unit (v_exp_f32 / v_rcp_f32).
 // Absolute error vs torch's F.selu / torch.tanh is ~1e-7 (fp32 round-off class), far inside the
 // 1e-4 per-block parity tolerance; a divergent `x > 0 ? ... : exp(...)` costs two branches and an

@@ -172,3 +172,18 @@ extern "C" int g4c_weighted_segment_mean(const float *x, int32_t x_ld, const int
         x, x_ld, x_idx, w, off, n_seg, width, out, out_ld, out_idx);
     return g4c::check_launch("g4c_weighted_segment_mean");
 }
+
+// test hook: the quotient routine of the fused aggregation's mean (g4c::mean_div4) on arrays — out[i] = a[i] / count[i / 4]
+__global__ void mean_div_check_kernel(const float *__restrict__ a, const int *__restrict__ count, float *__restrict__ out, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const g4c::mean_f32x4 v = *reinterpret_cast<const g4c::mean_f32x4 *>(a + 4 * i);
+    *reinterpret_cast<g4c::mean_f32x4 *>(out + 4 * i) = g4c::mean_div4(v, count[i]);
+}
+extern "C" int g4c_debug_mean_div(const float *a, const int32_t *count, float *out, int64_t n4, void *stream) {
+    G4C_REQUIRE(a && count && out && n4 >= 0, G4C_EINVAL, "g4c_debug_mean_div: null argument");
+    if (n4 == 0) return G4C_OK;
+    g4c::DeviceGuard guard(a);
+    mean_div_check_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(a, count, out, n4);
+    return g4c::check_launch("g4c_debug_mean_div");
+}

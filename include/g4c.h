@@ -230,6 +230,11 @@ int g4c_mlp_ws_enable(int on);
  * Same arithmetic, bit-identical results.  n_tiles >= 0 sets the limit (0 = never), -1 only queries.  Returns the previous limit. */
 int g4c_mlp_small_launch_tiles(int n_tiles);
 
+/* Test hook: out[4 i .. 4 i + 3] = a[4 i .. 4 i + 3] / count[i] by the quotient routine the fused aggregation's mean uses (a shared
+ * reciprocal + one correction per value, with the division itself as the fallback): must equal the IEEE quotient bit for bit
+ * (tests/test_gpu_parity.py::test_mean_div_is_the_ieee_quotient).  count[i] >= 1; a, out 16-byte aligned. */
+int g4c_debug_mean_div(const float *a, const int32_t *count, float *out, int64_t n4, void *stream);
+
 /* Which kernel family the calling thread's most recent fused-MLP launch (any g4c_mlp_forward* entry point) ran on — the library
  * picks it per launch (arithmetic, shape, row count), so a profiler-free caller that times launches with events (bench.py's
  * roofline leg) can label them by the kernel that executed instead of by the entry point: G4C_KERNEL_NONE (no launch yet, or the

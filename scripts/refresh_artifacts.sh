@@ -51,8 +51,8 @@ G4C_MLP_PRECISION=bf16x6 timeout 300 python scripts/bx6i_check.py --time 2>&1 | 
 bash scripts/build_ws_timing.sh > /dev/null 2>&1 && timeout 120 python scripts/ws_stamps.py graphs4cfd_amd/lib/libg4c_ws_timing.so 2>&1 | grep -v amdgpu.ids > $A/${TAG}_ws_stamps.log
 timeout 120 python scripts/ws_stamps.py graphs4cfd_amd/lib/libg4c_ws_timing.so bf16 2>&1 | grep -v amdgpu.ids > $A/${TAG}_ws_stamps_bf16_mode.log
 # pipe-utilisation counters of the shipped kernels in the DEFAULT arithmetic: level-1 message launch (mlp_ws_kernel) and node launch (mlp_bx6_kernel)
-bash scripts/pmc_ws.sh ws ${TAG}_ws util sq3 lds sq2 tcc > $A/${TAG}_pmc_mlp_ws.txt 2>&1
-PMC_EXTRA_ARGS=--node bash scripts/pmc_ws.sh tile ${TAG}_node util sq3 lds sq2 tcc > $A/${TAG}_pmc_mlp_bx6_node.txt 2>&1
+bash scripts/pmc_ws.sh ws ${TAG}_ws util sq3 lds sq2 tcc mix mix2 coexec > $A/${TAG}_pmc_mlp_ws.txt 2>&1
+PMC_EXTRA_ARGS=--node bash scripts/pmc_ws.sh tile ${TAG}_node util sq3 lds sq2 tcc mix mix2 coexec > $A/${TAG}_pmc_mlp_bx6_node.txt 2>&1
 # co-issue microbenchmarks (what hides behind one MFMA, by shape, waves per SIMD and instruction kind)
 hipcc -w --offload-arch=gfx950 -O3 -o /tmp/mfma_fillers scripts/micro/mfma_fillers.hip 2>/dev/null && /tmp/mfma_fillers > $A/${TAG}_mfma_fillers.log 2>&1
 for m in mfma_gap_patterns mfma_chain_probe mfma_lds_probe; do
@@ -64,4 +64,14 @@ done
 timeout 300 python scripts/bench_mugs.py 2>&1 | tail -3 > $A/${TAG}_bench_mugs.log
 # training path: step time + per-phase HIP-event times + the CPU leg
 timeout -k 10 900 python scripts/bench_train.py --steps 10 --cpu-steps 1 --phases 2> $A/train_stderr.log | tail -1 > $A/${TAG}_train_bench_100k.json
+# small launches: the tile kernel's deep-ring limit over four meshes (same process, bit-identity checked), the message launch over the
+# row count on the three kernels, per-phase stamps of a one-tile launch, idle time between the kernels of a replayed step
+timeout 600 python scripts/ab_small_launch.py --limits 0,512 2>&1 | grep -v amdgpu.ids > $A/${TAG}_ab_small_launch.log
+timeout 300 python scripts/sweep_message_launch.py 2>&1 | grep -v amdgpu.ids > $A/${TAG}_sweep_message_launch.log
+bash scripts/build_variant.sh "$GRAFT_REPO_ROOT/graphs4cfd_amd/lib/libg4c_timing.so" -DG4C_TIMING > /dev/null 2>&1 && \
+  G4C_LIB_PATH=graphs4cfd_amd/lib/libg4c_timing.so timeout 300 python scripts/small_launch_stamps.py 400 12500 100000 2>&1 | grep -v amdgpu.ids > $A/${TAG}_small_launch_stamps.log
+rm -f graphs4cfd_amd/lib/libg4c_timing.so
+( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $A/trace_small -o t -- \
+    python bench.py --nodes 12500 --steps 60 --warmup 5 --no-side-configs --no-cpu-baseline --no-strict-range --no-roofline --no-partition-check > /dev/null 2>&1 )
+python scripts/trace_gaps.py $A/trace_small > $A/${TAG}_trace_gaps_12k5.log 2>&1; rm -rf $A/trace_small
 ls -la $A

@@ -1,7 +1,7 @@
 """Message launch (first layer hoisted, fused aggregation) over the row count: tile kernel (ring of two), tile kernel with the
 small-launch deep ring, weight-stationary kernel — 16 launches over 4 different MLPs captured in a hipGraph (no host launch cost),
 median of 9 replays.  Decides ws_launch's minimum row count and g4c_mlp_small_launch_tiles' limit.
-Usage: python scripts/sweep_message_launch.py [rows ...]"""
+Usage: [LAYERS=2] python scripts/sweep_message_launch.py [rows ...]"""
 import os, statistics, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,8 +9,9 @@ from graphs4cfd_amd import _lib, ops, plan
 from graphs4cfd_amd.nn import blocks as B
 torch.set_grad_enabled(False)
 lib = _lib.load(); dev = torch.device("cuda", 0); H = 128
+LAYERS = int(os.environ.get("LAYERS", "3"))
 sizes = [int(a) for a in sys.argv[1:]] or [6000, 12000, 16000, 20000, 26000, 33000, 50000, 75000, 120000, 200000]
-blks = [B.GNBlock((3 * H, (H, H, H), True), (2 * H, (H, H, H), True)).to(dev) for _ in range(4)]
+blks = [B.GNBlock((3 * H, (H,) * LAYERS, True), (2 * H, (H, H, H), True)).to(dev) for _ in range(4)]
 for rows in sizes:
     n = rows // 6; rows = n * 6
     e, pr, pc = torch.randn(rows, H, device=dev), torch.randn(n, H, device=dev), torch.randn(n, H, device=dev)

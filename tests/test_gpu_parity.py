@@ -1524,3 +1524,36 @@ def test_f16_range_report_is_scoped_to_the_model_that_clipped():
         assert ops.f16_range_report(DEV) == ["an MLP created outside a model"]
     finally:
         ops.set_mlp_precision(old)
+
+
+def test_mean_div_is_the_ieee_quotient():
+    """g4c::mean_div4 (the quotient of the fused aggregation's mean in mlp_ws_kernel: shared reciprocal + one FMA correction per value,
+    the division itself for everything unusual) against torch's fp32 division, bit for bit: every count up to 4200 (past the routine's
+    own limit) with random numerators of several magnitudes; the whole binade [1, 2) of numerators for small counts; zeros, subnormal
+    quotients, infinities, NaNs."""
+    lib = _lib.load()
+
+    def run(a, cnt):
+        a = a.contiguous(); cnt = cnt.to(torch.int32).contiguous(); out = torch.empty_like(a)
+        rc = lib.g4c_debug_mean_div(a.data_ptr(), cnt.data_ptr(), out.data_ptr(), a.numel() // 4, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, _lib.last_error()
+        return out
+
+    def check(a, cnt, what):
+        got, ref = run(a, cnt), a / cnt.float().repeat_interleave(4)
+        same = (got.view(torch.int32) == ref.view(torch.int32)) | (torch.isnan(got) & torch.isnan(ref))
+        assert bool(same.all()), (what, a[~same][:4], cnt.repeat_interleave(4)[~same][:4], got[~same][:4], ref[~same][:4])
+
+    g = torch.Generator(device=DEV).manual_seed(0)
+    counts = torch.arange(1, 4201, device=DEV)
+    for scale in (1.0, 1e-3, 37.0, 1e30, 1e-30):
+        cnt = counts.repeat_interleave(256)
+        a = torch.randn(cnt.numel() * 4, device=DEV, generator=g) * scale
+        check(a, cnt, f"random numerators x {scale}")
+    binade = (torch.arange(1 << 23, device=DEV, dtype=torch.int32) + 0x3F800000).view(torch.float32)       # every float in [1, 2)
+    for c in (3, 5, 6, 7, 9, 11, 13, 127, 4095):
+        check(binade, torch.full((binade.numel() // 4,), c, device=DEV), f"binade, count {c}")
+    special = torch.tensor([0.0, -0.0, 1e-45, -3e-39, 1e-38, 2e-38, float("inf"), -float("inf"), float("nan"), 3.4e38, 1.0, -1.0], device=DEV)
+    for c in (1, 3, 6, 4096, 4097, 100000):
+        a = special.repeat_interleave(4)[: special.numel() * 4].reshape(-1, 4).repeat(1, 1).reshape(-1)
+        check(a, torch.full((a.numel() // 4,), c, device=DEV), f"special values, count {c}")
