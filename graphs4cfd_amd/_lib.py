@@ -90,6 +90,7 @@ _SIGNATURES = {
     "g4c_mlp_bx6i_enable": (C.c_int, [C.c_int]),
     "g4c_mlp_ws_enable": (C.c_int, [C.c_int]),
     "g4c_mlp_small_launch_tiles": (C.c_int, [C.c_int]),
+    "g4c_layer_norm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "g4c_debug_mean_div": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "g4c_mlp_last_kernel": (C.c_int, []),
     "g4c_mlp_forward_rows": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_int64, C.c_int64,

@@ -120,6 +120,49 @@ __global__ __launch_bounds__(256) void weighted_segment_mean_kernel(
     }
 }
 
+// LayerNorm over rows of ANY width (+ activation), in place or out of place: one wave per row, the row's values kept in registers for
+// up to 64 * LN_REGS columns (two passes over the values, like F.layer_norm: mean, then the centred sum of squares), re-read from
+// memory beyond that.  For the fused MLP kernels' envelope: their own LayerNorm epilogue takes <= 128 columns (MLP._run_stages).
+constexpr int LN_REGS = 16;
+__global__ __launch_bounds__(256) void layer_norm_rows_kernel(const float *__restrict__ x, int x_ld, long long n_rows, int width,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta, float eps, int act,
+                                                             float *__restrict__ out, int out_ld) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const float *xr = x + row * x_ld;
+    float v[LN_REGS];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_REGS; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = c < width ? xr[c] : 0.f;
+        sum += v[j];
+    }
+    for (int c = lane + 64 * LN_REGS; c < width; c += 64) sum += xr[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)width;
+    float var = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_REGS; ++j) {
+        const float d = v[j] - mean;
+        var += (lane + 64 * j < width) ? d * d : 0.f;
+    }
+    for (int c = lane + 64 * LN_REGS; c < width; c += 64) { const float d = xr[c] - mean; var += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+    const float rstd = rsqrtf(var / (float)width + eps);
+    float *orow = out + row * out_ld;
+#pragma unroll
+    for (int j = 0; j < LN_REGS; ++j) {
+        const int c = lane + 64 * j;
+        if (c < width) orow[c] = g4c::apply_act(fmaf((v[j] - mean) * rstd, gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f), act);
+    }
+    for (int c = lane + 64 * LN_REGS; c < width; c += 64)
+        orow[c] = g4c::apply_act(fmaf((xr[c] - mean) * rstd, gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f), act);
+}
+
 }  // namespace
 
 extern "C" int g4c_segment_reduce(const float *src, int32_t src_ld, const int32_t *perm, const int32_t *off,
@@ -186,4 +229,18 @@ extern "C" int g4c_debug_mean_div(const float *a, const int32_t *count, float *o
     g4c::DeviceGuard guard(a);
     mean_div_check_kernel<<<dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(a, count, out, n4);
     return g4c::check_launch("g4c_debug_mean_div");
+}
+
+extern "C" int g4c_layer_norm(const float *x, int32_t x_ld, int64_t n_rows, int32_t width, const float *gamma, const float *beta, float eps,
+                              int32_t act, float *out, int32_t out_ld, void *stream) {
+    G4C_REQUIRE(n_rows >= 0 && width > 0 && x_ld >= width && out_ld >= width, G4C_EINVAL,
+                "g4c_layer_norm: bad sizes n_rows=%lld width=%d x_ld=%d out_ld=%d", (long long)n_rows, width, x_ld, out_ld);
+    G4C_REQUIRE(act == G4C_ACT_NONE || act == G4C_ACT_SELU || act == G4C_ACT_TANH, G4C_EINVAL, "g4c_layer_norm: unknown activation %d", act);
+    if (n_rows == 0) return G4C_OK;
+    G4C_REQUIRE(x && out, G4C_EINVAL, "g4c_layer_norm: null pointer");
+    // (in place is fine at any width: every read of the statistics passes precedes the wave's first write, and the last pass re-reads a
+    // column in the lane that then writes it)
+    g4c::DeviceGuard on_device(out);
+    layer_norm_rows_kernel<<<dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(x, x_ld, n_rows, width, gamma, beta, eps, act, out, out_ld);
+    return g4c::check_launch("g4c_layer_norm");
 }

@@ -140,34 +140,59 @@ class MLP(nn.Module):
     def _run_stages(self, sources: Sequence[Source], n_rows: int, act_code: int, **kw) -> Tensor:
         """Any widths / depth as a chain of fused launches: consecutive layers of <= 128 outputs share a launch (at most
         _lib.MAX_LAYERS of them, SELU between them as always); a layer with more than 128 outputs is a launch per 128-column
-        chunk of its output (rows [c, c + 128) of its weight), whose results enter the next layer as its input blocks — so a layer
-        may be up to 128 * _lib.MAX_SRC wide.  LayerNorm and the caller's activation / residual / output index belong to the last
-        launch; a LayerNorm over more than 128 columns has no kernel here."""
+        chunk of its output (rows [c, c + 128) of its weight), whose results enter the next layer as its input blocks; a layer
+        with more than _lib.MAX_SRC input blocks is a chain of launches over groups of blocks, each adding its products to the
+        partial sums of the one before (an additive source).  LayerNorm and the caller's activation / residual / output index
+        belong to the last launch; a LayerNorm over more than 128 columns is its own launch (ops.layer_norm) behind the chunks."""
         if ops.grad_mode():
             raise NotImplementedError("training an MLP with a layer wider than 128 or more than 4 Linear layers")
         lin = self._linears()
         ln = getattr(self.MLP, "layer_norm", None)
-        if ln is not None and lin[-1].out_features > 128:
-            raise NotImplementedError("LayerNorm over more than 128 columns is outside the fused-MLP kernel envelope")
         dev = sources[0].tensor.device
         cur, i, n = list(_split_wide(sources)), 0, len(lin)
+
+        def one_layer(li: int, c: int, c1: int, blocks: Sequence[Source], act: int, ln_args, **kw2) -> Tensor:
+            """act(LayerNorm(W[c:c1] cat(blocks) + b[c:c1])) — in groups of <= MAX_SRC blocks when there are more"""
+            w, b = lin[li].weight[c:c1], (lin[li].bias[c:c1] if lin[li].bias is not None else None)
+            if len(blocks) <= _lib.MAX_SRC:
+                return ops.mlp_forward(self._stage((li, c), [w], [b], ln_args, blocks), blocks, n_rows, act, **kw2)
+            partial, k0 = None, 0
+            gsz = _lib.MAX_SRC - 1          # (the partial sums of the previous group take one of a launch's source slots)
+            groups = [blocks[g:g + gsz] for g in range(0, len(blocks), gsz)]
+            for gi, grp in enumerate(groups):
+                k1 = k0 + sum(s_.width for s_ in grp)
+                last_g = gi == len(groups) - 1
+                pk = self._stage((li, c, k0), [w[:, k0:k1]], [b if gi == 0 else None], ln_args if last_g else None, grp)
+                srcs = list(grp) + ([Source(partial, additive=True)] if partial is not None else [])
+                partial = ops.mlp_forward(pk, srcs, n_rows, act if last_g else _lib.ACT_NONE, **(kw2 if last_g else {}))
+                k0 = k1
+            return partial
+
         while i < n:
             if lin[i].out_features > 128:
                 w_out = lin[i].out_features
-                if (w_out + 127) // 128 > _lib.MAX_SRC and i + 1 < n:
-                    raise NotImplementedError(f"hidden layer width {w_out} > {128 * _lib.MAX_SRC} is outside the fused-MLP kernel envelope")
                 last = i == n - 1
                 if last and any(kw.get(k) is not None for k in ("out_idx32", "resid", "agg", "head_outs")):
                     raise NotImplementedError("output index / residual / aggregation / heads on an output wider than 128 columns")
+                wide_ln = last and ln is not None
                 wide = kw.get("out") if (last and kw.get("out") is not None) else torch.empty((n_rows, w_out), dtype=torch.float32, device=dev)
                 for c in range(0, w_out, 128):
                     c1 = min(c + 128, w_out)
-                    pk = self._stage((i, c), [lin[i].weight[c:c1]], [lin[i].bias[c:c1] if lin[i].bias is not None else None], None, cur)
-                    ops.mlp_forward(pk, cur, n_rows, act_code if last else _lib.ACT_SELU, out=wide[:, c:c1])
+                    one_layer(i, c, c1, cur, _lib.ACT_NONE if wide_ln else (act_code if last else _lib.ACT_SELU), None, out=wide[:, c:c1])
+                if wide_ln:         # (a LayerNorm over more than 128 columns: its own launch, in place)
+                    ops.layer_norm(wide, ln.weight, ln.bias, ln.eps, act_code, out=wide)
                 if last:
                     return wide
                 cur = [Source(wide, col0=c, width=min(128, w_out - c)) for c in range(0, w_out, 128)]
                 i += 1
+                continue
+            if len(cur) > _lib.MAX_SRC:          # (too many input blocks for one launch: this layer alone, group by group)
+                last = i == n - 1
+                ln_args = (ln.weight, ln.bias, ln.eps) if (last and ln is not None) else None
+                y = one_layer(i, 0, lin[i].out_features, cur, act_code if last else _lib.ACT_SELU, ln_args, **(kw if last else {}))
+                if last:
+                    return y
+                cur, i = [Source(y)], i + 1
                 continue
             j = i
             while j < n and j - i < _lib.MAX_LAYERS and lin[j].out_features <= 128:

@@ -260,6 +260,19 @@ def add_cols(a: Tensor, a_col0: int, b: Tensor, out: Tensor) -> Tensor:
     return out
 
 
+def layer_norm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float, act: int = _lib.ACT_NONE,
+               out: Optional[Tensor] = None) -> Tensor:
+    """Row-wise LayerNorm (+ activation) over any width (g4c_layer_norm): the fused MLP kernels' own epilogue covers <= 128 columns."""
+    lib = _lib.load()
+    x = _f32_2d(x, "x")
+    dev = _lib.require_hip(x, gamma, beta, out)
+    if out is None:
+        out = torch.empty((int(x.size(0)), int(x.size(1))), dtype=torch.float32, device=dev)
+    _lib.check(lib.g4c_layer_norm(_lib.ptr(x), _ld(x), int(x.size(0)), int(x.size(1)), _lib.ptr(gamma), _lib.ptr(beta), float(eps), int(act),
+                                  _lib.ptr(out), _ld(out), _lib.stream_handle(dev)))
+    return out
+
+
 def rollout_advance(field: Tensor, pred: Tensor, outputs: Tensor, step: Tensor, nf: int) -> None:
     lib = _lib.load()
     dev = _lib.require_hip(field, pred, outputs, step)

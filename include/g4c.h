@@ -230,6 +230,14 @@ int g4c_mlp_ws_enable(int on);
  * Same arithmetic, bit-identical results.  n_tiles >= 0 sets the limit (0 = never), -1 only queries.  Returns the previous limit. */
 int g4c_mlp_small_launch_tiles(int n_tiles);
 
+/* Row-wise LayerNorm (+ activation G4C_ACT_*) over rows of any width: out[r, :] = act((x[r, :] - mean) * rsqrt(var + eps) * gamma + beta),
+ * mean / biased variance over the row's `width` columns in two passes, as torch.nn.functional.layer_norm (nn/blocks.py:137-141: the
+ * reference's MLP puts a LayerNorm of the output width behind its last Linear layer, whatever that width is).  The fused MLP kernels
+ * normalise up to 128 columns in their own epilogue; wider outputs are produced without it and normalised by this launch.
+ * gamma / beta may be NULL (1 / 0).  In place (out == x) is allowed. */
+int g4c_layer_norm(const float *x, int32_t x_ld, int64_t n_rows, int32_t width, const float *gamma, const float *beta, float eps,
+                   int32_t act, float *out, int32_t out_ld, void *stream);
+
 /* Test hook: out[4 i .. 4 i + 3] = a[4 i .. 4 i + 3] / count[i] by the quotient routine the fused aggregation's mean uses (a shared
  * reciprocal + one correction per value, with the division itself as the fallback): must equal the IEEE quotient bit for bit
  * (tests/test_gpu_parity.py::test_mean_div_is_the_ieee_quotient).  count[i] >= 1; a, out 16-byte aligned. */

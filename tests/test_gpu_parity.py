@@ -820,12 +820,16 @@ def test_full_size_properties():
 # ------------------------------------------------------------------ error behaviour
 @pytest.mark.parametrize("prec", ["f16x3", "bf16x6", "fp32"])
 @pytest.mark.parametrize("shape", [(8, (256, 16), False), (300, (200, 300, 64), True), (128, (128,) * 6, True), (64, (64, 300), False),
-                                   (40, (512, 96, 96, 96, 96, 33), True), (128, (130, 128), True)],
-                         ids=["wide-hidden", "wide-in-and-hidden", "six-layers", "wide-out", "wide-then-deep", "just-over"])
+                                   (40, (512, 96, 96, 96, 96, 33), True), (128, (130, 128), True), (8, (16, 256), True), (70, (300, 1300), True),
+                                   (8, (1024, 16), False), (600, (700, 48), True), (24, (640, 640, 640), True)],
+                         ids=["wide-hidden", "wide-in-and-hidden", "six-layers", "wide-out", "wide-then-deep", "just-over", "wide-layernorm",
+                              "very-wide-layernorm", "hidden-over-512", "wide-in-over-512", "all-over-512"])
 def test_mlp_any_widths_and_depth(shape, prec):
     """The reference's MLP takes any widths and depth (nn/blocks.py:129-141); the fused kernels take <= 4 layers of <= 128 outputs per
     launch.  Outside that envelope the module runs a chain of launches (MLP._run_stages: a wide layer as one launch per 128-column
-    chunk of its output, deep MLPs as consecutive launches) — same result as torch's nn.Sequential on the same weights."""
+    chunk of its output, deep MLPs as consecutive launches, a layer with more than four 128-wide input blocks as launches over groups
+    of blocks that add to the previous group's partial sums, a LayerNorm over more than 128 columns as g4c_layer_norm behind the
+    chunks) — same result as torch's nn.Sequential on the same weights."""
     k_in, widths, ln = shape
     old = ops.set_mlp_precision(prec)
     try:
@@ -850,10 +854,6 @@ def test_errors():
         mlp(torch.randn(4, 8))
     with pytest.raises(ValueError):
         mlp(torch.randn(4, 9, device=DEV))
-    with pytest.raises(NotImplementedError):          # LayerNorm over more than 128 columns
-        B.MLP(8, (16, 256), True).to(DEV)(torch.randn(4, 8, device=DEV))
-    with pytest.raises(NotImplementedError):          # a hidden layer wider than 4 x 128
-        B.MLP(8, (1024, 16)).to(DEV)(torch.randn(4, 8, device=DEV))
     with pytest.raises(ValueError):
         gfd.nn.NsOneScaleGNN(model="no-such-model")
 
@@ -1557,3 +1557,18 @@ def test_mean_div_is_the_ieee_quotient():
     for c in (1, 3, 6, 4096, 4097, 100000):
         a = special.repeat_interleave(4)[: special.numel() * 4].reshape(-1, 4).repeat(1, 1).reshape(-1)
         check(a, torch.full((a.numel() // 4,), c, device=DEV), f"special values, count {c}")
+
+
+@pytest.mark.parametrize("width", [1, 33, 128, 200, 1024, 1500])
+def test_layer_norm_rows(width):
+    """g4c_layer_norm against torch.nn.functional.layer_norm (fp64) on rows of any width, strided views, in place, with an activation."""
+    torch.manual_seed(width)
+    x = torch.randn(301, width + 5, device=DEV)[:, 2:2 + width] * 3.0 + 0.7
+    g, b = torch.randn(width, device=DEV), torch.randn(width, device=DEV)
+    ref = torch.nn.functional.layer_norm(x.double(), (width,), g.double(), b.double(), 1e-5).float()
+    torch.testing.assert_close(ops.layer_norm(x, g, b, 1e-5), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ops.layer_norm(x, None, None, 1e-5, _lib.ACT_SELU),
+                               torch.nn.functional.selu(torch.nn.functional.layer_norm(x.double(), (width,), None, None, 1e-5)).float(), rtol=1e-5, atol=1e-5)
+    y = x.clone()
+    assert ops.layer_norm(y, g, b, 1e-5, out=y) is y
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)
