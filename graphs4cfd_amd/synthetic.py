@@ -96,6 +96,83 @@ def knn_query_device(points: torch.Tensor, queries: torch.Tensor, k: int) -> tor
     return out
 
 
+def _connect_knn_periodic_device(pos: torch.Tensor, k: int, per) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+    """connect_knn for device positions with any set of periodic axes.  The reference ranks neighbours by the Euclidean distance
+    between the points' embeddings (a periodic axis -> (cos, sin)(2 pi x / period) on the UNIT circle, transforms/connect.py:38-56: such
+    an axis counts in radians).  In the coordinates y = (2 pi x / period for a periodic axis, x otherwise) the chord of a periodic axis
+    grows monotonically with the wrapped difference dy and equals it up to a factor 1 - dy^2 / 24, so the k + 1 embedded-nearest
+    points of a centre are among its 16 nearest in the wrapped y metric — which a non-periodic search finds when the points within a
+    margin of every periodic face are repeated 2 pi away (ghosts, corners included).  The margin is checked per centre after the
+    search (its candidates' radius must stay inside the ghosted region) and grown if needed; the candidates are then ordered by their
+    float64 embedded distances (stably) and the host path's rule — drop the centre itself, or the farthest hit when coincident points
+    pushed it out — leaves k per centre.  None: the cloud is too small for ghosts (a margin would reach half a period) or k too
+    large for the grid search; the host path takes it."""
+    dim, n, dev = int(pos.size(1)), int(pos.size(0)), pos.device
+    kc = min(2 * k + 4, 15)          # (candidates per centre besides itself; the grid search returns at most 16)
+    if n <= kc + 1 or kc < k + 2:
+        return None
+    x = pos.detach().double()
+    lo, hi = x.min(0).values, x.max(0).values
+    lengths = []
+    for ax in range(dim):
+        d = per[ax]
+        lengths.append(None if d is None else (float(hi[ax] - lo[ax]) if isinstance(d, str) and d == "auto" else float(d)))
+    pax = [ax for ax in range(dim) if lengths[ax] is not None]
+    if any(lengths[ax] <= 0.0 or float(hi[ax] - lo[ax]) > lengths[ax] * (1 + 1e-12) for ax in pax):
+        return None
+    two_pi = 2 * np.pi
+    y, emb_cols = x.clone(), []
+    for ax in range(dim):
+        if lengths[ax] is None:
+            emb_cols.append(x[:, ax:ax + 1])
+        else:
+            a = two_pi / lengths[ax] * x[:, ax]
+            emb_cols.append(torch.stack((torch.cos(a), torch.sin(a)), 1))
+            y[:, ax] = two_pi / lengths[ax] * (x[:, ax] - lo[ax])                  # in [0, 2 pi]
+    emb = torch.cat(emb_cols, 1)
+    ylo = y.min(0).values
+    ext = (y.max(0).values - ylo).clamp(min=1e-300)
+    spacing = float(ext.prod()) ** (1.0 / dim) * float(n) ** (-1.0 / dim)
+    margin = 2.0 * spacing * float(kc + 1) ** (1.0 / dim)
+    ids = torch.arange(n, device=dev)
+    for _attempt in range(4):
+        if margin >= 0.5 * two_pi:
+            return None
+        pts, src = y, ids
+        for ax in pax:          # (one axis after the other over the growing set: the corners get their combinations)
+            low, high = pts[:, ax] < margin, pts[:, ax] > two_pi - margin
+            shift = torch.zeros(dim, dtype=torch.float64, device=dev)
+            shift[ax] = two_pi
+            pts = torch.cat((pts, pts[low] + shift, pts[high] - shift), 0)
+            src = torch.cat((src, src[low], src[high]), 0)
+        cand_aug = knn_query_device(pts.float(), y.float(), kc + 1)                       # [n, kc + 1] indices into pts, nearest first (fp32)
+        r = (pts[cand_aug[:, -1]] - y).norm(dim=1)
+        room = torch.full((n,), float("inf"), dtype=torch.float64, device=dev)
+        for ax in pax:
+            room = torch.minimum(room, torch.minimum(y[:, ax], two_pi - y[:, ax]))
+        need = float((r * (1 + 1e-6) - room).max())
+        if need <= margin:
+            break
+        margin = 1.25 * need
+    else:
+        return None
+    cand = src[cand_aug]                                                                   # original point numbers
+    d2 = ((emb[cand] - emb[:, None, :]) ** 2).sum(-1)
+    order = torch.sort(d2, dim=1, stable=True)[1][:, :k + 1]
+    nbr = torch.gather(cand, 1, order)
+    is_self = nbr == ids[:, None]
+    drop = torch.where(is_self.any(1), is_self.int().argmax(1), torch.full((n,), k, device=dev))
+    keep = torch.ones((n, k + 1), dtype=torch.bool, device=dev)
+    keep[ids, drop] = False
+    row = nbr[keep]
+    col = ids.repeat_interleave(k)
+    edge_attr = pos[col] - pos[row]
+    for ax in pax:
+        d, c = lengths[ax], edge_attr[:, ax]
+        edge_attr[:, ax] = torch.where(c < -d / 2, c + d, torch.where(c > d / 2, c - d, c))
+    return torch.stack([row, col], 0), edge_attr
+
+
 def connect_knn(pos: torch.Tensor, k: int, period=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """`connect_knn` (transforms/connect.py:9-72): edges neighbour -> centre, grouped by centre, k per centre, nearest
     first; edge_attr = pos[col] - pos[row].  `period`: one entry per axis — None (not periodic), a length, or "auto" (the
@@ -118,7 +195,7 @@ def connect_knn(pos: torch.Tensor, k: int, period=None) -> Tuple[torch.Tensor, t
         # search takes.  The grid works in fp32, the reference path in the embedded float64 coordinates: 2k + 2 candidates per
         # centre come from the grid, their float64 distances order them (stable: the grid's order for equal distances), the nearest
         # k stay — the host path's neighbours unless more than k + 2 points tie within fp32 resolution at the k-th distance.
-        # (two periodic axes embed in 4-D, periodic 3-D clouds in >= 4-D: host path below)
+        # (two periodic axes embed in 4-D, periodic 3-D clouds in >= 4-D: _connect_knn_periodic_device below)
         n = int(pos.size(0))
         ax = 0 if per[0] is not None else 1
         x = pos[:, ax].detach().double()
@@ -136,6 +213,13 @@ def connect_knn(pos: torch.Tensor, k: int, period=None) -> Tuple[torch.Tensor, t
         c = edge_attr[:, ax]
         edge_attr[:, ax] = torch.where(c < -d / 2, c + d, torch.where(c > d / 2, c - d, c))
         return torch.stack([row, col], 0), edge_attr
+    if pos.is_cuda:
+        # positions on the GPU, two or more periodic axes (or a periodic 3-D cloud): the embedding has >= 4 dimensions, more than the
+        # cell grid bins.  The candidates then come from a search in the RAW coordinates over the cloud + ghost copies of the points
+        # near the periodic faces (_knn_periodic_candidates), and the embedded float64 distances order them as above.
+        hit = _connect_knn_periodic_device(pos, k, per)
+        if hit is not None:
+            return hit
     lengths, cols = [], []
     for ax in range(dim):
         x = pos[:, ax].detach().cpu().double()
