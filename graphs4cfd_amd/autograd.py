@@ -440,6 +440,7 @@ class _FusedMLP(torch.autograd.Function):
                     # (sign and slope were applied when tt was formed from t: chain rule through them)
                     d_src[j] = finish(j, gt)
         dW[0] = dW1
+        db = [g_ if b_ is not None else None for g_, b_ in zip(db, b)]          # (a layer without a bias: no gradient slot to fill)
         grads = [None] + d_src + ([d_resid] if spec.has_resid else []) + dW + db
         if spec.has_ln:
             grads += [d_gamma, d_beta]

@@ -143,29 +143,44 @@ class MLP(nn.Module):
         chunk of its output (rows [c, c + 128) of its weight), whose results enter the next layer as its input blocks; a layer
         with more than _lib.MAX_SRC input blocks is a chain of launches over groups of blocks, each adding its products to the
         partial sums of the one before (an additive source).  LayerNorm and the caller's activation / residual / output index
-        belong to the last launch; a LayerNorm over more than 128 columns is its own launch (ops.layer_norm) behind the chunks."""
-        if ops.grad_mode():
-            raise NotImplementedError("training an MLP with a layer wider than 128 or more than 4 Linear layers")
+        belong to the last launch; a LayerNorm over more than 128 columns is its own launch (ops.layer_norm) behind the chunks.
+        Recorded for autograd (gradients enabled): every launch of the chain is a differentiable fused launch of its own; what joins
+        them — the concatenation of a wide last layer's chunks, the sum over groups of input blocks, a LayerNorm / activation behind
+        either — is then plain torch on the device (these shapes occur in no published architecture)."""
+        grad = ops.grad_mode()
+        if grad and any(kw.get(k) is not None for k in ("out", "out_idx32", "agg", "head_outs")):
+            raise NotImplementedError("out= / output index / aggregation / heads are inference-only forms; call under torch.no_grad()")
         lin = self._linears()
         ln = getattr(self.MLP, "layer_norm", None)
         dev = sources[0].tensor.device
         cur, i, n = list(_split_wide(sources)), 0, len(lin)
 
+        def torch_tail(y: Tensor, ln_args, act: int) -> Tensor:
+            if ln_args is not None:
+                y = torch.nn.functional.layer_norm(y, (y.size(1),), ln_args[0], ln_args[1], ln_args[2])
+            return torch.nn.functional.selu(y) if act == _lib.ACT_SELU else (torch.tanh(y) if act == _lib.ACT_TANH else y)
+
         def one_layer(li: int, c: int, c1: int, blocks: Sequence[Source], act: int, ln_args, **kw2) -> Tensor:
-            """act(LayerNorm(W[c:c1] cat(blocks) + b[c:c1])) — in groups of <= MAX_SRC blocks when there are more"""
+            """act(LayerNorm(W[c:c1] cat(blocks) + b[c:c1])) — in groups of blocks when there are more than a launch takes"""
             w, b = lin[li].weight[c:c1], (lin[li].bias[c:c1] if lin[li].bias is not None else None)
             if len(blocks) <= _lib.MAX_SRC:
                 return ops.mlp_forward(self._stage((li, c), [w], [b], ln_args, blocks), blocks, n_rows, act, **kw2)
-            partial, k0 = None, 0
-            gsz = _lib.MAX_SRC - 1          # (the partial sums of the previous group take one of a launch's source slots)
+            gsz = _lib.MAX_SRC if grad else _lib.MAX_SRC - 1      # (inference: the previous group's partial sums take a source slot)
             groups = [blocks[g:g + gsz] for g in range(0, len(blocks), gsz)]
+            partial, k0 = None, 0
             for gi, grp in enumerate(groups):
                 k1 = k0 + sum(s_.width for s_ in grp)
                 last_g = gi == len(groups) - 1
-                pk = self._stage((li, c, k0), [w[:, k0:k1]], [b if gi == 0 else None], ln_args if last_g else None, grp)
-                srcs = list(grp) + ([Source(partial, additive=True)] if partial is not None else [])
-                partial = ops.mlp_forward(pk, srcs, n_rows, act if last_g else _lib.ACT_NONE, **(kw2 if last_g else {}))
+                fused_tail = last_g and not grad
+                pk = self._stage((li, c, k0, grad), [w[:, k0:k1]], [b if gi == 0 else None], ln_args if fused_tail else None, grp)
+                srcs = list(grp) + ([Source(partial, additive=True)] if (partial is not None and not grad) else [])
+                y = ops.mlp_forward(pk, srcs, n_rows, act if fused_tail else _lib.ACT_NONE, **(kw2 if fused_tail else {}))
+                partial = y if (partial is None or not grad) else partial + y
                 k0 = k1
+            if grad:
+                if kw2.get("resid") is not None:
+                    raise NotImplementedError("a residual behind a layer of more than 4 input blocks, recorded for autograd")
+                partial = torch_tail(partial, ln_args, act)
             return partial
 
         while i < n:
@@ -175,15 +190,24 @@ class MLP(nn.Module):
                 if last and any(kw.get(k) is not None for k in ("out_idx32", "resid", "agg", "head_outs")):
                     raise NotImplementedError("output index / residual / aggregation / heads on an output wider than 128 columns")
                 wide_ln = last and ln is not None
+                act_i = _lib.ACT_NONE if wide_ln else (act_code if last else _lib.ACT_SELU)
+                spans = [(c, min(c + 128, w_out)) for c in range(0, w_out, 128)]
+                if grad:
+                    parts = [one_layer(i, c, c1, cur, act_i, None) for c, c1 in spans]
+                    if last:
+                        y = torch.cat(parts, 1)
+                        return torch_tail(y, (ln.weight, ln.bias, ln.eps), act_code) if wide_ln else y
+                    cur = [Source(t) for t in parts]
+                    i += 1
+                    continue
                 wide = kw.get("out") if (last and kw.get("out") is not None) else torch.empty((n_rows, w_out), dtype=torch.float32, device=dev)
-                for c in range(0, w_out, 128):
-                    c1 = min(c + 128, w_out)
-                    one_layer(i, c, c1, cur, _lib.ACT_NONE if wide_ln else (act_code if last else _lib.ACT_SELU), None, out=wide[:, c:c1])
+                for c, c1 in spans:
+                    one_layer(i, c, c1, cur, act_i, None, out=wide[:, c:c1])
                 if wide_ln:         # (a LayerNorm over more than 128 columns: its own launch, in place)
                     ops.layer_norm(wide, ln.weight, ln.bias, ln.eps, act_code, out=wide)
                 if last:
                     return wide
-                cur = [Source(wide, col0=c, width=min(128, w_out - c)) for c in range(0, w_out, 128)]
+                cur = [Source(wide, col0=c, width=c1 - c) for c, c1 in spans]
                 i += 1
                 continue
             if len(cur) > _lib.MAX_SRC:          # (too many input blocks for one launch: this layer alone, group by group)

@@ -428,3 +428,34 @@ def test_training_in_fp32_mfma_mode(monkeypatch):
     assert abs(loss - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref))
     worst = max(float((got[k].cpu() - ref[k]).abs().max()) / max(float(ref[k].abs().max()), 1e-7) for k in ref)
     assert worst < 2e-3, worst
+
+
+# ------------------------------------------------------------------ MLPs outside the one-launch envelope
+@pytest.mark.parametrize("shape", [(8, (256, 16), False), (300, (200, 300, 64), True), (128, (128,) * 6, True), (8, (16, 256), True),
+                                   (8, (1024, 16), False), (600, (700, 48), True)],
+                         ids=["wide-hidden", "wide-in-and-hidden", "six-layers", "wide-layernorm", "hidden-over-512", "wide-in-over-512"])
+def test_mlp_any_widths_and_depth_gradients(shape):
+    """The same launch chains recorded for autograd (gradients enabled is torch's default, so a bare `mlp(x)` takes this path): output,
+    input gradient and every parameter gradient against float64 autograd over the module's own torch layers."""
+    k_in, widths, ln = shape
+    torch.manual_seed(sum(widths) + 1)
+    mlp = B.MLP(k_in, widths, ln).to(DEV)
+    assert not mlp.fits_one_launch()
+    x = torch.randn(3000, k_in, device=DEV, requires_grad=True)
+    t = torch.randn(3000, widths[-1], device=DEV)
+    y = mlp(x)
+    (y * t).sum().backward()
+    got = {"x": x.grad.clone(), **{k: p.grad.clone() for k, p in mlp.named_parameters()}}
+    mlp.zero_grad(); x.grad = None
+    ref_net = mlp.MLP.double()
+    xd = x.detach().double().requires_grad_(True)
+    yd = ref_net(xd)
+    (yd * t.double()).sum().backward()
+    ref = {"x": xd.grad.float(), **{"MLP." + k: p.grad.float() for k, p in ref_net.named_parameters()}}
+    mlp.MLP.float()
+    torch.testing.assert_close(y.detach(), yd.detach().float(), rtol=1e-4, atol=1e-4)
+    # (a hidden pre-activation within rounding of 0 sits on SELU's kink — slope 1.76 on one side, 1.05 on the other — and the fp32 and
+    # fp64 paths may take different sides: isolated rows of a gradient then differ by a percent.  Hence the error in norm.)
+    for k in ref:
+        err = (got[k] - ref[k]).norm()
+        assert float(err) <= 2e-3 * float(ref[k].norm()) + 1e-30, (k, float(err), float(ref[k].norm()))
