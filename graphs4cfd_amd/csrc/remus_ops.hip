@@ -52,17 +52,25 @@ __global__ __launch_bounds__(256) void copy_cols_kernel(
 // GNN.solve bookkeeping (graphs4cfd/nn/model.py:316-327) with the step index read on device.
 __global__ __launch_bounds__(256) void rollout_advance_kernel(
     float *__restrict__ field, int field_cols, const float *__restrict__ pred, int nf,
-    float *__restrict__ outputs, int out_ld, const int *__restrict__ step, long long n_nodes) {
+    float *__restrict__ outputs, int out_ld, int *__restrict__ step, long long n_nodes) {
     const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_nodes) return;
-    const int t = *step;
-    float *fr = field + n * field_cols;
-    // roll left by nf, then append pred (row-local, in place, ascending order is safe)
-    for (int c = 0; c + nf < field_cols; ++c) fr[c] = fr[c + nf];
-    for (int c = 0; c < nf; ++c) {
-        const float y = pred[n * nf + c];
-        fr[field_cols - nf + c] = y;
-        outputs[n * out_ld + (long long)nf * t + c] = y;
+    const int t = __builtin_nontemporal_load(step);
+    if (n < n_nodes) {
+        float *fr = field + n * field_cols;
+        // roll left by nf, then append pred (row-local, in place, ascending order is safe)
+        for (int c = 0; c + nf < field_cols; ++c) fr[c] = fr[c + nf];
+        for (int c = 0; c < nf; ++c) {
+            const float y = pred[n * nf + c];
+            fr[field_cols - nf + c] = y;
+            outputs[n * out_ld + (long long)nf * t + c] = y;
+        }
+    }
+    // *step = t + 1 by the LAST workgroup to get here (step[1]: a ticket counter, zero between launches): every workgroup has read
+    // the step index before it takes its ticket, so nobody can see the new value — no trailing single-thread launch (4 us per step)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(step + 1, 1) == (int)gridDim.x - 1) { step[1] = 0; step[0] = t + 1; }
     }
 }
 
@@ -88,8 +96,6 @@ __global__ __launch_bounds__(256) void add_cols_kernel(const float *__restrict__
     if (r >= n_rows) return;
     out[r * out_ld + c] = a[r * a_ld + a_col0 + c] + b[r * b_ld + c];
 }
-
-__global__ void bump_step_kernel(int *step) { *step += 1; }
 
 }  // namespace
 
@@ -162,10 +168,7 @@ extern "C" int g4c_rollout_advance(float *field, int32_t field_cols, const float
     G4C_REQUIRE(nf > 0 && field_cols >= nf && out_ld >= nf && n_nodes >= 0, G4C_EINVAL,
                 "g4c_rollout_advance: bad sizes nf=%d field_cols=%d out_ld=%d", nf, field_cols, out_ld);
     hipStream_t s = (hipStream_t)stream;
-    if (n_nodes > 0) {
-        rollout_advance_kernel<<<dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, s>>>(
-            field, field_cols, pred, nf, outputs, out_ld, step, n_nodes);
-    }
-    bump_step_kernel<<<dim3(1), dim3(1), 0, s>>>(step);
+    const long long blocks = n_nodes > 0 ? (n_nodes + 255) / 256 : 1;          // (no nodes: one workgroup, for the step index)
+    rollout_advance_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(field, field_cols, pred, nf, outputs, out_ld, step, n_nodes);
     return g4c::check_launch("g4c_rollout_advance");
 }

@@ -279,7 +279,7 @@ class Rollout:
         self._orig_field = graph.field
         self.field = graph.field.to(torch.float32).clone(memory_format=torch.contiguous_format)
         self.outputs = torch.zeros((graph.num_nodes, self.nf * self.max_steps), dtype=torch.float32, device=dev)
-        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_counter = torch.zeros(2, dtype=torch.int32, device=dev)          # [step index, g4c_rollout_advance's ticket]
         self.steps_done = 0
         self._hipgraph, self._epoch, self._pins = None, -1, None
         graph.field = self.field
@@ -327,7 +327,7 @@ class Rollout:
         self.step_counter.zero_()
         self.steps_done = 1 if self.steps_done > 0 else 0
         if self.steps_done:   # slot 0 is kept so that replays continue from slot 1
-            self.step_counter.fill_(1)
+            self.step_counter[:1].fill_(1)
 
     def result(self) -> torch.Tensor:
         """`outputs` with its rows in the caller's node numbering.  In the default "f16x3" arithmetic a value this rollout's

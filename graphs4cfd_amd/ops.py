@@ -277,6 +277,8 @@ def rollout_advance(field: Tensor, pred: Tensor, outputs: Tensor, step: Tensor, 
     lib = _lib.load()
     dev = _lib.require_hip(field, pred, outputs, step)
     assert field.is_contiguous() and pred.is_contiguous() and outputs.is_contiguous()
+    if step.dtype != torch.int32 or step.numel() < 2:
+        raise ValueError("rollout_advance: `step` is an int32 tensor of two entries — [step index, the launch's ticket counter (zero)]")
     _lib.check(lib.g4c_rollout_advance(_lib.ptr(field), int(field.size(1)), _lib.ptr(pred), nf, _lib.ptr(outputs),
                                        int(outputs.size(1)), _lib.ptr(step), int(field.size(0)), _lib.stream_handle(dev)))
 

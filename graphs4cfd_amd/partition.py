@@ -550,7 +550,7 @@ class DistributedRollout:
         self.max_steps = max_steps
         self.field = self.mesh.inputs["field"] = self.mesh.inputs["field"].clone()
         self.outputs = torch.zeros((int(self.mesh.owned_global[0].numel()), self.nf * max_steps), dtype=torch.float32, device=device)
-        self.step_counter = torch.zeros(1, dtype=torch.int32, device=device)
+        self.step_counter = torch.zeros(2, dtype=torch.int32, device=device)          # [step index, g4c_rollout_advance's ticket]
         self.steps_done = 0
         self.capture = capture and device.type == "cuda"
         self.capture_error = None if self.capture else "capture not requested"
