@@ -41,6 +41,7 @@ struct AddSrc {          // pre-multiplied first-layer term, gathered per row an
     const float *ptr;
     const int *idx;
     int width, ld;
+    int bf16;            // rounded-bf16 mode: the rows are stored as bf16 (ptr is a __bf16 pointer in disguise, ld in elements; 128 wide)
 };
 
 struct Params {
@@ -71,6 +72,7 @@ struct Params {
     int n_heads;
     float *head_out[G4C_MAX_HEADS];
     int head_ld;
+    int head_bf16;           // rounded-bf16 mode: the head rows are stored as bf16 (head_out are __bf16 pointers in disguise, head_ld in elements)
     // fused aggregation (bf16x6 kernel): tiles of whole CSR segments (g4c_plan_tiles) instead of fixed 32-row tiles; after
     // the store, the tile's segments are summed / averaged from the LDS copy of the output rows into agg[segment, :]
     const int *tile_rows, *tile_seg, *seg_off;
@@ -286,6 +288,15 @@ int bx6i_launch(const Params &p, bool agg, bool f16x2, hipStream_t st);
 int ws_enable(int on);
 bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count);
 int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st);
+
+// four bf16 values (two dwords as loaded) widened to fp32: a shift / a mask each — exact
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 widen_bf16x4(u32x2 w) {
+    f32x4 x;
+    x[0] = __builtin_bit_cast(float, w[0] << 16); x[1] = __builtin_bit_cast(float, w[0] & 0xffff0000u);
+    x[2] = __builtin_bit_cast(float, w[1] << 16); x[3] = __builtin_bit_cast(float, w[1] & 0xffff0000u);
+    return x;
+}
 
 
 }  // namespace g4cm

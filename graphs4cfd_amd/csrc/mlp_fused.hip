@@ -903,6 +903,11 @@ __global__ __launch_bounds__(256, RD6 > 2 ? 2 : (SP == 2 ? G4C_F16_MINW : G4C_BX
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
             const float *pr = p.add[a].ptr + (long long)sRowAdd[a * ROWS + i + 32 * t] * p.add[a].ld;
+            if (SP == 1 && p.add[a].bf16) {          // bf16 rows (128 wide, 8-byte aligned: the launcher checks), widened by a shift / a mask
+                const __bf16 *pr16 = reinterpret_cast<const __bf16 *>(p.add[a].ptr) + (long long)sRowAdd[a * ROWS + i + 32 * t] * p.add[a].ld;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) tt[t][gq] = widen_bf16x4(*reinterpret_cast<const u32x2 *>(pr16 + fbase + 8 * gq));
+            } else
             if (vec) {
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
@@ -1077,10 +1082,13 @@ __global__ __launch_bounds__(256, RD6 > 2 ? 2 : (SP == 2 ? G4C_F16_MINW : G4C_BX
         const int nrows = __builtin_amdgcn_readfirstlane(left >= ROWS ? ROWS : (left > 0 ? (int)left : 0));
         const unsigned vo = (unsigned)(4 * h * p.head_ld + ct0 * 32 + i) * 4u;
         auto head_store = [&](int hd, const f32x16 (&a)[RT], const f32x16 (&a1)[RT]) __attribute__((always_inline)) {
-            const unsigned long long hb = reinterpret_cast<unsigned long long>(p.head_out[hd] + row0 * p.head_ld);
+            // (rounded-bf16 mode, head_bf16: the rows are stored as bf16 — 2-byte elements: a store instruction writes 64 contiguous
+            // bytes of each of two rows; their reader adds them to fp32 accumulators after widening)
+            const int esz = (SP == 1 && p.head_bf16) ? 2 : 4;
+            const unsigned long long hb = reinterpret_cast<unsigned long long>(p.head_out[hd]) + (unsigned long long)row0 * p.head_ld * esz;
             float *const hbase = reinterpret_cast<float *>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(hb >> 32)) << 32) |
                                                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)hb));
-            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(hbase, 0, nrows * p.head_ld * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(hbase, 0, nrows * p.head_ld * esz, 0x00020000);
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -1089,6 +1097,10 @@ __global__ __launch_bounds__(256, RD6 > 2 ? 2 : (SP == 2 ? G4C_F16_MINW : G4C_BX
                     for (int e = 0; e < 4; ++e) {
                         const float x = SP == 2 ? fmaf(a1[t][4 * gq + e], F16_LO_UNSCALE, a[t][4 * gq + e]) : a[t][4 * gq + e];
                         // (the row offset is part of the VECTOR offset: the scalar offset is not range-checked)
+                        if (SP == 1 && p.head_bf16)
+                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (__bf16)x), rh,
+                                                                  (vo >> 1) + (unsigned)((32 * t + 8 * gq + e) * p.head_ld) * 2u, 0, 0);
+                        else
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rh, vo + (unsigned)((32 * t + 8 * gq + e) * p.head_ld) * 4u, 0, 0);
                     }
         };
@@ -1242,6 +1254,8 @@ struct AggArgs {           // fused aggregation (g4c_mlp_forward_bx6_agg); all n
     int32_t out_ld, mean;
     int32_t rows_bf16;       // the MLP's output rows are stored as bf16 (g4c_mlp_forward_bf16_agg, out_dtype)
 };
+// rounded-bf16 mode, plain / heads launches: bf16 output rows (g4c_mlp_forward_bf16_out) and bf16 head rows (g4c_mlp_forward_heads_bf16_out)
+static thread_local int g_out_dtype = 0, g_head_dtype = 0;
 
 static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                       int64_t row_begin, int64_t row_count, int32_t tile_rows,
@@ -1287,6 +1301,29 @@ extern "C" int g4c_mlp_forward_heads_bf16(const g4c_mlp_t *mlp, const g4c_src_t 
     G4C_REQUIRE(n_heads >= 1 && n_heads <= G4C_MAX_HEADS && head_w && head_out, G4C_EINVAL, "g4c_mlp_forward_heads_bf16: bad heads (n=%d)", n_heads);
     return mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3216, out, out_ld, nullptr, act, nullptr, 0, 0,
                       (const float *)head_w, n_heads, head_out, head_ld, stream);
+}
+
+extern "C" int g4c_mlp_forward_heads_bf16_out(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                                              float *out, int32_t out_ld, int32_t act,
+                                              const void *head_w, int32_t n_heads, void *const *head_out, int32_t head_ld, int32_t head_dtype,
+                                              void *stream) {
+    G4C_REQUIRE(n_heads >= 1 && n_heads <= G4C_MAX_HEADS && head_w && head_out, G4C_EINVAL, "g4c_mlp_forward_heads_bf16_out: bad heads (n=%d)", n_heads);
+    G4C_REQUIRE(head_dtype == G4C_DTYPE_F32 || head_dtype == G4C_DTYPE_BF16, G4C_EINVAL, "g4c_mlp_forward_heads_bf16_out: unknown head_dtype %d", head_dtype);
+    g_head_dtype = head_dtype;
+    const int rc = mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3216, out, out_ld, nullptr, act, nullptr, 0, 0,
+                              (const float *)head_w, n_heads, (float *const *)head_out, head_ld, stream);
+    g_head_dtype = 0;
+    return rc;
+}
+
+extern "C" int g4c_mlp_forward_bf16_out(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                                        void *out, int32_t out_ld, int32_t out_dtype, int32_t act, void *stream) {
+    G4C_REQUIRE(out_dtype == G4C_DTYPE_F32 || out_dtype == G4C_DTYPE_BF16, G4C_EINVAL, "g4c_mlp_forward_bf16_out: unknown out_dtype %d", out_dtype);
+    g_out_dtype = out_dtype;
+    const int rc = mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3216, (float *)out, out_ld, nullptr, act, nullptr, 0, 0,
+                              nullptr, 0, nullptr, 0, stream);
+    g_out_dtype = 0;
+    return rc;
 }
 
 extern "C" int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
@@ -1389,9 +1426,17 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
             continue;
         }
         if (g.additive) {
-            G4C_REQUIRE(g.pre_act == G4C_ACT_NONE && g.width <= NP && g.dtype == G4C_DTYPE_F32, G4C_EINVAL, "g4c_mlp_forward: bad additive source %d", s);
+            G4C_REQUIRE(g.pre_act == G4C_ACT_NONE && g.width <= NP && (g.dtype == G4C_DTYPE_F32 || g.dtype == G4C_DTYPE_BF16), G4C_EINVAL,
+                        "g4c_mlp_forward: bad additive source %d", s);
             AddSrc &a = p.add[p.n_add++];
-            a.ptr = g.ptr + g.col0; a.idx = g.idx; a.width = g.width; a.ld = g.ld;
+            a.idx = g.idx; a.width = g.width; a.ld = g.ld; a.bf16 = g.dtype == G4C_DTYPE_BF16;
+            if (a.bf16) {
+                G4C_REQUIRE(round1 && g.width == NP && g.ld % 4 == 0 && g.col0 % 4 == 0 && (uintptr_t)g.ptr % 8 == 0, G4C_EUNSUPPORTED,
+                            "g4c_mlp_forward: bf16 additive rows need the rounded-bf16 mode (g4c_mlp_forward_bf16*) and a 128-wide, 8-byte aligned block");
+                a.ptr = reinterpret_cast<const float *>(reinterpret_cast<const __bf16 *>(g.ptr) + g.col0);
+            } else {
+                a.ptr = g.ptr + g.col0;
+            }
             continue;
         }
         G4C_REQUIRE(g.pre_act == G4C_ACT_NONE || g.pre_act == G4C_ACT_SELU, G4C_EUNSUPPORTED,
@@ -1419,7 +1464,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     if (nk == 0) p.src[0] = Src{nullptr, nullptr, 0, 0, 0, 0, 1, 0, nullptr, 0, nullptr, 0};
     for (int s = (nk ? nk : 1); s < G4C_MAX_SRC; ++s) p.src[s] = p.src[0];
     for (int s = p.n_nar; s < G4C_MAX_SRC; ++s) p.nar[s] = NarSrc{nullptr, nullptr, 0, 0};
-    for (int s = p.n_add; s < G4C_MAX_SRC; ++s) p.add[s] = AddSrc{nullptr, nullptr, 0, 0};
+    for (int s = p.n_add; s < G4C_MAX_SRC; ++s) p.add[s] = AddSrc{nullptr, nullptr, 0, 0, 0};
     G4C_REQUIRE(kp == mlp->k_pad[0], G4C_EINVAL, "g4c_mlp_forward: sources give %d padded columns, layer 1 packed for %d", kp, mlp->k_pad[0]);
     p.n_layers = mlp->n_layers;
     p.chunks0 = kp / KC;
@@ -1442,6 +1487,11 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     p.M = n_rows;
     p.out = out; p.out_ld = out_ld; p.out_idx = out_idx; p.act = act;
     p.out_bf16 = 0;
+    if (g_out_dtype) {
+        G4C_REQUIRE(round1 && !agg && !resid && !out_idx && p.n_out == NP && (out_ld & 3) == 0 && ((uintptr_t)out & 7) == 0, G4C_EUNSUPPORTED,
+                    "g4c_mlp_forward_bf16_out: bf16 output rows need the rounded-bf16 mode, a plain 128-wide output, out_ld a multiple of 4 and an 8-byte aligned out");
+        p.out_bf16 = g_out_dtype;
+    }
     p.resid = resid; p.resid_ld = resid_ld; p.resid_col0 = resid_col0;
     p.tile_rows = p.tile_seg = p.seg_off = nullptr; p.agg = nullptr; p.agg_ld = 0; p.agg_mean = 0;
     if (agg) {
@@ -1475,8 +1525,14 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     }
     p.range_flag = f16x2 ? mlp->range_flag : nullptr; p.range_slot = mlp->range_slot;
     G4C_REQUIRE(!p.range_flag || p.range_slot >= 0, G4C_EINVAL, "g4c_mlp_forward: negative range_slot");
-    p.n_heads = n_heads; p.head_ld = head_ld;
+    p.n_heads = n_heads; p.head_ld = head_ld; p.head_bf16 = 0;
     for (int hd = 0; hd < G4C_MAX_HEADS; ++hd) p.head_out[hd] = hd < n_heads ? head_out[hd] : nullptr;
+    if (n_heads && g_head_dtype) {
+        G4C_REQUIRE(round1 && (head_ld & 1) == 0, G4C_EUNSUPPORTED, "g4c_mlp_forward_heads_bf16_out: bf16 head rows need the rounded-bf16 mode and an even head_ld");
+        for (int hd = 0; hd < n_heads; ++hd)
+            G4C_REQUIRE(((uintptr_t)head_out[hd] & 3) == 0, G4C_EINVAL, "g4c_mlp_forward_heads_bf16_out: head output %d is not 4-byte aligned", hd);
+        p.head_bf16 = 1;
+    }
     if (n_heads) {
         G4C_REQUIRE((head_ld & 3) == 0 || !bx6, G4C_EINVAL, "g4c_mlp_forward_heads: head outputs need a leading dimension that is a multiple of 4");
         G4C_REQUIRE(p.n_out == NP && !resid && !out_idx && head_ld >= NP, G4C_EINVAL,
@@ -1504,7 +1560,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         bool full = all_vec;
         for (int s2 = 0; s2 < p.n_src; ++s2) full = full && p.src[s2].width == NP;
         for (int a = 0; a < p.n_add; ++a)
-            full = full && p.add[a].width == NP && (p.add[a].ld & 3) == 0 && ((uintptr_t)p.add[a].ptr & 15) == 0;
+            full = full && p.add[a].width == NP && (p.add[a].ld & 3) == 0 && ((uintptr_t)p.add[a].ptr & (p.add[a].bf16 ? 7 : 15)) == 0;
         const dim3 blk(256);
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
         if (p.n_tiles == 0) return G4C_OK;

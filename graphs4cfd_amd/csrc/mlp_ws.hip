@@ -111,6 +111,29 @@ __device__ __forceinline__ f32x2 selu2w(f32x2 x) {
 #define G4C_WS_MEAN_DIV 1
 #endif
 
+// Round-5 experiment (-DG4C_WS_EXP_POLY=1, not the default — measured slower): the SELU's
+// exponential without the transcendental unit.  exp(x) for x <= 0 (the clamp to [0, 1] of the shipped form is the range reduction's
+// med3 here) = 2^n * p(f), t = x log2(e) = n + f, |f| <= 1/2: n by the 1.5 * 2^23 rounding trick (its integer sits in the low
+// mantissa bits of t + magic), p = degree-5 minimax polynomial of 2^f (max relative error 1.8e-7), 2^n by an integer add into
+// the exponent field (v_lshl_add_u32).  Eleven plain vector instructions instead of v_mul + v_exp_f32: r04's gap microbenchmark says
+// plain instructions hide behind an MFMA and v_exp_f32 does not.
+#ifndef G4C_WS_EXP_POLY
+#define G4C_WS_EXP_POLY 0
+#endif
+__device__ __forceinline__ float exp_neg_poly(float x) {
+    const float t = __builtin_amdgcn_fmed3f(x * 1.4426950408889634f, -125.f, 0.f);
+    const float magic = 12582912.f;                       // 1.5 * 2^23
+    const float r = t + magic;
+    const float f = t - (r - magic);
+    float p = 1.3333558146e-3f;                            // 2^f on [-1/2, 1/2]: Taylor / minimax coefficients ln2^k / k!
+    p = fmaf(p, f, 9.6181291076e-3f);
+    p = fmaf(p, f, 5.5504108665e-2f);
+    p = fmaf(p, f, 2.4022650696e-1f);
+    p = fmaf(p, f, 6.9314718056e-1f);
+    p = fmaf(p, f, 1.0f);
+    return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, r) << 23) + __builtin_bit_cast(unsigned, p));
+}
+
 template <bool LOADED = false>
 __device__ __forceinline__ f32x2 selu2w_scaled(f32x2 x) {
     const float sa = 1.6732632423543772848170429916717f * 1.0507009873554804934193349852946f * F16_LO_SCALE;
@@ -118,7 +141,7 @@ __device__ __forceinline__ f32x2 selu2w_scaled(f32x2 x) {
     f32x2 r;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const float ex = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x[e] * 1.4426950408889634f), 0.f, 1.f);
+        const float ex = G4C_WS_EXP_POLY ? exp_neg_poly(x[e]) : __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x[e] * 1.4426950408889634f), 0.f, 1.f);
         float m;
         if constexpr (LOADED) asm("v_max_f32 %0, 0, %1" : "=v"(m) : "v"(x[e]));
         else m = fmaxf(x[e], 0.f);
@@ -279,10 +302,15 @@ __device__ __forceinline__ void other_all(const f32x4 (&accE)[2], const f32x4 (&
     for (int s = 0; s < 8; ++s) other_piece<SP, EK, PACT>(s, accE, accE1, xe, o, hold, rng);
 }
 
-// SP: 2 the f16x3 stream, 1 the rounded-bf16 mode;  NL: layers (2 or 3);  XB16 (SP = 1): the weighted block's rows are bf16
-template <bool AGG, bool DIRECT, bool ADDS, int SP, int NL, bool XB16>
+// SP: 2 the f16x3 stream, 1 the rounded-bf16 mode;  NL: layers (2 or 3);  XB16 (SP = 1): the weighted block's rows are bf16;
+// AB16 (SP = 1): the additive rows are bf16 (the first-layer products a g4c_mlp_forward_heads_bf16_out / _bf16_out launch stored:
+// half the bytes of the launch's largest gather stream — REMuS-GNN's level-1 angle launch reads 2 x 2.5 M of them)
+template <bool AGG, bool DIRECT, bool ADDS, int SP, int NL, bool XB16, bool AB16 = false>
 __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const int n_pairs) {
-    static_assert((SP == 1 || SP == 2) && (NL == 2 || NL == 3) && (SP == 1 || !XB16), "mlp_ws_kernel: unsupported instantiation");
+    static_assert((SP == 1 || SP == 2) && (NL == 2 || NL == 3) && (SP == 1 || !XB16) && (SP == 1 || !AB16) && (ADDS || !AB16),
+                  "mlp_ws_kernel: unsupported instantiation");
+    // an additive row piece as loaded: four fp32 values, or four bf16 values in two dwords (widened where they are added)
+    typedef typename std::conditional<AB16, u32x2, f32x4>::type AddV;
     __shared__ __attribute__((aligned(16))) __bf16 sP[2 * TILE_BF16];      // operand planes of tiles A, B (34 816 B)
     __shared__ __attribute__((aligned(16))) float sF[2 * FIN];             // fp32 final rows of tiles A, B (33 792 B)
     __shared__ int sIdx[2][2 * 3 * 32];          // ring of 2: [tile][weighted block, additive 0, additive 1][row]
@@ -401,13 +429,18 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
             }
         }
     };
-    auto gather_adds = [&](int t, int ring, f32x4 (&ad)[2][2]) __attribute__((always_inline)) {
+    auto gather_adds = [&](int t, int ring, AddV (&ad)[2][2]) __attribute__((always_inline)) {
         if (ADDS) {
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const int r = n + 16 * rb;
-                ad[rb][0] = *reinterpret_cast<const f32x4 *>(p.add[0].ptr + (long long)sIdx[ring][t * 96 + 32 + r] * p.add[0].ld + fcol);
-                ad[rb][1] = *reinterpret_cast<const f32x4 *>(p.add[1].ptr + (long long)sIdx[ring][t * 96 + 64 + r] * p.add[1].ld + fcol);
+                if constexpr (AB16) {
+                    ad[rb][0] = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const __bf16 *>(p.add[0].ptr) + (long long)sIdx[ring][t * 96 + 32 + r] * p.add[0].ld + fcol);
+                    ad[rb][1] = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const __bf16 *>(p.add[1].ptr) + (long long)sIdx[ring][t * 96 + 64 + r] * p.add[1].ld + fcol);
+                } else {
+                    ad[rb][0] = *reinterpret_cast<const f32x4 *>(p.add[0].ptr + (long long)sIdx[ring][t * 96 + 32 + r] * p.add[0].ld + fcol);
+                    ad[rb][1] = *reinterpret_cast<const f32x4 *>(p.add[1].ptr + (long long)sIdx[ring][t * 96 + 64 + r] * p.add[1].ld + fcol);
+                }
             }
         }
     };
@@ -419,6 +452,12 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
     const unsigned lo_b = 2u * (unsigned)((wave >> 1) * 8 * STEP6 + (g >> 1) * STEP6 + ((g & 1) * 32 + 16 * (wave & 1) + n) * 8);
     bf16x8 W[NL][4][SP];
     if (SP == 2) f16_range_mode();
+    // Round-5 experiment (-DG4C_WS_PRIO=1, not the default): the workgroup's waves w and w + 4 share a SIMD (waves are placed
+    // 0 -> 2 -> 1 -> 3 cyclically); giving one of the two a higher issue priority for the whole launch staggers them, so that one
+    // wave's MFMAs are preferred and the other's vector work fills the gaps
+#ifdef G4C_WS_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(G4C_WS_PRIO);
+#endif
     RangeV rng;                       // running max |value converted to fp16| (mlp_common.h range_track)
 
     Meta m0 = fix_meta(load_meta(p_begin)), m1 = fix_meta(load_meta(p_begin + 1)), m2 = fix_meta(load_meta(p_begin + 2));
@@ -463,21 +502,25 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
     // start of the FIRST pair: tile A's input rows -> planes (nothing to overlap with yet), both tiles' start values = bias + additive
     // rows (the later pairs: inside / after the previous pair's last matrix phase)
     // start values of a tile = bias + additive rows (in this order: what the tile kernels add)
-    auto start_values = [&](f32x4 (&acc)[2], f32x4 (&acc1)[2], const f32x4 (&a)[2][2]) __attribute__((always_inline)) {
+    auto start_values = [&](f32x4 (&acc)[2], f32x4 (&acc1)[2], const AddV (&a)[2][2]) __attribute__((always_inline)) {
         bias_init(acc, acc1, 0);
         if (ADDS) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < 2; ++rb) {
+                f32x4 a0, a1;
+                if constexpr (AB16) { a0 = widen_bf16x4(a[rb][0]); a1 = widen_bf16x4(a[rb][1]); }
+                else { a0 = a[rb][0]; a1 = a[rb][1]; }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[rb][e] = (acc[rb][e] + a[rb][0][e]) + a[rb][1][e];
+                for (int e = 0; e < 4; ++e) acc[rb][e] = (acc[rb][e] + a0[e]) + a1[e];
+            }
         }
     };
     // Loop-carried: xr[1] / adB = input rows / additive rows of the CURRENT pair's tile B (gathered in the previous tail: parked /
     // added in and after the first matrix phase), accA = tile A's start values, tile A's rows in its planes.
-    f32x4 adB[2][2];
+    AddV adB[2][2];
     unsigned rawB[2][2] = {{0u, 0u}, {0u, 0u}};        // (XB16: tile B's bf16 rows as loaded)
     {
-        f32x4 adA[2][2];
+        AddV adA[2][2];
         unsigned rawA[2][2] = {{0u, 0u}, {0u, 0u}};
         gather_x(m0, 0, 0, xr[0], rawA);
         gather_x(m0, 0, 1, xr[1], rawB);
@@ -505,7 +548,8 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         __syncthreads();
         WS_STAMP(2);
         // ---- tile A's rows one pair ahead (indices in LDS since the previous iteration); tile B's: in the tail
-        f32x4 nxa[2], nadA[2][2];
+        f32x4 nxa[2];
+        AddV nadA[2][2];
         unsigned nraw[2][2] = {{0u, 0u}, {0u, 0u}};
         gather_x(m1, (it + 1) & 1, 0, nxa, nraw);
         m_block<SP, 1>(paB, W[0], accB, accB1, accA, accA1, xr[1], oA, rng);                 // for A: epilogue of layer 0
@@ -742,7 +786,8 @@ bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, 
     const Src &s = p.src[0];
     if (s.width != NP || !s.vec || s.seg_off || (s.bf16 && !round1)) return false;
     for (int a = 0; a < p.n_add; ++a)
-        if (p.add[a].width != NP || (p.add[a].ld & 3) || ((uintptr_t)p.add[a].ptr & 15)) return false;
+        if (p.add[a].width != NP || (p.add[a].ld & 3) || ((uintptr_t)p.add[a].ptr & (p.add[a].bf16 ? 7 : 15)) || p.add[a].bf16 != p.add[0].bf16 ||
+            (p.add[a].bf16 && !round1)) return false;
     if (p.out && !p.out_bf16 && ((p.out_ld & 3) || ((uintptr_t)p.out & 15))) return false;
     if (p.gamma && (((uintptr_t)p.gamma & 15) || ((uintptr_t)p.beta & 15))) return false;
     if (((uintptr_t)p.b & 15)) return false;
@@ -756,12 +801,16 @@ int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st) {
     const int n_cu = g4c::cu_count();
     const dim3 grid(n_pairs < n_cu ? n_pairs : n_cu), blk(512);
     const bool direct = p.src[0].idx == nullptr, adds = p.n_add == 2, two = p.n_layers == 2, xb16 = p.src[0].bf16 != 0;
+    const bool ab16 = adds && p.add[0].bf16 != 0;
 #define G4C_WS_GO(AGG, DIRECT, ADDS, SP, NL, XB16) mlp_ws_kernel<AGG, DIRECT, ADDS, SP, NL, XB16><<<grid, blk, 0, st>>>(p, n_pairs)
+#define G4C_WS_GO1(AGG, DIRECT, NL, XB16)                                                            \
+    do { if (ab16) mlp_ws_kernel<AGG, DIRECT, true, 1, NL, XB16, true><<<grid, blk, 0, st>>>(p, n_pairs);       \
+         else mlp_ws_kernel<AGG, DIRECT, true, 1, NL, XB16, false><<<grid, blk, 0, st>>>(p, n_pairs); } while (0)
 #define G4C_WS_SHAPE(AGG, DIRECT)                                                                    \
     do {                                                                                             \
         if (round1) {                                                                                \
-            if (two) { if (xb16) G4C_WS_GO(AGG, DIRECT, true, 1, 2, true); else G4C_WS_GO(AGG, DIRECT, true, 1, 2, false); }      \
-            else { if (xb16) G4C_WS_GO(AGG, DIRECT, true, 1, 3, true); else G4C_WS_GO(AGG, DIRECT, true, 1, 3, false); }          \
+            if (two) { if (xb16) G4C_WS_GO1(AGG, DIRECT, 2, true); else G4C_WS_GO1(AGG, DIRECT, 2, false); }      \
+            else { if (xb16) G4C_WS_GO1(AGG, DIRECT, 3, true); else G4C_WS_GO1(AGG, DIRECT, 3, false); }          \
         } else if (two) {                                                                            \
             if (adds) G4C_WS_GO(AGG, DIRECT, true, 2, 2, false); else G4C_WS_GO(AGG, DIRECT, false, 2, 2, false);                 \
         } else {                                                                                     \
@@ -771,6 +820,7 @@ int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st) {
     if (agg) { if (direct) G4C_WS_SHAPE(true, true); else G4C_WS_SHAPE(true, false); }
     else { if (direct) G4C_WS_SHAPE(false, true); else G4C_WS_SHAPE(false, false); }
 #undef G4C_WS_SHAPE
+#undef G4C_WS_GO1
 #undef G4C_WS_GO
     return g4c::check_launch("g4c_mlp_forward (ws)");
 }

@@ -234,17 +234,19 @@ F16_INPUT_WARN = 4096.0
 
 
 def _warn_f16_range(graph: Graph) -> None:
-    """The default "f16x3" MLP arithmetic clips activations at +-65504 (ops.py).  Raw inputs go through the fp32 vector path, but
-    the first hidden layer they feed is split into fp16: inputs of this size mean un-normalised data, where that layer can get
-    there.  One small reduction per input tensor and one synchronisation per solve() call."""
+    """The default "f16x3" MLP arithmetic has fp16's exponent range (ops.py; a rollout that leaves it is recomputed in "bf16x6":
+    Rollout.validate).  Raw inputs go through the fp32 vector path, but the first hidden layer they feed is split into fp16: inputs
+    of this size mean un-normalised data, where that layer can get there — say so up front.  One small reduction per input tensor
+    and one synchronisation per solve() call."""
     big = []
     for name in ("field", "edge_attr", "loc", "glob", "omega"):
         x = getattr(graph, name, None)
         if torch.is_tensor(x) and x.is_floating_point() and x.numel():
             big.append(x.detach().abs().amax().reshape(1).float())
     if big and float(torch.cat(big).amax()) > F16_INPUT_WARN:
-        warnings.warn(f"solve(): an input tensor has magnitudes beyond {F16_INPUT_WARN:g}; the default 'f16x3' MLP arithmetic clips "
-                      "activations at +-65504 — gfd.set_mlp_precision('bf16x6') keeps the whole fp32 range for un-normalised data.",
+        warnings.warn(f"solve(): an input tensor has magnitudes beyond {F16_INPUT_WARN:g}: the default 'f16x3' MLP arithmetic (fp16 "
+                      "exponent range, +-65504) will probably be left and the rollout recomputed in 'bf16x6' — "
+                      "gfd.set_mlp_precision('bf16x6') runs un-normalised data in the full fp32 range straight away.",
                       RuntimeWarning)
 
 
@@ -290,6 +292,13 @@ class Rollout:
         self.label, self._sites = label, getattr(model, "_range_sites", None)
         if ops.mlp_precision() == "f16x3":
             ops.f16_range_clear(dev, self._sites)
+        # The default "f16x3" arithmetic is run OPTIMISTICALLY: its kernels flag every value that reached the end of the fp16 range
+        # (|x| >= 65504, clipped there), `result()` reads the flags, and a rollout that clipped anywhere is recomputed from the
+        # window it started from in "bf16x6" (fp32's exponent range; the reference's `solve` runs in fp32, nn/model.py:303-321) and
+        # stays in that arithmetic — so what `result()` hands out never contains a clipped value.
+        self._field0 = self.field.clone()        # the input window of slot `_first_slot`
+        self._first_slot = 0
+        self.exact_range = False                 # True once a clip made this rollout fall back to "bf16x6"
 
     def _one(self):
         with self.static:
@@ -299,10 +308,25 @@ class Rollout:
     def step(self) -> None:
         if self.steps_done >= self.max_steps:
             raise RuntimeError(f"rollout buffer holds {self.max_steps} steps")
+        if self.exact_range and ops.mlp_precision() == "f16x3":
+            old = ops.set_mlp_precision("bf16x6")
+            try:
+                self._step()
+            finally:
+                ops.set_mlp_precision(old)
+        else:
+            self._step()
+
+    def _step(self) -> None:
         with torch.no_grad():
             if self._epoch != -1 and ops.weights_epoch() != self._epoch:
                 # the weights changed since the last eager step (captured or not yet): the packed images are stale, and repacking
                 # (allocations + pack launches) must not happen inside a capture — one eager step first
+                self._hipgraph, self._epoch = None, -1
+            elif self._hipgraph is not None and self.static.stale():
+                # a per-mesh constant (edge_attr / angle_attr*) was edited in place, or the arithmetic changed: the captured step
+                # contains neither the encoder launches nor a look-up of their cached results — one eager step recomputes them,
+                # then the step is captured again
                 self._hipgraph, self._epoch = None, -1
             if self.steps_done == 0 or not self.capture or self._epoch == -1:
                 self._one()                               # eager: builds the plans and the packed weight images
@@ -328,12 +352,40 @@ class Rollout:
         self.steps_done = 1 if self.steps_done > 0 else 0
         if self.steps_done:   # slot 0 is kept so that replays continue from slot 1
             self.step_counter[:1].fill_(1)
+        self._field0.copy_(self.field)            # (a recomputation restarts here)
+        self._first_slot = self.steps_done
+
+    def _recompute_exact(self, hit) -> None:
+        """Steps `_first_slot .. steps_done` again from the saved input window in "bf16x6"; the rollout stays in that arithmetic."""
+        n = self.steps_done - self._first_slot
+        warnings.warn(f"{self.label}: the default 'f16x3' MLP arithmetic reached the end of the fp16 range (|x| >= 65504) in "
+                      f"{', '.join(hit[:8])}{' ...' if len(hit) > 8 else ''}: the {n} step(s) were recomputed in 'bf16x6' (fp32's exponent "
+                      "range) and this rollout continues in it — the result holds no clipped value.  gfd.set_mlp_precision('bf16x6') "
+                      "avoids the second pass for this model.", RuntimeWarning, stacklevel=3)
+        self.exact_range = True
+        self.field.copy_(self._field0)
+        self.step_counter.zero_()
+        if self._first_slot:
+            self.step_counter[:1].fill_(self._first_slot)
+        self._hipgraph, self._epoch = None, -1
+        self.steps_done = self._first_slot
+        self.run(n)
+
+    def validate(self) -> bool:
+        """Default "f16x3" arithmetic: read the range flags of this rollout's launches (one synchronisation) and, if a value was
+        clipped at the end of the fp16 range, recompute the steps in "bf16x6" (RuntimeWarning naming the MLPs).  Returns True when
+        that happened.  `result()` calls it; a benchmark calls it inside its timed region."""
+        if ops.mlp_precision() == "f16x3" and not self.exact_range:
+            hit = ops.f16_range_report(self.outputs.device, sites=self._sites)
+            if hit:
+                self._recompute_exact(hit)
+                return True
+        return False
 
     def result(self) -> torch.Tensor:
-        """`outputs` with its rows in the caller's node numbering.  In the default "f16x3" arithmetic a value this rollout's
-        launches clipped at the end of the fp16 range is reported here (RuntimeWarning naming the MLPs; one synchronisation)."""
-        if ops.mlp_precision() == "f16x3":
-            ops.check_f16_range(self.outputs.device, self.label, sites=self._sites)
+        """`outputs` with its rows in the caller's node numbering — validated first (`validate()`): the tensor returned never
+        contains a value the default arithmetic clipped."""
+        self.validate()
         if self._perm is None:
             return self.outputs
         out = torch.empty_like(self.outputs)

@@ -95,6 +95,17 @@ class StaticCache:
         self.store[name] = (key, val, tuple(inputs))      # (the inputs are kept alive: the key holds their addresses)
         return val
 
+    def stale(self) -> bool:
+        """True when an entry no longer matches what it was computed from (an in-place edit of a static input, new weights, another
+        arithmetic).  A captured step contains neither the cached launches nor a look-up, so a rollout asks this before every replay
+        and falls back to one eager step (which recomputes the entry) + a new capture — ADVICE r04: a replay must not keep reading
+        latents of an `edge_attr` that was edited since."""
+        head = (weights_epoch(), mlp_precision())
+        for key, _, inputs in self.store.values():
+            if key != head + tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in inputs):
+                return True
+        return False
+
 
 def static_launch(name: str, inputs: Sequence[Tensor], fn):
     """`fn()` — or its cached result when a rollout's StaticCache is active (never while a call is recorded for autograd)."""

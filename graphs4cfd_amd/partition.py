@@ -559,6 +559,9 @@ class DistributedRollout:
         self._sites = getattr(model, "_range_sites", None)
         if ops.mlp_precision() == "f16x3" and device.type == "cuda":
             ops.f16_range_clear(device, self._sites)
+        # optimistic "f16x3" (nn.model.Rollout): the input window the rollout started from, for the exact-range recomputation
+        self._field0 = self.field.clone()
+        self.exact_range = False
 
     def _one(self) -> None:
         with self.static:
@@ -570,11 +573,52 @@ class DistributedRollout:
         exchanges (every rank captures the same sequence), later steps replayed."""
         if self.steps_done >= self.max_steps:
             raise RuntimeError(f"rollout buffer holds {self.max_steps} steps")
+        if self.exact_range and ops.mlp_precision() == "f16x3":
+            old = ops.set_mlp_precision("bf16x6")
+            try:
+                self._step()
+            finally:
+                ops.set_mlp_precision(old)
+        else:
+            self._step()
+
+    def validate(self) -> bool:
+        """As nn.model.Rollout.validate, decided jointly: if ANY rank's launches clipped a value at the end of the fp16 range,
+        every rank recomputes its steps in "bf16x6" (the halo exchanges pair up again) and stays in that arithmetic."""
+        if ops.mlp_precision() != "f16x3" or self.exact_range or self.device.type != "cuda":
+            return False
+        hit = ops.f16_range_report(self.device, sites=self._sites)
+        clipped = bool(hit)
+        import torch.distributed as dist
+        if self.world > 1 and dist.is_available() and dist.is_initialized():
+            flag = torch.tensor([1 if clipped else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=getattr(self.fwd.xch, "group", None))
+            clipped = int(flag.item()) != 0
+        if not clipped:
+            return False
+        import warnings
+        n = self.steps_done
+        warnings.warn(f"DistributedRollout (rank {self.rank}): the default 'f16x3' MLP arithmetic reached the end of the fp16 range "
+                      f"(|x| >= 65504){' in ' + ', '.join(hit[:8]) if hit else ' on another rank'}: the {n} step(s) were recomputed in "
+                      "'bf16x6' (fp32's exponent range) and this rollout continues in it.", RuntimeWarning, stacklevel=3)
+        self.exact_range = True
+        self.field.copy_(self._field0)
+        self.step_counter.zero_()
+        self._hipgraph, self._epoch = None, -1
+        self.steps_done = 0
+        self.run(n)
+        return True
+
+    def _step(self) -> None:
         with torch.no_grad():
             if self._epoch != -1 and ops.weights_epoch() != self._epoch:
                 # (as nn.model.Rollout: the weights changed — load_state_dict, fit, invalidate_packed — so the captured step's packed
                 # images are stale or freed; one eager step repacks, then the step is captured again.  Every rank sees the same
                 # epoch sequence as long as every rank updates its replica of the model, which a partitioned rollout requires anyway)
+                self._hipgraph, self._epoch = None, -1
+            elif self._hipgraph is not None and self.static.stale():
+                # (a per-mesh constant edited in place, or another arithmetic: as nn.model.Rollout — and, like new weights, something
+                # every rank has to do alike, or a replaying rank would pair its captured collectives with an eager rank's)
                 self._hipgraph, self._epoch = None, -1
             if self.steps_done == 0 or not self.capture or self._epoch == -1:
                 self._one()
@@ -628,12 +672,11 @@ class DistributedRollout:
 
     def gather_outputs(self) -> torch.Tensor:
         import torch.distributed as dist
+        self.validate()          # (a clipped rollout is recomputed in "bf16x6" on every rank before anything is gathered)
         full = torch.zeros((self.n_global, self.outputs.size(1)), dtype=torch.float32, device=self.device)
         full[self.mesh.owned_global[0]] = self.outputs
         if self.world > 1:
             dist.all_reduce(full)
-        if ops.mlp_precision() == "f16x3":
-            ops.check_f16_range(self.device, f"DistributedRollout (rank {self.rank})", sites=self._sites)
         if self._perm is not None:        # rows back in the caller's numbering
             out = torch.empty_like(full)
             out[self._perm] = full

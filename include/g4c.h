@@ -125,8 +125,10 @@ typedef struct {
                            positions in seg_perm, which holds the row numbers (pool_edge's fine -> coarse edge plan,
                            nn/blocks.py:67: the pooled coarse edge latents are formed while the first coarse edge MLP gathers them). */
     int32_t dtype;      /* G4C_DTYPE_F32 (0): the rows are fp32.  G4C_DTYPE_BF16 (1), rounded-bf16 mode only (g4c_mlp_forward_bf16*),
-                           additive == 0, width 128, no seg_off: the rows are bf16 (ptr is a bf16 pointer, ld / col0 in elements) — the
-                           message rows a g4c_mlp_forward_bf16_agg launch stored with out_dtype = G4C_DTYPE_BF16. */
+                           width 128, no seg_off: the rows are bf16 (ptr is a bf16 pointer, ld / col0 in elements) — additive == 0: the
+                           message rows a g4c_mlp_forward_bf16_agg launch stored with out_dtype = G4C_DTYPE_BF16; additive == 1 (round 5):
+                           the first-layer products a g4c_mlp_forward_heads_bf16_out / g4c_mlp_forward_bf16_out launch stored as bf16
+                           (widened exactly and added to the fp32 accumulators: half the bytes of the largest gather stream). */
 } g4c_src_t;
 
 typedef struct {
@@ -300,6 +302,21 @@ int g4c_mlp_forward_heads_bf16(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *s
                                int64_t n_rows, float *out, int32_t out_ld, int32_t act,
                                const void *head_w, int32_t n_heads, float *const *head_out /*host*/, int32_t head_ld,
                                void *stream);
+
+/* Round 5, rounded-bf16 mode (BASELINE config 3): the first-layer products of a hoisted message MLP stored as bf16.  A product row
+ * is a pre-activation term of a layer whose operands are already rounded to bf16 (relative 2^-9 each); stored as bf16 it is rounded
+ * once more at the same relative size, and REMuS-GNN's level-1 angle launch — 2.5 M rows, two gathered product rows each, the
+ * launch's largest stream — reads half the bytes (nn/blocks.py:322-333: the `torch.cat` of gathered sender / receiver rows it
+ * replaces).  g4c_mlp_forward_heads_bf16_out = g4c_mlp_forward_heads_bf16 with head_dtype: G4C_DTYPE_BF16 stores the head rows as
+ * bf16 (head_out are then bf16 pointers, head_ld in elements, even).  g4c_mlp_forward_bf16_out = g4c_mlp_forward_bf16 (no output
+ * index / residual) with out_dtype: G4C_DTYPE_BF16 stores the output rows as bf16 (a 128-wide output, out_ld a multiple of 4, out
+ * 8-byte aligned) — the launch that multiplies the node-side inputs by their block of the first layer when no producer emitted them. */
+int g4c_mlp_forward_heads_bf16_out(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
+                                   int64_t n_rows, float *out, int32_t out_ld, int32_t act,
+                                   const void *head_w, int32_t n_heads, void *const *head_out /*host*/, int32_t head_ld,
+                                   int32_t head_dtype, void *stream);
+int g4c_mlp_forward_bf16_out(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
+                             int64_t n_rows, void *out, int32_t out_ld, int32_t out_dtype, int32_t act, void *stream);
 
 /* ---------------------------------------------------------------- REMuS helpers (HBM-bound)
  * out[e, f] = v[node[e], 2f]*U[e,0] + v[node[e], 2f+1]*U[e,1]

@@ -1369,12 +1369,14 @@ def test_ws_persistent_kernel_repeated_launches_are_identical(variant):
 
 
 # ------------------------------------------------------------------ the fp16 range of the default arithmetic is observable
-def test_f16_range_clip_is_reported_and_bf16x6_matches_the_oracle():
+def test_f16_range_clip_recomputes_in_bf16x6_and_matches_the_oracle():
     """Adversarial WEIGHTS, normal inputs: the LayerNorm gain of the first MP layer's message MLP x 3e4 puts its output latents
-    (|e'| up to ~1e5) beyond the fp16 range.  The reference computes in fp32 (nn/model.py:303-321).  In the default "f16x3" arithmetic
-    the launches that convert those latents clip them at 65504 — solve() must say so (RuntimeWarning naming the MLPs; nothing is
-    silent), and nothing may be reported for an ordinary model.  In "bf16x6" (fp32 exponent range) the result matches the oracle."""
+    (|e'| up to ~1e5) beyond the fp16 range.  The reference computes in fp32 (nn/model.py:303-321).  The default "f16x3" arithmetic
+    runs optimistically: the launches that convert those latents flag the clip, and solve() then recomputes the rollout in "bf16x6"
+    (fp32 exponent range) before it returns — with a RuntimeWarning naming the MLPs, nothing silent — so its result IS the bf16x6
+    result, bit for bit, and matches the oracle.  Nothing may be reported or recomputed for an ordinary model."""
     import warnings
+    from graphs4cfd_amd.nn.model import Rollout
     g = S.mus_graph(3000, levels=2, seed=3)
     torch.manual_seed(4)
     model = gfd.nn.NsTwoScaleGNN(arch=S.mus_arch("NsTwoScaleGNN", 128), device=DEV)
@@ -1382,25 +1384,73 @@ def test_f16_range_clip_is_reported_and_bf16x6_matches_the_oracle():
     try:
         ops.f16_range_report()                                  # (clear what earlier tests may have left)
         with warnings.catch_warnings():
-            warnings.simplefilter("error", RuntimeWarning)      # an ordinary model: no clip, no warning
+            warnings.simplefilter("error", RuntimeWarning)      # an ordinary model: no clip, no warning, no second pass
             model.solve(g.clone(), 2)
         assert ops.f16_range_report() == []
         with torch.no_grad():
             model.mp111.edge_mlp.MLP.layer_norm.weight.mul_(3e4)
         model.invalidate_packed()
         w = {k: v.cpu() for k, v in model.state_dict().items()}
-        ref = O.mus_solve("NsTwoScaleGNN", g.to_dict(), w, 2, model.num_fields)
-        with pytest.warns(RuntimeWarning, match="clipped values at the end of the fp16 range") as rec:
-            out16 = model.solve(g.clone(), 2)
-        assert any("NsTwoScaleGNN.mp11" in str(r.message) for r in rec), [str(r.message) for r in rec]
-        assert torch.isfinite(out16).all()                      # clipped, not inf / NaN
-        assert ops.f16_range_report() == []                     # reported once, then cleared
+        ref = O.mus_solve("NsTwoScaleGNN", g.to_dict(), w, 5, model.num_fields)
+        for capture in (False, True):                           # (5 steps: eager, captured, three replays)
+            with pytest.warns(RuntimeWarning, match="recomputed in 'bf16x6'") as rec:
+                out16 = model.solve(g.clone(), 5, capture=capture)
+            assert any("NsTwoScaleGNN.mp11" in str(r.message) for r in rec), [str(r.message) for r in rec]
+            assert ops.f16_range_report() == []                 # read once, then cleared
+            torch.testing.assert_close(out16.cpu(), ref, rtol=2e-3, atol=2e-3)
+            ops.set_mlp_precision("bf16x6")
+            with warnings.catch_warnings():
+                warnings.simplefilter("error", RuntimeWarning)
+                out = model.solve(g.clone(), 5, capture=capture)
+            ops.set_mlp_precision("f16x3")
+            assert torch.equal(out16, out), (out16 - out).abs().max().item()
+        # a rollout object that clipped stays in the exact-range arithmetic: later steps need no second pass
+        gd = g.clone().to(DEV)
+        gd.batch = torch.zeros(gd.num_nodes, dtype=torch.long, device=DEV)
+        with Rollout(model, gd, 6, capture=True, reorder=False) as ro:
+            ro.run(3)
+            with pytest.warns(RuntimeWarning, match="recomputed in 'bf16x6'"):
+                assert ro.validate() and ro.exact_range
+            ro.run(3)
+            with warnings.catch_warnings():
+                warnings.simplefilter("error", RuntimeWarning)
+                got = ro.result().clone()
         ops.set_mlp_precision("bf16x6")
-        model.invalidate_packed()
-        with warnings.catch_warnings():
-            warnings.simplefilter("error", RuntimeWarning)
-            out = model.solve(g.clone(), 2)
-        torch.testing.assert_close(out.cpu(), ref, rtol=2e-3, atol=2e-3)
+        ref6 = model.solve(g.clone(), 6, capture=True)
+        assert torch.equal(got, ref6)
+    finally:
+        ops.set_mlp_precision(old)
+
+
+def test_f16x3_is_range_safe_for_huge_and_tiny_input_rows():
+    """inputs far outside the fp16 range.  A field scaled by 1e5 makes the first hidden activations of the node
+    encoder ~1e5; scaled by 1e30 everything downstream is astronomically large.  The reference computes in fp32.  solve() in the
+    default arithmetic must return what "bf16x6" returns (it recomputes in it: bit-equal), finite, with a warning; a field scaled by
+    1e-6 (tiny rows) must NOT need the second pass and must agree with "bf16x6" to fp32 round-off."""
+    import warnings
+    torch.manual_seed(5)
+    model = gfd.nn.NsOneScaleGNN(arch=S.mus_arch("NsOneScaleGNN", 128), device=DEV)
+    old = ops.set_mlp_precision("f16x3")
+    try:
+        for scale, second_pass in ((1e5, True), (1e30, True), (1e-6, False)):
+            g = S.mus_graph(2000, levels=1, seed=6)
+            g.field = g.field * scale
+            ops.f16_range_report()
+            ops.set_mlp_precision("f16x3")
+            with warnings.catch_warnings(record=True) as rec:
+                warnings.simplefilter("always")
+                out = model.solve(g.clone(), 3)
+            redone = any("recomputed in 'bf16x6'" in str(r.message) for r in rec)
+            assert redone == second_pass, (scale, [str(r.message) for r in rec])
+            ops.set_mlp_precision("bf16x6")
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")          # (solve() notes inputs beyond 4096 in either arithmetic)
+                ref = model.solve(g.clone(), 3)
+            assert torch.isfinite(ref).all() and torch.isfinite(out).all(), scale
+            if second_pass:
+                assert torch.equal(out, ref), scale
+            else:
+                torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
     finally:
         ops.set_mlp_precision(old)
 
@@ -1485,6 +1535,25 @@ def test_static_encoder_cache_is_bit_identical_and_invalidates(family):
     att.mul_(1.5)
     b, _ = _manual_rollout(model, g, last, 2)
     assert torch.equal(got, torch.cat([a, b], dim=1))
+    # ... and by a CAPTURED rollout: the replayed step contains neither the encoder launches nor a look-up, so the
+    # rollout checks its cache before every replay, runs one eager step when an entry is stale and captures again
+    att.copy_(att0)
+    g.field = f0.clone()
+    with Rollout(model, g, 6, capture=True, reorder=False) as ro:
+        ro.run(3)                                # eager, captured, replayed
+        assert ro._hipgraph is not None
+        att.mul_(1.5)
+        ro.run(1)                                # stale: eager again
+        assert ro.static.misses == n_static + 1
+        ro.run(2)                                # captured again, replayed
+        assert ro._hipgraph is not None
+        got = ro.result().clone()
+    att.copy_(att0)
+    a, last = _manual_rollout(model, g, f0.clone(), 3)
+    att.mul_(1.5)
+    b, _ = _manual_rollout(model, g, last, 3)
+    assert torch.equal(got, torch.cat([a, b], dim=1))
+    att.copy_(att0)
 
 
 def test_f16_range_report_is_scoped_to_the_model_that_clipped():
