@@ -413,11 +413,37 @@ def roofline_blocks(args, result, model, graph_cpu, dev, ops, Rollout):
 def partition_check(args, runner, model, graph_cpu, dev, rank, world, Rollout):
     """Two partitioned steps against a single-rank rollout of the same mesh (rank 0 computes it), then one instrumented eager
     step: per-rank compute time, per-exchange time, halo bytes."""
+    import ctypes as C
     import torch.distributed as dist
+    from graphs4cfd_amd import _lib, ops
+    # ---- every rank first says where its launches go (VERDICT r04 item 6: ranks 1..N-1 run code paths a one-GPU box never executes —
+    # the DeviceGuard of every C entry point, the per-device range-flag buffers, the CU count the persistent grids are sized with) and
+    # the job stops, with the offending rank's own message, before anything is timed if a rank's buffers are not on ITS device
+    def where():
+        d_lib, d_cu = C.c_int32(-1), C.c_int32(-1)
+        _lib.check(_lib.load().g4c_device_info(runner.field.data_ptr(), C.byref(d_lib), C.byref(d_cu)))
+        flags = ops._range_bufs.get(ops._indexed(dev))
+        other = [str(d) for d in ops._range_bufs if d != ops._indexed(dev)]          # flag buffers this process made on ANOTHER device
+        m = {"rank": rank, "device": str(dev), "torch_current_device": int(torch.cuda.current_device()), "library_device": int(d_lib.value),
+             "cu_count": int(d_cu.value), "field_device": str(runner.field.device),
+             "range_flags_device": None if flags is None else str(flags.device), "range_flags_elsewhere": other,
+             "weights_device": str(next(model.parameters()).device)}
+        wrong = [k for k in ("field_device", "range_flags_device", "weights_device") if m[k] not in (None, str(dev))]
+        if m["library_device"] != dev.index or m["torch_current_device"] != dev.index or other:
+            wrong.append("library_device / torch_current_device / range_flags_elsewhere")
+        m["ok"] = not wrong
+        everyone = [None] * world
+        dist.all_gather_object(everyone, m)
+        if any(not x["ok"] for x in everyone):
+            raise SystemExit("partition_check: a rank's buffers / launches are not on its own device: " +
+                             "; ".join(json.dumps(x) for x in everyone if not x["ok"]))
+        return everyone
+    where()                                     # (before the first launch: model, field, library)
     runner.run(2)                               # step 1 eager, step 2 captured (or eager when capture is off / failed)
+    everyone = where()                          # (after it: the range-flag buffers exist now)
     full = runner.gather_outputs()              # [N, nf * max_steps] on every rank
     nf = runner.nf
-    out = {"steps": 2, "tol": 5e-4, "capture": bool(runner.capture), "capture_note": runner.capture_error}
+    out = {"steps": 2, "tol": 5e-4, "capture": bool(runner.capture), "capture_note": runner.capture_error, "devices": everyone}
     if rank == 0:
         single = Rollout(model, graph_cpu.clone().to(dev), 2, capture=False)
         single.run(2)

@@ -51,6 +51,7 @@ class g4c_mlp_t(C.Structure):
 
 _SIGNATURES = {
     "g4c_version": (C.c_int, []),
+    "g4c_device_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "g4c_last_error": (C.c_char_p, []),
     "g4c_plan_csr": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "g4c_plan_pool_edge": (C.c_int64, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
@@ -80,6 +81,10 @@ _SIGNATURES = {
                                             C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "g4c_mlp_forward_heads_bf16_out": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
                                                  C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
+    "g4c_mp_layer_forward_bx6": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                           C.POINTER(g4c_mlp_t), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                           C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "g4c_mlp_forward_bf16_out": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_void_p]),
     "g4c_plan_tiles": (C.c_int64, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]),

@@ -34,4 +34,13 @@ int cu_count() {
 }  // namespace g4c
 
 extern "C" int g4c_version(void) { return 1; }
+extern "C" int g4c_device_info(const void *device_ptr, int32_t *device, int32_t *cu_count) {
+    G4C_REQUIRE(device_ptr && device && cu_count, G4C_EINVAL, "g4c_device_info: null pointer");
+    g4c::DeviceGuard on_device(device_ptr);
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); g4c::set_error("g4c_device_info: hipGetDevice failed"); return G4C_ELAUNCH; }
+    *device = dev;
+    *cu_count = g4c::cu_count();
+    return G4C_OK;
+}
 extern "C" const char *g4c_last_error(void) { return g4c::g_err; }

@@ -73,7 +73,9 @@ __device__ __forceinline__ mean_f32x4 mean_div4(mean_f32x4 a, int count) {
     for (int e = 0; e < 4; ++e) {
         const float q0 = a[e] * y;
         q[e] = fmaf(fmaf(-c, q0, a[e]), y, q0);
-        rare |= !(fabsf(q[e]) >= 0x1p-100f);            // (true for NaN as well)
+        // (true for NaN as well; a numerator of +0 — an empty segment, a padding row — gives the exact quotient +0 on the fast path and
+        // must not send the whole wave down the slow one)
+        rare |= (__builtin_bit_cast(unsigned, a[e]) != 0u) && !(fabsf(q[e]) >= 0x1p-100f);
     }
     if (__builtin_amdgcn_ballot_w64(rare) != 0ull) {
 #pragma unroll

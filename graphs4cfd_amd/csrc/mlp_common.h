@@ -95,6 +95,27 @@ struct Params {
     int range_slot;
 };
 
+// The node update fused behind the message launch of an MP layer (g4c_mp_layer_forward_bx6, mlp_ws_kernel<.., NODE>): after its
+// last tile pair a workgroup runs the node MLP ([aggregate | v] -> Linear/SELU chain -> LayerNorm -> activation, + heads) on the targets
+// whose aggregates it has just written.  Same depth as the message MLP; f16x3 stream; blocks of the stream in the order
+// [aggregate, v], layer 2, (layer 3), heads.
+struct NodeParams {
+    const float *v;          // [n_targets, v_ld] node latents (input block 1; block 0 is the aggregate the message phase wrote to Params::agg)
+    int v_ld;
+    const float *w;          // packed stream of the node MLP (heads continue it)
+    const float *b;          // [n_layers][128]
+    const float *gamma, *beta;
+    float eps;
+    int act;
+    float *out;              // v' [n_targets, out_ld]
+    int out_ld;
+    int n_heads;
+    float *head_out[G4C_MAX_HEADS];
+    int head_ld;
+    int *range_flag;
+    int range_slot;
+};
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int HB = 128 + 8;                 // LDS row stride of a bf16 operand plane (272 B: conflict-free ds_read_b128)
@@ -286,8 +307,8 @@ int bx6i_launch(const Params &p, bool agg, bool f16x2, hipStream_t st);
 
 // weight-stationary persistent kernel (mlp_ws.hip): f16x3 stream only
 int ws_enable(int on);
-bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count);
-int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st);
+bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count, bool any_size = false);
+int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st, const NodeParams *node = nullptr);
 
 // four bf16 values (two dwords as loaded) widened to fp32: a shift / a mask each — exact
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));

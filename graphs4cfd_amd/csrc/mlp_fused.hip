@@ -1257,12 +1257,24 @@ struct AggArgs {           // fused aggregation (g4c_mlp_forward_bx6_agg); all n
 // rounded-bf16 mode, plain / heads launches: bf16 output rows (g4c_mlp_forward_bf16_out) and bf16 head rows (g4c_mlp_forward_heads_bf16_out)
 static thread_local int g_out_dtype = 0, g_head_dtype = 0;
 
+struct NodeArgs {          // the node update fused behind the message launch (g4c_mp_layer_forward_bx6)
+    const g4c_mlp_t *upd;
+    const float *v;
+    int32_t v_ld, act;
+    float *v_out;
+    int32_t v_out_ld;
+    const void *head_w;
+    int32_t n_heads;
+    float *const *head_out;
+    int32_t head_ld;
+};
+
 static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                       int64_t row_begin, int64_t row_count, int32_t tile_rows,
                       float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                       const float *resid, int32_t resid_ld, int32_t resid_col0,
                       const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream,
-                      const AggArgs *agg = nullptr, const SaveArgs *save = nullptr);
+                      const AggArgs *agg = nullptr, const SaveArgs *save = nullptr, const NodeArgs *node = nullptr);
 
 extern "C" int g4c_mlp_forward_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                     int64_t row_begin, int64_t row_count, int32_t tile_rows,
@@ -1336,6 +1348,19 @@ extern "C" int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp, const g4c_src_t *sr
                       nullptr, 0, nullptr, 0, stream, &a);
 }
 
+extern "C" int g4c_mp_layer_forward_bx6(const g4c_mlp_t *msg, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                                        float *e_out, int32_t e_ld,
+                                        const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,
+                                        float *agg, int32_t agg_ld, int32_t agg_mean,
+                                        const g4c_mlp_t *upd, const float *v, int32_t v_ld, int32_t act, float *v_out, int32_t v_out_ld,
+                                        const void *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream) {
+    G4C_REQUIRE(tile_rows && tile_seg && seg_off && agg && n_tiles >= 0 && agg_ld >= NP, G4C_EINVAL, "g4c_mp_layer_forward_bx6: bad aggregation plan");
+    const AggArgs a{tile_rows, tile_seg, seg_off, n_tiles, agg, agg_ld, agg_mean, 0};
+    const NodeArgs nd{upd, v, v_ld, act, v_out, v_out_ld, head_w, n_heads, head_out, head_ld};
+    return mlp_launch(msg, srcs, n_src, n_rows, 0, n_rows, 3248, e_out, e_ld ? e_ld : NP, nullptr, G4C_ACT_NONE, nullptr, 0, 0,
+                      nullptr, 0, nullptr, 0, stream, &a, nullptr, &nd);
+}
+
 extern "C" int g4c_mlp_forward_bf16_agg(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                         void *out, int32_t out_ld, int32_t out_dtype, int32_t act,
                                         const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,
@@ -1382,7 +1407,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
                       float *out, int32_t out_ld, const int32_t *out_idx, int32_t act,
                       const float *resid, int32_t resid_ld, int32_t resid_col0,
                       const float *head_w, int32_t n_heads, float *const *head_out, int32_t head_ld, void *stream,
-                      const AggArgs *agg, const SaveArgs *save) {
+                      const AggArgs *agg, const SaveArgs *save, const NodeArgs *node) {
     g_last_kernel = G4C_KERNEL_NONE;
     const bool force_tiles = (tile_rows == 3249) || (tile_rows == 3217);     // 3248 / 3216 on the 32-row-tile kernel only (tests, A/B)
     if (force_tiles) tile_rows -= 1;
@@ -1546,6 +1571,51 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     if (row_count == 0) return G4C_OK;
     p.row_base = row_begin;
     p.M = row_begin + row_count;          // rows past the range are neither gathered nor stored
+    if (node) {
+        // one launch per MP layer: the message MLP on the weight-stationary kernel, the node update behind it (mlp_ws.hip, NODE)
+        const g4c_mlp_t *u = node->upd;
+        G4C_REQUIRE(f16x2 && agg && agg->out && u && u->w_format == G4C_WFMT_F16X2, G4C_EUNSUPPORTED,
+                    "g4c_mp_layer_forward_bx6: both MLPs need the f16x3 stream (g4c_mlp_pack_layer_f16x3) and the aggregation plan");
+        G4C_REQUIRE(u->n_layers == mlp->n_layers && u->k_pad[0] == 2 * NP && u->n_out == NP && u->w[0] && u->b[0], G4C_EUNSUPPORTED,
+                    "g4c_mp_layer_forward_bx6: the node MLP must have the message MLP's depth (%d), two 128-wide input blocks and a 128-wide output",
+                    mlp->n_layers);
+        for (int l = 0; l < u->n_layers; ++l) {
+            G4C_REQUIRE(u->n_pad[l] == NP && (l == 0 || u->k_pad[l] == NP), G4C_EUNSUPPORTED, "g4c_mp_layer_forward_bx6: node layer %d is not 128 wide", l);
+            if (l > 0) G4C_REQUIRE((const char *)u->w[l] == (const char *)u->w[l - 1] + (size_t)u->k_pad[l - 1] * NP * 6 &&
+                                   (const float *)u->b[l] == (const float *)u->b[l - 1] + NP, G4C_EINVAL,
+                                   "g4c_mp_layer_forward_bx6: the node MLP's packed layers / biases must be contiguous (layer %d)", l);
+        }
+        G4C_REQUIRE((u->ln_gamma == nullptr) == (u->ln_beta == nullptr), G4C_EINVAL, "g4c_mp_layer_forward_bx6: LayerNorm needs both gamma and beta");
+        G4C_REQUIRE(!u->ln_gamma || (((uintptr_t)u->ln_gamma & 15) == 0 && ((uintptr_t)u->ln_beta & 15) == 0), G4C_EINVAL,
+                    "g4c_mp_layer_forward_bx6: LayerNorm parameters must be 16-byte aligned");
+        G4C_REQUIRE(node->v && node->v_out && (node->v_ld & 3) == 0 && node->v_ld >= NP && (node->v_out_ld & 3) == 0 && node->v_out_ld >= NP &&
+                    ((uintptr_t)node->v & 15) == 0 && ((uintptr_t)node->v_out & 15) == 0 && (agg->out_ld & 3) == 0 && ((uintptr_t)agg->out & 15) == 0,
+                    G4C_EINVAL, "g4c_mp_layer_forward_bx6: v / v_out / agg need 16-byte aligned rows of at least 128 columns");
+        G4C_REQUIRE(node->act >= 0 && node->act <= 2 && node->n_heads >= 0 && node->n_heads <= G4C_MAX_HEADS, G4C_EINVAL, "g4c_mp_layer_forward_bx6: bad activation / head count");
+        NodeParams q{};
+        q.v = node->v; q.v_ld = node->v_ld; q.w = (const float *)u->w[0]; q.b = (const float *)u->b[0];
+        q.gamma = u->ln_gamma; q.beta = u->ln_beta; q.eps = u->ln_eps; q.act = node->act;
+        q.out = node->v_out; q.out_ld = node->v_out_ld; q.n_heads = node->n_heads; q.head_ld = node->head_ld;
+        q.range_flag = u->range_flag; q.range_slot = u->range_slot;
+        G4C_REQUIRE(!q.range_flag || q.range_slot >= 0, G4C_EINVAL, "g4c_mp_layer_forward_bx6: negative range_slot");
+        for (int hd = 0; hd < G4C_MAX_HEADS; ++hd) q.head_out[hd] = nullptr;
+        if (node->n_heads) {
+            const int last = u->n_layers - 1;
+            G4C_REQUIRE(node->head_w && node->head_out && (const char *)node->head_w == (const char *)u->w[last] + (size_t)u->k_pad[last] * NP * 6, G4C_EINVAL,
+                        "g4c_mp_layer_forward_bx6: head weights must continue the node MLP's packed stream");
+            G4C_REQUIRE((node->head_ld & 3) == 0 && node->head_ld >= NP, G4C_EINVAL, "g4c_mp_layer_forward_bx6: head_ld must be a multiple of 4 and >= 128");
+            for (int hd = 0; hd < node->n_heads; ++hd) {
+                G4C_REQUIRE(node->head_out[hd] && ((uintptr_t)node->head_out[hd] & 15) == 0, G4C_EINVAL, "g4c_mp_layer_forward_bx6: bad head output %d", hd);
+                q.head_out[hd] = node->head_out[hd];
+            }
+        }
+        G4C_REQUIRE(ws_eligible(p, false, true, false, true, row_count, true), G4C_EUNSUPPORTED,
+                    "g4c_mp_layer_forward_bx6: the message launch is outside the weight-stationary kernel's envelope (one 128-wide weighted block, "
+                    "two 128-wide additive blocks, two or three 128-wide layers, aligned rows)");
+        p.n_tiles = agg->n_tiles;
+        g_last_kernel = G4C_KERNEL_MLP_WS;
+        return ws_launch(p, true, false, st, &q);
+    }
     if (bx6 && !force_tiles && ws_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
         // weight-stationary persistent kernel (mlp_ws.hip): pairs of 32-row tiles (whole segments with aggregation), one workgroup per CU
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);

@@ -305,10 +305,20 @@ __device__ __forceinline__ void other_all(const f32x4 (&accE)[2], const f32x4 (&
 // SP: 2 the f16x3 stream, 1 the rounded-bf16 mode;  NL: layers (2 or 3);  XB16 (SP = 1): the weighted block's rows are bf16;
 // AB16 (SP = 1): the additive rows are bf16 (the first-layer products a g4c_mlp_forward_heads_bf16_out / _bf16_out launch stored:
 // half the bytes of the launch's largest gather stream — REMuS-GNN's level-1 angle launch reads 2 x 2.5 M of them)
-template <bool AGG, bool DIRECT, bool ADDS, int SP, int NL, bool XB16, bool AB16 = false>
-__global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const int n_pairs) {
-    static_assert((SP == 1 || SP == 2) && (NL == 2 || NL == 3) && (SP == 1 || !XB16) && (SP == 1 || !AB16) && (ADDS || !AB16),
-                  "mlp_ws_kernel: unsupported instantiation");
+// NODE (SP = 2, with AGG): the node update of the MP layer fused behind the message launch (NodeParams, mlp_common.h): when its tile
+// pairs are done a workgroup holds, in L2, the aggregates of a contiguous range of targets that no other workgroup touches — it runs
+// the node MLP (same depth, weights streamed block by block: the message MLP's stationary registers are dead by then) on those
+// targets, 32 at a time, and stores v' and the heads.  One launch per MP layer instead of two (three with a separate aggregation):
+// small and medium levels are bound by the dependent chain of each launch, not by throughput.
+// Rounded-bf16 mode (SP = 1): one product per multiply-add and no low plane — the launch is bound by its LayerNorm / aggregation tails
+// and barriers, not by a pipe — so TWO workgroups per CU (four waves per SIMD, <= 128 registers; -DG4C_WS_SP1_MINW=2 restores one)
+#ifndef G4C_WS_SP1_MINW
+#define G4C_WS_SP1_MINW 2
+#endif
+template <bool AGG, bool DIRECT, bool ADDS, int SP, int NL, bool XB16, bool AB16 = false, bool NODE = false>
+__global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_kernel(const Params p, const int n_pairs, const NodeParams q) {
+    static_assert((SP == 1 || SP == 2) && (NL == 2 || NL == 3) && (SP == 1 || !XB16) && (SP == 1 || !AB16) && (ADDS || !AB16) &&
+                  (!NODE || (AGG && SP == 2)), "mlp_ws_kernel: unsupported instantiation");
     // an additive row piece as loaded: four fp32 values, or four bf16 values in two dwords (widened where they are added)
     typedef typename std::conditional<AB16, u32x2, f32x4>::type AddV;
     __shared__ __attribute__((aligned(16))) __bf16 sP[2 * TILE_BF16];      // operand planes of tiles A, B (34 816 B)
@@ -320,6 +330,8 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
     __shared__ __attribute__((aligned(16))) float sBias[3 * NP];
     __shared__ __attribute__((aligned(16))) float sGB[2 * NP];
     __shared__ __attribute__((aligned(16))) float sZero[NP];               // a row of zeros (the aggregation's padding rows)
+    __shared__ __attribute__((aligned(16))) float sBiasN[NODE ? 3 * NP : 4];    // NODE: the node MLP's biases and LayerNorm parameters
+    __shared__ __attribute__((aligned(16))) float sGBN[NODE ? 2 * NP : 4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -475,6 +487,13 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
     if (tid < NL * NP) sBias[tid] = p.b[tid];
     if (tid < NP) sZero[tid] = 0.f;
     if (tid < 2 * NP) sGB[tid] = p.gamma ? (tid < NP ? p.gamma[tid] : p.beta[tid - NP]) : 0.f;
+    int S0 = 0, S1 = 0;                   // NODE: this workgroup's targets = the segments of its tiles
+    if constexpr (NODE) {
+        if (tid < NL * NP) sBiasN[tid] = q.b[tid];
+        if (tid < 2 * NP) sGBN[tid] = q.gamma ? (tid < NP ? q.gamma[tid] : q.beta[tid - NP]) : 0.f;
+        const int t1 = 2 * p_end < p.n_tiles ? 2 * p_end : p.n_tiles;
+        S0 = __builtin_amdgcn_readfirstlane(p.tile_seg[2 * p_begin]); S1 = __builtin_amdgcn_readfirstlane(p.tile_seg[t1]);
+    }
     __syncthreads();
 
     const bool pact = p.src[0].pre_act != 0;
@@ -751,6 +770,236 @@ __global__ __launch_bounds__(512, 2) void mlp_ws_kernel(const Params p, const in
         WS_STAMP(10);
         m0 = m1; m1 = m2; m2 = fix_meta(m3raw);
     }
+
+    if constexpr (NODE) {
+        // ================================================================ node update of this workgroup's targets [S0, S1)
+        // The aggregates were written to p.agg by this workgroup's OWN waves (same CU, same write-through L1, lines nobody read before):
+        // workgroup scope is enough — the stores have left the waves (vmcnt) before the barrier.  (Agent scope costs a write-back of
+        // the XCD's L2 per workgroup: measured +23 us per launch.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(q.w), 0, 0x7fffffff, 0x00020000);
+        RangeV rngN;
+        const int n_blk = NL + 1 + q.n_heads;          // blocks of the node MLP's stream (a head block that does not exist is not fetched)
+        auto ld_block = [&](bf16x8 (&Wb)[4][SP], int blk) __attribute__((always_inline)) {
+            if (blk >= n_blk) return;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < SP; ++pl) Wb[ks][pl] = ldw(rq, lo_b + 1024u * pl, (unsigned)blk * 2u * BLOCK6 + (unsigned)ks * 4u * STEP6);
+        };
+        auto bias_n = [&](f32x4 (&acc)[2], f32x4 (&acc1)[2], int l) __attribute__((always_inline)) {
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (l >= 0) b4 = *reinterpret_cast<const f32x4 *>(sBiasN + l * NP + fcol);
+            acc[0] = b4; acc[1] = b4;
+            acc1[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        const int rowL = wave * 4 + g;                                   // LayerNorm / row-store layout: 16 lanes per row
+        const int cqn[2] = {n * 4, 64 + n * 4};
+        // LayerNorm / activation of the fp32 rows of one tile (rows [rb, rb + nrows) of the launch), stored from the registers; with
+        // heads the finished rows go back to the buffer (the heads' operand)
+        auto finish_rows = [&](float *frows, int rb, int nrows) __attribute__((always_inline)) {
+            float x[8];
+            float *const rowp = frows + rowL * HS;
+#pragma unroll
+            for (int c = 0; c < 8; c += 4) {
+                const f32x4 v4 = *reinterpret_cast<const f32x4 *>(rowp + cqn[c >> 2]);
+                x[c] = v4[0]; x[c + 1] = v4[1]; x[c + 2] = v4[2]; x[c + 3] = v4[3];
+            }
+            if (q.gamma) {
+                float sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) sum += x[c];
+                sum = row16_sum(sum);
+                const float mean = sum * (1.0f / NP);
+                float var = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { const float dl = x[c] - mean; var += dl * dl; }
+                var = row16_sum(var);
+                const float rstd = rsqrtf(var * (1.0f / NP) + q.eps);
+#pragma unroll
+                for (int c = 0; c < 8; c += 4) {
+                    const f32x4 g4 = *reinterpret_cast<const f32x4 *>(sGBN + cqn[c >> 2]), b4 = *reinterpret_cast<const f32x4 *>(sGBN + NP + cqn[c >> 2]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[c + u] = fmaf((x[c + u] - mean) * rstd, g4[u], b4[u]);
+                }
+            }
+            if (q.act == G4C_ACT_SELU) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) x[c] = g4c::selu_f(x[c]);
+            } else if (q.act == G4C_ACT_TANH) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) x[c] = g4c::tanh_f(x[c]);
+            }
+            f32x4 v0, v1;
+            v0[0] = x[0]; v0[1] = x[1]; v0[2] = x[2]; v0[3] = x[3]; v1[0] = x[4]; v1[1] = x[5]; v1[2] = x[6]; v1[3] = x[7];
+            if (q.n_heads) { *reinterpret_cast<f32x4 *>(rowp + cqn[0]) = v0; *reinterpret_cast<f32x4 *>(rowp + cqn[1]) = v1; }
+            if (rowL < nrows) {
+                float *op = q.out + (long long)(rb + rowL) * q.out_ld;
+                *reinterpret_cast<f32x4 *>(op + cqn[0]) = v0; *reinterpret_cast<f32x4 *>(op + cqn[1]) = v1;
+            }
+        };
+        auto store_head = [&](int hd, const float *frows, int rb, int nrows) __attribute__((always_inline)) {
+            if (rowL < nrows) {
+                const float *rowp = frows + rowL * HS;
+                float *op = q.head_out[hd] + (long long)(rb + rowL) * q.head_ld;
+                *reinterpret_cast<f32x4 *>(op + cqn[0]) = *reinterpret_cast<const f32x4 *>(rowp + cqn[0]);
+                *reinterpret_cast<f32x4 *>(op + cqn[1]) = *reinterpret_cast<const f32x4 *>(rowp + cqn[1]);
+            }
+        };
+        // rows [rb, rb + nrows) of a [., ld] tensor in the park layout (rows past the range: clamped copies)
+        auto load_rows = [&](const float *base, int ld, int rb, int nrows, f32x4 (&x)[2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int r = prow + 16 * hh;
+                x[hh] = *reinterpret_cast<const f32x4 *>(base + (long long)(rb + (r < nrows ? r : nrows - 1)) * ld + pc);
+            }
+        };
+        for (int r0 = S0; r0 < S1; r0 += 64) {
+            const int nr = (S1 - r0) < 64 ? (S1 - r0) : 64;
+            bf16x8 Wa[4][SP], Wb[4][SP];
+            ld_block(Wa, 0); ld_block(Wb, 1);
+            if (nr > 32) {
+                // ================================ two tiles (A: 32 rows, B: nr - 32): every matrix phase of one tile carries the other tile's
+                // vector work (park / epilogue / fp32 rows), as in the message loop; a block of weights serves both tiles
+                const int nB = nr - 32;
+                f32x4 ga[2], va[2], gb[2], vb[2];
+                load_rows(p.agg, p.agg_ld, r0, 32, ga); load_rows(p.agg, p.agg_ld, r0 + 32, nB, gb);
+                load_rows(q.v, q.v_ld, r0, 32, va); load_rows(q.v, q.v_ld, r0 + 32, nB, vb);
+                other_all<SP, 2, false>(accA, accA1, ga, oA, rngN);
+                other_all<SP, 2, false>(accA, accA1, gb, oB, rngN);
+                bias_n(accA, accA1, 0); bias_n(accB, accB1, 0);
+                __syncthreads();
+                m_block<SP, 0>(paA, Wa, accA, accA1, accA, accA1, ga, oA, rngN);                    // M(A, aggregate block)
+                __syncthreads();
+                m_block<SP, 2, false>(paB, Wa, accB, accB1, accB, accB1, va, oA, rngN);             // M(B, aggregate block); A's v rows -> A's planes
+                ld_block(Wa, 2);
+                __syncthreads();
+                m_block<SP, 2, false>(paA, Wb, accA, accA1, accA, accA1, vb, oB, rngN);             // M(A, v block); B's v rows -> B's planes
+                __syncthreads();
+                m_block<SP, 1>(paB, Wb, accB, accB1, accA, accA1, va, oA, rngN);                    // M(B, v block); A: epilogue of layer 0
+                ld_block(Wb, 3);
+                bias_n(accA, accA1, 1);
+                __syncthreads();
+                m_block<SP, 1>(paA, Wa, accA, accA1, accB, accB1, va, oB, rngN);                    // M(A, layer 1); B: epilogue of layer 0
+                bias_n(accB, accB1, 1);
+                __syncthreads();
+                if constexpr (NL == 3) {
+                    m_block<SP, 1>(paB, Wa, accB, accB1, accA, accA1, va, oA, rngN);                // M(B, layer 1); A: epilogue of layer 1
+                    ld_block(Wa, 4);
+                    bias_n(accA, accA1, 2);
+                    __syncthreads();
+                    m_block<SP, 1>(paA, Wb, accA, accA1, accB, accB1, va, oB, rngN);                // M(A, layer 2); B: epilogue of layer 1
+                    bias_n(accB, accB1, 2);
+                    __syncthreads();
+                    m_block<SP, 3>(paB, Wb, accB, accB1, accA, accA1, va, oA, rngN);                // M(B, layer 2); A: fp32 rows
+                    ld_block(Wb, 5);
+                } else {
+                    m_block<SP, 3>(paB, Wa, accB, accB1, accA, accA1, va, oA, rngN);                // M(B, layer 1); A: fp32 rows
+                    ld_block(Wa, 4);
+                }
+                other_all<SP, 3, false>(accB, accB1, va, oB, rngN);                                 // B: fp32 rows
+                __syncthreads();
+                finish_rows(fA, r0, 32);
+                finish_rows(fB, r0 + 32, nB);
+                if (q.n_heads) {
+                    __syncthreads();
+                    f32x4 ha[2], hb[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        ha[hh] = *reinterpret_cast<const f32x4 *>(fA + (prow + 16 * hh) * HS + pc);
+                        hb[hh] = *reinterpret_cast<const f32x4 *>(fB + (prow + 16 * hh) * HS + pc);
+                    }
+                    other_all<SP, 2, false>(accA, accA1, ha, oA, rngN);
+                    other_all<SP, 2, false>(accA, accA1, hb, oB, rngN);
+                    bias_n(accA, accA1, -1); bias_n(accB, accB1, -1);
+                    __syncthreads();
+                    // (NL == 3: head 0 = block 4 in Wa, head 1 = block 5 in Wb;  NL == 2: head 0 = block 3 in Wb, head 1 = block 4 in Wa)
+                    auto &H0 = (NL == 3) ? Wa : Wb;
+                    auto &H1 = (NL == 3) ? Wb : Wa;
+                    m_block<SP, 0>(paA, H0, accA, accA1, accA, accA1, va, oA, rngN);                // head 0 of A
+                    m_block<SP, 3>(paB, H0, accB, accB1, accA, accA1, va, oA, rngN);                // head 0 of B; A's head rows -> fA
+                    bias_n(accA, accA1, -1);
+                    __syncthreads();
+                    store_head(0, fA, r0, 32);
+                    if (q.n_heads > 1) {
+                        m_block<SP, 3>(paA, H1, accA, accA1, accB, accB1, va, oB, rngN);            // head 1 of A; B's head-0 rows -> fB
+                        bias_n(accB, accB1, -1);
+                        __syncthreads();
+                        store_head(0, fB, r0 + 32, nB);
+                        m_block<SP, 3>(paB, H1, accB, accB1, accA, accA1, va, oA, rngN);            // head 1 of B; A's head-1 rows -> fA
+                        __syncthreads();
+                        store_head(1, fA, r0, 32);
+                        other_all<SP, 3, false>(accB, accB1, va, oB, rngN);
+                        __syncthreads();
+                        store_head(1, fB, r0 + 32, nB);
+                    } else {
+                        other_all<SP, 3, false>(accB, accB1, va, oB, rngN);
+                        __syncthreads();
+                        store_head(0, fB, r0 + 32, nB);
+                    }
+                }
+                __syncthreads();          // the next tiles overwrite the planes and the fp32 rows
+                continue;
+            }
+            // ================================ one tile (nr <= 32 rows)
+            f32x4 xa[2], xv[2];
+            load_rows(p.agg, p.agg_ld, r0, nr, xa);
+            load_rows(q.v, q.v_ld, r0, nr, xv);
+            other_all<SP, 2, false>(accA, accA1, xa, oA, rngN);          // the aggregate rows -> A's planes
+            other_all<SP, 2, false>(accA, accA1, xv, oB, rngN);          // the node rows -> B's planes
+            bias_n(accA, accA1, 0);
+            __syncthreads();
+            m_block<SP, 0>(paA, Wa, accA, accA1, accA, accA1, xa, oA, rngN);
+            ld_block(Wa, 2);
+            m_block<SP, 0>(paB, Wb, accA, accA1, accA, accA1, xa, oA, rngN);
+            ld_block(Wb, 3);
+            __syncthreads();                                              // everybody has read both sets of planes
+            other_all<SP, 1, false>(accA, accA1, xa, oA, rngN);          // layer 0's epilogue -> A's planes
+            bias_n(accA, accA1, 1);
+            __syncthreads();
+            m_block<SP, 0>(paA, Wa, accA, accA1, accA, accA1, xa, oA, rngN);
+            if constexpr (NL == 3) {
+                ld_block(Wa, 4);
+                other_all<SP, 1, false>(accA, accA1, xa, oB, rngN);      // layer 1's epilogue -> B's planes (nobody reads them in this phase)
+                bias_n(accA, accA1, 2);
+                __syncthreads();
+                m_block<SP, 0>(paB, Wb, accA, accA1, accA, accA1, xa, oA, rngN);
+                ld_block(Wb, 5);
+            } else {
+                ld_block(Wa, 4);          // (NL == 2: blocks 3, 4 are the heads — Wb holds block 3 already)
+            }
+            other_all<SP, 3, false>(accA, accA1, xa, oA, rngN);          // the last layer's fp32 rows -> fA
+            __syncthreads();
+            finish_rows(fA, r0, nr);
+            if (q.n_heads) {
+                // ---- heads: v' rows -> A's planes, one 128-k block per head, fp32 rows through fB / fA, whole-row stores
+                __syncthreads();
+                f32x4 xh[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) xh[hh] = *reinterpret_cast<const f32x4 *>(fA + (prow + 16 * hh) * HS + pc);
+                other_all<SP, 2, false>(accA, accA1, xh, oA, rngN);
+                bias_n(accA, accA1, -1);
+                bias_n(accB, accB1, -1);
+                __syncthreads();
+                auto &H0 = (NL == 3) ? Wa : Wb;
+                auto &H1 = (NL == 3) ? Wb : Wa;
+                m_block<SP, 0>(paA, H0, accA, accA1, accA, accA1, xa, oA, rngN);
+                if (q.n_heads > 1) m_block<SP, 0>(paA, H1, accB, accB1, accA, accA1, xa, oA, rngN);
+                other_all<SP, 3, false>(accA, accA1, xa, oB, rngN);      // head 0 -> fB
+                other_all<SP, 3, false>(accB, accB1, xa, oA, rngN);      // head 1 -> fA (its rows are in the planes)
+                __syncthreads();
+                store_head(0, fB, r0, nr);
+                if (q.n_heads > 1) store_head(1, fA, r0, nr);
+            }
+            __syncthreads();          // the next tile overwrites the planes and the fp32 rows
+        }
+        if (G4C_WS_SCALED && !(G4C_WS_ABLATE & 48)) rngN.m *= F16_LO_UNSCALE;
+        if (q.range_flag && range_hit(rngN)) {
+            if ((threadIdx.x & 63) == 0) q.range_flag[q.range_slot] = 1;
+        }
+    }
     WS_STAMP_ONCE(13, __builtin_readcyclecounter());
     if (SP == 2) {
         if (G4C_WS_SCALED && !(G4C_WS_ABLATE & 48)) rng.m *= F16_LO_UNSCALE;       // (tracked in units of 2^-11)
@@ -773,9 +1022,9 @@ int ws_enable(int on) {
     return old;
 }
 
-bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count) {
+bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count, bool any_size) {
     constexpr long long min_rows = 20000;          // (same-box sweeps of round 3: ahead of the tile kernel from ~20 k rows)
-    const int mode = ws_enable(-1);
+    const int mode = any_size ? 2 : ws_enable(-1);          // (any_size: the fused MP layer asks whether the SHAPE fits, whatever the mode)
     if (!mode || save || !(f16x2 || round1)) return false;          // (the bf16x6 stream keeps mlp_bx6i_kernel / mlp_bx6_kernel)
     if (mode == 1 && row_count < min_rows) return false;
     if (p.n_src != 1 || p.n_nar != 0 || (p.n_add != 0 && p.n_add != 2) || p.n_heads) return false;
@@ -795,17 +1044,27 @@ bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, 
     return true;
 }
 
-int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st) {
+int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st, const NodeParams *node) {
     const int n_pairs = (p.n_tiles + 1) / 2;
     if (n_pairs == 0) return G4C_OK;
-    const int n_cu = g4c::cu_count();
-    const dim3 grid(n_pairs < n_cu ? n_pairs : n_cu), blk(512);
+    const int n_wg = g4c::cu_count() * (round1 ? G4C_WS_SP1_MINW / 2 : 1);          // persistent workgroups: one (SP = 1: G4C_WS_SP1_MINW / 2) per CU
+    const dim3 grid(n_pairs < n_wg ? n_pairs : n_wg), blk(512);
     const bool direct = p.src[0].idx == nullptr, adds = p.n_add == 2, two = p.n_layers == 2, xb16 = p.src[0].bf16 != 0;
     const bool ab16 = adds && p.add[0].bf16 != 0;
-#define G4C_WS_GO(AGG, DIRECT, ADDS, SP, NL, XB16) mlp_ws_kernel<AGG, DIRECT, ADDS, SP, NL, XB16><<<grid, blk, 0, st>>>(p, n_pairs)
+    NodeParams q{};
+    if (node) {          // the fused MP layer (g4c_mp_layer_forward_bx6): f16x3 stream, hoisted message MLP, fused aggregation
+        G4C_REQUIRE(agg && !round1 && adds, G4C_EUNSUPPORTED, "g4c_mp_layer_forward_bx6: needs the hoisted f16x3 message launch with the fused aggregation");
+        q = *node;
+#define G4C_WS_NODE(DIRECT, NL) mlp_ws_kernel<true, DIRECT, true, 2, NL, false, false, true><<<grid, blk, 0, st>>>(p, n_pairs, q)
+        if (direct) { if (two) G4C_WS_NODE(true, 2); else G4C_WS_NODE(true, 3); }
+        else { if (two) G4C_WS_NODE(false, 2); else G4C_WS_NODE(false, 3); }
+#undef G4C_WS_NODE
+        return g4c::check_launch("g4c_mp_layer_forward_bx6");
+    }
+#define G4C_WS_GO(AGG, DIRECT, ADDS, SP, NL, XB16) mlp_ws_kernel<AGG, DIRECT, ADDS, SP, NL, XB16><<<grid, blk, 0, st>>>(p, n_pairs, q)
 #define G4C_WS_GO1(AGG, DIRECT, NL, XB16)                                                            \
-    do { if (ab16) mlp_ws_kernel<AGG, DIRECT, true, 1, NL, XB16, true><<<grid, blk, 0, st>>>(p, n_pairs);       \
-         else mlp_ws_kernel<AGG, DIRECT, true, 1, NL, XB16, false><<<grid, blk, 0, st>>>(p, n_pairs); } while (0)
+    do { if (ab16) mlp_ws_kernel<AGG, DIRECT, true, 1, NL, XB16, true><<<grid, blk, 0, st>>>(p, n_pairs, q);       \
+         else mlp_ws_kernel<AGG, DIRECT, true, 1, NL, XB16, false><<<grid, blk, 0, st>>>(p, n_pairs, q); } while (0)
 #define G4C_WS_SHAPE(AGG, DIRECT)                                                                    \
     do {                                                                                             \
         if (round1) {                                                                                \

@@ -252,6 +252,33 @@ class MLP(nn.Module):
         pk = self.packed([s.width for s in sources], [s.negate for s in sources], _narrow_flags(sources))
         return ops.mlp_forward(pk, sources, n_rows, act_code, **kw)
 
+    def _heads_packed(self, seg_widths: Sequence[int], consumer: "MLP", k_cols: int, widths: Sequence[int]) -> Optional[ops.PackedMLP]:
+        """This MLP (plain 128-wide input blocks `seg_widths`) packed with heads = the column blocks `widths` behind the first `k_cols`
+        columns of `consumer`'s first layer (see run_with_heads; same cache entry)."""
+        if self.output_size != 128 or any(int(w) != 128 for w in widths) or not 1 <= len(widths) <= _lib.MAX_HEADS or not self.fits_one_launch():
+            return None
+        prec = ops.effective_precision(seg_widths)
+        narrow = (False,) * len(seg_widths)
+        key = ("heads", id(consumer), k_cols, tuple(widths), tuple(seg_widths), (False,) * len(seg_widths), prec, narrow)
+        sig = (self._signature(), consumer._signature())
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != sig:
+            lin = self._linears()
+            ln = getattr(self.MLP, "layer_norm", None)
+            w1 = consumer._linears()[0].weight.detach()
+            if int(w1.size(0)) != 128:
+                return None
+            heads, off = [], k_cols
+            for w in widths:
+                heads.append(w1[:, off:off + w].contiguous())
+                off += w
+            pk = ops.PackedMLP([l.weight for l in lin], [l.bias for l in lin],
+                               None if ln is None else (ln.weight, ln.bias, ln.eps), key[4], key[5], heads=heads, precision=prec,
+                               narrow=narrow, site=self._site)
+            self._packed[key] = (sig, pk)
+            hit = self._packed[key]
+        return hit[1]
+
     def run_with_heads(self, sources: Sequence[Source], n_rows: int, act_code: int, consumer: "MLP", k_cols: int,
                        widths: Sequence[int], out: Optional[Tensor] = None,
                        head_outs: Optional[Sequence[Optional[Tensor]]] = None) -> Optional[Tuple[Tensor, List[Tensor]]]:
@@ -293,9 +320,11 @@ class MLP(nn.Module):
         pk = hit[1]
         dev = sources[0].tensor.device
         y = out if out is not None else torch.empty((n_rows, 128), dtype=torch.float32, device=dev)
+        given = [t for t in (head_outs or ()) if t is not None]
+        hdt = given[0].dtype if given else (torch.bfloat16 if (prec == "bf16" and PRODUCTS_BF16) else torch.float32)
         outs = [(head_outs[j] if head_outs is not None and head_outs[j] is not None else
-                 torch.empty((n_rows, 128), dtype=torch.float32, device=dev)) for j in range(len(widths))]
-        if any(_ld_of(t) != _ld_of(outs[0]) for t in outs):        # one leading dimension for all heads (g4c_mlp_forward_heads)
+                 torch.empty((n_rows, 128), dtype=hdt, device=dev)) for j in range(len(widths))]
+        if any(_ld_of(t) != _ld_of(outs[0]) or t.dtype != hdt for t in outs):        # one leading dimension / type for all heads (g4c_mlp_forward_heads)
             return None
         ops.mlp_forward(pk, sources, n_rows, act_code, out=y, head_outs=outs)
         return y, outs
@@ -347,7 +376,9 @@ class MLP(nn.Module):
             else:
                 chunks = [(c, min(128, w_t - c)) for c in range(0, w_t, 128)] if (w_t > 128 and not ops.grad_mode()) else [(0, w_t)]
                 pk1 = self._packed_cols("hoist1", off, off + w_t, [w for _, w in chunks], [False] * len(chunks), True)
-                part = ops.mlp_forward(pk1, [Source(t, col0=c, width=w) for c, w in chunks], int(t.size(0)))
+                part16 = (torch.empty((int(t.size(0)), 128), dtype=torch.bfloat16, device=t.device)
+                          if (ops.mlp_precision() == "bf16" and PRODUCTS_BF16 and pk1.n_out == 128 and pk1.precision == "bf16") else None)
+                part = ops.mlp_forward(pk1, [Source(t, col0=c, width=w) for c, w in chunks], int(t.size(0)), out=part16)
             adds.append(Source(part, index=idx, additive=True))
             off += w_t
         if off != self.input_size:
@@ -441,6 +472,56 @@ COMPACT_MESSAGES = True
 # sender rows: 1160 -> 1130 us) but on per-tile latency and vector work; hoisted, with the products from the producer's launch
 # (g4c_mlp_forward_heads_bf16) and the message launch on mlp_ws_kernel<SP = 1>, it takes 1160 -> 800 us.
 HOIST_BF16 = True
+# Round 5, rounded-bf16 mode: those hoisted first-layer products are STORED as bf16 (g4c_mlp_forward_heads_bf16_out / _bf16_out) and
+# widened when the message launch adds them: REMuS-GNN's level-1 angle launch gathers 2 x 2.5 M product rows per EdgeMP — its
+# largest stream — at half the bytes.  One more rounding (relative 2^-9) of a pre-activation term whose operands were rounded to
+# bf16 already; error against the fp32 reference restatement: scripts/remus_bf16_err.py and the 20k-node REMuS parity test.
+PRODUCTS_BF16 = True
+
+
+# One launch per MP layer (round 5, ops.mp_layer_forward / g4c_mp_layer_forward_bx6): message MLP + aggregation + node MLP (+ the next
+# layer's products) in the same persistent workgroups.  For launches whose time is the dependent chain inside each kernel — the coarse
+# levels of a multi-scale model, whole small meshes (a rank's share of a partitioned mesh) — not for throughput-bound ones: at
+# FUSE_LAYER_MAX_ROWS edge rows and beyond the node update of 100k nodes runs faster as its own chip-filling launch.
+FUSE_LAYER = os.environ.get("G4C_FUSE_LAYER", "1") != "0"
+FUSE_LAYER_MIN_ROWS = 2048
+FUSE_LAYER_MAX_ROWS = 120_000
+
+
+def _can_fuse_layer(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e, csr, v_src, n_targets, v_out, compact_messages: bool) -> bool:
+    if not FUSE_LAYER or ops.grad_mode() or ops.mlp_precision() != "f16x3" or v_src is not None or n_targets is not None or v_out is not None:
+        return False
+    if compact_messages or csr.perm is not None or not (FUSE_LAYER_MIN_ROWS <= csr.n < FUSE_LAYER_MAX_ROWS) or csr.tiles() is None:
+        return False
+    lm, lu = msg_mlp._linears(), upd_mlp._linears()
+    if len(lm) != len(lu) or len(lm) not in (2, 3) or any(l.out_features != 128 for l in lm + lu):
+        return False
+    e_t = e.tensor if isinstance(e, Source) else e
+    if isinstance(e, Source) and (e.index is not None or e.col0 != 0 or e.negate or e.segments is not None or e.additive):
+        return False
+    return (int(v.size(1)) == 128 and int(e_t.size(1)) == 128 and e_t.dtype == torch.float32 and msg_mlp.input_size == 384
+            and upd_mlp.input_size == 256)
+
+
+def _fused_layer(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e_src: Source, ep, csr, mean: bool, act_code: int, products,
+                 next_msg: Optional[MLP], keep_e: bool):
+    """The MP layer as one launch.  Returns (v', e' or None, next products or None)."""
+    H = 128
+    dev = v.device
+    n_t = int(v.size(0))
+    if products is None:          # the node-side products of this layer's first layer: W1[:, H:2H] v, W1[:, 2H:3H] v (MLP.run_hoisted)
+        products = [ops.mlp_forward(msg_mlp._packed_cols("hoist1", H * (1 + j), H * (2 + j), [H], [False], True), [Source(v)], n_t) for j in range(2)]
+    pk_msg = msg_mlp._packed_cols("hoist", 0, H, [H], [e_src.negate], False)
+    srcs = [e_src, Source(products[0], index=ep.row, additive=True), Source(products[1], index=ep.col, additive=True)]
+    heads = None
+    if next_msg is not None and next_msg.input_size == 3 * H and next_msg._linears()[0].out_features == H:
+        pk_upd = upd_mlp._heads_packed([H, H], next_msg, next_msg.input_size - 2 * H, [H, H])
+        if pk_upd is not None:
+            heads = [torch.empty((n_t, H), dtype=torch.float32, device=dev) for _ in range(2)]
+    if heads is None:
+        pk_upd = upd_mlp.packed([H, H], [False, False])
+    e_new, v_new, _ = ops.mp_layer_forward(pk_msg, srcs, ep.n_edges, csr, mean, pk_upd, v, act_code, store_rows=keep_e, head_outs=heads)
+    return v_new, e_new, heads
 
 
 def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, aggr: str, act_code: int,
@@ -472,6 +553,9 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
     senders = v if v_src is None else v_src
     mean = aggr == "mean"
     e_src = e if isinstance(e, Source) else Source(e, pre_act=e_pre_act)
+    if _can_fuse_layer(msg_mlp, upd_mlp, v, e, csr, v_src, n_targets, v_out, compact_messages):
+        v_new, e_new, nxt = _fused_layer(msg_mlp, upd_mlp, v, e_src, ep, csr, mean, act_code, products, next_msg, keep_e)
+        return (v_new, e_new, nxt) if next_msg is not None else (v_new, e_new)
     if ops.can_fuse_aggregation(csr, msg_mlp.output_size):
         # the edge launch reduces the rows it has just computed (whole CSR segments per row tile, g4c_mlp_forward_bx6_agg):
         # no second pass over the messages; with keep_e=False (the model discards e', nn/mus_gnn.py:199-200) they are not

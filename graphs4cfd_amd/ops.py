@@ -630,6 +630,46 @@ def _src_array(sources: Sequence[Source]):
     return arr
 
 
+def mp_layer_forward(msg: PackedMLP, sources: Sequence[Source], n_rows: int, csr: CsrPlan, agg_mean: bool, upd: PackedMLP,
+                     v: Tensor, act: int, store_rows: bool = True, head_outs: Optional[Sequence[Tensor]] = None,
+                     v_out: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Tensor, Optional[Sequence[Tensor]]]:
+    """One launch for a whole MP layer (g4c_mp_layer_forward_bx6; reference nn/blocks.py:175-186): the hoisted message MLP `msg`
+    on `sources` (one 128-wide weighted block + the two gathered node-side products as additive sources) with the aggregation over
+    `csr`, and — in the same persistent workgroups — the node MLP `upd` on [aggregate | v] with LayerNorm / `act` and, when
+    `head_outs` is given, the heads packed behind `upd` (the next layer's products).  f16x3 arithmetic only, inference only.
+    Returns (e' rows or None, v', head_outs)."""
+    lib = _lib.load()
+    dev = _lib.require_hip(*[s.tensor for s in sources], *[s.index for s in sources], v, v_out)
+    if msg.split != "f16x2" or upd.split != "f16x2":
+        raise NotImplementedError("mp_layer_forward needs both MLPs packed for the f16x3 arithmetic")
+    tiles = csr.tiles()
+    if tiles is None or n_rows != csr.n:
+        raise ValueError("mp_layer_forward: the rows must be in segment order with segments of at most 32 rows")
+    v = _f32_2d(v, "v")
+    n_t = csr.n_seg
+    t_rows, t_seg, nt = tiles
+    e_out = torch.empty((n_rows, 128), dtype=torch.float32, device=dev) if store_rows else None
+    agg = torch.empty((n_t, 128), dtype=torch.float32, device=dev)          # (scratch: written and re-read by the same workgroup, L2-resident)
+    if v_out is None:
+        v_out = torch.empty((n_t, 128), dtype=torch.float32, device=dev)
+    n_heads = 0 if head_outs is None else len(head_outs)
+    if n_heads and (n_heads != upd.n_heads):
+        raise ValueError(f"{n_heads} head outputs for a packing with {upd.n_heads} heads")
+    ho = (C.c_void_p * max(n_heads, 1))(*([h.data_ptr() for h in head_outs] if n_heads else [None]))
+    arr = _src_array(sources)
+    call = lambda: _lib.check(lib.g4c_mp_layer_forward_bx6(
+        C.byref(msg.desc), arr, len(sources), n_rows, _lib.ptr(e_out), 128 if e_out is None else _ld(e_out),
+        _lib.ptr(t_rows), _lib.ptr(t_seg), _lib.ptr(csr.off), nt, _lib.ptr(agg), _ld(agg), 1 if agg_mean else 0,
+        C.byref(upd.desc), _lib.ptr(v), _ld(v), act, _lib.ptr(v_out), _ld(v_out),
+        upd.head_w if n_heads else None, n_heads, ho, _ld(head_outs[0]) if n_heads else 128, _lib.stream_handle(dev)))
+    if KernelTimer.active is None:
+        call()
+    else:
+        in_b = 4.0 * 128 * (n_rows * (2 if store_rows else 1) + n_t * (2 + n_heads))
+        _timed("mlp_bx6_kernel", msg.flops_per_row * n_rows + upd.flops_per_row * n_t, in_b, call)
+    return e_out, v_out, head_outs
+
+
 def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: int = _lib.ACT_NONE,
                 out: Optional[Tensor] = None, out_idx32: Optional[Tensor] = None,
                 resid: Optional[Tensor] = None, resid_col0: int = 0, tile_mode: Optional[int] = None,
@@ -751,10 +791,24 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                 raise NotImplementedError("heads with an output index / residual")
             _lib.require_hip(*head_outs)
             ho = (C.c_void_p * len(head_outs))(*[h.data_ptr() for h in head_outs])
-            heads_fn = lib.g4c_mlp_forward_heads_bf16 if packed.precision == "bf16" else lib.g4c_mlp_forward_heads_bx6
-            call = lambda: _lib.check(heads_fn(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out),
-                                               _ld(out), act, packed.head_w, len(head_outs), ho,
-                                               _ld(head_outs[0]), _lib.stream_handle(dev)))
+            if any(h.dtype == torch.bfloat16 for h in head_outs):
+                # rounded-bf16 mode: the head rows (the next message MLP's first-layer products) stored as bf16 (g4c_mlp_forward_heads_bf16_out)
+                if packed.precision != "bf16" or any(h.dtype != torch.bfloat16 for h in head_outs):
+                    raise TypeError("bf16 head outputs need the rounded-bf16 mode, and every head in bf16")
+                call = lambda: _lib.check(lib.g4c_mlp_forward_heads_bf16_out(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out),
+                                                                             _ld(out), act, packed.head_w, len(head_outs), ho,
+                                                                             _ld(head_outs[0]), 1, _lib.stream_handle(dev)))
+            else:
+                heads_fn = lib.g4c_mlp_forward_heads_bf16 if packed.precision == "bf16" else lib.g4c_mlp_forward_heads_bx6
+                call = lambda: _lib.check(heads_fn(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out),
+                                                   _ld(out), act, packed.head_w, len(head_outs), ho,
+                                                   _ld(head_outs[0]), _lib.stream_handle(dev)))
+        elif out is not None and out.dtype == torch.bfloat16:
+            # rounded-bf16 mode: plain 128-wide output rows stored as bf16 (g4c_mlp_forward_bf16_out: first-layer products)
+            if packed.precision != "bf16" or out_idx32 is not None or resid is not None:
+                raise TypeError("a bf16 `out` needs the rounded-bf16 mode and no output index / residual")
+            call = lambda: _lib.check(lib.g4c_mlp_forward_bf16_out(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out), _ld(out), 1, act,
+                                                                   _lib.stream_handle(dev)))
         else:
             fwd = lib.g4c_mlp_forward_bf16 if packed.precision == "bf16" else lib.g4c_mlp_forward_bx6
             call = lambda: _lib.check(fwd(C.byref(packed.desc), arr, len(sources), n_rows, *args))

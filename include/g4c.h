@@ -38,6 +38,10 @@ extern "C" {
 #define G4C_NARROW_MAX 8
 
 int g4c_version(void);
+/* Where a launch on `device_ptr`'s buffers goes: the ordinal of the device that owns it (every launching entry point switches to that
+ * device for the call, whatever the caller's current device is) and the compute-unit count the persistent kernels size their grids
+ * with there (cached per ordinal).  A multi-GPU job checks both on every rank before it times anything (bench.py partition_check). */
+int g4c_device_info(const void *device_ptr, int32_t *device /*host, out*/, int32_t *cu_count /*host, out*/);
 const char *g4c_last_error(void);
 
 /* ---------------------------------------------------------------- static mesh plan (host)
@@ -302,6 +306,23 @@ int g4c_mlp_forward_heads_bf16(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *s
                                int64_t n_rows, float *out, int32_t out_ld, int32_t act,
                                const void *head_w, int32_t n_heads, float *const *head_out /*host*/, int32_t head_ld,
                                void *stream);
+
+/* Round 5: ONE launch per MP layer — `GNBlock.forward` (nn/blocks.py:175-186): e' = edge_mlp([e | v[row] | v[col]]), aggregation of e'
+ * per target, v' = act(node_mlp([aggr | v])) — for the f16x3 stream.  The message part is g4c_mlp_forward_bx6_agg's launch on the
+ * weight-stationary kernel (one 128-wide weighted block `e`, the two hoisted node-side products as additive sources, two or three
+ * 128-wide layers; e_out may be NULL: the rows are then not stored); a persistent workgroup's tile pairs cover a contiguous range of
+ * targets, so once they are done it runs the node MLP `upd` (same depth; input blocks [aggregate | v], both 128 wide) on exactly those
+ * targets — the aggregates go through `agg` ([n_targets, agg_ld] scratch, L2-resident) — and stores v' = act(LayerNorm(...)) to v_out
+ * and, with n_heads > 0, the heads of g4c_mlp_forward_heads_bx6 (the NEXT layer's node-side products).  Same arithmetic per element as
+ * the two separate launches (g4c_mlp_forward_bx6_agg, g4c_mlp_forward_heads_bx6); sums over k are associated as in the
+ * weight-stationary kernel.  Small and medium levels of a multi-scale model are bound by the dependent chain inside each launch, not
+ * by throughput: this halves the number of chains per MP layer. */
+int g4c_mp_layer_forward_bx6(const g4c_mlp_t *msg /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src, int64_t n_rows,
+                             float *e_out, int32_t e_ld,
+                             const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,
+                             float *agg, int32_t agg_ld, int32_t agg_mean,
+                             const g4c_mlp_t *upd /*host*/, const float *v, int32_t v_ld, int32_t act, float *v_out, int32_t v_out_ld,
+                             const void *head_w, int32_t n_heads, float *const *head_out /*host*/, int32_t head_ld, void *stream);
 
 /* Round 5, rounded-bf16 mode (BASELINE config 3): the first-layer products of a hoisted message MLP stored as bf16.  A product row
  * is a pre-activation term of a layer whose operands are already rounded to bf16 (relative 2^-9 each); stored as bf16 it is rounded

@@ -1476,6 +1476,128 @@ def test_remus_bf16_compact_messages_are_bit_identical():
         ops.set_mlp_precision(old)
 
 
+def test_bf16_product_rows_are_exact_copies():
+    """Rounded-bf16 mode, round 5 (blocks.PRODUCTS_BF16): the hoisted first-layer products are stored as bf16.  The kernels only
+    change representation — (a) head rows / plain output rows stored as bf16 are the round-to-nearest bf16 of the fp32 rows the same
+    launch stores otherwise; (b) a message launch that gathers bf16 additive rows gives bit for bit what it gives for their fp32
+    widening, on the weight-stationary kernel (large launch, fused aggregation) and on the tile kernel (small launch)."""
+    lib = _lib.load()
+    old = ops.set_mlp_precision("bf16")
+    try:
+        torch.manual_seed(91)
+        H = 128
+        blk = B.GNBlock((3 * H, (H, H), True), (2 * H, (H, H), True)).to(DEV)
+        nxt = B.GNBlock((3 * H, (H, H), True), (2 * H, (H, H), True)).to(DEV)
+        n = 12000                      # (>= the 10 000 targets of the larger message launch below)
+        v, agg = torch.randn(n, H, device=DEV), torch.randn(n, H, device=DEV)
+        with torch.no_grad():
+            was = B.PRODUCTS_BF16
+            try:
+                B.PRODUCTS_BF16 = False
+                y32, h32 = blk.node_mlp.run_with_heads([ops.Source(agg), ops.Source(v)], n, _lib.ACT_SELU, nxt.edge_mlp, H, [H, H])
+                B.PRODUCTS_BF16 = True
+                y16, h16 = blk.node_mlp.run_with_heads([ops.Source(agg), ops.Source(v)], n, _lib.ACT_SELU, nxt.edge_mlp, H, [H, H])
+            finally:
+                B.PRODUCTS_BF16 = was
+            assert h16[0].dtype == torch.bfloat16 and h32[0].dtype == torch.float32 and torch.equal(y32, y16)
+            for a, b in zip(h32, h16):
+                assert torch.equal(a.to(torch.bfloat16), b)
+            # plain launch: the first layer's block alone (MLP.run_hoisted's "hoist1" launch)
+            pk1 = nxt.edge_mlp._packed_cols("hoist1", H, 2 * H, [H], [False], True)
+            p32 = ops.mlp_forward(pk1, [ops.Source(v)], n)
+            p16 = ops.mlp_forward(pk1, [ops.Source(v)], n, out=torch.empty(n, H, dtype=torch.bfloat16, device=DEV))
+            assert torch.equal(p32.to(torch.bfloat16), p16)
+            # the consumer: bf16 additive rows == their fp32 widening
+            pk = nxt.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+            for rows, deg in ((60000, 6), (900, 6)):
+                nn_ = rows // deg
+                e = torch.randn(rows, H, device=DEV)
+                colh = torch.arange(nn_).repeat_interleave(deg)
+                ei = torch.stack([torch.randint(0, nn_, (rows,)), colh]).to(DEV)
+                ep, csr = plan.edge_csr(ei, nn_)
+                pr16, pc16 = h16[0][:nn_].contiguous(), h16[1][:nn_].contiguous()
+                outs = []
+                for pr, pc in ((pr16, pc16), (pr16.float(), pc16.float())):
+                    src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+                    ag = torch.empty(nn_, H, device=DEV)
+                    y = ops.mlp_forward(pk, src, rows, agg=(csr, ag, True))
+                    outs.append((y.clone(), ag.clone(), int(lib.g4c_mlp_last_kernel())))
+                assert outs[0][2] == outs[1][2]
+                assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), rows
+            # fp32 additive rows in another arithmetic are refused loudly
+        ops.set_mlp_precision("f16x3")
+        pkf = nxt.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+        with pytest.raises(NotImplementedError, match="rounded-bf16 mode"):
+            ops.mlp_forward(pkf, [ops.Source(e), ops.Source(pr16, index=ep.row, additive=True), ops.Source(pc16, index=ep.col, additive=True)], rows)
+    finally:
+        ops.set_mlp_precision(old)
+
+
+# ------------------------------------------------------------------ one launch per MP layer (round 5)
+@pytest.mark.parametrize("layers", [3, 2])
+def test_fused_mp_layer_matches_the_separate_launches(layers):
+    """ops.mp_layer_forward / g4c_mp_layer_forward_bx6 (message MLP + aggregation + node MLP + the next layer's products in one
+    launch; reference nn/blocks.py:175-186) against the separate launches of the same GNBlock, at sizes from less than one tile to
+    several tile pairs per workgroup, constant and ragged in-degrees (empty segments, trailing targets without edges: node tiles of
+    1 .. 64 rows per workgroup), with and without heads, with and without stored messages.  Same arithmetic per element; sums over k
+    are associated as in the weight-stationary kernel (the node update otherwise runs on the 32x32x16 tile kernel): 2e-5."""
+    H = 128
+    old = ops.set_mlp_precision("f16x3")
+    was = (B.FUSE_LAYER, B.FUSE_LAYER_MIN_ROWS)
+    try:
+        torch.manual_seed(100 + layers)
+        hid = (H,) * layers
+        blk = B.GNBlock((3 * H, hid, True), (2 * H, hid, True)).to(DEV)
+        nxt = B.GNBlock((3 * H, hid, True), (2 * H, hid, True)).to(DEV)
+        W1 = nxt.edge_mlp._linears()[0].weight
+        B.FUSE_LAYER_MIN_ROWS = 1
+        for n, deg, ragged in ((6, 6, False), (37, 6, True), (1500, 6, True), (12500, 6, False), (20000, 4, True)):
+            gen = torch.Generator().manual_seed(n)
+            if ragged:
+                d = torch.randint(0, 2 * deg + 1, (n,), generator=gen); d[0] = 0; d[-3:] = 0
+            else:
+                d = torch.full((n,), deg)
+            col = torch.arange(n).repeat_interleave(d)
+            ei = torch.stack([torch.randint(0, n, (int(col.numel()),), generator=gen), col]).to(DEV)
+            E = int(ei.size(1))
+            v, e = torch.randn(n, H, device=DEV), torch.randn(E, H, device=DEV)
+            for heads, keep in ((True, True), (False, True), (True, False), (False, False)):
+                res = []
+                with torch.no_grad():
+                    for fuse in (False, True):
+                        B.FUSE_LAYER = fuse
+                        res.append(blk.step(v, e, ei, _lib.ACT_SELU, e_pre_act=_lib.ACT_SELU, next_msg=nxt.edge_mlp if heads else None, keep_e=keep))
+                tag = (layers, n, E, heads, keep)
+                torch.testing.assert_close(res[1][0], res[0][0], rtol=0, atol=2e-5, msg=lambda m: f"v' {tag}: {m}")
+                if keep:
+                    torch.testing.assert_close(res[1][1], res[0][1], rtol=0, atol=2e-5, msg=lambda m: f"e' {tag}: {m}")
+                else:
+                    assert res[1][1] is None
+                if heads:      # (the separate form makes products from HOIST_MIN_ROWS edges on only: otherwise compare with W1 v')
+                    assert res[1][2] is not None
+                    for j in range(2):
+                        want = res[0][2][j] if res[0][2] is not None else res[0][0] @ W1[:, H * (1 + j):H * (2 + j)].T
+                        torch.testing.assert_close(res[1][2][j], want, rtol=0, atol=2e-5 if res[0][2] is not None else 1e-4)
+        # a whole model: every MP layer of the levels inside the size window runs fused; eager == hipGraph-replayed, bit for bit
+        B.FUSE_LAYER_MIN_ROWS = was[1]
+        g = S.mus_graph(4000, levels=3, seed=12)
+        torch.manual_seed(13)
+        model = gfd.nn.NsThreeScaleGNN(arch=S.mus_arch("NsThreeScaleGNN", 128), device=DEV)
+        w = {k: v.cpu() for k, v in model.state_dict().items()}
+        ref = O.mus_solve("NsThreeScaleGNN", g.to_dict(), w, 4, model.num_fields)
+        outs = {}
+        for fuse in (False, True):
+            B.FUSE_LAYER = fuse
+            for capture in (False, True):
+                outs[(fuse, capture)] = model.solve(g.clone(), 4, capture=capture)
+        assert torch.equal(outs[(True, False)], outs[(True, True)])
+        torch.testing.assert_close(outs[(True, True)], outs[(False, True)], rtol=0, atol=1e-4)
+        torch.testing.assert_close(outs[(True, True)].cpu(), ref, rtol=1e-3, atol=1e-3)
+    finally:
+        B.FUSE_LAYER, B.FUSE_LAYER_MIN_ROWS = was
+        ops.set_mlp_precision(old)
+
+
 # ------------------------------------------------------------------ per-mesh constants are cached across rollout steps (round 4)
 def _manual_rollout(model, g, field, n_out):
     """solve() spelled out with bare forward() calls (which never use the cache); n_in = 1: the next input is the prediction.

@@ -156,13 +156,13 @@ class OracleImpl:
         return field[:, -nf:] + O.mlp(v_own, self.w, "node_decoder")
 
 
-def _worker(rank, world, port, model_name, levels, out_dir, use_products):
+def _worker(rank, world, port, model_name, levels, out_dir, use_products, n_nodes=1500):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        torch.set_num_threads(2)
-        g = S.mus_graph(1500, levels=levels, seed=5)
+        torch.set_num_threads(2 if world <= 4 else 1)
+        g = S.mus_graph(n_nodes, levels=levels, seed=5)
         arch = S.mus_arch(model_name, 32)
         torch.manual_seed(11)
         import graphs4cfd_amd as gfd
@@ -195,6 +195,19 @@ def test_partitioned_forward_matches_global_on_two_gloo_ranks(tmp_path, model_na
     mp.spawn(_worker, args=(2, port, model_name, levels, str(tmp_path), use_products), nprocs=2, join=True)
     r = torch.load(os.path.join(str(tmp_path), "result.pt"))
     assert all(h > 0 for h in r["halo"][0]), "the test mesh must actually have halos on every level"
+    torch.testing.assert_close(r["full"], r["ref"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_partitioned_forward_matches_global_on_four_and_eight_gloo_ranks(tmp_path, world):
+    """the partition at the world sizes of BASELINE configs 4 and 5 (every rank its own process, gloo transport,
+    products carried by the halo exchange): a 3-scale mesh cut 4 and 8 ways — ranks with several neighbours, coarse levels on which
+    some ranks own next to nothing — reassembles to the global forward."""
+    import torch.multiprocessing as mp
+    port = 29300 + (os.getpid() % 250) + world
+    mp.spawn(_worker, args=(world, port, "NsThreeScaleGNN", 3, str(tmp_path), True, 3000), nprocs=world, join=True)
+    r = torch.load(os.path.join(str(tmp_path), "result.pt"))
+    assert r["halo"][0][0] > 0
     torch.testing.assert_close(r["full"], r["ref"], rtol=1e-4, atol=1e-4)
 
 
