@@ -302,6 +302,252 @@ __device__ __forceinline__ void other_all(const f32x4 (&accE)[2], const f32x4 (&
     for (int s = 0; s < 8; ++s) other_piece<SP, EK, PACT>(s, accE, accE1, xe, o, hold, rng);
 }
 
+// ---- the node MLP on a contiguous range of rows [S0, S1) by ONE 8-wave workgroup: [x0 | q.v] -> Linear / SELU chain (weights streamed
+// block by block from q.w: 32 registers per wave and block, the next block fetched while this one multiplies) -> LayerNorm ->
+// activation -> q.out, + the heads.  Rows are taken 64 at a time as two 32-row tiles whose matrix phases carry each other's vector work
+// (park / epilogue / fp32 rows), as in the message loop of mlp_ws_kernel; a remainder of <= 32 rows runs as one tile.  Used behind the
+// message phase (mlp_ws_kernel<.., NODE>: x0 = the aggregates the workgroup has just written) and on its own (mlp_node_kernel).
+struct NodeCtx {
+    int tid, wave, n, g, fcol, prow, pc;
+    unsigned lo_b;
+    const float *sBiasN, *sGBN;
+    float *fA, *fB;
+    Other oA, oB;
+    const __bf16 *paA[4], *paB[4];
+};
+
+template <int SP, int NL>
+__device__ __forceinline__ void node_phase(const NodeCtx &c, const float *x0, const int x0_ld, const NodeParams &q, const int S0, const int S1) {
+    const int wave = c.wave, n = c.n, g = c.g, fcol = c.fcol, prow = c.prow, pc = c.pc;
+    const unsigned lo_b = c.lo_b;
+    const float *const sBiasN = c.sBiasN, *const sGBN = c.sGBN;
+    float *const fA = c.fA, *const fB = c.fB;
+    const Other &oA = c.oA, &oB = c.oB;
+    const __bf16 *const (&paA)[4] = c.paA;
+    const __bf16 *const (&paB)[4] = c.paB;
+    f32x4 accA[2], accB[2], accA1[2], accB1[2];
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(q.w), 0, 0x7fffffff, 0x00020000);
+    RangeV rngN;
+    const int n_blk = NL + 1 + q.n_heads;          // blocks of the node MLP's stream (a head block that does not exist is not fetched)
+    auto ld_block = [&](bf16x8 (&Wb)[4][SP], int blk) __attribute__((always_inline)) {
+        if (blk >= n_blk) return;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int pl = 0; pl < SP; ++pl) Wb[ks][pl] = ldw(rq, lo_b + 1024u * pl, (unsigned)blk * 2u * BLOCK6 + (unsigned)ks * 4u * STEP6);
+    };
+    auto bias_n = [&](f32x4 (&acc)[2], f32x4 (&acc1)[2], int l) __attribute__((always_inline)) {
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (l >= 0) b4 = *reinterpret_cast<const f32x4 *>(sBiasN + l * NP + fcol);
+        acc[0] = b4; acc[1] = b4;
+        acc1[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    const int rowL = wave * 4 + g;                                   // LayerNorm / row-store layout: 16 lanes per row
+    const int cqn[2] = {n * 4, 64 + n * 4};
+    // LayerNorm / activation of the fp32 rows of one tile (rows [rb, rb + nrows) of the launch), stored from the registers; with
+    // heads the finished rows go back to the buffer (the heads' operand)
+    auto finish_rows = [&](float *frows, int rb, int nrows) __attribute__((always_inline)) {
+        float x[8];
+        float *const rowp = frows + rowL * HS;
+#pragma unroll
+        for (int c = 0; c < 8; c += 4) {
+            const f32x4 v4 = *reinterpret_cast<const f32x4 *>(rowp + cqn[c >> 2]);
+            x[c] = v4[0]; x[c + 1] = v4[1]; x[c + 2] = v4[2]; x[c + 3] = v4[3];
+        }
+        if (q.gamma) {
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sum += x[c];
+            sum = row16_sum(sum);
+            const float mean = sum * (1.0f / NP);
+            float var = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { const float dl = x[c] - mean; var += dl * dl; }
+            var = row16_sum(var);
+            const float rstd = rsqrtf(var * (1.0f / NP) + q.eps);
+#pragma unroll
+            for (int c = 0; c < 8; c += 4) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4 *>(sGBN + cqn[c >> 2]), b4 = *reinterpret_cast<const f32x4 *>(sGBN + NP + cqn[c >> 2]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[c + u] = fmaf((x[c + u] - mean) * rstd, g4[u], b4[u]);
+            }
+        }
+        if (q.act == G4C_ACT_SELU) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x[c] = g4c::selu_f(x[c]);
+        } else if (q.act == G4C_ACT_TANH) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x[c] = g4c::tanh_f(x[c]);
+        }
+        f32x4 v0, v1;
+        v0[0] = x[0]; v0[1] = x[1]; v0[2] = x[2]; v0[3] = x[3]; v1[0] = x[4]; v1[1] = x[5]; v1[2] = x[6]; v1[3] = x[7];
+        if (q.n_heads) { *reinterpret_cast<f32x4 *>(rowp + cqn[0]) = v0; *reinterpret_cast<f32x4 *>(rowp + cqn[1]) = v1; }
+        if (rowL < nrows) {
+            float *op = q.out + (long long)(rb + rowL) * q.out_ld;
+            *reinterpret_cast<f32x4 *>(op + cqn[0]) = v0; *reinterpret_cast<f32x4 *>(op + cqn[1]) = v1;
+        }
+    };
+    auto store_head = [&](int hd, const float *frows, int rb, int nrows) __attribute__((always_inline)) {
+        if (rowL < nrows) {
+            const float *rowp = frows + rowL * HS;
+            float *op = q.head_out[hd] + (long long)(rb + rowL) * q.head_ld;
+            *reinterpret_cast<f32x4 *>(op + cqn[0]) = *reinterpret_cast<const f32x4 *>(rowp + cqn[0]);
+            *reinterpret_cast<f32x4 *>(op + cqn[1]) = *reinterpret_cast<const f32x4 *>(rowp + cqn[1]);
+        }
+    };
+    // rows [rb, rb + nrows) of a [., ld] tensor in the park layout (rows past the range: clamped copies)
+    auto load_rows = [&](const float *base, int ld, int rb, int nrows, f32x4 (&x)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int r = prow + 16 * hh;
+            x[hh] = *reinterpret_cast<const f32x4 *>(base + (long long)(rb + (r < nrows ? r : nrows - 1)) * ld + pc);
+        }
+    };
+    // (Requesting the next step's rows and first weight blocks during this step — software pipelining over the 64-row steps — was
+    // measured SLOWER: it pushes the kernel past 256 registers, 11 - 14 dwords per lane go to scratch, the level-1 node launch took
+    // 137 us instead of 131 and the fused MP layer at 60k edges 62.6 us instead of 55.8: profiles/r05_node_kernel.log.)
+    for (int r0 = S0; r0 < S1; r0 += 64) {
+        const int nr = (S1 - r0) < 64 ? (S1 - r0) : 64;
+        bf16x8 Wa[4][SP], Wb[4][SP];
+        ld_block(Wa, 0); ld_block(Wb, 1);
+        auto &H0 = (NL == 3) ? Wa : Wb;          // (NL == 3: head 0 = block 4 in Wa, head 1 = block 5 in Wb;  NL == 2: head 0 = block 3 in Wb, head 1 = block 4 in Wa)
+        auto &H1 = (NL == 3) ? Wb : Wa;
+        f32x4 ga[2], va[2], gb[2], vb[2];
+        {
+            const int nA = nr < 32 ? nr : 32;
+            load_rows(x0, x0_ld, r0, nA, ga); load_rows(q.v, q.v_ld, r0, nA, va);
+            if (nr > 32) { load_rows(x0, x0_ld, r0 + 32, nr - 32, gb); load_rows(q.v, q.v_ld, r0 + 32, nr - 32, vb); }
+        }
+        if (nr > 32) {
+            // ================================ two tiles (A: 32 rows, B: nr - 32): every matrix phase of one tile carries the other tile's
+            // vector work (park / epilogue / fp32 rows), as in the message loop; a block of weights serves both tiles
+            const int nB = nr - 32;
+            other_all<SP, 2, false>(accA, accA1, ga, oA, rngN);
+            other_all<SP, 2, false>(accA, accA1, gb, oB, rngN);
+            bias_n(accA, accA1, 0); bias_n(accB, accB1, 0);
+            __syncthreads();
+            m_block<SP, 0>(paA, Wa, accA, accA1, accA, accA1, ga, oA, rngN);                    // M(A, aggregate block)
+            __syncthreads();
+            m_block<SP, 2, false>(paB, Wa, accB, accB1, accB, accB1, va, oA, rngN);             // M(B, aggregate block); A's v rows -> A's planes
+            ld_block(Wa, 2);
+            __syncthreads();
+            m_block<SP, 2, false>(paA, Wb, accA, accA1, accA, accA1, vb, oB, rngN);             // M(A, v block); B's v rows -> B's planes
+            __syncthreads();
+            m_block<SP, 1>(paB, Wb, accB, accB1, accA, accA1, va, oA, rngN);                    // M(B, v block); A: epilogue of layer 0
+            ld_block(Wb, 3);
+            bias_n(accA, accA1, 1);
+            __syncthreads();
+            m_block<SP, 1>(paA, Wa, accA, accA1, accB, accB1, va, oB, rngN);                    // M(A, layer 1); B: epilogue of layer 0
+            bias_n(accB, accB1, 1);
+            __syncthreads();
+            if constexpr (NL == 3) {
+                m_block<SP, 1>(paB, Wa, accB, accB1, accA, accA1, va, oA, rngN);                // M(B, layer 1); A: epilogue of layer 1
+                ld_block(Wa, 4);
+                bias_n(accA, accA1, 2);
+                __syncthreads();
+                m_block<SP, 1>(paA, Wb, accA, accA1, accB, accB1, va, oB, rngN);                // M(A, layer 2); B: epilogue of layer 1
+                bias_n(accB, accB1, 2);
+                __syncthreads();
+                m_block<SP, 3>(paB, Wb, accB, accB1, accA, accA1, va, oA, rngN);                // M(B, layer 2); A: fp32 rows
+                ld_block(Wb, 5);
+            } else {
+                m_block<SP, 3>(paB, Wa, accB, accB1, accA, accA1, va, oA, rngN);                // M(B, layer 1); A: fp32 rows
+                ld_block(Wa, 4);
+            }
+            other_all<SP, 3, false>(accB, accB1, va, oB, rngN);                                 // B: fp32 rows
+            __syncthreads();
+            finish_rows(fA, r0, 32);
+            finish_rows(fB, r0 + 32, nB);
+            if (q.n_heads) {
+                __syncthreads();
+                f32x4 ha[2], hb[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    ha[hh] = *reinterpret_cast<const f32x4 *>(fA + (prow + 16 * hh) * HS + pc);
+                    hb[hh] = *reinterpret_cast<const f32x4 *>(fB + (prow + 16 * hh) * HS + pc);
+                }
+                other_all<SP, 2, false>(accA, accA1, ha, oA, rngN);
+                other_all<SP, 2, false>(accA, accA1, hb, oB, rngN);
+                bias_n(accA, accA1, -1); bias_n(accB, accB1, -1);
+                __syncthreads();
+                m_block<SP, 0>(paA, H0, accA, accA1, accA, accA1, va, oA, rngN);                // head 0 of A
+                m_block<SP, 3>(paB, H0, accB, accB1, accA, accA1, va, oA, rngN);                // head 0 of B; A's head rows -> fA
+                bias_n(accA, accA1, -1);
+                __syncthreads();
+                store_head(0, fA, r0, 32);
+                if (q.n_heads > 1) {
+                    m_block<SP, 3>(paA, H1, accA, accA1, accB, accB1, va, oB, rngN);            // head 1 of A; B's head-0 rows -> fB
+                    bias_n(accB, accB1, -1);
+                    __syncthreads();
+                    store_head(0, fB, r0 + 32, nB);
+                    m_block<SP, 3>(paB, H1, accB, accB1, accA, accA1, va, oA, rngN);            // head 1 of B; A's head-1 rows -> fA
+                    __syncthreads();
+                    store_head(1, fA, r0, 32);
+                    other_all<SP, 3, false>(accB, accB1, va, oB, rngN);
+                    __syncthreads();
+                    store_head(1, fB, r0 + 32, nB);
+                } else {
+                    other_all<SP, 3, false>(accB, accB1, va, oB, rngN);
+                    __syncthreads();
+                    store_head(0, fB, r0 + 32, nB);
+                }
+            }
+            __syncthreads();          // the next tiles overwrite the planes and the fp32 rows
+            continue;
+        }
+        // ================================ one tile (nr <= 32 rows): always the last step of the range
+        other_all<SP, 2, false>(accA, accA1, ga, oA, rngN);          // the aggregate rows -> A's planes
+        other_all<SP, 2, false>(accA, accA1, va, oB, rngN);          // the node rows -> B's planes
+        bias_n(accA, accA1, 0);
+        __syncthreads();
+        m_block<SP, 0>(paA, Wa, accA, accA1, accA, accA1, ga, oA, rngN);
+        ld_block(Wa, 2);
+        m_block<SP, 0>(paB, Wb, accA, accA1, accA, accA1, ga, oA, rngN);
+        ld_block(Wb, 3);
+        __syncthreads();                                              // everybody has read both sets of planes
+        other_all<SP, 1, false>(accA, accA1, ga, oA, rngN);          // layer 0's epilogue -> A's planes
+        bias_n(accA, accA1, 1);
+        __syncthreads();
+        m_block<SP, 0>(paA, Wa, accA, accA1, accA, accA1, ga, oA, rngN);
+        if constexpr (NL == 3) {
+            ld_block(Wa, 4);
+            other_all<SP, 1, false>(accA, accA1, ga, oB, rngN);      // layer 1's epilogue -> B's planes (nobody reads them in this phase)
+            bias_n(accA, accA1, 2);
+            __syncthreads();
+            m_block<SP, 0>(paB, Wb, accA, accA1, accA, accA1, ga, oA, rngN);
+            ld_block(Wb, 5);
+        } else {
+            ld_block(Wa, 4);          // (NL == 2: blocks 3, 4 are the heads — Wb holds block 3 already)
+        }
+        other_all<SP, 3, false>(accA, accA1, ga, oA, rngN);          // the last layer's fp32 rows -> fA
+        __syncthreads();
+        finish_rows(fA, r0, nr);
+        if (q.n_heads) {
+            // ---- heads: v' rows -> A's planes, one 128-k block per head, fp32 rows through fB / fA, whole-row stores
+            __syncthreads();
+            f32x4 xh[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) xh[hh] = *reinterpret_cast<const f32x4 *>(fA + (prow + 16 * hh) * HS + pc);
+            other_all<SP, 2, false>(accA, accA1, xh, oA, rngN);
+            bias_n(accA, accA1, -1);
+            bias_n(accB, accB1, -1);
+            __syncthreads();
+            m_block<SP, 0>(paA, H0, accA, accA1, accA, accA1, ga, oA, rngN);
+            if (q.n_heads > 1) m_block<SP, 0>(paA, H1, accB, accB1, accA, accA1, ga, oA, rngN);
+            other_all<SP, 3, false>(accA, accA1, ga, oB, rngN);      // head 0 -> fB
+            other_all<SP, 3, false>(accB, accB1, ga, oA, rngN);      // head 1 -> fA (its rows are in the planes)
+            __syncthreads();
+            store_head(0, fB, r0, nr);
+            if (q.n_heads > 1) store_head(1, fA, r0, nr);
+        }
+        __syncthreads();          // (a step of <= 32 rows is the last one)
+    }
+    if (G4C_WS_SCALED && !(G4C_WS_ABLATE & 48)) rngN.m *= F16_LO_UNSCALE;
+    if (q.range_flag && range_hit(rngN)) {
+        if ((threadIdx.x & 63) == 0) q.range_flag[q.range_slot] = 1;
+    }
+}
+
 // SP: 2 the f16x3 stream, 1 the rounded-bf16 mode;  NL: layers (2 or 3);  XB16 (SP = 1): the weighted block's rows are bf16;
 // AB16 (SP = 1): the additive rows are bf16 (the first-layer products a g4c_mlp_forward_heads_bf16_out / _bf16_out launch stored:
 // half the bytes of the launch's largest gather stream — REMuS-GNN's level-1 angle launch reads 2 x 2.5 M of them)
@@ -779,232 +1025,63 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(q.w), 0, 0x7fffffff, 0x00020000);
-        RangeV rngN;
-        const int n_blk = NL + 1 + q.n_heads;          // blocks of the node MLP's stream (a head block that does not exist is not fetched)
-        auto ld_block = [&](bf16x8 (&Wb)[4][SP], int blk) __attribute__((always_inline)) {
-            if (blk >= n_blk) return;
+        NodeCtx nc;
+        nc.tid = tid; nc.wave = wave; nc.n = n; nc.g = g; nc.fcol = fcol; nc.prow = prow; nc.pc = pc; nc.lo_b = lo_b;
+        nc.sBiasN = sBiasN; nc.sGBN = sGBN; nc.fA = fA; nc.fB = fB; nc.oA = oA; nc.oB = oB;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int pl = 0; pl < SP; ++pl) Wb[ks][pl] = ldw(rq, lo_b + 1024u * pl, (unsigned)blk * 2u * BLOCK6 + (unsigned)ks * 4u * STEP6);
-        };
-        auto bias_n = [&](f32x4 (&acc)[2], f32x4 (&acc1)[2], int l) __attribute__((always_inline)) {
-            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-            if (l >= 0) b4 = *reinterpret_cast<const f32x4 *>(sBiasN + l * NP + fcol);
-            acc[0] = b4; acc[1] = b4;
-            acc1[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        };
-        const int rowL = wave * 4 + g;                                   // LayerNorm / row-store layout: 16 lanes per row
-        const int cqn[2] = {n * 4, 64 + n * 4};
-        // LayerNorm / activation of the fp32 rows of one tile (rows [rb, rb + nrows) of the launch), stored from the registers; with
-        // heads the finished rows go back to the buffer (the heads' operand)
-        auto finish_rows = [&](float *frows, int rb, int nrows) __attribute__((always_inline)) {
-            float x[8];
-            float *const rowp = frows + rowL * HS;
-#pragma unroll
-            for (int c = 0; c < 8; c += 4) {
-                const f32x4 v4 = *reinterpret_cast<const f32x4 *>(rowp + cqn[c >> 2]);
-                x[c] = v4[0]; x[c + 1] = v4[1]; x[c + 2] = v4[2]; x[c + 3] = v4[3];
-            }
-            if (q.gamma) {
-                float sum = 0.f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) sum += x[c];
-                sum = row16_sum(sum);
-                const float mean = sum * (1.0f / NP);
-                float var = 0.f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) { const float dl = x[c] - mean; var += dl * dl; }
-                var = row16_sum(var);
-                const float rstd = rsqrtf(var * (1.0f / NP) + q.eps);
-#pragma unroll
-                for (int c = 0; c < 8; c += 4) {
-                    const f32x4 g4 = *reinterpret_cast<const f32x4 *>(sGBN + cqn[c >> 2]), b4 = *reinterpret_cast<const f32x4 *>(sGBN + NP + cqn[c >> 2]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) x[c + u] = fmaf((x[c + u] - mean) * rstd, g4[u], b4[u]);
-                }
-            }
-            if (q.act == G4C_ACT_SELU) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) x[c] = g4c::selu_f(x[c]);
-            } else if (q.act == G4C_ACT_TANH) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) x[c] = g4c::tanh_f(x[c]);
-            }
-            f32x4 v0, v1;
-            v0[0] = x[0]; v0[1] = x[1]; v0[2] = x[2]; v0[3] = x[3]; v1[0] = x[4]; v1[1] = x[5]; v1[2] = x[6]; v1[3] = x[7];
-            if (q.n_heads) { *reinterpret_cast<f32x4 *>(rowp + cqn[0]) = v0; *reinterpret_cast<f32x4 *>(rowp + cqn[1]) = v1; }
-            if (rowL < nrows) {
-                float *op = q.out + (long long)(rb + rowL) * q.out_ld;
-                *reinterpret_cast<f32x4 *>(op + cqn[0]) = v0; *reinterpret_cast<f32x4 *>(op + cqn[1]) = v1;
-            }
-        };
-        auto store_head = [&](int hd, const float *frows, int rb, int nrows) __attribute__((always_inline)) {
-            if (rowL < nrows) {
-                const float *rowp = frows + rowL * HS;
-                float *op = q.head_out[hd] + (long long)(rb + rowL) * q.head_ld;
-                *reinterpret_cast<f32x4 *>(op + cqn[0]) = *reinterpret_cast<const f32x4 *>(rowp + cqn[0]);
-                *reinterpret_cast<f32x4 *>(op + cqn[1]) = *reinterpret_cast<const f32x4 *>(rowp + cqn[1]);
-            }
-        };
-        // rows [rb, rb + nrows) of a [., ld] tensor in the park layout (rows past the range: clamped copies)
-        auto load_rows = [&](const float *base, int ld, int rb, int nrows, f32x4 (&x)[2]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int r = prow + 16 * hh;
-                x[hh] = *reinterpret_cast<const f32x4 *>(base + (long long)(rb + (r < nrows ? r : nrows - 1)) * ld + pc);
-            }
-        };
-        for (int r0 = S0; r0 < S1; r0 += 64) {
-            const int nr = (S1 - r0) < 64 ? (S1 - r0) : 64;
-            bf16x8 Wa[4][SP], Wb[4][SP];
-            ld_block(Wa, 0); ld_block(Wb, 1);
-            if (nr > 32) {
-                // ================================ two tiles (A: 32 rows, B: nr - 32): every matrix phase of one tile carries the other tile's
-                // vector work (park / epilogue / fp32 rows), as in the message loop; a block of weights serves both tiles
-                const int nB = nr - 32;
-                f32x4 ga[2], va[2], gb[2], vb[2];
-                load_rows(p.agg, p.agg_ld, r0, 32, ga); load_rows(p.agg, p.agg_ld, r0 + 32, nB, gb);
-                load_rows(q.v, q.v_ld, r0, 32, va); load_rows(q.v, q.v_ld, r0 + 32, nB, vb);
-                other_all<SP, 2, false>(accA, accA1, ga, oA, rngN);
-                other_all<SP, 2, false>(accA, accA1, gb, oB, rngN);
-                bias_n(accA, accA1, 0); bias_n(accB, accB1, 0);
-                __syncthreads();
-                m_block<SP, 0>(paA, Wa, accA, accA1, accA, accA1, ga, oA, rngN);                    // M(A, aggregate block)
-                __syncthreads();
-                m_block<SP, 2, false>(paB, Wa, accB, accB1, accB, accB1, va, oA, rngN);             // M(B, aggregate block); A's v rows -> A's planes
-                ld_block(Wa, 2);
-                __syncthreads();
-                m_block<SP, 2, false>(paA, Wb, accA, accA1, accA, accA1, vb, oB, rngN);             // M(A, v block); B's v rows -> B's planes
-                __syncthreads();
-                m_block<SP, 1>(paB, Wb, accB, accB1, accA, accA1, va, oA, rngN);                    // M(B, v block); A: epilogue of layer 0
-                ld_block(Wb, 3);
-                bias_n(accA, accA1, 1);
-                __syncthreads();
-                m_block<SP, 1>(paA, Wa, accA, accA1, accB, accB1, va, oB, rngN);                    // M(A, layer 1); B: epilogue of layer 0
-                bias_n(accB, accB1, 1);
-                __syncthreads();
-                if constexpr (NL == 3) {
-                    m_block<SP, 1>(paB, Wa, accB, accB1, accA, accA1, va, oA, rngN);                // M(B, layer 1); A: epilogue of layer 1
-                    ld_block(Wa, 4);
-                    bias_n(accA, accA1, 2);
-                    __syncthreads();
-                    m_block<SP, 1>(paA, Wb, accA, accA1, accB, accB1, va, oB, rngN);                // M(A, layer 2); B: epilogue of layer 1
-                    bias_n(accB, accB1, 2);
-                    __syncthreads();
-                    m_block<SP, 3>(paB, Wb, accB, accB1, accA, accA1, va, oA, rngN);                // M(B, layer 2); A: fp32 rows
-                    ld_block(Wb, 5);
-                } else {
-                    m_block<SP, 3>(paB, Wa, accB, accB1, accA, accA1, va, oA, rngN);                // M(B, layer 1); A: fp32 rows
-                    ld_block(Wa, 4);
-                }
-                other_all<SP, 3, false>(accB, accB1, va, oB, rngN);                                 // B: fp32 rows
-                __syncthreads();
-                finish_rows(fA, r0, 32);
-                finish_rows(fB, r0 + 32, nB);
-                if (q.n_heads) {
-                    __syncthreads();
-                    f32x4 ha[2], hb[2];
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        ha[hh] = *reinterpret_cast<const f32x4 *>(fA + (prow + 16 * hh) * HS + pc);
-                        hb[hh] = *reinterpret_cast<const f32x4 *>(fB + (prow + 16 * hh) * HS + pc);
-                    }
-                    other_all<SP, 2, false>(accA, accA1, ha, oA, rngN);
-                    other_all<SP, 2, false>(accA, accA1, hb, oB, rngN);
-                    bias_n(accA, accA1, -1); bias_n(accB, accB1, -1);
-                    __syncthreads();
-                    // (NL == 3: head 0 = block 4 in Wa, head 1 = block 5 in Wb;  NL == 2: head 0 = block 3 in Wb, head 1 = block 4 in Wa)
-                    auto &H0 = (NL == 3) ? Wa : Wb;
-                    auto &H1 = (NL == 3) ? Wb : Wa;
-                    m_block<SP, 0>(paA, H0, accA, accA1, accA, accA1, va, oA, rngN);                // head 0 of A
-                    m_block<SP, 3>(paB, H0, accB, accB1, accA, accA1, va, oA, rngN);                // head 0 of B; A's head rows -> fA
-                    bias_n(accA, accA1, -1);
-                    __syncthreads();
-                    store_head(0, fA, r0, 32);
-                    if (q.n_heads > 1) {
-                        m_block<SP, 3>(paA, H1, accA, accA1, accB, accB1, va, oB, rngN);            // head 1 of A; B's head-0 rows -> fB
-                        bias_n(accB, accB1, -1);
-                        __syncthreads();
-                        store_head(0, fB, r0 + 32, nB);
-                        m_block<SP, 3>(paB, H1, accB, accB1, accA, accA1, va, oA, rngN);            // head 1 of B; A's head-1 rows -> fA
-                        __syncthreads();
-                        store_head(1, fA, r0, 32);
-                        other_all<SP, 3, false>(accB, accB1, va, oB, rngN);
-                        __syncthreads();
-                        store_head(1, fB, r0 + 32, nB);
-                    } else {
-                        other_all<SP, 3, false>(accB, accB1, va, oB, rngN);
-                        __syncthreads();
-                        store_head(0, fB, r0 + 32, nB);
-                    }
-                }
-                __syncthreads();          // the next tiles overwrite the planes and the fp32 rows
-                continue;
-            }
-            // ================================ one tile (nr <= 32 rows)
-            f32x4 xa[2], xv[2];
-            load_rows(p.agg, p.agg_ld, r0, nr, xa);
-            load_rows(q.v, q.v_ld, r0, nr, xv);
-            other_all<SP, 2, false>(accA, accA1, xa, oA, rngN);          // the aggregate rows -> A's planes
-            other_all<SP, 2, false>(accA, accA1, xv, oB, rngN);          // the node rows -> B's planes
-            bias_n(accA, accA1, 0);
-            __syncthreads();
-            m_block<SP, 0>(paA, Wa, accA, accA1, accA, accA1, xa, oA, rngN);
-            ld_block(Wa, 2);
-            m_block<SP, 0>(paB, Wb, accA, accA1, accA, accA1, xa, oA, rngN);
-            ld_block(Wb, 3);
-            __syncthreads();                                              // everybody has read both sets of planes
-            other_all<SP, 1, false>(accA, accA1, xa, oA, rngN);          // layer 0's epilogue -> A's planes
-            bias_n(accA, accA1, 1);
-            __syncthreads();
-            m_block<SP, 0>(paA, Wa, accA, accA1, accA, accA1, xa, oA, rngN);
-            if constexpr (NL == 3) {
-                ld_block(Wa, 4);
-                other_all<SP, 1, false>(accA, accA1, xa, oB, rngN);      // layer 1's epilogue -> B's planes (nobody reads them in this phase)
-                bias_n(accA, accA1, 2);
-                __syncthreads();
-                m_block<SP, 0>(paB, Wb, accA, accA1, accA, accA1, xa, oA, rngN);
-                ld_block(Wb, 5);
-            } else {
-                ld_block(Wa, 4);          // (NL == 2: blocks 3, 4 are the heads — Wb holds block 3 already)
-            }
-            other_all<SP, 3, false>(accA, accA1, xa, oA, rngN);          // the last layer's fp32 rows -> fA
-            __syncthreads();
-            finish_rows(fA, r0, nr);
-            if (q.n_heads) {
-                // ---- heads: v' rows -> A's planes, one 128-k block per head, fp32 rows through fB / fA, whole-row stores
-                __syncthreads();
-                f32x4 xh[2];
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) xh[hh] = *reinterpret_cast<const f32x4 *>(fA + (prow + 16 * hh) * HS + pc);
-                other_all<SP, 2, false>(accA, accA1, xh, oA, rngN);
-                bias_n(accA, accA1, -1);
-                bias_n(accB, accB1, -1);
-                __syncthreads();
-                auto &H0 = (NL == 3) ? Wa : Wb;
-                auto &H1 = (NL == 3) ? Wb : Wa;
-                m_block<SP, 0>(paA, H0, accA, accA1, accA, accA1, xa, oA, rngN);
-                if (q.n_heads > 1) m_block<SP, 0>(paA, H1, accB, accB1, accA, accA1, xa, oA, rngN);
-                other_all<SP, 3, false>(accA, accA1, xa, oB, rngN);      // head 0 -> fB
-                other_all<SP, 3, false>(accB, accB1, xa, oA, rngN);      // head 1 -> fA (its rows are in the planes)
-                __syncthreads();
-                store_head(0, fB, r0, nr);
-                if (q.n_heads > 1) store_head(1, fA, r0, nr);
-            }
-            __syncthreads();          // the next tile overwrites the planes and the fp32 rows
-        }
-        if (G4C_WS_SCALED && !(G4C_WS_ABLATE & 48)) rngN.m *= F16_LO_UNSCALE;
-        if (q.range_flag && range_hit(rngN)) {
-            if ((threadIdx.x & 63) == 0) q.range_flag[q.range_slot] = 1;
-        }
+        for (int ks = 0; ks < 4; ++ks) { nc.paA[ks] = paA[ks]; nc.paB[ks] = paB[ks]; }
+        node_phase<SP, NL>(nc, p.agg, p.agg_ld, q, S0, S1);
     }
     WS_STAMP_ONCE(13, __builtin_readcyclecounter());
     if (SP == 2) {
         if (G4C_WS_SCALED && !(G4C_WS_ABLATE & 48)) rng.m *= F16_LO_UNSCALE;       // (tracked in units of 2^-11)
         range_report(p, rng);
     }
+}
+
+// The node MLP as a launch of its own (round 5): two plain 128-wide input blocks (MuS-GNN's node update [aggregate | v], nn/blocks.py:185),
+// two or three 128-wide layers, LayerNorm / activation, heads — one persistent 8-wave workgroup per CU on a contiguous range of 32-row
+// tiles, node_phase above.  Replaces the 4-wave tile kernel (mlp_bx6_kernel) for these launches: a block of streamed weights serves
+// 64 rows instead of 32, and one tile's epilogue runs under the other tile's MFMAs.
+template <int NL>
+__global__ __launch_bounds__(512, 2) void mlp_node_kernel(const float *x0, const int x0_ld, const NodeParams q, const int n_rows) {
+    __shared__ __attribute__((aligned(16))) __bf16 sP[2 * TILE_BF16];
+    __shared__ __attribute__((aligned(16))) float sF[2 * FIN];
+    __shared__ __attribute__((aligned(16))) float sBiasN[3 * NP];
+    __shared__ __attribute__((aligned(16))) float sGBN[2 * NP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    int S0, S1;
+    {
+        const int G = gridDim.x, b = blockIdx.x;
+        const int slot = (G & 7) ? b : (b & 7) * (G >> 3) + (b >> 3);          // (XCD-aware: each XCD gets a contiguous share)
+        const int n_tiles = (n_rows + 31) >> 5;
+        const int t0 = (int)(((long long)slot * n_tiles) / G), t1 = (int)(((long long)(slot + 1) * n_tiles) / G);
+        S0 = __builtin_amdgcn_readfirstlane(t0 * 32);
+        S1 = __builtin_amdgcn_readfirstlane(t1 * 32 < n_rows ? t1 * 32 : n_rows);
+    }
+    if (S0 >= S1) return;
+    f16_range_mode();
+    NodeCtx c;
+    c.tid = tid; c.wave = wave; c.n = n; c.g = g;
+    c.fcol = 16 * wave + 4 * g; c.prow = tid >> 5; c.pc = (tid & 31) * 4;
+    c.lo_b = 2u * (unsigned)((wave >> 1) * 8 * STEP6 + (g >> 1) * STEP6 + ((g & 1) * 32 + 16 * (wave & 1) + n) * 8);
+    c.sBiasN = sBiasN; c.sGBN = sGBN; c.fA = sF; c.fB = sF + FIN;
+    {
+        __bf16 *const sA = sP, *const sB = sP + TILE_BF16;
+        const int l32 = tid & 31;
+        const int acc_off = n * PS + 8 * ((2 * wave + (g >> 1)) ^ n) + 4 * (g & 1);
+        const int park_off = c.prow * PS + 8 * ((l32 >> 1) ^ c.prow) + 4 * (l32 & 1);
+        c.oA.plane_acc = sA + acc_off; c.oA.plane_park = sA + park_off; c.oA.fin = c.fA + n * HS + c.fcol;
+        c.oB.plane_acc = sB + acc_off; c.oB.plane_park = sB + park_off; c.oB.fin = c.fB + n * HS + c.fcol;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { c.paA[ks] = sA + n * PS + 8 * ((4 * ks + g) ^ n); c.paB[ks] = c.paA[ks] + TILE_BF16; }
+    }
+    if (tid < NL * NP) sBiasN[tid] = q.b[tid];
+    if (tid < 2 * NP) sGBN[tid] = q.gamma ? (tid < NP ? q.gamma[tid] : q.beta[tid - NP]) : 0.f;
+    __syncthreads();
+    node_phase<2, NL>(c, x0, x0_ld, q, S0, S1);
 }
 
 }  // namespace
@@ -1042,6 +1119,56 @@ bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, 
     if (((uintptr_t)p.b & 15)) return false;
     if (p.M >= (1LL << 31)) return false;
     return true;
+}
+
+// the node MLP's own launch (mlp_node_kernel): 0 off (DEFAULT: measured slower than the tile kernel — 131 against 108 us at 100k rows,
+// equal at <= 25k, profiles/r05_node_kernel.log: eight waves in lock step expose every load and LayerNorm round trip that four
+// independent 4-wave workgroups per CU hide by occupancy; the same code is what the fused MP layer runs behind its message phase,
+// where it replaces a whole launch), 1 launches of at least min_rows rows, 2 every launch it can take (tests, scripts/node_check.py)
+static int g_node = -1;
+int node_enable(int on) {
+    if (g_node < 0) g_node = 0;
+    const int old = g_node;
+    if (on >= 0) g_node = on > 2 ? 2 : on;
+    return old;
+}
+
+bool node_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count) {
+    constexpr long long min_rows = 16384;          // (below: the launch is a handful of tiles per CU either way; same-box sweep of round 5)
+    const int mode = node_enable(-1);
+    if (!mode || save || agg || round1 || !f16x2) return false;
+    if (mode == 1 && row_count < min_rows) return false;
+    if (p.n_src != 2 || p.n_add != 0 || p.n_nar != 0 || (p.n_layers != 2 && p.n_layers != 3) || p.n_out != NP) return false;
+    if (p.resid || p.out_idx || !p.out || p.out_bf16 || (p.out_ld & 3) || ((uintptr_t)p.out & 15) || p.row_base != 0) return false;
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const Src &s = p.src[s2];
+        if (s.width != NP || !s.vec || s.idx || s.pre_act || s.seg_off || s.bf16 || (s.ld & 3) || (s.col0 & 3) || ((uintptr_t)s.ptr & 15)) return false;
+    }
+    if (p.gamma && (((uintptr_t)p.gamma & 15) || ((uintptr_t)p.beta & 15))) return false;
+    if (((uintptr_t)p.b & 15) || p.M >= (1LL << 31)) return false;
+    if (p.n_heads < 0 || p.n_heads > G4C_MAX_HEADS) return false;
+    if (p.n_heads && ((p.head_ld & 3) || p.head_bf16)) return false;
+    for (int hd = 0; hd < p.n_heads; ++hd)
+        if ((uintptr_t)p.head_out[hd] & 15) return false;
+    return true;
+}
+
+int node_launch(const Params &p, hipStream_t st) {
+    NodeParams q{};
+    q.v = p.src[1].ptr + p.src[1].col0; q.v_ld = p.src[1].ld;
+    q.w = p.w; q.b = p.b; q.gamma = p.gamma; q.beta = p.beta; q.eps = p.eps; q.act = p.act;
+    q.out = p.out; q.out_ld = p.out_ld; q.n_heads = p.n_heads; q.head_ld = p.head_ld;
+    for (int hd = 0; hd < G4C_MAX_HEADS; ++hd) q.head_out[hd] = p.head_out[hd];
+    q.range_flag = p.range_flag; q.range_slot = p.range_slot;
+    const int n_rows = (int)p.M;
+    const int n_tiles = (n_rows + 31) / 32;
+    if (n_tiles == 0) return G4C_OK;
+    const int n_cu = g4c::cu_count();
+    const dim3 grid(n_tiles < n_cu ? n_tiles : n_cu), blk(512);
+    const float *x0 = p.src[0].ptr + p.src[0].col0;
+    if (p.n_layers == 2) mlp_node_kernel<2><<<grid, blk, 0, st>>>(x0, p.src[0].ld, q, n_rows);
+    else mlp_node_kernel<3><<<grid, blk, 0, st>>>(x0, p.src[0].ld, q, n_rows);
+    return g4c::check_launch("g4c_mlp_forward (node)");
 }
 
 int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st, const NodeParams *node) {
@@ -1087,3 +1214,4 @@ int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st, const Node
 }  // namespace g4cm
 
 extern "C" int g4c_mlp_ws_enable(int on) { return g4cm::ws_enable(on); }
+extern "C" int g4c_mlp_node_enable(int on) { return g4cm::node_enable(on); }

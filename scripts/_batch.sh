@@ -1,5 +1,4 @@
 cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out/b7
-timeout 300 python scripts/_dbg_fuse.py 2>&1 | grep -v amdgpu.ids | tail -3 > gpurun_out/b7/dbg.log
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "amdgpu.ids" | cut -c1-250 > gpurun_out/b7/pytest_gpu_full.log
-tail -c 5000 gpurun_out/b7/pytest_gpu_full.log > gpurun_out/b7/pytest_tail.log
+mkdir -p gpurun_out/b11
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "node_kernel or fused_mp_layer or range" 2>&1 | tail -5 > gpurun_out/b11/pytest_subset.log
+timeout 600 python scripts/mp_layer_check.py --time --no-check 2>&1 | grep -v "amdgpu.ids" | grep -v "^ok" > gpurun_out/b11/mp_layer_time.log
