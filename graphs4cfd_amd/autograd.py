@@ -128,24 +128,42 @@ FUSED_LINEAR_MIN_ROWS = 65536      # below: packing the weights for one launch c
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int = _lib.ACT_NONE) -> Tensor:
-    """act(x weight^T + bias) for the [M, 128 k] x [<= 128, 128 k] products of the backward pass (recomputed hidden layers,
-    input gradients): ONE layer of the fused-MLP kernel — the forward's arithmetic (exact operand split on the bf16 matrix pipe,
-    fp32-accurate) with bias and activation in the epilogue — instead of an fp32 library GEMM plus separate bias / activation
-    passes.  Other shapes go to rocBLAS."""
+    """act(x weight^T + bias) for the products of the backward pass (recomputed hidden layers, input gradients), ANY shape, as
+    launches of the fused-MLP kernel (one Linear layer each: the forward's arithmetic — exact operand split on the matrix pipe, fp32
+    accumulate — with bias and activation in the epilogue): the [M, 128 j] x [<= 128, 128 j] shapes of the published architectures
+    are one launch; more than 128 outputs are computed 128 columns at a time, more than four 128-column input blocks group by group,
+    each group adding to the previous group's partial sums (an additive source); narrow / ragged input blocks are padded by the
+    pack.  No library GEMM (round 5: `torch.mm / addmm` went to rocBLAS for every other shape and below 64k rows)."""
     n_out, k = int(weight.size(0)), int(weight.size(1))
-    if not (FUSED_LINEAR and int(x.size(0)) >= FUSED_LINEAR_MIN_ROWS and n_out <= 128 and k % 128 == 0
-            and 128 <= k <= 128 * _lib.MAX_SRC and x.stride(1) == 1):
-        y = torch.mm(x, weight.t()) if bias is None else torch.addmm(bias, x, weight.t())
-        return y if act == _lib.ACT_NONE else ops.activation_(y, act)
-    blocks = k // 128
+    M = int(x.size(0))
+    x = _dense(x)
+    if M == 0 or n_out == 0:
+        return torch.zeros((M, n_out), dtype=torch.float32, device=x.device)
     # (this is the backward pass: x may hold gradient rows — 1e-6 .. 1e-9 per row for a mean loss over 1e5+ nodes, i.e. fp16's
     # subnormal range, where the two-way fp16 split keeps a few bits only and nothing below 1.5e-11.  Like backward_chain, these
     # products use the three-way bf16 split, which has fp32's exponent range, whatever the forward's arithmetic is.)
-    prec = ops.effective_precision([128] * blocks)
-    pk = ops.PackedMLP([weight.detach()], [None if bias is None else bias.detach()], None, [128] * blocks, [False] * blocks,
-                       precision="bf16x6" if prec == "f16x3" else prec)
-    pk.params = None                                        # (never differentiated through)
-    return ops.mlp_forward(pk, [Source(x, col0=128 * j, width=128) for j in range(blocks)], int(x.size(0)), act)
+    blocks = [(k0, min(128, k - k0)) for k0 in range(0, k, 128)]
+    prec = ops.effective_precision([w for _, w in blocks])
+    prec = "bf16x6" if prec == "f16x3" else prec
+    out = None if n_out <= 128 else torch.empty((M, n_out), dtype=torch.float32, device=x.device)
+    w_d, b_d = weight.detach(), (None if bias is None else bias.detach())
+    y = None
+    for c in range(0, n_out, 128):
+        c1 = min(c + 128, n_out)
+        partial, i = None, 0
+        while i < len(blocks):
+            grp = blocks[i:i + (_lib.MAX_SRC if partial is None else _lib.MAX_SRC - 1)]
+            i += len(grp)
+            last = i >= len(blocks)
+            k0, k1 = grp[0][0], grp[-1][0] + grp[-1][1]
+            pk = ops.PackedMLP([w_d[c:c1, k0:k1]], [b_d[c:c1] if (b_d is not None and partial is None) else None], None,
+                               [w for _, w in grp], [False] * len(grp), precision=prec)
+            pk.params = None                                    # (never differentiated through)
+            srcs = [Source(x, col0=q0, width=w) for q0, w in grp] + ([Source(partial, additive=True)] if partial is not None else [])
+            dst = out[:, c:c1] if (last and out is not None) else None
+            partial = ops.mlp_forward(pk, srcs, M, act if last else _lib.ACT_NONE, out=dst)
+        y = partial
+    return y if out is None else out
 
 
 FUSED_CHAIN = True
@@ -170,57 +188,66 @@ def backward_chain(g: Tensor, weights: Sequence[Tensor], acts: Sequence[Tensor],
     return D, gx
 
 
-WGRAD_KERNEL_MIN_ROWS = 4096
+def _wgrad_tile(g: Tensor, blk: Tensor, M: int, with_bias: bool, scratch: Tensor) -> Tensor:
+    """One g4c_weight_grad launch: [128 x 128 | 128] = (g^T blk | column sums of g) for 128-wide g and a 128-column window `blk`."""
+    lib = _lib.load()
+    out = torch.empty(128 * 128 + 128, dtype=torch.float32, device=g.device)
+    _lib.check(lib.g4c_weight_grad(_lib.ptr(g), _ld(g), _lib.ptr(blk), _ld(blk), M, _lib.ptr(scratch), _lib.ptr(out),
+                                   1 if with_bias else 0, _lib.stream_handle(g.device)))
+    return out
+
+
+def _pad128(t: Tensor, c0: int, c1: int) -> Tensor:
+    """Columns [c0, c1) of t as a 128-wide, 16-byte aligned window: a view when they already are one, else a zero-padded copy."""
+    w = c1 - c0
+    if w == 128 and t.stride(1) == 1 and _ld(t) % 4 == 0 and (t.data_ptr() + 4 * c0) % 16 == 0:
+        return t[:, c0:c1]
+    p = torch.zeros((int(t.size(0)), 128), dtype=torch.float32, device=t.device)
+    ops.copy_cols(t if t.stride(1) == 1 else t.contiguous(), p, 0, scol0=c0, width=w)
+    return p
 
 
 def weight_bias_grad(g: Tensor, a: Tensor, want_bias: bool = True):
-    """(dW [N, K], db [N] or None) = (g^T a, column sums of g).  128-wide g and 128-column blocks of a: g4c_weight_grad (one
-    pass over both operands, MFMA, deterministic partial-tile sum; the bias gradient rides on the first block's pass);
-    any other shape: the split-row rocBLAS GEMM below + g4c_colsum."""
+    """(dW [N, K], db [N] or None) = (g^T a, column sums of g) by g4c_weight_grad (one pass over both operands, fp32 MFMA, a
+    deterministic sum of the workgroups' partial tiles; the bias gradient rides on the first block's pass), 128 x 128 tiles of dW
+    at a time.  128-wide g and 128-column blocks of a — every hidden layer of every published architecture — are read in place;
+    any other shape (narrow encoder inputs, a 3-wide decoder output, wide generic MLPs, few rows) through zero-padded 128-wide
+    copies of the odd blocks (round 5: those went to a split-row rocBLAS GEMM)."""
     M, N, K = int(g.size(0)), int(g.size(1)), int(a.size(1))
-    ok = (N == 128 and K % 128 == 0 and M >= WGRAD_KERNEL_MIN_ROWS and g.stride(1) == 1 and a.stride(1) == 1
-          and _ld(g) % 4 == 0 and _ld(a) % 4 == 0 and g.data_ptr() % 16 == 0 and a.data_ptr() % 16 == 0)
-    if not ok:
-        return weight_grad(g, a), (colsum(g) if want_bias else None)
-    lib = _lib.load()
     dev = _lib.require_hip(g, a)
+    if M == 0:
+        return torch.zeros((N, K), dtype=torch.float32, device=dev), (torch.zeros(N, dtype=torch.float32, device=dev) if want_bias else None)
+    lib = _lib.load()
     scratch = torch.empty(int(lib.g4c_weight_grad_scratch_floats(M)), dtype=torch.float32, device=dev)
-    dW = torch.empty((N, K), dtype=torch.float32, device=dev)
-    db = None
-    for j in range(K // 128):
-        out = torch.empty(128 * 128 + 128, dtype=torch.float32, device=dev)
-        blk = a[:, 128 * j:128 * (j + 1)]
-        with_bias = want_bias and j == 0
-        _lib.check(lib.g4c_weight_grad(_lib.ptr(g), _ld(g), _lib.ptr(blk), _ld(a), M, _lib.ptr(scratch), _lib.ptr(out),
-                                       1 if with_bias else 0, _lib.stream_handle(dev)))
-        if K == 128:
-            dW = out[:128 * 128].view(128, 128)
-        else:
-            dW[:, 128 * j:128 * (j + 1)] = out[:128 * 128].view(128, 128)
-        if with_bias:
-            db = out[128 * 128:]
+    single = N == 128 and K == 128
+    dW = None if single else torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = torch.empty(N, dtype=torch.float32, device=dev) if (want_bias and N != 128) else None
+    a_blocks = {}
+    for n0 in range(0, N, 128):
+        n1 = min(n0 + 128, N)
+        gp = _pad128(g, n0, n1)
+        for j, k0 in enumerate(range(0, K, 128)):
+            k1 = min(k0 + 128, K)
+            if k0 not in a_blocks:
+                a_blocks[k0] = _pad128(a, k0, k1)
+            with_bias = want_bias and j == 0
+            out = _wgrad_tile(gp, a_blocks[k0], M, with_bias, scratch)
+            tile = out[:128 * 128].view(128, 128)
+            if single:
+                dW = tile
+            else:
+                dW[n0:n1, k0:k1] = tile[:n1 - n0, :k1 - k0]
+            if with_bias:
+                if N == 128:
+                    db = out[128 * 128:]
+                else:
+                    db[n0:n1] = out[128 * 128:128 * 128 + n1 - n0]
     return dW, db
 
 
-WGRAD_CHUNK = 4096      # rows per split of a weight-gradient GEMM
-
-
 def weight_grad(g: Tensor, a: Tensor) -> Tensor:
-    """dW = g^T a for g [M, N], a [M, K] with M >> N, K: one [N, K] output tile and a contraction over up to millions of
-    rows is the worst shape for a library GEMM (a single tile's worth of parallelism).  Split the rows into chunks, contract
-    them as ONE strided-batched rocBLAS GEMM (no copies: the batch is a view), and add the per-chunk results in a fixed
-    order with g4c_colsum."""
-    M, N, K = int(g.size(0)), int(g.size(1)), int(a.size(1))
-    nb = M // WGRAD_CHUNK
-    if nb < 2 or not (g.is_contiguous() and a.is_contiguous()):
-        return torch.mm(g.t(), a)
-    m_main = nb * WGRAD_CHUNK
-    tail = M > m_main
-    part = torch.empty((nb + (1 if tail else 0), N, K), dtype=torch.float32, device=g.device)
-    torch.bmm(g[:m_main].view(nb, WGRAD_CHUNK, N).transpose(1, 2), a[:m_main].view(nb, WGRAD_CHUNK, K), out=part[:nb])
-    if tail:
-        torch.mm(g[m_main:].t(), a[m_main:], out=part[nb])
-    return colsum(part.view(part.size(0), N * K)).view(N, K)
+    """dW = g^T a for g [M, N], a [M, K] (weight_bias_grad without the bias)."""
+    return weight_bias_grad(g, a, False)[0]
 
 
 def _dense(t: Tensor) -> Tensor:
@@ -407,7 +434,7 @@ class _FusedMLP(torch.autograd.Function):
             if need_dx_dense:
                 if gX is None:
                     with _phase("dX GEMM"):
-                        gX = linear(g, W_d.t().contiguous(), None) if kd <= 128 else torch.mm(g, W_d)
+                        gX = linear(g, W_d.t().contiguous(), None)
                 with _phase("input adjoint: gather / aggregation"):
                     d0 = 0
                     for j in dense:
@@ -435,7 +462,7 @@ class _FusedMLP(torch.autograd.Function):
                 dW1[:, cols[j]:cols[j] + w] = weight_bias_grad(G, tt[j], False)[0]
             if needs[1 + j]:
                 with _phase("dX GEMM"):
-                    gt = torch.mm(G, W1[:, cols[j]:cols[j] + w])
+                    gt = linear(G, W1[:, cols[j]:cols[j] + w].t().contiguous(), None)
                 with _phase("input adjoint: gather / aggregation"):
                     # (sign and slope were applied when tt was formed from t: chain rule through them)
                     d_src[j] = finish(j, gt)
@@ -600,8 +627,11 @@ class _EdgeScalarToNodeVector(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout: Tensor):
         unit_inv, n, k, f = ctx.args
-        g = dout.reshape(n, f, 2).transpose(1, 2)                          # [n, 2, F]
-        return torch.bmm(unit_inv.transpose(1, 2), g).reshape(n * k, f), None, None, None
+        # d e[(n, j), f] = sum_c Uinv[n, c, j] dout[n, 2 f + c]: the projection of the node vectors dout[n] on the edges' "unit vectors"
+        # Uinv[n, :, j] — g4c_project_to_edges with node = edge // k (no batched library GEMM)
+        unit = unit_inv.transpose(1, 2).reshape(n * k, 2).contiguous()
+        node32 = torch.arange(n, dtype=torch.int32, device=dout.device).repeat_interleave(k)
+        return ops.project_to_edges(_dense(dout), node32, unit, n * k, f), None, None, None
 
 
 def edge_scalar_to_node_vector(e: Tensor, unit_inv: Tensor, n_nodes: int, k: int) -> Tensor:
