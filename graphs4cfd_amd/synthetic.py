@@ -157,8 +157,18 @@ def _connect_knn_periodic_device(pos: torch.Tensor, k: int, per) -> Optional[Tup
     else:
         return None
     cand = src[cand_aug]                                                                   # original point numbers
+    if bool((torch.sort(cand, dim=1).values.diff(dim=1) == 0).any()):                     # a point AND its own periodic image among one
+        return None                                                                        # centre's candidates (tiny clouds): host path
     d2 = ((emb[cand] - emb[:, None, :]) ** 2).sum(-1)
-    order = torch.sort(d2, dim=1, stable=True)[1][:, :k + 1]
+    d2s, order = torch.sort(d2, dim=1, stable=True)
+    # Completeness: the candidates are the kc + 1 nearest in the WRAPPED angle metric y, the reference orders by the
+    # EMBEDDED (chord) metric.  A point at chord distance D is at most 2 asin(D / 2) away in y (all of it along one periodic axis), so
+    # every point nearer than the (k + 1)-th chord distance is among the candidates iff that bound stays inside the candidates'
+    # y-radius; otherwise a true neighbour may be missing: host path.
+    dk = d2s[:, k].clamp(min=0).sqrt()
+    if bool((dk >= 2.0).any()) or bool((2.0 * torch.asin((dk * 0.5).clamp(max=1.0)) * (1 + 1e-9) > r).any()):
+        return None
+    order = order[:, :k + 1]
     nbr = torch.gather(cand, 1, order)
     is_self = nbr == ids[:, None]
     drop = torch.where(is_self.any(1), is_self.int().argmax(1), torch.full((n,), k, device=dev))

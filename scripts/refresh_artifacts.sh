@@ -2,14 +2,19 @@
 # Round artifacts, produced on the GPU box into gpurun_out/artifacts_<tag>/ (copy them into profiles/ afterwards):
 #   pytest -m gpu tail, bench lines of every named workload, rocprofv3 kernel stats of the headline and REMuS benches, PMC HBM
 #   traffic of both, MFMA ceiling, training benches.
-# Usage: gpurun --timeout 3000 -- 'bash scripts/refresh_artifacts.sh r04'
-TAG=${1:-r04}
+# Usage: gpurun --timeout 3000 -- 'bash scripts/refresh_artifacts.sh r05'
+TAG=${1:-r05}
 cd "$GRAFT_REPO_ROOT"
 A=gpurun_out/artifacts_$TAG; rm -rf $A; mkdir -p $A
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $A/${TAG}_pytest_gpu.log
 # PMC first: bench.py's roofline block quotes the newest profiles/*_pmc_traffic*.json
 timeout 1200 bash scripts/collect_pmc_traffic.sh $TAG > $A/pmc.log 2>&1; cp profiles/${TAG}_pmc_traffic.json $A/ 2>/dev/null
 timeout 1200 bash scripts/collect_pmc_traffic.sh $TAG c3 > $A/pmc_c3.log 2>&1; cp profiles/${TAG}_pmc_traffic_c3.json $A/ 2>/dev/null
+# pipe-utilisation counters of the shipped kernels in the DEFAULT arithmetic, BEFORE the bench (bench.py imports the newest
+# profiles/*_pmc_mlp_ws.txt / *_pmc_mlp_bx6_node.txt and says whether they were collected from the kernel sources it runs): level-1 message
+# launch (mlp_ws_kernel) and node launch (mlp_bx6_kernel)
+bash scripts/pmc_ws.sh ws ${TAG}_ws util sq3 lds sq2 tcc mix mix2 coexec > profiles/${TAG}_pmc_mlp_ws.txt 2>&1; cp profiles/${TAG}_pmc_mlp_ws.txt $A/
+PMC_EXTRA_ARGS=--node bash scripts/pmc_ws.sh tile ${TAG}_node util sq3 lds sq2 tcc mix mix2 coexec > profiles/${TAG}_pmc_mlp_bx6_node.txt 2>&1; cp profiles/${TAG}_pmc_mlp_bx6_node.txt $A/
 timeout 900 python bench.py > $A/bench_stdout.log 2> $A/bench_stderr.log; tail -1 $A/bench_stdout.log > $A/${TAG}_bench_n1.json
 for wl in c2 c3 c5-1gpu; do
   timeout 900 python bench.py --workload $wl 2> $A/bench_${wl}_stderr.log | tail -1 > $A/${TAG}_bench_${wl}.json
@@ -50,9 +55,13 @@ G4C_MLP_PRECISION=bf16x6 timeout 300 python scripts/bx6i_check.py --time 2>&1 | 
 # cycle stamps of the weight-stationary kernel's pair loop (DESIGN.md 4.1 / 9 quote them)
 bash scripts/build_ws_timing.sh > /dev/null 2>&1 && timeout 120 python scripts/ws_stamps.py graphs4cfd_amd/lib/libg4c_ws_timing.so 2>&1 | grep -v amdgpu.ids > $A/${TAG}_ws_stamps.log
 timeout 120 python scripts/ws_stamps.py graphs4cfd_amd/lib/libg4c_ws_timing.so bf16 2>&1 | grep -v amdgpu.ids > $A/${TAG}_ws_stamps_bf16_mode.log
-# pipe-utilisation counters of the shipped kernels in the DEFAULT arithmetic: level-1 message launch (mlp_ws_kernel) and node launch (mlp_bx6_kernel)
-bash scripts/pmc_ws.sh ws ${TAG}_ws util sq3 lds sq2 tcc mix mix2 coexec > $A/${TAG}_pmc_mlp_ws.txt 2>&1
-PMC_EXTRA_ARGS=--node bash scripts/pmc_ws.sh tile ${TAG}_node util sq3 lds sq2 tcc mix mix2 coexec > $A/${TAG}_pmc_mlp_bx6_node.txt 2>&1
+# round 5: the fused MP layer and the node update's own kernel against the separate launches / the tile kernel
+timeout 600 python scripts/mp_layer_check.py --time 2>&1 | grep -v "^ok\|amdgpu.ids" > $A/${TAG}_mp_layer_check_and_ab.log
+timeout 600 python scripts/node_check.py --time 2>&1 | grep -v "^ok\|amdgpu.ids" > $A/${TAG}_node_check_and_ab.log
+{ for f in 0 1; do for wl in "--workload c2" "--nodes 12500 --steps 100 --no-side-configs"; do
+    echo "G4C_FUSE_LAYER=$f bench.py $wl: $(G4C_FUSE_LAYER=$f timeout 300 python bench.py $wl --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys;print(round(json.loads(sys.stdin.read())['value'],1))") steps/s"
+  done; done; } > $A/${TAG}_ab_fused_layer.log 2>&1
+timeout 300 python scripts/remus_bf16_err.py 2>&1 | grep -v amdgpu.ids > $A/${TAG}_remus_bf16_products_err.log
 # co-issue microbenchmarks (what hides behind one MFMA, by shape, waves per SIMD and instruction kind)
 hipcc -w --offload-arch=gfx950 -O3 -o /tmp/mfma_fillers scripts/micro/mfma_fillers.hip 2>/dev/null && /tmp/mfma_fillers > $A/${TAG}_mfma_fillers.log 2>&1
 for m in mfma_gap_patterns mfma_chain_probe mfma_lds_probe; do
