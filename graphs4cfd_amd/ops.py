@@ -298,10 +298,11 @@ def rollout_advance(field: Tensor, pred: Tensor, outputs: Tensor, step: Tensor, 
 #   "f16x3" (default)   fp32-class products on the f16 matrix pipe: both operands split two ways into fp16 terms,
 #                       x = h + l * 2^-11 (22 significand bits), three partial products, the 2^-11 terms in their own fp32
 #                       accumulator (g4c_mlp_pack_layer_f16x3 + the g4c_mlp_forward_bx6* entry points); measured error against fp64
-#                       below that of the fp32-MFMA kernel (scripts/mlp_accuracy.py, test_mlp_precisions_vs_fp64).  Range: an MLP
-#                       input or hidden activation beyond +-65504 is clipped there (no inf / NaN) — normalised CFD fields and
-#                       LayerNorm'd latents are far inside, raw inputs only pass the fp32 vector path; Model.solve warns about inputs
-#                       large enough to get near it; "bf16x6" has no such limit;
+#                       below that of the fp32-MFMA kernel (scripts/mlp_accuracy.py, test_mlp_precisions_vs_fp64).  Range: fp16's — an MLP
+#                       input or hidden activation beyond +-65504 is clipped there (no inf / NaN) AND FLAGGED on the device; the
+#                       arithmetic is run optimistically: a rollout reads its flags where it hands out results (Rollout.validate) and
+#                       recomputes itself in "bf16x6" if anything was clipped, so solve() never returns a clipped value (normalised CFD
+#                       fields and LayerNorm'd latents are far inside the range; raw inputs only pass the fp32 vector path);
 #   "bf16x6"            the same kernels with both operands split EXACTLY into three bf16 terms (fp32 exponent range), the six
 #                       largest partial products accumulated in fp32 (g4c_mlp_forward_bx6): twice the matrix-pipe work;
 #                       MLPs outside the envelope of these two (an input block wider than 128) use the fp32 kernels;
@@ -331,10 +332,10 @@ AGG_ON_LOAD_MIN_ROWS = 50000
 # ---- fp16 range of the "f16x3" arithmetic made observable (g4c_mlp_t.range_flag): every launch in that arithmetic carries a slot
 # of a per-device int32 array; a kernel that converted a value of magnitude >= 65504 to fp16 (it was clipped there) writes 1 into
 # its slot.  Slots are named after the MLP that launched ("NsThreeScaleGNN.mp112.edge_mlp"); f16_range_report() reads the array
-# (one device synchronisation), check_f16_range() turns a non-empty report into a RuntimeWarning.  Rollout.result (hence
-# Model.solve), DistributedRollout.gather_outputs and GNN.fit (per epoch) call it, so a clip is never silent on those paths; a
-# rollout clears its own model's slots on entry and reports only those, so a clip is attributed to the model that launched it.
-# After a bare model.forward() call gfd.check_f16_range() yourself.
+# (one device synchronisation), check_f16_range() turns a non-empty report into a RuntimeWarning.  Rollout.validate (called by
+# Rollout.result, hence Model.solve) and DistributedRollout.validate (gather_outputs) read it and RECOMPUTE a clipped rollout in "bf16x6";
+# GNN.fit warns per epoch; a rollout clears its own model's slots on entry and looks at those only, so a clip is attributed to the
+# model that launched it.  After a bare model.forward() call gfd.check_f16_range() yourself.
 RANGE_SLOTS = 4096
 _range_bufs = {}            # device -> int32 [RANGE_SLOTS]
 _range_sites: List[set] = [set() for _ in range(RANGE_SLOTS)]
