@@ -110,6 +110,13 @@ __device__ __forceinline__ f32x2 selu2w(f32x2 x) {
 #ifndef G4C_WS_MEAN_DIV
 #define G4C_WS_MEAN_DIV 1
 #endif
+// G4C_WS_SKEW (round 5): the tails of a pair (LayerNorm / row stores, aggregation) have no matrix work, and with all eight waves in
+// lock step the matrix pipes idle through them.  The two waves of a SIMD are waves w and w + 4 of the workgroup: the tails of pair i
+// move into the first two phase intervals of pair i + 1, where waves 0 - 3 run them BEFORE their matrix phase and waves 4 - 7 AFTER
+// it — one wave's tail under the other wave's MFMAs, between the same two barriers (which also order LayerNorm -> aggregation).
+#ifndef G4C_WS_SKEW
+#define G4C_WS_SKEW 0
+#endif
 
 // Round-5 experiment (-DG4C_WS_EXP_POLY=1, not the default — measured slower): the SELU's
 // exponential without the transcendental unit.  exp(x) for x <= 0 (the clamp to [0, 1] of the shipped form is the range reduction's
@@ -780,80 +787,8 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
             }
         }
     };
-    // Loop-carried: xr[1] / adB = input rows / additive rows of the CURRENT pair's tile B (gathered in the previous tail: parked /
-    // added in and after the first matrix phase), accA = tile A's start values, tile A's rows in its planes.
-    AddV adB[2][2];
-    unsigned rawB[2][2] = {{0u, 0u}, {0u, 0u}};        // (XB16: tile B's bf16 rows as loaded)
-    {
-        AddV adA[2][2];
-        unsigned rawA[2][2] = {{0u, 0u}, {0u, 0u}};
-        gather_x(m0, 0, 0, xr[0], rawA);
-        gather_x(m0, 0, 1, xr[1], rawB);
-        gather_adds(0, 0, adA);
-        gather_adds(1, 0, adB);
-        widen_x(xr[0], rawA);
-        if (pact) other_all<SP, 2, true>(accA, accA1, xr[0], oA, rng);
-        else other_all<SP, 2, false>(accA, accA1, xr[0], oA, rng);
-        start_values(accA, accA1, adA);
-    }
-    __syncthreads();                                       // tile A's planes of the first pair visible
-
-    for (int it = 0, pair = p_begin; pair < p_end; ++pair, ++it) {
-        WS_STAMP(0);
-        // ---- tables two pairs ahead (their meta was loaded an iteration ago), meta three pairs ahead
-        const Meta m3raw = load_meta(pair + 3);
-        const int tv = load_tables(m2);
-        // (tile A's planes were written in the previous iteration's last matrix phase — before the loop for the first pair — and
-        // that phase's barrier lies between; nothing the stragglers of the previous tail still read is written in this phase)
-        WS_STAMP(1);
-        widen_x(xr[1], rawB);
-        if (pact) m_block<SP, 2, true>(paA, W[0], accA, accA1, accA, accA1, xr[1], oB, rng);                 // for B: park
-        else m_block<SP, 2, false>(paA, W[0], accA, accA1, accA, accA1, xr[1], oB, rng);
-        start_values(accB, accB1, adB);
-        __syncthreads();
-        WS_STAMP(2);
-        // ---- tile A's rows one pair ahead (indices in LDS since the previous iteration); tile B's: in the tail
-        f32x4 nxa[2];
-        AddV nadA[2][2];
-        unsigned nraw[2][2] = {{0u, 0u}, {0u, 0u}};
-        gather_x(m1, (it + 1) & 1, 0, nxa, nraw);
-        m_block<SP, 1>(paB, W[0], accB, accB1, accA, accA1, xr[1], oA, rng);                 // for A: epilogue of layer 0
-        bias_init(accA, accA1, 1);
-        __syncthreads();
-        WS_STAMP(3);
-        gather_adds(0, (it + 1) & 1, nadA);
-        m_block<SP, 1>(paA, W[1], accA, accA1, accB, accB1, xr[1], oB, rng);                 // for B: epilogue of layer 0
-        bias_init(accB, accB1, 1);
-        __syncthreads();
-        WS_STAMP(4);
-        if constexpr (NL == 3) {
-            m_block<SP, 1>(paB, W[1], accB, accB1, accA, accA1, xr[1], oA, rng);             // for A: epilogue of layer 1
-            bias_init(accA, accA1, 2);
-            __syncthreads();
-            WS_STAMP(5);
-            m_block<SP, 1>(paA, W[2], accA, accA1, accB, accB1, xr[1], oB, rng);             // for B: epilogue of layer 1
-            bias_init(accB, accB1, 2);
-            __syncthreads();
-            WS_STAMP(6);
-        }
-        // for A: last layer's fp32 rows — and the NEXT pair's tile A parked into A's planes (their last readers, M(A, NL - 1), are
-        // behind the previous barrier; the rows were gathered four phases ago): this phase has next to no vector work of its own
-        widen_x(nxa, nraw);
-        if (pact) m_block<SP, 4, true>(paB, W[NL - 1], accB, accB1, accA, accA1, nxa, oA, rng);
-        else m_block<SP, 4, false>(paB, W[NL - 1], accB, accB1, accA, accA1, nxa, oA, rng);
-        other_all<SP, 3, false>(accB, accB1, xr[1], oB, rng);                                // B's last layer -> fp32 rows
-        __syncthreads();
-        WS_STAMP(7);
-        // ---- the next pair's tile A start values; then its tile B rows (parked under its M(A', 0)) are gathered: in front of this
-        // tail's stores (memory returns in order per wave), a tail and a phase ahead of their use, so that they are not live across
-        // this pair's matrix phases (tile B's additive rows: at the end of the tail)
-        start_values(accA, accA1, nadA);
-        gather_x(m1, (it + 1) & 1, 1, xr[1], rawB);
-        // the tables fetched at the top of this iteration (older than every other load in flight) go to the ring slot of the pair
-        // whose rows were gathered in the previous iteration; the next iteration's top barrier publishes them
-        store_tables(tv, it + 2);
-        WS_STAMP(8);
-
+    // LayerNorm / activation / row stores of a finished pair (its fp32 rows in fA / fB; `mm` = that pair's rows)
+    auto ln_tail = [&](const Meta &mm) __attribute__((always_inline)) {
         // ---- tail of this pair: LayerNorm / activation of both tiles.  16 lanes per row (8 columns each), so the row sums are
         // reduced inside a 16-lane DPP row (quad_perm, row_half_mirror, row_mirror: no LDS round trips); a wave takes 4 rows per
         // pass, the workgroup a whole tile per pass.  The finished rows are stored straight from the registers (16 lanes = one
@@ -923,8 +858,8 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
                 f32x4 v0, v1;
                 v0[0] = x[t][0]; v0[1] = x[t][1]; v0[2] = x[t][2]; v0[3] = x[t][3]; v1[0] = x[t][4]; v1[1] = x[t][5]; v1[2] = x[t][6]; v1[3] = x[t][7];
                 if (AGG) { *reinterpret_cast<f32x4 *>(rowp[t] + cq[0]) = v0; *reinterpret_cast<f32x4 *>(rowp[t] + cq[1]) = v1; }
-                if (p.out && row < m0.n[t]) {
-                    const long long orow = (!AGG && p.out_idx) ? p.out_idx[m0.r0[t] + row] : m0.r0[t] + row;
+                if (p.out && row < mm.n[t]) {
+                    const long long orow = (!AGG && p.out_idx) ? p.out_idx[mm.r0[t] + row] : mm.r0[t] + row;
                     if (SP == 1 && p.out_bf16) {
                         // rows kept in bf16 (g4c_mlp_forward_bf16_agg out_dtype; == 2: the reader's pending SELU applied before the one
                         // rounding — the aggregation below still sees the fp32 rows without it), 16 bytes per lane
@@ -941,21 +876,15 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
                 }
             }
         }
-        // (rounded-bf16 mode: the row stores are half as many bytes, and the gathers in front of the aggregation's barrier measure
-        // 1.8 % faster per pair than behind the aggregation; f16x3 stream: 3 % slower — they queue behind the fp32 row stores)
-        if constexpr (SP == 1) gather_adds(1, (it + 1) & 1, adB);
-        WS_STAMP(9);
-        // (no barrier at the end of a tail without the aggregation: the next pair's parked rows — what a wave that runs ahead into
-        // M(A', 0) reads — were written before the barrier that closed the last matrix phase)
-        if (AGG) {
-            __syncthreads();
-            WS_STAMP(15);
+    };
+    // aggregation of a finished pair's targets from the LayerNorm'd rows in fA / fB (`itp` = that pair's iteration: its slot of sSeg)
+    auto agg_tail = [&](const Meta &mm, const int itp) __attribute__((always_inline)) {
             // aggregation of the targets whose messages the tiles hold (rows in CSR order): the rows of a segment are added in order
             // (clamped loads, predicated adds) and divided by max(count, 1) like segment_reduce_kernel does, so the result is
             // bit-identical to the separate launch.  32 lanes per target (16 bytes each), 16 targets per pass over both tiles.
             const int c4 = (tid & 31) * 4;
-            const int *sg_tab = sSeg[it & 3];
-            const int nsA = m0.s1[0] - m0.s0[0], nsB = m0.s1[1] - m0.s0[1];
+            const int *sg_tab = sSeg[itp & 3];
+            const int nsA = mm.s1[0] - mm.s0[0], nsB = mm.s1[1] - mm.s0[1];
             auto reduce_rows = [&](const float *sH, int b, int e, int sg) __attribute__((always_inline)) {
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
                 for (int r0 = b; r0 < e; r0 += 8) {
@@ -995,19 +924,115 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
             for (int q = tid >> 5; q < nsA + nsB; q += 16) {
                 const int t = q >= nsA ? 1 : 0, j = q - (t ? nsA : 0);
                 if (j < SEGCAP) {
-                    const int b = sg_tab[t * (SEGCAP + 1) + j] - m0.r0[t], e = sg_tab[t * (SEGCAP + 1) + j + 1] - m0.r0[t];
-                    reduce_rows(t ? fB : fA, b, e, m0.s0[t] + j);
+                    const int b = sg_tab[t * (SEGCAP + 1) + j] - mm.r0[t], e = sg_tab[t * (SEGCAP + 1) + j + 1] - mm.r0[t];
+                    reduce_rows(t ? fB : fA, b, e, mm.s0[t] + j);
                 }
             }
             if (nsA > SEGCAP || nsB > SEGCAP) {          // (a tile with a long run of empty segments: their offsets from global memory)
                 for (int q = tid >> 5; q < nsA + nsB; q += 16) {
                     const int t = q >= nsA ? 1 : 0, j = q - (t ? nsA : 0);
                     if (j >= SEGCAP) {
-                        const int sg = m0.s0[t] + j;
-                        reduce_rows(t ? fB : fA, p.seg_off[sg] - m0.r0[t], p.seg_off[sg + 1] - m0.r0[t], sg);
+                        const int sg = mm.s0[t] + j;
+                        reduce_rows(t ? fB : fA, p.seg_off[sg] - mm.r0[t], p.seg_off[sg + 1] - mm.r0[t], sg);
                     }
                 }
             }
+    };
+    // Loop-carried: xr[1] / adB = input rows / additive rows of the CURRENT pair's tile B (gathered in the previous tail: parked /
+    // added in and after the first matrix phase), accA = tile A's start values, tile A's rows in its planes.
+    AddV adB[2][2];
+    unsigned rawB[2][2] = {{0u, 0u}, {0u, 0u}};        // (XB16: tile B's bf16 rows as loaded)
+    {
+        AddV adA[2][2];
+        unsigned rawA[2][2] = {{0u, 0u}, {0u, 0u}};
+        gather_x(m0, 0, 0, xr[0], rawA);
+        gather_x(m0, 0, 1, xr[1], rawB);
+        gather_adds(0, 0, adA);
+        gather_adds(1, 0, adB);
+        widen_x(xr[0], rawA);
+        if (pact) other_all<SP, 2, true>(accA, accA1, xr[0], oA, rng);
+        else other_all<SP, 2, false>(accA, accA1, xr[0], oA, rng);
+        start_values(accA, accA1, adA);
+    }
+    __syncthreads();                                       // tile A's planes of the first pair visible
+
+    Meta mp = m0;          // G4C_WS_SKEW: the previous pair
+    for (int it = 0, pair = p_begin; pair < p_end; ++pair, ++it) {
+        WS_STAMP(0);
+        // ---- tables two pairs ahead (their meta was loaded an iteration ago), meta three pairs ahead
+        const Meta m3raw = load_meta(pair + 3);
+        const int tv = load_tables(m2);
+        // (tile A's planes were written in the previous iteration's last matrix phase — before the loop for the first pair — and
+        // that phase's barrier lies between; nothing the stragglers of the previous tail still read is written in this phase)
+        WS_STAMP(1);
+        widen_x(xr[1], rawB);
+        if constexpr (G4C_WS_SKEW) { if (it > 0 && wave < 4) ln_tail(mp); }
+        if (pact) m_block<SP, 2, true>(paA, W[0], accA, accA1, accA, accA1, xr[1], oB, rng);                 // for B: park
+        else m_block<SP, 2, false>(paA, W[0], accA, accA1, accA, accA1, xr[1], oB, rng);
+        if constexpr (G4C_WS_SKEW) { if (it > 0 && wave >= 4) ln_tail(mp); }
+        start_values(accB, accB1, adB);
+        __syncthreads();
+        WS_STAMP(2);
+        // ---- tile A's rows one pair ahead (indices in LDS since the previous iteration); tile B's: in the tail
+        f32x4 nxa[2];
+        AddV nadA[2][2];
+        unsigned nraw[2][2] = {{0u, 0u}, {0u, 0u}};
+        gather_x(m1, (it + 1) & 1, 0, nxa, nraw);
+        if constexpr (G4C_WS_SKEW && AGG) { if (it > 0 && wave < 4) agg_tail(mp, it - 1); }
+        m_block<SP, 1>(paB, W[0], accB, accB1, accA, accA1, xr[1], oA, rng);                 // for A: epilogue of layer 0
+        if constexpr (G4C_WS_SKEW && AGG) { if (it > 0 && wave >= 4) agg_tail(mp, it - 1); }
+        bias_init(accA, accA1, 1);
+        __syncthreads();
+        WS_STAMP(3);
+        gather_adds(0, (it + 1) & 1, nadA);
+        m_block<SP, 1>(paA, W[1], accA, accA1, accB, accB1, xr[1], oB, rng);                 // for B: epilogue of layer 0
+        bias_init(accB, accB1, 1);
+        __syncthreads();
+        WS_STAMP(4);
+        if constexpr (NL == 3) {
+            m_block<SP, 1>(paB, W[1], accB, accB1, accA, accA1, xr[1], oA, rng);             // for A: epilogue of layer 1
+            bias_init(accA, accA1, 2);
+            __syncthreads();
+            WS_STAMP(5);
+            m_block<SP, 1>(paA, W[2], accA, accA1, accB, accB1, xr[1], oB, rng);             // for B: epilogue of layer 1
+            bias_init(accB, accB1, 2);
+            __syncthreads();
+            WS_STAMP(6);
+        }
+        // for A: last layer's fp32 rows — and the NEXT pair's tile A parked into A's planes (their last readers, M(A, NL - 1), are
+        // behind the previous barrier; the rows were gathered four phases ago): this phase has next to no vector work of its own
+        widen_x(nxa, nraw);
+        if (pact) m_block<SP, 4, true>(paB, W[NL - 1], accB, accB1, accA, accA1, nxa, oA, rng);
+        else m_block<SP, 4, false>(paB, W[NL - 1], accB, accB1, accA, accA1, nxa, oA, rng);
+        other_all<SP, 3, false>(accB, accB1, xr[1], oB, rng);                                // B's last layer -> fp32 rows
+        __syncthreads();
+        WS_STAMP(7);
+        // ---- the next pair's tile A start values; then its tile B rows (parked under its M(A', 0)) are gathered: in front of this
+        // tail's stores (memory returns in order per wave), a tail and a phase ahead of their use, so that they are not live across
+        // this pair's matrix phases (tile B's additive rows: at the end of the tail)
+        start_values(accA, accA1, nadA);
+        gather_x(m1, (it + 1) & 1, 1, xr[1], rawB);
+        // the tables fetched at the top of this iteration (older than every other load in flight) go to the ring slot of the pair
+        // whose rows were gathered in the previous iteration; the next iteration's top barrier publishes them
+        store_tables(tv, it + 2);
+        WS_STAMP(8);
+
+        if constexpr (!G4C_WS_SKEW) {
+            ln_tail(m0);
+            // (rounded-bf16 mode: the row stores are half as many bytes, and the gathers in front of the aggregation's barrier measure
+        // 1.8 % faster per pair than behind the aggregation; f16x3 stream: 3 % slower — they queue behind the fp32 row stores)
+        if constexpr (SP == 1) gather_adds(1, (it + 1) & 1, adB);
+        WS_STAMP(9);
+        // (no barrier at the end of a tail without the aggregation: the next pair's parked rows — what a wave that runs ahead into
+        // M(A', 0) reads — were written before the barrier that closed the last matrix phase)
+            if (AGG) {
+                __syncthreads();
+                WS_STAMP(15);
+                agg_tail(m0, it);
+            }
+        } else {
+            if constexpr (SP == 1) gather_adds(1, (it + 1) & 1, adB);
+            mp = m0;          // (this pair's LayerNorm / aggregation: inside the next pair's first two phase intervals)
         }
         // the next pair's tile B additive rows (added after its M(A', 0)): behind this tail's stores — issued together with tile B's
         // rows at the top of the tail, the six loads per lane held up the LayerNorm's stores (tail 3.4 k -> 6.6 k ticks)
@@ -1015,6 +1040,13 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
         if constexpr (SP != 1) gather_adds(1, (it + 1) & 1, adB);
         WS_STAMP(10);
         m0 = m1; m1 = m2; m2 = fix_meta(m3raw);
+    }
+    if constexpr (G4C_WS_SKEW) {          // the last pair's tails
+        ln_tail(mp);
+        if (AGG) {
+            __syncthreads();
+            agg_tail(mp, p_end - p_begin - 1);
+        }
     }
 
     if constexpr (NODE) {
