@@ -244,6 +244,10 @@ __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const
 // vector instructions scheduled behind each MFMA of a slice (measured: 3, 4, 6 and MFMAs in bursts of 3 / 6 with the vector work behind
 // them all within 3 % of each other — DESIGN.md 4.1 "What bounds it")
 constexpr int WS_VALU_PER_MFMA = 4;
+// slices the B fragments are fetched ahead of their MFMAs (round 5: 3 — + 8 registers — measured against 2 in profiles/r05_ws_variants_ab.log)
+#ifndef WS_FRAG_AHEAD
+#define WS_FRAG_AHEAD 2
+#endif
 // One 128-k block for one tile: acc += W(layer) x planes, 8 slices (k-step ks = s / 2, sample row block rb = s % 2) of three
 // products each: (Wh, xl) and (Wl, xh) into acc1 (the 2^-11 terms), (Wh, xh) into acc.  pa[ks]: this lane's B-operand address
 // (row n, granule (4 ks + g) ^ n) in the tile's h plane.
@@ -251,10 +255,11 @@ constexpr int WS_VALU_PER_MFMA = 4;
 template <int SP, int EK, bool PACT = false>
 __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16x8 (&W)[4][SP], f32x4 (&acc)[2], f32x4 (&acc1)[2],
                                         const f32x4 (&accE)[2], const f32x4 (&accE1)[2], const f32x4 (&xe)[2], const Other &o, RangeV &rng) {
-    // B fragments (h, l planes) of slice s: row block s % 2, k-step s / 2; fetched two slices ahead of their MFMAs
-    bf16x8 fh[3], fl[3];
+    // B fragments (h, l planes) of slice s: row block s % 2, k-step s / 2; fetched WS_FRAG_AHEAD slices ahead of their MFMAs
+    constexpr int AH = WS_FRAG_AHEAD, RING = AH + 1;
+    bf16x8 fh[RING], fl[RING];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < AH; ++s) {
         const __bf16 *pn = pa[s >> 1] + (s & 1) * 16 * PS;
         fh[s] = *reinterpret_cast<const bf16x8 *>(pn);
         if (SP == 2) fl[s] = *reinterpret_cast<const bf16x8 *>(pn + PLN);
@@ -263,10 +268,10 @@ __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int ks = s >> 1, rb = s & 1;
-        if (s + 2 < 8 && !(G4C_WS_ABLATE & 4)) {
-            const __bf16 *pn = pa[(s + 2) >> 1] + ((s + 2) & 1) * 16 * PS;
-            fh[(s + 2) % 3] = *reinterpret_cast<const bf16x8 *>(pn);
-            if (SP == 2) fl[(s + 2) % 3] = *reinterpret_cast<const bf16x8 *>(pn + PLN);
+        if (s + AH < 8 && !(G4C_WS_ABLATE & 4)) {
+            const __bf16 *pn = pa[(s + AH) >> 1] + ((s + AH) & 1) * 16 * PS;
+            fh[(s + AH) % RING] = *reinterpret_cast<const bf16x8 *>(pn);
+            if (SP == 2) fl[(s + AH) % RING] = *reinterpret_cast<const bf16x8 *>(pn + PLN);
         }
         if (!EK) __builtin_amdgcn_sched_barrier(0);
         if constexpr (EK == 4) {          // last layer's fp32 rows of accE, then the NEXT pair's first tile parked into the same tile's planes
@@ -275,11 +280,11 @@ __device__ __forceinline__ void m_block(const __bf16 *const (&pa)[4], const bf16
         } else {
             other_piece<SP, EK, PACT>(s, accE, accE1, xe, o, hold, rng);
         }
-        const bf16x8 ch = fh[s % 3];
+        const bf16x8 ch = fh[s % RING];
         if constexpr (SP == 1) {
             acc[rb] = mfma16<1>(W[ks][0], ch, acc[rb]);
         } else {
-            const bf16x8 cl = fl[s % 3];
+            const bf16x8 cl = fl[s % RING];
             if (G4C_WS_ABLATE & 2) {
                 asm volatile("" :: "v"(ch), "v"(cl));
             } else {
