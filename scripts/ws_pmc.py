@@ -19,7 +19,14 @@ ep, csr = plan.edge_csr(ei, n)
 pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
 src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
 out, agg = torch.empty(rows, H, device=dev), torch.empty(n, H, device=dev)
-if "--node" in sys.argv:          # the level-1 node launch: [aggregate | v] -> MLP -> LayerNorm -> SELU, + the next layer's two first-layer products (heads)
+if "--fused" in sys.argv:        # one launch per MP layer (g4c_mp_layer_forward_bx6) at config 2's level-1 size: 10k nodes, 60k edges, heads
+    rows = 60000; n = rows // 6
+    e, v = torch.randn(rows, H, device=dev), torch.randn(n, H, device=dev)
+    ei = torch.stack([torch.randint(0, n, (rows,)), torch.arange(n).repeat_interleave(6)]).to(dev)
+    for _ in range(6):
+        out = blk.step(v, e, ei, _lib.ACT_SELU, e_pre_act=_lib.ACT_SELU, next_msg=blk.edge_mlp)
+    assert int(lib.g4c_mlp_last_kernel()) == 4
+elif "--node" in sys.argv:          # the level-1 node launch: [aggregate | v] -> MLP -> LayerNorm -> SELU, + the next layer's two first-layer products (heads)
     v = torch.randn(n, H, device=dev)
     res = None
     for _ in range(6):
