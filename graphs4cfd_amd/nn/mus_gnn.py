@@ -60,7 +60,11 @@ class _MuSGNN(GNN):
         that will hoist its first layer, the launch also emits its node-side products (MLP.run_with_heads).
         Returns (output, products or None)."""
         nxt = self._PROGRAM[k] if k < len(self._PROGRAM) else ""
-        if nxt.startswith("mp") and n_edges >= _blocks.HOIST_MIN_ROWS:
+        # (the consumer hoists from HOIST_MIN_ROWS edges on — and always when it runs as one fused launch per MP layer, whose message
+        # part takes the products as additive rows: without them it would make them itself, two more launches at the level's entry)
+        fused = (_blocks.FUSE_LAYER and not ops.grad_mode() and ops.mlp_precision() == "f16x3"
+                 and _blocks.FUSE_LAYER_MIN_ROWS <= n_edges < _blocks.FUSE_LAYER_MAX_ROWS)
+        if nxt.startswith("mp") and (n_edges >= _blocks.HOIST_MIN_ROWS or fused):
             cons = getattr(self, nxt).edge_mlp
             w = mlp.output_size
             res = mlp.run_with_heads(sources, n_rows, act_code, cons, cons.input_size - 2 * w, [w, w])
