@@ -1000,6 +1000,40 @@ def test_distributed_rollout_single_rank_equals_rollout():
     torch.testing.assert_close(dr.gather_outputs(), ref, rtol=1e-4, atol=1e-4)
 
 
+def test_distributed_rollout_recomputes_a_clipped_rollout_in_bf16x6():
+    """DistributedRollout.validate (called by gather_outputs): as nn.model.Rollout — a partitioned rollout whose launches reached the end
+    of the fp16 range is recomputed from its input window in "bf16x6" (the decision is an all-reduce over the ranks; world size 1
+    here) and stays in that arithmetic; what gather_outputs returns equals the bf16x6 solve of the same model."""
+    import warnings
+    from graphs4cfd_amd import partition as P
+    g = S.mus_graph(3000, levels=2, seed=16)
+    torch.manual_seed(17)
+    model = gfd.nn.NsTwoScaleGNN(arch=S.mus_arch("NsTwoScaleGNN", 128), device=DEV)
+    with torch.no_grad():
+        model.mp111.edge_mlp.MLP.layer_norm.weight.mul_(3e4)
+    model.invalidate_packed()
+    old = ops.set_mlp_precision("f16x3")
+    try:
+        ops.f16_range_clear()
+        for capture in (False, True):
+            dr = P.DistributedRollout(model, g, 4, 0, 1, DEV, capture=capture)
+            dr.run(4)
+            with pytest.warns(RuntimeWarning, match="recomputed in"):
+                got = dr.gather_outputs()
+            assert dr.exact_range and dr.steps_done == 4
+            with warnings.catch_warnings():
+                warnings.simplefilter("error", RuntimeWarning)
+                assert torch.equal(dr.gather_outputs(), got)          # nothing left to report, nothing recomputed twice
+            ops.set_mlp_precision("bf16x6")
+            with warnings.catch_warnings():
+                warnings.simplefilter("error", RuntimeWarning)
+                ref = model.solve(g.clone().to(DEV), 4, capture=False)
+            ops.set_mlp_precision("f16x3")
+            torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    finally:
+        ops.set_mlp_precision(old)
+
+
 def test_distributed_remus_single_rank_and_two_ranks_in_process():
     """REMuS-GNN through DistributedRollout: world = 1 == model.solve; and a 2-rank partition run in ONE process (both ranks'
     forwards interleaved by a fake transport that copies halo rows between the two meshes) == the single-rank forward."""
