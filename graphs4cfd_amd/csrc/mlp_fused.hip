@@ -1613,6 +1613,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
                     "g4c_mp_layer_forward_bx6: the message launch is outside the weight-stationary kernel's envelope (one 128-wide weighted block, "
                     "two 128-wide additive blocks, two or three 128-wide layers, aligned rows)");
         p.n_tiles = agg->n_tiles;
+        if (p.n_tiles == 0) return G4C_OK;
         g_last_kernel = G4C_KERNEL_MLP_WS;
         return ws_launch(p, true, false, st, &q);
     }
@@ -1624,11 +1625,13 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     if (bx6 && !force_tiles && ws_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
         // weight-stationary persistent kernel (mlp_ws.hip): pairs of 32-row tiles (whole segments with aggregation), one workgroup per CU
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
+        if (p.n_tiles == 0) return G4C_OK;          // (nothing launches: g4c_mlp_last_kernel stays G4C_KERNEL_NONE — ADVICE r04)
         g_last_kernel = G4C_KERNEL_MLP_WS;
         return ws_launch(p, agg != nullptr, round1, st);
     } else if (bx6 && !force_tiles && bx6i_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
         // dual-tile software-pipelined kernel (mlp_bx6i.hip): pairs of 32-row tiles (whole segments with aggregation)
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);
+        if (p.n_tiles == 0) return G4C_OK;
         g_last_kernel = G4C_KERNEL_MLP_BX6I;
         return bx6i_launch(p, agg != nullptr, f16x2, st);
     } else if (bx6) {
