@@ -1,6 +1,7 @@
 """bench.py — rollout timesteps/s of the graphs4cfd message-passing hot path on MI355X.
 
     python bench.py [--workload headline|c2|c3|c5-1gpu] [--gpus 1] [--steps 200] [--warmup 5]
+    python bench.py --gpus N ...          (N > 1 outside a torch.distributed.run job: starts its own N ranks, same line as below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Workloads (BASELINE.json `configs`):
@@ -79,6 +80,42 @@ def parse():
     a.dim = w["dim"]
     a.metric = w["metric"]
     return a
+
+
+def launcher_needed(gpus, env):
+    """`python bench.py --gpus N` (N > 1) outside a torch.distributed.run job: this process is not a rank, it starts them."""
+    return gpus > 1 and "WORLD_SIZE" not in env and "RANK" not in env
+
+
+def launcher_command(gpus, argv, port):
+    """The driver's own launch line (one process per GPU of ONE node, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_ranks(gpus, argv):
+    """Re-runs this script as `gpus` ranks; rank 0's JSON line goes straight to stdout, the ranks' stderr is passed on (its tail
+    again after a failure, beside the return code of the job)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = launcher_command(gpus, argv, port)
+    proc = subprocess.Popen(cmd, env=env, stdout=None, stderr=subprocess.PIPE, text=True, errors="replace")
+    tail = []
+    for line in proc.stderr:
+        sys.stderr.write(line)
+        tail.append(line)
+        del tail[:-60]
+    rc = proc.wait()
+    if rc != 0:
+        sys.stderr.write(f"bench.py: the {gpus}-rank job ({' '.join(cmd)}) exited with rc {rc}; last lines of the ranks' stderr:\n")
+        sys.stderr.write("".join(tail[-30:]))
+    return rc
 
 
 def build_workload(args, gfd, S, dev):
@@ -636,6 +673,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if launcher_needed(args.gpus, os.environ):
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     import graphs4cfd_amd as gfd
@@ -699,6 +738,9 @@ def main():
         n_mp = sum(1 for n in S.MUS_LAYERS[args.model].split() if n.startswith("mp"))
         what = (f"{args.model} (published arch, H={args.hidden}) rollout on a {args.nodes}-node synthetic {args.dim}D mesh, "
                 f"kNN k=6, {MUS_LEVELS[args.model]} grid-clustered scale(s), hipGraph-replayed step")
+    if world > 1 and args.workload == "headline" and not args.custom:
+        what = (f"BASELINE config {'4' if world == 4 else '4-style'} (100k-node mesh node-partitioned {world}-way, halo exchange via RCCL/xGMI, "
+                f"{world} MI355X): " + what)
     result = {
         "metric": args.metric if not args.custom else f"rollout timesteps/s ({args.model}, {args.nodes} nodes)",
         "value": args.steps / elapsed, "unit": "rollout timesteps/s",

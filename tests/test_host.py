@@ -236,3 +236,33 @@ def test_mlp_precision_names_and_f16_range_warning():
     g.field = g.field * (2.0 * M.F16_INPUT_WARN / float(g.field.abs().max()))
     with pytest.warns(RuntimeWarning, match="f16x3"):
         M._warn_f16_range(g)
+
+
+def test_bench_starts_its_own_ranks_when_not_under_torchrun(monkeypatch):
+    """`python bench.py --gpus N` (the driver's command shape) must not die in argument checking: outside a
+    torch.distributed.run job it launches the N ranks itself, inside one it is a rank."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("g4c_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.launcher_needed(2, {}) and bench.launcher_needed(8, {"PATH": "/bin"})
+    assert not bench.launcher_needed(1, {})
+    assert not bench.launcher_needed(2, {"WORLD_SIZE": "2", "RANK": "0"})
+    cmd = bench.launcher_command(4, ["--gpus", "4", "--steps", "3"], 29511)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3"]
+    # main() takes the launcher branch (and returns the job's return code) before it touches a GPU
+    seen = {}
+
+    def fake_launch(gpus, argv):
+        seen["gpus"], seen["argv"] = gpus, list(argv)
+        return 7
+    monkeypatch.setattr(bench, "launch_ranks", fake_launch)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 7 and seen == {"gpus": 2, "argv": ["--gpus", "2", "--steps", "2", "--warmup", "1"]}
