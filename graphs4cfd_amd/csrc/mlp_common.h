@@ -78,6 +78,7 @@ struct Params {
     const int *tile_rows, *tile_seg, *seg_off;
     float *agg;
     int agg_ld, agg_mean;
+    int agg_deg;              // > 0: every segment has exactly this many rows (G4C_AGG_UNIFORM)
     // narrow input blocks of the first layer, multiplied in fp32 on the vector ALUs (bf16x6 kernel)
     NarSrc nar[G4C_MAX_SRC];
     int n_nar;

@@ -32,9 +32,13 @@ extern "C" int g4c_ws_read_stamps(unsigned long long *host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g4c_ws_stamps), sizeof(unsigned long long) * n);
 }
 #define WS_STAMP(k) do { if (it == 1 && tid == 0 && blockIdx.x < 256) g4c_ws_stamps[blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
+// inside the tail lambdas (`its` = the iteration they were called from); the stamp's own s_waitcnt lgkmcnt(0) makes it a point where
+// every LDS read issued before it has landed
+#define WS_STAMP_T(k) do { if (its == 1 && tid == 0 && blockIdx.x < 256) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g4c_ws_stamps[blockIdx.x * 32 + (k)] = __builtin_readcyclecounter(); } } while (0)
 #define WS_STAMP_ONCE(k, v) do { if (tid == 0 && blockIdx.x < 256) g4c_ws_stamps[blockIdx.x * 32 + (k)] = (v); } while (0)      // 12 kernel start, 13 end, 14 pairs
 #else
 #define WS_STAMP(k) do {} while (0)
+#define WS_STAMP_T(k) do {} while (0)
 #define WS_STAMP_ONCE(k, v) do {} while (0)
 #endif
 
@@ -110,36 +114,7 @@ __device__ __forceinline__ f32x2 selu2w(f32x2 x) {
 #ifndef G4C_WS_MEAN_DIV
 #define G4C_WS_MEAN_DIV 1
 #endif
-// G4C_WS_SKEW (round 5): the tails of a pair (LayerNorm / row stores, aggregation) have no matrix work, and with all eight waves in
-// lock step the matrix pipes idle through them.  The two waves of a SIMD are waves w and w + 4 of the workgroup: the tails of pair i
-// move into the first two phase intervals of pair i + 1, where waves 0 - 3 run them BEFORE their matrix phase and waves 4 - 7 AFTER
-// it — one wave's tail under the other wave's MFMAs, between the same two barriers (which also order LayerNorm -> aggregation).
-#ifndef G4C_WS_SKEW
-#define G4C_WS_SKEW 0
-#endif
 
-// Round-5 experiment (-DG4C_WS_EXP_POLY=1, not the default — measured slower): the SELU's
-// exponential without the transcendental unit.  exp(x) for x <= 0 (the clamp to [0, 1] of the shipped form is the range reduction's
-// med3 here) = 2^n * p(f), t = x log2(e) = n + f, |f| <= 1/2: n by the 1.5 * 2^23 rounding trick (its integer sits in the low
-// mantissa bits of t + magic), p = degree-5 minimax polynomial of 2^f (max relative error 1.8e-7), 2^n by an integer add into
-// the exponent field (v_lshl_add_u32).  Eleven plain vector instructions instead of v_mul + v_exp_f32: r04's gap microbenchmark says
-// plain instructions hide behind an MFMA and v_exp_f32 does not.
-#ifndef G4C_WS_EXP_POLY
-#define G4C_WS_EXP_POLY 0
-#endif
-__device__ __forceinline__ float exp_neg_poly(float x) {
-    const float t = __builtin_amdgcn_fmed3f(x * 1.4426950408889634f, -125.f, 0.f);
-    const float magic = 12582912.f;                       // 1.5 * 2^23
-    const float r = t + magic;
-    const float f = t - (r - magic);
-    float p = 1.3333558146e-3f;                            // 2^f on [-1/2, 1/2]: Taylor / minimax coefficients ln2^k / k!
-    p = fmaf(p, f, 9.6181291076e-3f);
-    p = fmaf(p, f, 5.5504108665e-2f);
-    p = fmaf(p, f, 2.4022650696e-1f);
-    p = fmaf(p, f, 6.9314718056e-1f);
-    p = fmaf(p, f, 1.0f);
-    return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, r) << 23) + __builtin_bit_cast(unsigned, p));
-}
 
 template <bool LOADED = false>
 __device__ __forceinline__ f32x2 selu2w_scaled(f32x2 x) {
@@ -148,7 +123,7 @@ __device__ __forceinline__ f32x2 selu2w_scaled(f32x2 x) {
     f32x2 r;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const float ex = G4C_WS_EXP_POLY ? exp_neg_poly(x[e]) : __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x[e] * 1.4426950408889634f), 0.f, 1.f);
+        const float ex = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x[e] * 1.4426950408889634f), 0.f, 1.f);
         float m;
         if constexpr (LOADED) asm("v_max_f32 %0, 0, %1" : "=v"(m) : "v"(x[e]));
         else m = fmaxf(x[e], 0.f);
@@ -244,10 +219,8 @@ __device__ __forceinline__ void other_piece(int s, const f32x4 (&accE)[2], const
 // vector instructions scheduled behind each MFMA of a slice (measured: 3, 4, 6 and MFMAs in bursts of 3 / 6 with the vector work behind
 // them all within 3 % of each other — DESIGN.md 4.1 "What bounds it")
 constexpr int WS_VALU_PER_MFMA = 4;
-// slices the B fragments are fetched ahead of their MFMAs (round 5: 3 — + 8 registers — measured against 2 in profiles/r05_ws_variants_ab.log)
-#ifndef WS_FRAG_AHEAD
-#define WS_FRAG_AHEAD 2
-#endif
+// slices the B fragments are fetched ahead of their MFMAs (3 / 4: + 8 / 16 registers, scratch, slower: HISTORY.md 4.1)
+constexpr int WS_FRAG_AHEAD = 2;
 // One 128-k block for one tile: acc += W(layer) x planes, 8 slices (k-step ks = s / 2, sample row block rb = s % 2) of three
 // products each: (Wh, xl) and (Wl, xh) into acc1 (the 2^-11 terms), (Wh, xh) into acc.  pa[ks]: this lane's B-operand address
 // (row n, granule (4 ks + g) ^ n) in the tile's h plane.
@@ -568,11 +541,8 @@ __device__ __forceinline__ void node_phase(const NodeCtx &c, const float *x0, co
 // the node MLP (same depth, weights streamed block by block: the message MLP's stationary registers are dead by then) on those
 // targets, 32 at a time, and stores v' and the heads.  One launch per MP layer instead of two (three with a separate aggregation):
 // small and medium levels are bound by the dependent chain of each launch, not by throughput.
-// Rounded-bf16 mode (SP = 1): one product per multiply-add and no low plane — the launch is bound by its LayerNorm / aggregation tails
-// and barriers, not by a pipe — so TWO workgroups per CU (four waves per SIMD, <= 128 registers; -DG4C_WS_SP1_MINW=2 restores one)
-#ifndef G4C_WS_SP1_MINW
-#define G4C_WS_SP1_MINW 2
-#endif
+// Rounded-bf16 mode (SP = 1): two waves per SIMD as well (four — 128 registers, scratch — measured slower: HISTORY.md 4.1)
+constexpr int G4C_WS_SP1_MINW = 2;
 template <bool AGG, bool DIRECT, bool ADDS, int SP, int NL, bool XB16, bool AB16 = false, bool NODE = false>
 __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_kernel(const Params p, const int n_pairs, const NodeParams q) {
     static_assert((SP == 1 || SP == 2) && (NL == 2 || NL == 3) && (SP == 1 || !XB16) && (SP == 1 || !AB16) && (ADDS || !AB16) &&
@@ -588,6 +558,7 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
     __shared__ __attribute__((aligned(16))) float sBias[3 * NP];
     __shared__ __attribute__((aligned(16))) float sGB[2 * NP];
     __shared__ __attribute__((aligned(16))) float sZero[NP];               // a row of zeros (the aggregation's padding rows)
+    __shared__ __attribute__((aligned(16))) float sCarry[NP];              // dense mode: partial sum of the segment cut by the end of a pair
     __shared__ __attribute__((aligned(16))) float sBiasN[NODE ? 3 * NP : 4];    // NODE: the node MLP's biases and LayerNorm parameters
     __shared__ __attribute__((aligned(16))) float sGBN[NODE ? 2 * NP : 4];
 
@@ -598,12 +569,25 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
     const int prow = tid >> 5, pc = (tid & 31) * 4;         // park layout: rows prow, prow + 16, four columns from pc
 
     // contiguous range of pairs of this workgroup (XCD-aware: each XCD gets a contiguous share when the grid is a multiple of 8)
-    int p_begin, p_end;
+    // Dense mode (AGG with G4C_AGG_UNIFORM(K), 4 <= K <= 8: the level-1 launches of a kNN mesh): every segment has K rows, so nothing
+    // about the rows needs a table.  The rows are split over the workgroups at segment boundaries, evenly in segments, and a workgroup
+    // cuts ITS range [R0, R1) into pairs of 64 consecutive rows — full 32-row tiles (tiles of whole segments hold 30 of 32 rows at
+    // K = 6 or 5: 6.7 % more tiles) whose segments may straddle tile and pair boundaries: the aggregation works on the pair's 64 fp32
+    // rows (fA | fB contiguous) and carries the partial sum of a segment cut by the pair's end to the next pair (agg_tail).
+    const int KU = (AGG && p.agg_deg >= 4 && p.agg_deg <= 8) ? p.agg_deg : 0;
+    int p_begin, p_end, R0 = 0, R1 = 0;
     {
         const int G = gridDim.x, b = blockIdx.x;
         const int slot = (G & 7) ? b : (b & 7) * (G >> 3) + (b >> 3);
-        p_begin = __builtin_amdgcn_readfirstlane((int)(((long long)slot * n_pairs) / G));
-        p_end = __builtin_amdgcn_readfirstlane((int)(((long long)(slot + 1) * n_pairs) / G));
+        if (KU) {
+            const long long n_seg = p.M / KU;
+            R0 = __builtin_amdgcn_readfirstlane((int)(((long long)slot * n_seg) / G) * KU);
+            R1 = __builtin_amdgcn_readfirstlane((int)(((long long)(slot + 1) * n_seg) / G) * KU);
+            p_begin = 0; p_end = (R1 - R0 + 63) >> 6;          // (local pair numbers)
+        } else {
+            p_begin = __builtin_amdgcn_readfirstlane((int)(((long long)slot * n_pairs) / G));
+            p_end = __builtin_amdgcn_readfirstlane((int)(((long long)(slot + 1) * n_pairs) / G));
+        }
     }
     if (p_begin >= p_end) return;
     WS_STAMP_ONCE(12, __builtin_readcyclecounter());
@@ -612,6 +596,15 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
     // (the loads are issued where load_meta is called; fix_meta — the v_readfirstlanes that wait for them — an iteration later)
     auto load_meta = [&](int pair) __attribute__((always_inline)) {
         Meta m;
+        if (AGG && KU) {
+            if (pair > p_end - 1) pair = p_end - 1;
+            const int r0 = R0 + 64 * pair, nr = (R1 - r0) < 64 ? (R1 - r0) : 64;
+            m.r0[0] = r0; m.n[0] = nr < 32 ? nr : 32; m.r0[1] = r0 + 32; m.n[1] = nr - m.n[0];
+            m.s0[0] = r0 / KU;          // the segment the pair's first row belongs to (it started before the pair unless KU s0 == r0)
+            m.s1[0] = m.s0[1] = m.s1[1] = 0;
+            if (m.n[1] == 0) m.r0[1] = m.r0[0];
+            return m;
+        }
         if (pair > n_pairs - 1) pair = n_pairs - 1;          // (prefetch past the end: a valid pair again, never used)
         const int t0 = 2 * pair;
         if (AGG) {
@@ -653,7 +646,7 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
         const int *ix = (k == 0) ? ix0 : (k == 1 ? ix1 : ix2);
         const int *addr = ix ? ix + gr : dummy;
         int j = 0, ts = 0;
-        if (AGG) {
+        if (AGG && !KU) {
             const int q = tid - 256;
             const bool is_seg = q >= 0 && q < 2 * (SEGCAP + 1);
             ts = is_seg && q >= SEGCAP + 1 ? 1 : 0;
@@ -667,7 +660,7 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
     };
     auto store_tables = [&](int v, int it) __attribute__((always_inline)) {
         if (tid < 192) sIdx[it & 1][tid] = v;
-        if (AGG && tid >= 256 && tid < 256 + 2 * (SEGCAP + 1)) sSeg[it & 3][tid - 256] = v;
+        if (AGG && !KU && tid >= 256 && tid < 256 + 2 * (SEGCAP + 1)) sSeg[it & 3][tid - 256] = v;
     };
     // input rows of the weighted block (park layout) and additive rows (accumulator layout) of a pair whose indices are in sIdx[ring].
     // Three batches of four 16-byte loads per lane, issued in three different phases: a CU's share of the HBM bandwidth is ~13 bytes
@@ -722,12 +715,6 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
     const unsigned lo_b = 2u * (unsigned)((wave >> 1) * 8 * STEP6 + (g >> 1) * STEP6 + ((g & 1) * 32 + 16 * (wave & 1) + n) * 8);
     bf16x8 W[NL][4][SP];
     if (SP == 2) f16_range_mode();
-    // Round-5 experiment (-DG4C_WS_PRIO=1, not the default): the workgroup's waves w and w + 4 share a SIMD (waves are placed
-    // 0 -> 2 -> 1 -> 3 cyclically); giving one of the two a higher issue priority for the whole launch staggers them, so that one
-    // wave's MFMAs are preferred and the other's vector work fills the gaps
-#ifdef G4C_WS_PRIO
-    if (wave >= 4) __builtin_amdgcn_s_setprio(G4C_WS_PRIO);
-#endif
     RangeV rng;                       // running max |value converted to fp16| (mlp_common.h range_track)
 
     Meta m0 = fix_meta(load_meta(p_begin)), m1 = fix_meta(load_meta(p_begin + 1)), m2 = fix_meta(load_meta(p_begin + 2));
@@ -749,8 +736,12 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
     if constexpr (NODE) {
         if (tid < NL * NP) sBiasN[tid] = q.b[tid];
         if (tid < 2 * NP) sGBN[tid] = q.gamma ? (tid < NP ? q.gamma[tid] : q.beta[tid - NP]) : 0.f;
-        const int t1 = 2 * p_end < p.n_tiles ? 2 * p_end : p.n_tiles;
-        S0 = __builtin_amdgcn_readfirstlane(p.tile_seg[2 * p_begin]); S1 = __builtin_amdgcn_readfirstlane(p.tile_seg[t1]);
+        if (KU) {
+            S0 = R0 / KU; S1 = R1 / KU;
+        } else {
+            const int t1 = 2 * p_end < p.n_tiles ? 2 * p_end : p.n_tiles;
+            S0 = __builtin_amdgcn_readfirstlane(p.tile_seg[2 * p_begin]); S1 = __builtin_amdgcn_readfirstlane(p.tile_seg[t1]);
+        }
     }
     __syncthreads();
 
@@ -793,7 +784,7 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
         }
     };
     // LayerNorm / activation / row stores of a finished pair (its fp32 rows in fA / fB; `mm` = that pair's rows)
-    auto ln_tail = [&](const Meta &mm) __attribute__((always_inline)) {
+    auto ln_tail = [&](const Meta &mm, const int its) __attribute__((always_inline)) {
         // ---- tail of this pair: LayerNorm / activation of both tiles.  16 lanes per row (8 columns each), so the row sums are
         // reduced inside a 16-lane DPP row (quad_perm, row_half_mirror, row_mirror: no LDS round trips); a wave takes 4 rows per
         // pass, the workgroup a whole tile per pass.  The finished rows are stored straight from the registers (16 lanes = one
@@ -819,6 +810,7 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
                     const f32x4 v = *reinterpret_cast<const f32x4 *>(rowp[t] + cq[c >> 2]);
                     x[t][c] = v[0]; x[t][c + 1] = v[1]; x[t][c + 2] = v[2]; x[t][c + 3] = v[3];
                 }
+            WS_STAMP_T(17);
             if (p.gamma) {
                 float sum[2], mean[2], var[2], rstd[2];
 #pragma unroll
@@ -858,11 +850,13 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
 #pragma unroll
                     for (int c = 0; c < 8; ++c) x[t][c] = g4c::tanh_f(x[t][c]);
             }
+            WS_STAMP_T(18);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x4 v0, v1;
                 v0[0] = x[t][0]; v0[1] = x[t][1]; v0[2] = x[t][2]; v0[3] = x[t][3]; v1[0] = x[t][4]; v1[1] = x[t][5]; v1[2] = x[t][6]; v1[3] = x[t][7];
                 if (AGG) { *reinterpret_cast<f32x4 *>(rowp[t] + cq[0]) = v0; *reinterpret_cast<f32x4 *>(rowp[t] + cq[1]) = v1; }
+                if (G4C_WS_ABLATE & 64) { asm volatile("" :: "v"(v0), "v"(v1)); continue; }
                 if (p.out && row < mm.n[t]) {
                     const long long orow = (!AGG && p.out_idx) ? p.out_idx[mm.r0[t] + row] : mm.r0[t] + row;
                     if (SP == 1 && p.out_bf16) {
@@ -884,6 +878,7 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
     };
     // aggregation of a finished pair's targets from the LayerNorm'd rows in fA / fB (`itp` = that pair's iteration: its slot of sSeg)
     auto agg_tail = [&](const Meta &mm, const int itp) __attribute__((always_inline)) {
+            const int its = itp; (void)its;
             // aggregation of the targets whose messages the tiles hold (rows in CSR order): the rows of a segment are added in order
             // (clamped loads, predicated adds) and divided by max(count, 1) like segment_reduce_kernel does, so the result is
             // bit-identical to the separate launch.  32 lanes per target (16 bytes each), 16 targets per pass over both tiles.
@@ -892,6 +887,7 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
             const int nsA = mm.s1[0] - mm.s0[0], nsB = mm.s1[1] - mm.s0[1];
             auto reduce_rows = [&](const float *sH, int b, int e, int sg) __attribute__((always_inline)) {
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                WS_STAMP_T(20);
                 for (int r0 = b; r0 < e; r0 += 8) {
                     f32x4 v[8];
                     if constexpr (SP == 1) {
@@ -915,6 +911,7 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
                         }
                     }
                 }
+                WS_STAMP_T(21);
                 if (p.agg_mean) {
                     if (G4C_WS_MEAN_DIV) {
                         a = g4c::mean_div4(a, (e - b) > 1 ? (e - b) : 1);          // (the IEEE quotient, bit for bit: g4c_common.h)
@@ -924,8 +921,71 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
                         for (int el = 0; el < 4; ++el) a[el] /= cnt;
                     }
                 }
+                WS_STAMP_T(22);
                 *reinterpret_cast<f32x4 *>(p.agg + (long long)sg * p.agg_ld + c4) = a;
             };
+            // Dense mode: every segment has K rows, the pair holds rows [r0, r0 + nr) of the workgroup's range as 64 contiguous fp32 rows
+            // (fA | fB).  `lead` rows at the top finish the segment the previous pair cut (its partial sum waits in sCarry), then come
+            // nfull whole segments, then `rest` rows of a segment the next pair finishes.  Whole segments: 32 lanes per target, K loads
+            // at immediate offsets, the adds in segment order, the mean as the correctly rounded quotient (Markstein's correction with
+            // the exact reciprocal of the constant) — no offsets to read, a third of the generic path's instructions
+            // (profiles/r06_tail_stamps.log: offsets + addresses 316, rows 724, mean 296 cycles of a tail).  The two partial segments are
+            // wave 7's (lanes 0 - 31 the leading one, lanes 32 - 63 the trailing one: the same wave reads the carry before it writes
+            // the next, in program order, and no other wave touches it).  The sums are those of g4c_segment_reduce, bit for bit.
+            auto reduce_uniform = [&](auto KC) __attribute__((always_inline)) {
+                constexpr int K = decltype(KC)::value;
+                constexpr float cK = (float)K, yK = 1.0f / (float)K;          // (yK: the correctly rounded reciprocal)
+                const int r0 = mm.r0[0], nr = mm.n[0] + mm.n[1], j0 = mm.s0[0];
+                const int lead = (j0 * K < r0) ? (j0 * K + K - r0) : 0;
+                const int nfull = (nr - lead) / K, rest = nr - lead - nfull * K;
+                const int jf = j0 + (lead ? 1 : 0);          // target of the first whole segment
+                auto mean4 = [&](f32x4 a) __attribute__((always_inline)) {
+                    if (p.agg_mean) {
+#pragma unroll
+                        for (int el = 0; el < 4; ++el) {
+                            const float q0 = a[el] * yK;
+                            a[el] = fmaf(fmaf(-cK, q0, a[el]), yK, q0);
+                        }
+                    }
+                    return a;
+                };
+                for (int q = tid >> 5; q < nfull; q += 16) {
+                    const float *base = fA + __umul24((unsigned)(lead + q * K), (unsigned)HS) + c4;
+                    f32x4 v[K];
+                    WS_STAMP_T(20);
+#pragma unroll
+                    for (int u = 0; u < K; ++u) v[u] = *reinterpret_cast<const f32x4 *>(base + u * HS);
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < K; ++u) a += v[u];
+                    WS_STAMP_T(21);
+                    a = mean4(a);
+                    WS_STAMP_T(22);
+                    *reinterpret_cast<f32x4 *>(p.agg + (long long)(jf + q) * p.agg_ld + c4) = a;
+                }
+                if (wave == 7 && (lead | rest)) {
+                    const bool hi = lane >= 32;
+                    const int b = hi ? nr - rest : 0, cnt = hi ? rest : lead;          // this half-wave's rows [b, b + cnt), cnt < K
+                    f32x4 v[K - 1];
+#pragma unroll
+                    for (int u = 0; u < K - 1; ++u) v[u] = *reinterpret_cast<const f32x4 *>((u < cnt ? fA + __umul24((unsigned)(b + u), (unsigned)HS) : sZero) + c4);
+                    f32x4 a = *reinterpret_cast<const f32x4 *>((hi || !lead ? sZero : sCarry) + c4);
+#pragma unroll
+                    for (int u = 0; u < K - 1; ++u) a += v[u];          // (rows past cnt: + 0.f, as the predicated form adds)
+                    if (!hi && lead) *reinterpret_cast<f32x4 *>(p.agg + (long long)j0 * p.agg_ld + c4) = mean4(a);
+                    if (hi && rest) *reinterpret_cast<f32x4 *>(sCarry + c4) = a;
+                }
+            };
+            if (KU) {
+                typedef std::integral_constant<int, 4> K4; typedef std::integral_constant<int, 5> K5; typedef std::integral_constant<int, 6> K6;
+                typedef std::integral_constant<int, 7> K7; typedef std::integral_constant<int, 8> K8;
+                if (KU == 6) reduce_uniform(K6{});
+                else if (KU == 5) reduce_uniform(K5{});
+                else if (KU == 4) reduce_uniform(K4{});
+                else if (KU == 7) reduce_uniform(K7{});
+                else reduce_uniform(K8{});
+                return;
+            }
             for (int q = tid >> 5; q < nsA + nsB; q += 16) {
                 const int t = q >= nsA ? 1 : 0, j = q - (t ? nsA : 0);
                 if (j < SEGCAP) {
@@ -961,7 +1021,6 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
     }
     __syncthreads();                                       // tile A's planes of the first pair visible
 
-    Meta mp = m0;          // G4C_WS_SKEW: the previous pair
     for (int it = 0, pair = p_begin; pair < p_end; ++pair, ++it) {
         WS_STAMP(0);
         // ---- tables two pairs ahead (their meta was loaded an iteration ago), meta three pairs ahead
@@ -971,10 +1030,8 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
         // that phase's barrier lies between; nothing the stragglers of the previous tail still read is written in this phase)
         WS_STAMP(1);
         widen_x(xr[1], rawB);
-        if constexpr (G4C_WS_SKEW) { if (it > 0 && wave < 4) ln_tail(mp); }
         if (pact) m_block<SP, 2, true>(paA, W[0], accA, accA1, accA, accA1, xr[1], oB, rng);                 // for B: park
         else m_block<SP, 2, false>(paA, W[0], accA, accA1, accA, accA1, xr[1], oB, rng);
-        if constexpr (G4C_WS_SKEW) { if (it > 0 && wave >= 4) ln_tail(mp); }
         start_values(accB, accB1, adB);
         __syncthreads();
         WS_STAMP(2);
@@ -983,9 +1040,7 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
         AddV nadA[2][2];
         unsigned nraw[2][2] = {{0u, 0u}, {0u, 0u}};
         gather_x(m1, (it + 1) & 1, 0, nxa, nraw);
-        if constexpr (G4C_WS_SKEW && AGG) { if (it > 0 && wave < 4) agg_tail(mp, it - 1); }
         m_block<SP, 1>(paB, W[0], accB, accB1, accA, accA1, xr[1], oA, rng);                 // for A: epilogue of layer 0
-        if constexpr (G4C_WS_SKEW && AGG) { if (it > 0 && wave >= 4) agg_tail(mp, it - 1); }
         bias_init(accA, accA1, 1);
         __syncthreads();
         WS_STAMP(3);
@@ -1016,42 +1071,36 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
         // tail's stores (memory returns in order per wave), a tail and a phase ahead of their use, so that they are not live across
         // this pair's matrix phases (tile B's additive rows: at the end of the tail)
         start_values(accA, accA1, nadA);
+        // (pinned here: hipcc otherwise sinks these adds — and their wait for the additive rows — to the end of the iteration, behind
+        // the tail's stores, where s_waitcnt vmcnt(0) also waits for every store to be acknowledged)
+        asm volatile("" : "+v"(accA[0]), "+v"(accA[1]) :: "memory");
+        // (the meta three pairs ahead, requested at the top: taken here, in front of the tail's stores — at the end of the iteration
+        // the wait for these loads would also wait for every store of the tail, which memory acknowledges in order)
+        const Meta m3 = fix_meta(m3raw);
         gather_x(m1, (it + 1) & 1, 1, xr[1], rawB);
         // the tables fetched at the top of this iteration (older than every other load in flight) go to the ring slot of the pair
         // whose rows were gathered in the previous iteration; the next iteration's top barrier publishes them
         store_tables(tv, it + 2);
         WS_STAMP(8);
 
-        if constexpr (!G4C_WS_SKEW) {
-            ln_tail(m0);
-            // (rounded-bf16 mode: the row stores are half as many bytes, and the gathers in front of the aggregation's barrier measure
+        if (!(G4C_WS_ABLATE & 256)) ln_tail(m0, it);
+        // (rounded-bf16 mode: the row stores are half as many bytes, and the gathers in front of the aggregation's barrier measure
         // 1.8 % faster per pair than behind the aggregation; f16x3 stream: 3 % slower — they queue behind the fp32 row stores)
         if constexpr (SP == 1) gather_adds(1, (it + 1) & 1, adB);
         WS_STAMP(9);
         // (no barrier at the end of a tail without the aggregation: the next pair's parked rows — what a wave that runs ahead into
         // M(A', 0) reads — were written before the barrier that closed the last matrix phase)
-            if (AGG) {
-                __syncthreads();
-                WS_STAMP(15);
-                agg_tail(m0, it);
-            }
-        } else {
-            if constexpr (SP == 1) gather_adds(1, (it + 1) & 1, adB);
-            mp = m0;          // (this pair's LayerNorm / aggregation: inside the next pair's first two phase intervals)
+        if (AGG) {
+            __syncthreads();
+            WS_STAMP(15);
+            if (!(G4C_WS_ABLATE & 128)) agg_tail(m0, it);
         }
         // the next pair's tile B additive rows (added after its M(A', 0)): behind this tail's stores — issued together with tile B's
         // rows at the top of the tail, the six loads per lane held up the LayerNorm's stores (tail 3.4 k -> 6.6 k ticks)
         WS_STAMP(16);
         if constexpr (SP != 1) gather_adds(1, (it + 1) & 1, adB);
         WS_STAMP(10);
-        m0 = m1; m1 = m2; m2 = fix_meta(m3raw);
-    }
-    if constexpr (G4C_WS_SKEW) {          // the last pair's tails
-        ln_tail(mp);
-        if (AGG) {
-            __syncthreads();
-            agg_tail(mp, p_end - p_begin - 1);
-        }
+        m0 = m1; m1 = m2; m2 = m3;
     }
 
     if constexpr (NODE) {
@@ -1209,7 +1258,9 @@ int node_launch(const Params &p, hipStream_t st) {
 }
 
 int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st, const NodeParams *node) {
-    const int n_pairs = (p.n_tiles + 1) / 2;
+    // (dense mode — uniform segments of 4 .. 8 rows — cuts the rows into pairs of 64 itself: n_pairs only sizes the grid there)
+    const bool dense = agg && p.agg_deg >= 4 && p.agg_deg <= 8;
+    const int n_pairs = dense ? (int)((p.M + 63) / 64) : (p.n_tiles + 1) / 2;
     if (n_pairs == 0) return G4C_OK;
     const int n_wg = g4c::cu_count() * (round1 ? G4C_WS_SP1_MINW / 2 : 1);          // persistent workgroups: one (SP = 1: G4C_WS_SP1_MINW / 2) per CU
     const dim3 grid(n_pairs < n_wg ? n_pairs : n_wg), blk(512);

@@ -631,6 +631,11 @@ def _src_array(sources: Sequence[Source]):
     return arr
 
 
+def _agg_mode(agg_mean: bool, csr: CsrPlan) -> int:
+    """`agg_mean` argument of the fused-aggregation launches: bit 0 = mean, G4C_AGG_UNIFORM(k) when every segment has k rows."""
+    return (1 if agg_mean else 0) | (csr.uniform_deg << 8)
+
+
 def mp_layer_forward(msg: PackedMLP, sources: Sequence[Source], n_rows: int, csr: CsrPlan, agg_mean: bool, upd: PackedMLP,
                      v: Tensor, act: int, store_rows: bool = True, head_outs: Optional[Sequence[Tensor]] = None,
                      v_out: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Tensor, Optional[Sequence[Tensor]]]:
@@ -660,7 +665,7 @@ def mp_layer_forward(msg: PackedMLP, sources: Sequence[Source], n_rows: int, csr
     arr = _src_array(sources)
     call = lambda: _lib.check(lib.g4c_mp_layer_forward_bx6(
         C.byref(msg.desc), arr, len(sources), n_rows, _lib.ptr(e_out), 128 if e_out is None else _ld(e_out),
-        _lib.ptr(t_rows), _lib.ptr(t_seg), _lib.ptr(csr.off), nt, _lib.ptr(agg), _ld(agg), 1 if agg_mean else 0,
+        _lib.ptr(t_rows), _lib.ptr(t_seg), _lib.ptr(csr.off), nt, _lib.ptr(agg), _ld(agg), _agg_mode(agg_mean, csr),
         C.byref(upd.desc), _lib.ptr(v), _ld(v), act, _lib.ptr(v_out), _ld(v_out),
         upd.head_w if n_heads else None, n_heads, ho, _ld(head_outs[0]) if n_heads else 128, _lib.stream_handle(dev)))
     if KernelTimer.active is None:
@@ -737,7 +742,7 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
             return y
         _lib.require_hip(agg_out)
         t_rows, t_seg, nt = tiles
-        tail = (_lib.ptr(t_rows), _lib.ptr(t_seg), _lib.ptr(csr.off), nt, _lib.ptr(agg_out), _ld(agg_out), 1 if agg_mean else 0,
+        tail = (_lib.ptr(t_rows), _lib.ptr(t_seg), _lib.ptr(csr.off), nt, _lib.ptr(agg_out), _ld(agg_out), _agg_mode(agg_mean, csr),
                 _lib.stream_handle(dev))
         o_ld = _ld(out) if out is not None else 128
         if packed.precision == "bf16x6":

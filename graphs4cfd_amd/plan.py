@@ -32,6 +32,7 @@ class CsrPlan:
     n: int
     n_seg: int
     max_deg: int
+    uniform_deg: int = 0           # k when EVERY segment has exactly k rows (kNN meshes), else 0
     _tiles: object = False         # cache of tiles(): False = not built yet, None = not tileable
 
     def tiles(self, max_rows: int = 32):
@@ -105,6 +106,14 @@ def remember_host(dev_tensor: torch.Tensor, host) -> None:
     _host_copies.put(_Cache.key(dev_tensor), (dev_tensor,), (arr, src, src._version if src is not None else 0))
 
 
+def _uniform(deg: np.ndarray) -> int:
+    """k if every segment has exactly k rows (1 <= k <= 32), else 0."""
+    if deg.size == 0:
+        return 0
+    k = int(deg.max())
+    return k if 1 <= k <= 32 and int(deg.min()) == k else 0
+
+
 def build_csr(keys: torch.Tensor, n_seg: int, device: torch.device, drop_last_segment: bool = False) -> CsrPlan:
     """Group positions by key (stable). `drop_last_segment`: keys == n_seg-1 are a trash bin."""
     lib = _lib.load()
@@ -124,7 +133,7 @@ def build_csr(keys: torch.Tensor, n_seg: int, device: torch.device, drop_last_se
     out = CsrPlan(
         perm=None if identity else _upload(perm.copy(), device),
         off=_upload(off_h, device),
-        n=n_kept, n_seg=n_seg, max_deg=int(deg.max()) if deg.size else 0)
+        n=n_kept, n_seg=n_seg, max_deg=int(deg.max()) if deg.size else 0, uniform_deg=_uniform(deg))
     remember_host(out.off, off_h)
     return out
 
@@ -349,7 +358,7 @@ def pool_edge_plan(idx_hr_to_lr: torch.Tensor, edge_index: torch.Tensor, target_
         off = off[: n_coarse + 1].copy()
         deg = np.diff(off)
         csr = CsrPlan(perm=_upload(perm[:n_kept].copy(), dev), off=_upload(off, dev),
-                      n=n_kept, n_seg=n_coarse, max_deg=int(deg.max()) if deg.size else 0)
+                      n=n_kept, n_seg=n_coarse, max_deg=int(deg.max()) if deg.size else 0, uniform_deg=_uniform(deg))
         flat_h = flat.copy()
         plan = PoolEdgePlan(edge_index=_upload(flat_h, dev), csr=csr, n_coarse=n_coarse)
         remember_host(plan.edge_index, flat_h)

@@ -286,7 +286,12 @@ int g4c_mlp_forward_bf16(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*
  * same order and formula as g4c_segment_reduce, i.e. the `scatter(e', col, reduce)` of nn/blocks.py:183 without
  * re-reading e' from HBM.  tile_rows / tile_seg / seg_off are device int32 arrays.  out == NULL: the rows themselves are
  * not stored, only their aggregate — the last MP layer of a level, whose edge output the reference discards
- * (nn/mus_gnn.py:199-200,211-212). */
+ * (nn/mus_gnn.py:199-200,211-212).
+ * agg_mean: 0 sum, 1 mean; OR-ed with G4C_AGG_UNIFORM(k) the caller promises that EVERY segment has exactly k rows (1 <= k <= 32:
+ * the in-degree of a kNN mesh) — the weight-stationary kernel then aggregates with static addressing instead of reading segment
+ * offsets (same sums in the same order; the mean as the correctly rounded quotient by Markstein's correction, which differs from
+ * the IEEE division only below 2^-100). */
+#define G4C_AGG_UNIFORM(k) ((int32_t)(k) << 8)
 int64_t g4c_plan_tiles(const int32_t *off /*host*/, int32_t n_seg, int32_t max_rows, int32_t *tile_rows /*host, out*/,
                        int32_t *tile_seg /*host, out*/, int64_t capacity);
 int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,

@@ -56,6 +56,12 @@ for a_, b_, nm in ((9, 15, "  of which: wait at the aggregation barrier"), (15, 
     if st[:, 15].any():
         d = st[:, b_] - st[:, a_]
         print(f"{nm:62s} median {int(np.median(d)):7d}  (p10 {int(np.percentile(d, 10)):7d}, p90 {int(np.percentile(d, 90)):7d})")
+if st[:, 17].any():
+    for a_, b_, nm in ((8, 17, "  LayerNorm: the fp32 rows read back from LDS"), (17, 18, "  LayerNorm: statistics (DPP), normalise[, activation]"),
+                       (18, 9, "  LayerNorm: rows back to LDS + global row stores issued"), (15, 20, "  aggregation: segment offsets read, addresses"),
+                       (20, 21, "  aggregation: rows read from LDS and added"), (21, 22, "  aggregation: mean"), (22, 16, "  aggregation: store issued, loop exit")):
+        d = st[:, b_] - st[:, a_]
+        print(f"{nm:62s} median {int(np.median(d)):7d}  (p10 {int(np.percentile(d, 10)):7d}, p90 {int(np.percentile(d, 90)):7d})")
 print("pair period (loop top -> end of tail) median", int(np.median(st[:, 10] - st[:, 0])))
 live = st[:, 14] > 0
 per = (st[live, 13] - st[live, 12]) / st[live, 14]

@@ -1386,6 +1386,53 @@ def test_ws_persistent_kernel_equals_tile_kernel(rows, variant):
             assert torch.equal(got[f"agg_only_{mean}"], got[f"agg_{mean}"])
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "bf16"])
+@pytest.mark.parametrize("deg", [4, 5, 6, 7, 8])
+def test_ws_dense_pairs_of_uniform_segments(deg, prec):
+    """G4C_AGG_UNIFORM(k): on a mesh whose every target has k incoming edges the weight-stationary kernel cuts each workgroup's rows
+    into pairs of 64 consecutive rows — segments straddle tiles and pairs, the partial sum of a segment cut by a pair's end is carried
+    to the next pair — and aggregates with static addressing.  The rows are those of the tile kernel (2e-5), the aggregate is the
+    segment reduction of the rows the launch stored, bit for bit, at sizes that put every remainder at the pair boundaries (one
+    workgroup with a single short pair, ranges that end inside a tile, more workgroups than pairs)."""
+    if ops.mlp_precision() != "f16x3":
+        pytest.skip("runs under the default arithmetic only (it sets the mode itself)")
+    lib = _lib.load()
+    H = 128
+    old_prec = ops.set_mlp_precision(prec)
+    old_ws, old_i = lib.g4c_mlp_ws_enable(0), lib.g4c_mlp_bx6i_enable(0)
+    try:
+        for n in (1, 9, 11, 173, 2999, 20011):
+            torch.manual_seed(100 * deg + n)
+            layers = 3 if prec == "f16x3" else 2
+            blk = B.GNBlock((3 * H, (H,) * layers, True), (2 * H, (H,) * layers, True)).to(DEV)
+            E = n * deg
+            col = torch.arange(n).repeat_interleave(deg)
+            edge_index = torch.stack([torch.randint(0, n, (E,)), col]).to(DEV)
+            ep, csr = plan.edge_csr(edge_index, n)
+            assert csr.uniform_deg == deg and csr.tiles() is not None
+            e, pr, pc = torch.randn(E, H, device=DEV), torch.randn(n, H, device=DEV), torch.randn(n, H, device=DEV)
+            pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+            src = [ops.Source(e, pre_act=_lib.ACT_SELU), ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+            lib.g4c_mlp_ws_enable(0)
+            ref = ops.mlp_forward(pk, src, E)
+            lib.g4c_mlp_ws_enable(2)
+            for mean in (True, False):
+                a = torch.full((n, H), float("nan"), device=DEV)
+                y = ops.mlp_forward(pk, src, E, agg=(csr, a, mean))
+                assert int(lib.g4c_mlp_last_kernel()) == 4
+                if prec == "f16x3":
+                    torch.testing.assert_close(y, ref, rtol=2e-5, atol=2e-5, msg=lambda m: f"rows {(deg, n, mean)}: {m}")
+                else:
+                    assert (y - ref).abs().mean().item() < 2e-4 and (y - ref).abs().max().item() < 0.1
+                assert torch.equal(a, ops.segment_reduce(y, csr, mean)), (deg, n, mean)
+                a2 = torch.full((n, H), float("nan"), device=DEV)
+                ops.mlp_forward(pk, src, E, agg=(csr, a2, mean), store_rows=False)
+                assert torch.equal(a2, a), (deg, n, mean)
+    finally:
+        lib.g4c_mlp_ws_enable(old_ws); lib.g4c_mlp_bx6i_enable(old_i)
+        ops.set_mlp_precision(old_prec)
+
+
 @pytest.mark.parametrize("variant", [("f16x3", 3, "ws"), ("f16x3", 2, "ws"), ("bf16", 2, "ws"), ("bf16x6", 3, "bx6i")],
                          ids=lambda v: f"{v[2]}-{v[0]}-{v[1]}layers")
 def test_ws_persistent_kernel_repeated_launches_are_identical(variant):
