@@ -543,7 +543,8 @@ __device__ __forceinline__ void node_phase(const NodeCtx &c, const float *x0, co
 // small and medium levels are bound by the dependent chain of each launch, not by throughput.
 // Rounded-bf16 mode (SP = 1): two waves per SIMD as well (four — 128 registers, scratch — measured slower: HISTORY.md 4.1)
 constexpr int G4C_WS_SP1_MINW = 2;
-template <bool AGG, bool DIRECT, bool ADDS, int SP, int NL, bool XB16, bool AB16 = false, bool NODE = false>
+// DENSE (with AGG): the launch's segments all have the same number of rows, 4 .. 8 (G4C_AGG_UNIFORM) — dense pairs, below
+template <bool AGG, bool DIRECT, bool ADDS, int SP, int NL, bool XB16, bool AB16 = false, bool NODE = false, bool DENSE = false>
 __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_kernel(const Params p, const int n_pairs, const NodeParams q) {
     static_assert((SP == 1 || SP == 2) && (NL == 2 || NL == 3) && (SP == 1 || !XB16) && (SP == 1 || !AB16) && (ADDS || !AB16) &&
                   (!NODE || (AGG && SP == 2)), "mlp_ws_kernel: unsupported instantiation");
@@ -574,7 +575,8 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
     // cuts ITS range [R0, R1) into pairs of 64 consecutive rows — full 32-row tiles (tiles of whole segments hold 30 of 32 rows at
     // K = 6 or 5: 6.7 % more tiles) whose segments may straddle tile and pair boundaries: the aggregation works on the pair's 64 fp32
     // rows (fA | fB contiguous) and carries the partial sum of a segment cut by the pair's end to the next pair (agg_tail).
-    const int KU = (AGG && p.agg_deg >= 4 && p.agg_deg <= 8) ? p.agg_deg : 0;
+    static_assert((AGG || !DENSE) && !(NODE && DENSE), "dense pairs belong to the fused aggregation of a plain message launch");
+    const int KU = DENSE ? p.agg_deg : 0;
     int p_begin, p_end, R0 = 0, R1 = 0;
     {
         const int G = gridDim.x, b = blockIdx.x;
@@ -736,12 +738,8 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
     if constexpr (NODE) {
         if (tid < NL * NP) sBiasN[tid] = q.b[tid];
         if (tid < 2 * NP) sGBN[tid] = q.gamma ? (tid < NP ? q.gamma[tid] : q.beta[tid - NP]) : 0.f;
-        if (KU) {
-            S0 = R0 / KU; S1 = R1 / KU;
-        } else {
-            const int t1 = 2 * p_end < p.n_tiles ? 2 * p_end : p.n_tiles;
-            S0 = __builtin_amdgcn_readfirstlane(p.tile_seg[2 * p_begin]); S1 = __builtin_amdgcn_readfirstlane(p.tile_seg[t1]);
-        }
+        const int t1 = 2 * p_end < p.n_tiles ? 2 * p_end : p.n_tiles;
+        S0 = __builtin_amdgcn_readfirstlane(p.tile_seg[2 * p_begin]); S1 = __builtin_amdgcn_readfirstlane(p.tile_seg[t1]);
     }
     __syncthreads();
 
@@ -1259,7 +1257,9 @@ int node_launch(const Params &p, hipStream_t st) {
 
 int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st, const NodeParams *node) {
     // (dense mode — uniform segments of 4 .. 8 rows — cuts the rows into pairs of 64 itself: n_pairs only sizes the grid there)
-    const bool dense = agg && p.agg_deg >= 4 && p.agg_deg <= 8;
+    // Not for the fused MP layer: its launches are a few pairs per workgroup (nothing to win from denser pairs), and its three-layer
+    // instantiation sits at 256 registers — with the dense bookkeeping it spills (config 2: 1 786 -> 1 734 steps/s, same box).
+    const bool dense = agg && !node && p.agg_deg >= 4 && p.agg_deg <= 8;
     const int n_pairs = dense ? (int)((p.M + 63) / 64) : (p.n_tiles + 1) / 2;
     if (n_pairs == 0) return G4C_OK;
     const int n_wg = g4c::cu_count() * (round1 ? G4C_WS_SP1_MINW / 2 : 1);          // persistent workgroups: one (SP = 1: G4C_WS_SP1_MINW / 2) per CU
@@ -1276,9 +1276,13 @@ int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st, const Node
 #undef G4C_WS_NODE
         return g4c::check_launch("g4c_mp_layer_forward_bx6");
     }
-#define G4C_WS_GO(AGG, DIRECT, ADDS, SP, NL, XB16) mlp_ws_kernel<AGG, DIRECT, ADDS, SP, NL, XB16><<<grid, blk, 0, st>>>(p, n_pairs, q)
-#define G4C_WS_GO1(AGG, DIRECT, NL, XB16)                                                            \
-    do { if (ab16) mlp_ws_kernel<AGG, DIRECT, true, 1, NL, XB16, true><<<grid, blk, 0, st>>>(p, n_pairs, q);       \
+#define G4C_WS_GO(AGG, DIRECT, ADDS, SP, NL, XB16)                                                                                      \
+    do { if (AGG && dense) mlp_ws_kernel<AGG, DIRECT, ADDS, SP, NL, XB16, false, false, AGG><<<grid, blk, 0, st>>>(p, n_pairs, q);       \
+         else mlp_ws_kernel<AGG, DIRECT, ADDS, SP, NL, XB16><<<grid, blk, 0, st>>>(p, n_pairs, q); } while (0)
+#define G4C_WS_GO1(AGG, DIRECT, NL, XB16)                                                                                               \
+    do { if (AGG && dense) { if (ab16) mlp_ws_kernel<AGG, DIRECT, true, 1, NL, XB16, true, false, AGG><<<grid, blk, 0, st>>>(p, n_pairs, q);       \
+                             else mlp_ws_kernel<AGG, DIRECT, true, 1, NL, XB16, false, false, AGG><<<grid, blk, 0, st>>>(p, n_pairs, q); }        \
+         else if (ab16) mlp_ws_kernel<AGG, DIRECT, true, 1, NL, XB16, true><<<grid, blk, 0, st>>>(p, n_pairs, q);                        \
          else mlp_ws_kernel<AGG, DIRECT, true, 1, NL, XB16, false><<<grid, blk, 0, st>>>(p, n_pairs, q); } while (0)
 #define G4C_WS_SHAPE(AGG, DIRECT)                                                                    \
     do {                                                                                             \
