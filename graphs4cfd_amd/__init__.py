@@ -15,6 +15,7 @@ from .graph import Graph
 from . import nn, plan, ops, synthetic, transforms, metrics, datasets
 from .loader import DataLoader, Collater
 from .ops import check_f16_range, f16_range_report     # clipped values of the default arithmetic are reported, never silent (ops.py)
+from .nn.model import set_forward_validation            # bare forward() calls validate their own fp16 range (one flag read per call)
 from .ops import mlp_precision, set_mlp_precision      # "f16x3" (default: fp32-class two-way fp16 split on the matrix pipe) | "bf16x6" | "fp32" | "bf16" (opt-in)
 
 __version__ = "0.1.0"

@@ -144,7 +144,7 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], act: int = _lib.AC
     # products use the three-way bf16 split, which has fp32's exponent range, whatever the forward's arithmetic is.)
     blocks = [(k0, min(128, k - k0)) for k0 in range(0, k, 128)]
     prec = ops.effective_precision([w for _, w in blocks])
-    prec = "bf16x6" if prec == "f16x3" else prec
+    prec = "bf16x6" if prec in ("f16x3", "bf16") else prec          # (the rounded-bf16 forward too — as backward_chain does)
     out = None if n_out <= 128 else torch.empty((M, n_out), dtype=torch.float32, device=x.device)
     w_d, b_d = weight.detach(), (None if bias is None else bias.detach())
     y = None

@@ -488,19 +488,32 @@ FUSE_LAYER_MIN_ROWS = 2048
 FUSE_LAYER_MAX_ROWS = 120_000
 
 
-def _can_fuse_layer(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e, csr, v_src, n_targets, v_out, compact_messages: bool) -> bool:
-    if not FUSE_LAYER or ops.grad_mode() or ops.mlp_precision() != "f16x3" or v_src is not None or n_targets is not None or v_out is not None:
+def will_fuse_layer(msg_mlp: MLP, upd_mlp: MLP, edge_index: Tensor, n_nodes: int) -> bool:
+    """The part of the one-launch-per-MP-layer decision that the PRODUCER of the layer's node input can evaluate too (the
+    model's `_launch_for` emits the layer's products exactly when the layer will fuse — one predicate, not two copies): arithmetic,
+    mode, the level's size, rows in target order in tiles of whole segments, both MLPs two or three 128-wide layers."""
+    if not FUSE_LAYER or ops.grad_mode() or ops.mlp_precision() != "f16x3":
         return False
-    if compact_messages or csr.perm is not None or not (FUSE_LAYER_MIN_ROWS <= csr.n < FUSE_LAYER_MAX_ROWS) or csr.tiles() is None:
+    if not (FUSE_LAYER_MIN_ROWS <= int(edge_index.size(1)) < FUSE_LAYER_MAX_ROWS):
         return False
     lm, lu = msg_mlp._linears(), upd_mlp._linears()
     if len(lm) != len(lu) or len(lm) not in (2, 3) or any(l.out_features != 128 for l in lm + lu):
         return False
+    if msg_mlp.input_size != 384 or upd_mlp.input_size != 256:
+        return False
+    _, csr = plan.edge_csr(edge_index, n_nodes)
+    return csr.perm is None and csr.tiles() is not None
+
+
+def _can_fuse_layer(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e, edge_index: Tensor, csr, v_src, n_targets, v_out, compact_messages: bool) -> bool:
+    if v_src is not None or n_targets is not None or v_out is not None or compact_messages:
+        return False
+    if not will_fuse_layer(msg_mlp, upd_mlp, edge_index, int(v.size(0))):
+        return False
     e_t = e.tensor if isinstance(e, Source) else e
     if isinstance(e, Source) and (e.index is not None or e.col0 != 0 or e.negate or e.segments is not None or e.additive):
         return False
-    return (int(v.size(1)) == 128 and int(e_t.size(1)) == 128 and e_t.dtype == torch.float32 and msg_mlp.input_size == 384
-            and upd_mlp.input_size == 256)
+    return int(v.size(1)) == 128 and int(e_t.size(1)) == 128 and e_t.dtype == torch.float32
 
 
 def _fused_layer(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e_src: Source, ep, csr, mean: bool, act_code: int, products,
@@ -553,7 +566,7 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
     senders = v if v_src is None else v_src
     mean = aggr == "mean"
     e_src = e if isinstance(e, Source) else Source(e, pre_act=e_pre_act)
-    if _can_fuse_layer(msg_mlp, upd_mlp, v, e, csr, v_src, n_targets, v_out, compact_messages):
+    if _can_fuse_layer(msg_mlp, upd_mlp, v, e, index, csr, v_src, n_targets, v_out, compact_messages):
         v_new, e_new, nxt = _fused_layer(msg_mlp, upd_mlp, v, e_src, ep, csr, mean, act_code, products, next_msg, keep_e)
         return (v_new, e_new, nxt) if next_msg is not None else (v_new, e_new)
     if ops.can_fuse_aggregation(csr, msg_mlp.output_size):

@@ -87,6 +87,14 @@ class GNN(nn.Module):
         self.device = torch.device(device) if device is not None else torch.device('cpu')
         self.load_model(arch, weights, checkpoint)
 
+    def __init_subclass__(cls, **kwargs):
+        """Every model class's `forward` (the reference's other public entry point, e.g. nn/mus_gnn.py:173-218) is wrapped so that a
+        BARE call — outside `solve` / `Rollout`, outside autograd — carries the same range guarantee as `solve`: VERDICT r05 item 6."""
+        super().__init_subclass__(**kwargs)
+        f = cls.__dict__.get("forward")
+        if f is not None and not getattr(f, "_g4c_range_checked", False):
+            cls.forward = _range_checked_forward(f)
+
     def load_model(self, arch, weights, checkpoint):
         """Builds the modules and fills them: either from an arch dict (+ an optional state-dict file), or from a `.chk` written by
         `save_checkpoint` (the reference's format, nn/model.py:112-150: 'arch', 'weights', optimiser state ...).  Any other
@@ -227,6 +235,49 @@ class GNN(nn.Module):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
 
 
+FORWARD_VALIDATION = os.environ.get("G4C_FORWARD_VALIDATION", "1") != "0"
+
+
+def set_forward_validation(on: bool) -> bool:
+    """Bare `model.forward(graph)` calls in the default "f16x3" arithmetic read the fp16 range flags of their own launches when they
+    return (one 16 KB device -> host copy = one synchronisation per call) and run again in "bf16x6" if a value was clipped.  Turn it
+    off for forwards issued inside your own stream capture or a latency-critical loop (then `gfd.check_f16_range()` is yours to
+    call).  Returns the previous setting."""
+    global FORWARD_VALIDATION
+    old, FORWARD_VALIDATION = FORWARD_VALIDATION, bool(on)
+    return old
+
+
+def _range_checked_forward(f):
+    import functools
+
+    @functools.wraps(f)
+    def forward(self, graph, *args, **kwargs):
+        field = getattr(graph, "field", None)
+        if (not FORWARD_VALIDATION or ops.StaticCache.active is not None or ops.mlp_precision() != "f16x3" or ops.grad_mode()
+                or not torch.is_tensor(field) or field.device.type != "cuda" or torch.cuda.is_current_stream_capturing()):
+            return f(self, graph, *args, **kwargs)          # (inside a rollout step / training / another arithmetic: validated elsewhere)
+        watch = ops.RangeWatch(field.device, getattr(self, "_range_sites", None), drain=False)
+        try:
+            out = f(self, graph, *args, **kwargs)
+            hit = watch.take()
+        finally:
+            watch.close()
+        if hit:
+            warnings.warn(f"{type(self).__name__}.forward(): the default 'f16x3' MLP arithmetic reached the end of the fp16 range (|x| >= "
+                          f"65504) in {', '.join(hit[:8])}{' ...' if len(hit) > 8 else ''}: the forward was computed again in 'bf16x6' (fp32's "
+                          "exponent range) — the result holds no clipped value.  gfd.set_mlp_precision('bf16x6') avoids the second pass.",
+                          RuntimeWarning, stacklevel=2)
+            old = ops.set_mlp_precision("bf16x6")
+            try:
+                out = f(self, graph, *args, **kwargs)
+            finally:
+                ops.set_mlp_precision(old)
+        return out
+    forward._g4c_range_checked = True
+    return forward
+
+
 REORDER_MIN_NODES = 50_000      # below, the gathered rows stay in L2 whatever the numbering
 
 
@@ -280,7 +331,8 @@ class Rollout:
         dev = graph.field.device
         self._orig_field = graph.field
         self.field = graph.field.to(torch.float32).clone(memory_format=torch.contiguous_format)
-        self.outputs = torch.zeros((graph.num_nodes, self.nf * self.max_steps), dtype=torch.float32, device=dev)
+        # step-major [steps, N, nf]: a step's predictions are one contiguous block (`outputs` gives the reference's [N, nf * steps])
+        self._out_steps = torch.zeros((self.max_steps, graph.num_nodes, self.nf), dtype=torch.float32, device=dev)
         self.step_counter = torch.zeros(2, dtype=torch.int32, device=dev)          # [step index, g4c_rollout_advance's ticket]
         self.steps_done = 0
         self._hipgraph, self._epoch, self._pins = None, -1, None
@@ -290,8 +342,7 @@ class Rollout:
         # fp16 range flags: this rollout answers for its own model's launches only — whatever an earlier launch of these MLPs
         # left behind is dropped here, other models' flags are left alone
         self.label, self._sites = label, getattr(model, "_range_sites", None)
-        if ops.mlp_precision() == "f16x3":
-            ops.f16_range_clear(dev, self._sites)
+        self._watch = ops.RangeWatch(dev, self._sites) if ops.mlp_precision() == "f16x3" else None
         # The default "f16x3" arithmetic is run OPTIMISTICALLY: its kernels flag every value that reached the end of the fp16 range
         # (|x| >= 65504, clipped there), `result()` reads the flags, and a rollout that clipped anywhere is recomputed from the
         # window it started from in "bf16x6" (fp32's exponent range; the reference's `solve` runs in fp32, nn/model.py:303-321) and
@@ -300,10 +351,16 @@ class Rollout:
         self._first_slot = 0
         self.exact_range = False                 # True once a clip made this rollout fall back to "bf16x6"
 
+    @property
+    def outputs(self) -> torch.Tensor:
+        """[N, nf * max_steps] in the rollout's node numbering, as `GNN.solve` lays its result out (nn/model.py:322-326) — a fresh
+        transposed copy of the step-major buffer on every access (no validation: `result()` is the delivered form)."""
+        return ops.steps_to_columns(self._out_steps)
+
     def _one(self):
         with self.static:
             pred = self.model.forward(self.graph, self.steps_done)
-        ops.rollout_advance(self.field, pred, self.outputs, self.step_counter, self.nf)
+        ops.rollout_advance(self.field, pred, self._out_steps, self.step_counter, self.nf)
 
     def step(self) -> None:
         if self.steps_done >= self.max_steps:
@@ -323,10 +380,11 @@ class Rollout:
                 # the weights changed since the last eager step (captured or not yet): the packed images are stale, and repacking
                 # (allocations + pack launches) must not happen inside a capture — one eager step first
                 self._hipgraph, self._epoch = None, -1
-            elif self._hipgraph is not None and self.static.stale():
-                # a per-mesh constant (edge_attr / angle_attr*) was edited in place, or the arithmetic changed: the captured step
-                # contains neither the encoder launches nor a look-up of their cached results — one eager step recomputes them,
-                # then the step is captured again
+            elif self.static.stale():
+                # a per-mesh constant (edge_attr / angle_attr*) was edited in place, or the arithmetic changed: a captured step
+                # contains neither the encoder launches nor a look-up of their cached results, and a step ABOUT to be captured
+                #  would bake the recomputation — and, after a precision change, the repacking — into every replay:
+                # one eager step recomputes them, then the step is captured (again)
                 self._hipgraph, self._epoch = None, -1
             if self.steps_done == 0 or not self.capture or self._epoch == -1:
                 self._one()                               # eager: builds the plans and the packed weight images
@@ -347,7 +405,9 @@ class Rollout:
             self.step()
 
     def rewind(self) -> None:
-        """Restart writing at step 0 (benchmarks: keeps the captured hipGraph and the current field)."""
+        """Restart writing at step 0 (benchmarks: keeps the captured hipGraph and the current field).  Validates first: the
+        field a later recomputation restarts from must not come from steps that clipped."""
+        self.validate()
         self.step_counter.zero_()
         self.steps_done = 1 if self.steps_done > 0 else 0
         if self.steps_done:   # slot 0 is kept so that replays continue from slot 1
@@ -376,7 +436,9 @@ class Rollout:
         clipped at the end of the fp16 range, recompute the steps in "bf16x6" (RuntimeWarning naming the MLPs).  Returns True when
         that happened.  `result()` calls it; a benchmark calls it inside its timed region."""
         if ops.mlp_precision() == "f16x3" and not self.exact_range:
-            hit = ops.f16_range_report(self.outputs.device, sites=self._sites)
+            if self._watch is None:          # (the arithmetic was switched to f16x3 after this rollout was built)
+                self._watch = ops.RangeWatch(self._out_steps.device, self._sites, drain=False)
+            hit = self._watch.take()
             if hit:
                 self._recompute_exact(hit)
                 return True
@@ -386,14 +448,17 @@ class Rollout:
         """`outputs` with its rows in the caller's node numbering — validated first (`validate()`): the tensor returned never
         contains a value the default arithmetic clipped."""
         self.validate()
+        cols = self.outputs
         if self._perm is None:
-            return self.outputs
-        out = torch.empty_like(self.outputs)
-        out[self._perm] = self.outputs
+            return cols
+        out = torch.empty_like(cols)
+        out[self._perm] = cols
         return out
 
     def close(self) -> None:
         self.graph.field = self._orig_field
+        if self._watch is not None:
+            self._watch.close()
 
     def __enter__(self):
         return self

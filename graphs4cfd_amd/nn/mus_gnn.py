@@ -55,16 +55,16 @@ class _MuSGNN(GNN):
         self.node_decoder = MLP(*arch["decoder"])
         self.to(self.device)
 
-    def _launch_for(self, mlp: MLP, sources, n_rows: int, act_code: int, k: int, n_edges: int):
+    def _launch_for(self, mlp: MLP, sources, n_rows: int, act_code: int, k: int, edge_index: torch.Tensor):
         """One launch of `mlp` whose output is the node input of program entry k.  When that entry is an MP layer
         that will hoist its first layer, the launch also emits its node-side products (MLP.run_with_heads).
         Returns (output, products or None)."""
         nxt = self._PROGRAM[k] if k < len(self._PROGRAM) else ""
         # (the consumer hoists from HOIST_MIN_ROWS edges on — and always when it runs as one fused launch per MP layer, whose message
         # part takes the products as additive rows: without them it would make them itself, two more launches at the level's entry)
-        fused = (_blocks.FUSE_LAYER and not ops.grad_mode() and ops.mlp_precision() == "f16x3"
-                 and _blocks.FUSE_LAYER_MIN_ROWS <= n_edges < _blocks.FUSE_LAYER_MAX_ROWS)
-        if nxt.startswith("mp") and (n_edges >= _blocks.HOIST_MIN_ROWS or fused):
+        n_edges = int(edge_index.size(1))
+        if nxt.startswith("mp") and (n_edges >= _blocks.HOIST_MIN_ROWS
+                                     or _blocks.will_fuse_layer(getattr(self, nxt).edge_mlp, getattr(self, nxt).node_mlp, edge_index, n_rows)):
             cons = getattr(self, nxt).edge_mlp
             w = mlp.output_size
             res = mlp.run_with_heads(sources, n_rows, act_code, cons, cons.input_size - 2 * w, [w, w])
@@ -82,7 +82,7 @@ class _MuSGNN(GNN):
         e = ops.static_launch("edge_encoder", [graph.edge_attr],
                               lambda: self.edge_encoder.run_coded([Source(graph.edge_attr)], int(graph.edge_attr.size(0)), SELU))
         # `products`: first-layer node-side terms of the next MP layer, when the launch producing its `v` made them
-        v, products = self._launch_for(self.node_encoder, inputs, n, SELU, 0, int(edge_index.size(1)))
+        v, products = self._launch_for(self.node_encoder, inputs, n, SELU, 0, edge_index)
         e_pending = NONE          # activation not yet applied to `e` (deferred to its readers)
         stash = []
         prog = self._PROGRAM
@@ -94,8 +94,7 @@ class _MuSGNN(GNN):
                 e_pending, products = NONE, None
             elif name.startswith("up_mp"):
                 v_old, edge_index, e, e_pending = stash.pop()
-                v, products = self._launch_for(block.up_mlp, block.sources(graph, v, v_old), int(v_old.size(0)), TANH,
-                                               k + 1, int(edge_index.size(1)))
+                v, products = self._launch_for(block.up_mlp, block.sources(graph, v, v_old), int(v_old.size(0)), TANH, k + 1, edge_index)
             else:
                 nxt = prog[k + 1] if k + 1 < len(prog) else ""
                 if nxt.startswith("mp"):      # next MP layer runs on the same graph: its node-side products ride along

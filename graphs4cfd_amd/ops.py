@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -290,8 +291,19 @@ def rollout_advance(field: Tensor, pred: Tensor, outputs: Tensor, step: Tensor, 
     assert field.is_contiguous() and pred.is_contiguous() and outputs.is_contiguous()
     if step.dtype != torch.int32 or step.numel() < 2:
         raise ValueError("rollout_advance: `step` is an int32 tensor of two entries — [step index, the launch's ticket counter (zero)]")
+    if outputs.dim() == 3:          # step-major [steps, n_nodes, nf]: a step writes one contiguous block
+        if outputs.size(1) != field.size(0) or outputs.size(2) != nf:
+            raise ValueError(f"rollout_advance: step-major outputs {tuple(outputs.shape)} for {field.size(0)} nodes x {nf} fields")
+        out_ld = 0
+    else:
+        out_ld = int(outputs.size(1))
     _lib.check(lib.g4c_rollout_advance(_lib.ptr(field), int(field.size(1)), _lib.ptr(pred), nf, _lib.ptr(outputs),
-                                       int(outputs.size(1)), _lib.ptr(step), int(field.size(0)), _lib.stream_handle(dev)))
+                                       out_ld, _lib.ptr(step), int(field.size(0)), _lib.stream_handle(dev)))
+
+
+def steps_to_columns(out_steps: Tensor) -> Tensor:
+    """Step-major rollout outputs [steps, n_nodes, nf] -> the reference's layout [n_nodes, nf * steps] (nn/model.py:322-326)."""
+    return out_steps.permute(1, 0, 2).reshape(out_steps.size(1), -1)
 
 
 # Arithmetic of the fused MLPs — all fp32 in, fp32 out:
@@ -335,7 +347,8 @@ AGG_ON_LOAD_MIN_ROWS = 50000
 # (one device synchronisation), check_f16_range() turns a non-empty report into a RuntimeWarning.  Rollout.validate (called by
 # Rollout.result, hence Model.solve) and DistributedRollout.validate (gather_outputs) read it and RECOMPUTE a clipped rollout in "bf16x6";
 # GNN.fit warns per epoch; a rollout clears its own model's slots on entry and looks at those only, so a clip is attributed to the
-# model that launched it.  After a bare model.forward() call gfd.check_f16_range() yourself.
+# model that launched it (RangeWatch below: every reader hands hits to all live consumers before it clears).  A bare model.forward()
+# validates itself the same way (nn/model.py: GNN.__init_subclass__): one flag read per call, the forward again in "bf16x6" if it clipped.
 RANGE_SLOTS = 4096
 _range_bufs = {}            # device -> int32 [RANGE_SLOTS]
 _range_sites: List[set] = [set() for _ in range(RANGE_SLOTS)]
@@ -380,46 +393,85 @@ def range_slots_of(sites) -> List[int]:
     return sorted({_range_slot_of[s] for s in sites if s in _range_slot_of})
 
 
-def f16_range_clear(device: Optional[torch.device] = None, sites=None) -> None:
-    """Forget recorded clips: every slot, or only those of `sites` (names as in f16_range_report) — what a rollout does on entry so
-    that it reports its own launches only.  Enqueued on the current stream (no synchronisation)."""
-    device = _indexed(device)
-    for dev, buf in list(_range_bufs.items()):
-        if device is not None and device != dev:
-            continue
-        if sites is None:
-            buf.zero_()
-        else:
-            slots = range_slots_of(sites)
-            if slots:
-                buf[torch.tensor(slots, dtype=torch.long, device=dev)] = 0
+class RangeWatch:
+    """One consumer of the fp16 range flags: a `Rollout`, a `DistributedRollout`, a validated bare `forward()`.  The flags are one
+    int per MLP site and device, shared by everything that launches that MLP; whoever reads them (`f16_range_poll`: one
+    synchronisation) hands every hit to ALL live watches that name the site and only then clears the device array — so a second
+    rollout of the same model, a bare forward between two steps or a `check_f16_range()` call can no longer erase the evidence
+    another rollout still has to act on.  A hit that cannot be told apart (two live consumers of one site) reaches
+    both: each recomputes in the exact arithmetic, which is always right.  `drain=True` (a rollout's entry): the flags are read
+    once first, so that what earlier launches of these MLPs left behind goes to the watches that were live then, not to this one."""
+    _live = weakref.WeakSet()
+
+    def __init__(self, device, sites=None, drain: bool = True):
+        self.device = _indexed(device)
+        self.sites = None if sites is None else frozenset(sites)
+        self.hits = set()
+        if drain:
+            f16_range_poll(self.device)
+        RangeWatch._live.add(self)
+
+    def wants(self, site: str) -> bool:
+        return self.sites is None or site in self.sites
+
+    def take(self) -> List[str]:
+        """Names of this watch's MLPs whose launches clipped a value since the last take (synchronises with the device)."""
+        f16_range_poll(self.device)
+        out = sorted(self.hits)
+        self.hits.clear()
+        return out
+
+    def close(self) -> None:
+        RangeWatch._live.discard(self)
 
 
-def f16_range_report(device: Optional[torch.device] = None, clear: bool = True, sites=None) -> List[str]:
-    """Names of the MLPs whose launches clipped a value at the end of the fp16 range since the last report / clear (all devices, or
-    one; `sites`: only these names — a model's own MLPs — are looked at and cleared).  Synchronises with the device(s)."""
-    hit: List[str] = []
+_range_unclaimed = set()            # (device, site) of hits no live watch asked for: what f16_range_report / check_f16_range answer from
+
+
+def f16_range_poll(device: Optional[torch.device] = None) -> List[str]:
+    """Read the flag array(s) (one synchronisation per device), distribute the hits to the live watches, clear the array(s).
+    Returns every name that was set."""
     device = _indexed(device)
-    only = None if sites is None else set(sites)
+    names_out: List[str] = []
     for dev, buf in list(_range_bufs.items()):
         if device is not None and device != dev:
             continue
         flags = buf.cpu()
-        mine = []
-        for slot in torch.nonzero(flags).flatten().tolist():
-            names = sorted(_range_sites[slot]) or [f"slot {slot}"]
-            if only is not None:
-                names = [n for n in names if n in only]
-                if not names:
-                    continue
-            mine.append(slot)
-            hit += names
-        if clear and mine:
-            if only is None:
-                buf.zero_()
-            else:
-                buf[torch.tensor(mine, dtype=torch.long, device=dev)] = 0
-    return hit
+        slots = torch.nonzero(flags).flatten().tolist()
+        if not slots:
+            continue
+        buf.zero_()
+        watches = [w for w in list(RangeWatch._live) if w.device is None or w.device == dev]
+        for slot in slots:
+            for name in sorted(_range_sites[slot]) or [f"slot {slot}"]:
+                names_out.append(name)
+                claimed = False
+                for w in watches:
+                    if w.wants(name):
+                        w.hits.add(name)
+                        claimed = True
+                if not claimed:
+                    _range_unclaimed.add((dev, name))
+    return names_out
+
+
+def f16_range_clear(device: Optional[torch.device] = None, sites=None) -> None:
+    """Forget the recorded clips that no live watch is waiting for: every site, or only `sites` (names as in f16_range_report).
+    Synchronises (the flags are read first: what a live `Rollout` still has to see reaches it)."""
+    f16_range_report(device, clear=True, sites=sites)
+
+
+def f16_range_report(device: Optional[torch.device] = None, clear: bool = True, sites=None) -> List[str]:
+    """Names of the MLPs whose launches clipped a value at the end of the fp16 range and that no rollout / validated forward has
+    dealt with, since the last report / clear (all devices, or one; `sites`: only these names are looked at and cleared).
+    Synchronises with the device(s)."""
+    f16_range_poll(device)
+    device = _indexed(device)
+    only = None if sites is None else set(sites)
+    mine = sorted(k for k in _range_unclaimed if (device is None or k[0] == device) and (only is None or k[1] in only))
+    if clear:
+        _range_unclaimed.difference_update(mine)
+    return [name for _, name in mine]
 
 
 def check_f16_range(device: Optional[torch.device] = None, where: str = "", sites=None) -> List[str]:

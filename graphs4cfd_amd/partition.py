@@ -549,7 +549,7 @@ class DistributedRollout:
             self.fwd = MusPartitionedForward(program, self.mesh, HipImpl(model), HaloExchanger(self.mesh, group), width, self.nf)
         self.max_steps = max_steps
         self.field = self.mesh.inputs["field"] = self.mesh.inputs["field"].clone()
-        self.outputs = torch.zeros((int(self.mesh.owned_global[0].numel()), self.nf * max_steps), dtype=torch.float32, device=device)
+        self._out_steps = torch.zeros((max_steps, int(self.mesh.owned_global[0].numel()), self.nf), dtype=torch.float32, device=device)
         self.step_counter = torch.zeros(2, dtype=torch.int32, device=device)          # [step index, g4c_rollout_advance's ticket]
         self.steps_done = 0
         self.capture = capture and device.type == "cuda"
@@ -557,8 +557,7 @@ class DistributedRollout:
         self._hipgraph, self._epoch = None, -1
         self.static = ops.StaticCache()        # per-mesh constants (edge / angle encoders), as nn.model.Rollout
         self._sites = getattr(model, "_range_sites", None)
-        if ops.mlp_precision() == "f16x3" and device.type == "cuda":
-            ops.f16_range_clear(device, self._sites)
+        self._watch = ops.RangeWatch(device, self._sites) if ops.mlp_precision() == "f16x3" and device.type == "cuda" else None
         # optimistic "f16x3" (nn.model.Rollout): the input window the rollout started from, for the exact-range recomputation
         self._field0 = self.field.clone()
         self.exact_range = False
@@ -566,7 +565,7 @@ class DistributedRollout:
     def _one(self) -> None:
         with self.static:
             pred = self.fwd.forward()
-        ops.rollout_advance(self.field, pred, self.outputs, self.step_counter, self.nf)
+        ops.rollout_advance(self.field, pred, self._out_steps, self.step_counter, self.nf)
 
     def step(self) -> None:
         """Step 1 eager (plans, packing), step 2 captured into a hipGraph together with its RCCL halo
@@ -587,7 +586,9 @@ class DistributedRollout:
         every rank recomputes its steps in "bf16x6" (the halo exchanges pair up again) and stays in that arithmetic."""
         if ops.mlp_precision() != "f16x3" or self.exact_range or self.device.type != "cuda":
             return False
-        hit = ops.f16_range_report(self.device, sites=self._sites)
+        if self._watch is None:
+            self._watch = ops.RangeWatch(self.device, self._sites, drain=False)
+        hit = self._watch.take()
         clipped = bool(hit)
         import torch.distributed as dist
         if self.world > 1 and dist.is_available() and dist.is_initialized():
@@ -616,8 +617,8 @@ class DistributedRollout:
                 # images are stale or freed; one eager step repacks, then the step is captured again.  Every rank sees the same
                 # epoch sequence as long as every rank updates its replica of the model, which a partitioned rollout requires anyway)
                 self._hipgraph, self._epoch = None, -1
-            elif self._hipgraph is not None and self.static.stale():
-                # (a per-mesh constant edited in place, or another arithmetic: as nn.model.Rollout — and, like new weights, something
+            elif self.static.stale():
+                # (a per-mesh constant edited in place, or another arithmetic — also just BEFORE the capture: as nn.model.Rollout — and, like new weights, something
                 # every rank has to do alike, or a replaying rank would pair its captured collectives with an eager rank's)
                 self._hipgraph, self._epoch = None, -1
             if self.steps_done == 0 or not self.capture or self._epoch == -1:
@@ -670,11 +671,17 @@ class DistributedRollout:
         for _ in range(n):
             self.step()
 
+    @property
+    def outputs(self) -> torch.Tensor:
+        """The owned rows as [n_own, nf * max_steps] (a transposed copy of the step-major buffer)."""
+        return ops.steps_to_columns(self._out_steps)
+
     def gather_outputs(self) -> torch.Tensor:
         import torch.distributed as dist
         self.validate()          # (a clipped rollout is recomputed in "bf16x6" on every rank before anything is gathered)
-        full = torch.zeros((self.n_global, self.outputs.size(1)), dtype=torch.float32, device=self.device)
-        full[self.mesh.owned_global[0]] = self.outputs
+        mine = self.outputs
+        full = torch.zeros((self.n_global, mine.size(1)), dtype=torch.float32, device=self.device)
+        full[self.mesh.owned_global[0]] = mine
         if self.world > 1:
             dist.all_reduce(full)
         if self._perm is not None:        # rows back in the caller's numbering

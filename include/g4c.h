@@ -389,7 +389,9 @@ int g4c_knn_grid_query(const float *pos_sorted, const int32_t *order, const int3
  * One step's bookkeeping without host involvement: t = *step;
  * outputs[:, nf*t : nf*(t+1)] = pred;  field = roll(field, -nf, dim=1); field[:, -nf:] = pred;
  * then step[0] = t + 1, written by the last workgroup of the launch to finish.  `step` points to TWO int32: [0] the step index, [1] a
- * ticket counter the launch uses for that (zero before the first launch; it leaves it zero). */
+ * ticket counter the launch uses for that (zero before the first launch; it leaves it zero).
+ * out_ld == 0: `outputs` is step-major, [steps][n_nodes][nf] contiguous — outputs[t] = pred (one contiguous block per step; the
+ * caller transposes once at the end of the rollout). */
 int g4c_rollout_advance(float *field, int32_t field_cols, const float *pred, int32_t nf,
                         float *outputs, int32_t out_ld, int32_t *step, int64_t n_nodes, void *stream);
 

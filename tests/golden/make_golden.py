@@ -386,6 +386,18 @@ def gen_rollout():
     save("rollout.pt", out)
 
 
+def gen_solve_list():
+    # nn/model.py:308-309: solve() on a LIST of graphs = one rollout of their PyG batch (two meshes of different sizes, n_in = 1)
+    H = 32
+    g1, g2 = mus_graph(220, 6, None, seed=45), mus_graph(140, 6, None, seed=46)
+    arch = mus_arch("NsOneScaleGNN", H, 3, 5)
+    torch.manual_seed(302)
+    model = gfd.nn.NsOneScaleGNN(arch=arch)
+    d1, d2 = graph_dict(g1), graph_dict(g2)
+    save("solve_list.pt", dict(ref="nn/model.py:303-321 (308-309: Batch.from_data_list)", arch=arch, weights=sd(model), graphs=[d1, d2],
+                               solve3=model.solve([g1, g2], 3)))
+
+
 def gen_remus_model():
     H = 32
     g = remus_graph(260, 5, seed=50)
@@ -544,6 +556,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "mus3d":
         gen_mus_3d()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "solve_list":
+        gen_solve_list()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "training":      # (adds one fixture without rewriting the others)
         gen_training()
         sys.exit(0)
@@ -552,6 +567,7 @@ if __name__ == "__main__":
     gen_mus_3d()
     gen_mugs_models()
     gen_rollout()
+    gen_solve_list()
     gen_remus_model()
     gen_checkpoint()
     gen_transforms()

@@ -73,7 +73,36 @@ class Data:
 class Batch(Data):
     @classmethod
     def from_data_list(cls, data_list):
-        raise NotImplementedError("batched rollouts are outside the golden-vector scope")
+        """`torch_geometric.data.Batch.from_data_list` as PyG documents it (Data.__cat_dim__ / Data.__inc__): a tensor attribute
+        whose name contains 'index' (or is 'face') is concatenated along its LAST dimension with the running node count added to
+        each graph's copy, every other tensor along dim 0 unchanged; `batch` = graph id of every node, `ptr` = node offsets;
+        numbers are stacked into a tensor, other objects collected in a list.  (The reference's own Collater corrects the REMuS
+        angle indices BEFORE this call, loader.py:17-51 — `solve([g1, g2])`, nn/model.py:308-309, calls it bare.)"""
+        out = cls()
+        keys = data_list[0].keys()
+        offset, batch, ptr = 0, [], [0]
+        cols = {k: [] for k in keys}
+        for gi, g in enumerate(data_list):
+            n = g.num_nodes
+            for k in keys:
+                v = getattr(g, k)
+                if torch.is_tensor(v):
+                    cols[k].append(v + offset if ("index" in k or k == "face") else v)
+                else:
+                    cols[k].append(v)
+            batch.append(torch.full((n,), gi, dtype=torch.long))
+            offset += n
+            ptr.append(offset)
+        for k, vs in cols.items():
+            if torch.is_tensor(vs[0]):
+                setattr(out, k, torch.cat(vs, dim=-1 if ("index" in k or k == "face") else 0))
+            elif isinstance(vs[0], (int, float)):
+                setattr(out, k, torch.tensor(vs))
+            else:
+                setattr(out, k, vs)
+        out.batch = torch.cat(batch)
+        out.ptr = torch.tensor(ptr)
+        return out
 
 
 class Dataset(torch.utils.data.Dataset):

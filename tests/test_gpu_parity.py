@@ -610,6 +610,23 @@ def test_rollouts_eager_and_hipgraph(golden):
         model.solve(g, 0)
 
 
+def test_solve_list_of_graphs(golden):
+    """solve([g1, g2]) (nn/model.py:308-309: one rollout of the PyG batch of the graphs — node tensors concatenated, `*index*`
+    tensors offset by the running node count) against the reference's own result on two meshes of different sizes; the rows of
+    each mesh equal its own single-graph rollout; eager == captured."""
+    c = golden("solve_list.pt")
+    model = gfd.nn.NsOneScaleGNN(arch=c["arch"], device=DEV)
+    model.load_state_dict(c["weights"])
+    graphs = [gfd.Graph(**cu(d)) for d in c["graphs"]]
+    out = model.solve([gfd.Graph(**cu(d)) for d in c["graphs"]], 3, capture=False)
+    assert out.shape == c["solve3"].shape
+    torch.testing.assert_close(out.cpu(), c["solve3"], rtol=1e-3, atol=1e-3)
+    n1 = graphs[0].num_nodes
+    torch.testing.assert_close(out[:n1], model.solve(graphs[0], 3, capture=False), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out[n1:], model.solve(graphs[1], 3, capture=False), rtol=1e-5, atol=1e-5)
+    assert torch.equal(model.solve([gfd.Graph(**cu(d)) for d in c["graphs"]], 4, capture=True)[:, :9], out)
+
+
 def test_rollout_on_the_renumbered_mesh(golden):
     """Rollout(reorder=True) (the default from 50k nodes): same result rows, in the caller's numbering, up to the summation order
     inside clusters / coarse edges; captured == eager; the caller's Graph is untouched."""
@@ -1529,6 +1546,71 @@ def test_f16_range_clip_recomputes_in_bf16x6_and_matches_the_oracle():
         ops.set_mlp_precision(old)
 
 
+def test_bare_forward_is_range_validated_and_rollouts_keep_their_evidence():
+    """VERDICT r05 item 6 / ADVICE r05: (a) a bare `model.forward(graph)` in the default arithmetic (the reference's other public
+    entry, nn/mus_gnn.py:173-218) returns — with a RuntimeWarning — the "bf16x6" forward bit for bit when a value left the fp16 range,
+    and an ordinary forward costs exactly one read of the flags, no warning, nothing recomputed; (b) a second Rollout on the same
+    model, a bare forward or a check_f16_range() call between the steps of a live rollout no longer erase the clip that rollout
+    still has to act on."""
+    import warnings
+    from graphs4cfd_amd.nn.model import Rollout
+    torch.manual_seed(8)
+    model = gfd.nn.NsOneScaleGNN(arch=S.mus_arch("NsOneScaleGNN", 128), device=DEV)
+    old = ops.set_mlp_precision("f16x3")
+    polls = []
+    real_poll = ops.f16_range_poll
+    try:
+        g = S.mus_graph(2000, levels=1, seed=9).to(DEV)
+        big = g.clone(); big.field = big.field * 1e5
+        ops.f16_range_report()
+        ops.f16_range_poll = lambda dev=None: (polls.append(1), real_poll(dev))[1]
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)
+            y = model.forward(g).clone()
+        assert len(polls) == 1, "an ordinary bare forward reads the range flags once"
+        ops.f16_range_poll = real_poll
+        with torch.no_grad(), pytest.warns(RuntimeWarning, match="computed again in 'bf16x6'"):
+            y_big = model.forward(big).clone()
+        ops.set_mlp_precision("bf16x6")
+        with torch.no_grad():
+            ref, ref_big = model.forward(g).clone(), model.forward(big).clone()
+        ops.set_mlp_precision("f16x3")
+        assert torch.equal(y_big, ref_big) and torch.isfinite(y_big).all()
+        torch.testing.assert_close(y, ref, rtol=2e-5, atol=2e-5)
+        assert ops.f16_range_report() == []
+        # validation off: the clipped forward is delivered as computed, and says so when asked
+        was = gfd.set_forward_validation(False)
+        try:
+            with torch.no_grad(), warnings.catch_warnings():
+                warnings.simplefilter("error", RuntimeWarning)
+                model.forward(big)
+            assert any("NsOneScaleGNN" in n for n in ops.f16_range_report())
+        finally:
+            gfd.set_forward_validation(was)
+        # (b) rollout A clips; then rollout B (ordinary input) is built on the same model, a bare forward and a report run in between
+        big.batch = torch.zeros(big.num_nodes, dtype=torch.long, device=DEV)
+        g.batch = big.batch
+        ro_a = Rollout(model, big, 4, capture=False, reorder=False, label="A")
+        ro_a.run(2)
+        ro_b = Rollout(model, g, 4, capture=False, reorder=False, label="B")
+        with torch.no_grad():
+            model.forward(g)
+        ops.check_f16_range()
+        ro_b.run(2)
+        with pytest.warns(RuntimeWarning, match="recomputed in 'bf16x6'"):
+            out_a = ro_a.result().clone()
+        assert ro_a.exact_range
+        ro_a.close(); ro_b.close()
+        ops.set_mlp_precision("bf16x6")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref_a = model.solve(big.clone(), 4, capture=False)
+        assert torch.equal(out_a[:, :6], ref_a[:, :6])
+    finally:
+        ops.f16_range_poll = real_poll
+        ops.set_mlp_precision(old)
+
+
 def test_f16x3_is_range_safe_for_huge_and_tiny_input_rows():
     """inputs far outside the fp16 range.  A field scaled by 1e5 makes the first hidden activations of the node
     encoder ~1e5; scaled by 1e30 everything downstream is astronomically large.  The reference computes in fp32.  solve() in the
@@ -1819,8 +1901,9 @@ def test_static_encoder_cache_is_bit_identical_and_invalidates(family):
 
 
 def test_f16_range_report_is_scoped_to_the_model_that_clipped():
-    """A clip in model A's launches must not be reported by model B's solve() (the flags are per device, not per model: a rollout
-    clears its own model's slots on entry and reports only those), and it must still be reported when A is asked."""
+    """A clip in model A's launches must not be reported by model B's solve() (the flags are per device, not per model: whoever reads
+    them hands each hit to the consumers that named its site — ops.RangeWatch — and keeps the rest for f16_range_report), and it
+    must still be reported when A is asked."""
     import warnings
     old = ops.set_mlp_precision("f16x3")
     try:
@@ -1835,8 +1918,12 @@ def test_f16_range_report_is_scoped_to_the_model_that_clipped():
         a.invalidate_packed()
         ga = g.clone().to(DEV)
         ga.batch = torch.zeros(ga.num_nodes, dtype=torch.long, device=DEV)
-        with torch.no_grad():
-            a.forward(ga)                                   # bare forward: sets A's flags, nobody asked yet
+        was = gfd.set_forward_validation(False)             # (a validated bare forward would deal with its clip itself)
+        try:
+            with torch.no_grad():
+                a.forward(ga)                               # bare forward: sets A's flags, nobody asked yet
+        finally:
+            gfd.set_forward_validation(was)
         # a clip of an MLP that belongs to no model at all (the stale flag GPUTEST_r03 showed in an unrelated test's warnings)
         mlp = B.MLP(128, (128, 128), True).to(DEV)
         mlp(torch.full((64, 128), 1e5, device=DEV))
