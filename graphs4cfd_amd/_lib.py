@@ -19,7 +19,7 @@ ACT_NONE, ACT_SELU, ACT_TANH = 0, 1, 2
 MAX_SRC, MAX_LAYERS = 4, 4
 MAX_HEADS = 2
 NARROW_MAX = 8
-KERNEL_NAMES = {0: "none", 1: "mlp_split_kernel", 2: "mlp_bx6_kernel", 3: "mlp_bx6i_kernel", 4: "mlp_ws_kernel", 5: "mlp_node_kernel"}   # g4c_mlp_last_kernel
+KERNEL_NAMES = {0: "none", 1: "mlp_split_kernel", 2: "mlp_bx6_kernel", 3: "mlp_bx6i_kernel", 4: "mlp_ws_kernel"}   # g4c_mlp_last_kernel
 
 _ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "selu": ACT_SELU, "tanh": ACT_TANH}
 
@@ -98,7 +98,6 @@ _SIGNATURES = {
                                   C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "g4c_mlp_bx6i_enable": (C.c_int, [C.c_int]),
     "g4c_mlp_ws_enable": (C.c_int, [C.c_int]),
-    "g4c_mlp_node_enable": (C.c_int, [C.c_int]),
     "g4c_mlp_small_launch_tiles": (C.c_int, [C.c_int]),
     "g4c_layer_norm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "g4c_debug_mean_div": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -311,10 +311,6 @@ int ws_enable(int on);
 bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count, bool any_size = false);
 int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st, const NodeParams *node = nullptr);
 
-// the node MLP on its own persistent pair-pipelined kernel (mlp_ws.hip, mlp_node_kernel): f16x3 stream, two plain 128-wide blocks
-int node_enable(int on);
-bool node_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count);
-int node_launch(const Params &p, hipStream_t st);
 
 // four bf16 values (two dwords as loaded) widened to fp32: a shift / a mask each — exact
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));

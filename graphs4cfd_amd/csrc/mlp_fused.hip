@@ -1620,11 +1620,6 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         g_last_kernel = G4C_KERNEL_MLP_WS;
         return ws_launch(p, true, false, st, &q);
     }
-    if (bx6 && !force_tiles && node_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
-        // the node update [aggregate | v] on the persistent pair-pipelined kernel (mlp_ws.hip, mlp_node_kernel)
-        g_last_kernel = G4C_KERNEL_MLP_NODE;
-        return node_launch(p, st);
-    }
     if (bx6 && !force_tiles && ws_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
         // weight-stationary persistent kernel (mlp_ws.hip): pairs of 32-row tiles (whole segments with aggregation), one workgroup per CU
         p.n_tiles = agg ? agg->n_tiles : (int)((row_count + 31) / 32);

@@ -291,7 +291,8 @@ __device__ __forceinline__ void other_all(const f32x4 (&accE)[2], const f32x4 (&
 // block by block from q.w: 32 registers per wave and block, the next block fetched while this one multiplies) -> LayerNorm ->
 // activation -> q.out, + the heads.  Rows are taken 64 at a time as two 32-row tiles whose matrix phases carry each other's vector work
 // (park / epilogue / fp32 rows), as in the message loop of mlp_ws_kernel; a remainder of <= 32 rows runs as one tile.  Used behind the
-// message phase (mlp_ws_kernel<.., NODE>: x0 = the aggregates the workgroup has just written) and on its own (mlp_node_kernel).
+// message phase (mlp_ws_kernel<.., NODE>: x0 = the aggregates the workgroup has just written).  (Round 5 also ran it as a launch of
+// its own, mlp_node_kernel: 131 against 108 us of the tile kernel at 100k rows — removed in round 6, HISTORY.md 4.1.)
 struct NodeCtx {
     int tid, wave, n, g, fcol, prow, pc;
     unsigned lo_b;
@@ -1123,50 +1124,6 @@ __global__ __launch_bounds__(512, SP == 1 ? G4C_WS_SP1_MINW : 2) void mlp_ws_ker
     }
 }
 
-// The node MLP as a launch of its own (round 5): two plain 128-wide input blocks (MuS-GNN's node update [aggregate | v], nn/blocks.py:185),
-// two or three 128-wide layers, LayerNorm / activation, heads — one persistent 8-wave workgroup per CU on a contiguous range of 32-row
-// tiles, node_phase above.  Replaces the 4-wave tile kernel (mlp_bx6_kernel) for these launches: a block of streamed weights serves
-// 64 rows instead of 32, and one tile's epilogue runs under the other tile's MFMAs.
-template <int NL>
-__global__ __launch_bounds__(512, 2) void mlp_node_kernel(const float *x0, const int x0_ld, const NodeParams q, const int n_rows) {
-    __shared__ __attribute__((aligned(16))) __bf16 sP[2 * TILE_BF16];
-    __shared__ __attribute__((aligned(16))) float sF[2 * FIN];
-    __shared__ __attribute__((aligned(16))) float sBiasN[3 * NP];
-    __shared__ __attribute__((aligned(16))) float sGBN[2 * NP];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 15, g = lane >> 4;
-    int S0, S1;
-    {
-        const int G = gridDim.x, b = blockIdx.x;
-        const int slot = (G & 7) ? b : (b & 7) * (G >> 3) + (b >> 3);          // (XCD-aware: each XCD gets a contiguous share)
-        const int n_tiles = (n_rows + 31) >> 5;
-        const int t0 = (int)(((long long)slot * n_tiles) / G), t1 = (int)(((long long)(slot + 1) * n_tiles) / G);
-        S0 = __builtin_amdgcn_readfirstlane(t0 * 32);
-        S1 = __builtin_amdgcn_readfirstlane(t1 * 32 < n_rows ? t1 * 32 : n_rows);
-    }
-    if (S0 >= S1) return;
-    f16_range_mode();
-    NodeCtx c;
-    c.tid = tid; c.wave = wave; c.n = n; c.g = g;
-    c.fcol = 16 * wave + 4 * g; c.prow = tid >> 5; c.pc = (tid & 31) * 4;
-    c.lo_b = 2u * (unsigned)((wave >> 1) * 8 * STEP6 + (g >> 1) * STEP6 + ((g & 1) * 32 + 16 * (wave & 1) + n) * 8);
-    c.sBiasN = sBiasN; c.sGBN = sGBN; c.fA = sF; c.fB = sF + FIN;
-    {
-        __bf16 *const sA = sP, *const sB = sP + TILE_BF16;
-        const int l32 = tid & 31;
-        const int acc_off = n * PS + 8 * ((2 * wave + (g >> 1)) ^ n) + 4 * (g & 1);
-        const int park_off = c.prow * PS + 8 * ((l32 >> 1) ^ c.prow) + 4 * (l32 & 1);
-        c.oA.plane_acc = sA + acc_off; c.oA.plane_park = sA + park_off; c.oA.fin = c.fA + n * HS + c.fcol;
-        c.oB.plane_acc = sB + acc_off; c.oB.plane_park = sB + park_off; c.oB.fin = c.fB + n * HS + c.fcol;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) { c.paA[ks] = sA + n * PS + 8 * ((4 * ks + g) ^ n); c.paB[ks] = c.paA[ks] + TILE_BF16; }
-    }
-    if (tid < NL * NP) sBiasN[tid] = q.b[tid];
-    if (tid < 2 * NP) sGBN[tid] = q.gamma ? (tid < NP ? q.gamma[tid] : q.beta[tid - NP]) : 0.f;
-    __syncthreads();
-    node_phase<2, NL>(c, x0, x0_ld, q, S0, S1);
-}
 
 }  // namespace
 
@@ -1203,56 +1160,6 @@ bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, 
     if (((uintptr_t)p.b & 15)) return false;
     if (p.M >= (1LL << 31)) return false;
     return true;
-}
-
-// the node MLP's own launch (mlp_node_kernel): 0 off (DEFAULT: measured slower than the tile kernel — 131 against 108 us at 100k rows,
-// equal at <= 25k, profiles/r05_node_kernel.log: eight waves in lock step expose every load and LayerNorm round trip that four
-// independent 4-wave workgroups per CU hide by occupancy; the same code is what the fused MP layer runs behind its message phase,
-// where it replaces a whole launch), 1 launches of at least min_rows rows, 2 every launch it can take (tests, scripts/node_check.py)
-static int g_node = -1;
-int node_enable(int on) {
-    if (g_node < 0) g_node = 0;
-    const int old = g_node;
-    if (on >= 0) g_node = on > 2 ? 2 : on;
-    return old;
-}
-
-bool node_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, long long row_count) {
-    constexpr long long min_rows = 16384;          // (below: the launch is a handful of tiles per CU either way; same-box sweep of round 5)
-    const int mode = node_enable(-1);
-    if (!mode || save || agg || round1 || !f16x2) return false;
-    if (mode == 1 && row_count < min_rows) return false;
-    if (p.n_src != 2 || p.n_add != 0 || p.n_nar != 0 || (p.n_layers != 2 && p.n_layers != 3) || p.n_out != NP) return false;
-    if (p.resid || p.out_idx || !p.out || p.out_bf16 || (p.out_ld & 3) || ((uintptr_t)p.out & 15) || p.row_base != 0) return false;
-    for (int s2 = 0; s2 < 2; ++s2) {
-        const Src &s = p.src[s2];
-        if (s.width != NP || !s.vec || s.idx || s.pre_act || s.seg_off || s.bf16 || (s.ld & 3) || (s.col0 & 3) || ((uintptr_t)s.ptr & 15)) return false;
-    }
-    if (p.gamma && (((uintptr_t)p.gamma & 15) || ((uintptr_t)p.beta & 15))) return false;
-    if (((uintptr_t)p.b & 15) || p.M >= (1LL << 31)) return false;
-    if (p.n_heads < 0 || p.n_heads > G4C_MAX_HEADS) return false;
-    if (p.n_heads && ((p.head_ld & 3) || p.head_bf16)) return false;
-    for (int hd = 0; hd < p.n_heads; ++hd)
-        if ((uintptr_t)p.head_out[hd] & 15) return false;
-    return true;
-}
-
-int node_launch(const Params &p, hipStream_t st) {
-    NodeParams q{};
-    q.v = p.src[1].ptr + p.src[1].col0; q.v_ld = p.src[1].ld;
-    q.w = p.w; q.b = p.b; q.gamma = p.gamma; q.beta = p.beta; q.eps = p.eps; q.act = p.act;
-    q.out = p.out; q.out_ld = p.out_ld; q.n_heads = p.n_heads; q.head_ld = p.head_ld;
-    for (int hd = 0; hd < G4C_MAX_HEADS; ++hd) q.head_out[hd] = p.head_out[hd];
-    q.range_flag = p.range_flag; q.range_slot = p.range_slot;
-    const int n_rows = (int)p.M;
-    const int n_tiles = (n_rows + 31) / 32;
-    if (n_tiles == 0) return G4C_OK;
-    const int n_cu = g4c::cu_count();
-    const dim3 grid(n_tiles < n_cu ? n_tiles : n_cu), blk(512);
-    const float *x0 = p.src[0].ptr + p.src[0].col0;
-    if (p.n_layers == 2) mlp_node_kernel<2><<<grid, blk, 0, st>>>(x0, p.src[0].ld, q, n_rows);
-    else mlp_node_kernel<3><<<grid, blk, 0, st>>>(x0, p.src[0].ld, q, n_rows);
-    return g4c::check_launch("g4c_mlp_forward (node)");
 }
 
 int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st, const NodeParams *node) {
@@ -1306,4 +1213,3 @@ int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st, const Node
 }  // namespace g4cm
 
 extern "C" int g4c_mlp_ws_enable(int on) { return g4cm::ws_enable(on); }
-extern "C" int g4c_mlp_node_enable(int on) { return g4cm::node_enable(on); }

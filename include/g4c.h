@@ -230,16 +230,6 @@ int g4c_mlp_bx6i_enable(int on);
  * g4c_mlp_bx6i_enable takes the bf16x6 stream only since round 3. */
 int g4c_mlp_ws_enable(int on);
 
-/* Round 5: the node update's own launch (nn/blocks.py:185, `node_mlp(cat(aggr, v))`; also what g4c_mp_layer_forward_bx6 runs behind its
- * message phase): f16x3 stream, two plain 128-wide input blocks, two or three 128-wide layers, LayerNorm / activation, 0 - 2 heads —
- * one persistent 8-wave workgroup per CU takes a contiguous range of rows 64 at a time as two 32-row tiles, each tile's epilogue under
- * the other tile's MFMAs, a streamed block of weights serving both (mlp_ws.hip, mlp_node_kernel) instead of one 4-wave workgroup per
- * 32-row tile.  Same arithmetic per element as the tile kernel; sums over k associated as in the weight-stationary kernel.
- * 0 = never (the DEFAULT: as a launch of its own it measures slower than the tile kernel at 100k rows and equal below 25k — the
- * code earns its keep behind the message phase of g4c_mp_layer_forward_bx6), 1 = launches of at least 16 384 rows, 2 = every launch
- * it can take (tests); -1 only queries. */
-int g4c_mlp_node_enable(int on);
-
 /* Small launches of the tile kernel (at most n_tiles 32-row tiles; default 512 = two workgroups per CU) run an instantiation that
  * keeps a whole 128-k block of weights in flight per wave — the next block's weights are requested while this block multiplies —
  * instead of the two-step ring the chip-filling launches use: with one or two waves per SIMD nothing else hides the L2 round trip.
@@ -269,7 +259,6 @@ int g4c_debug_mean_div(const float *a, const int32_t *count, float *out, int64_t
 #define G4C_KERNEL_MLP_BX6 2
 #define G4C_KERNEL_MLP_BX6I 3
 #define G4C_KERNEL_MLP_WS 4
-#define G4C_KERNEL_MLP_NODE 5
 int g4c_mlp_last_kernel(void);
 
 /* Rounded-bf16 variant (opt-in only; BASELINE config 3 "bf16 edge-MLP MFMA"): the same stream and kernel structure, but

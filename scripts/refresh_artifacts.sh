@@ -57,7 +57,6 @@ bash scripts/build_ws_timing.sh > /dev/null 2>&1 && timeout 120 python scripts/w
 timeout 120 python scripts/ws_stamps.py graphs4cfd_amd/lib/libg4c_ws_timing.so bf16 2>&1 | grep -v amdgpu.ids > $A/${TAG}_ws_stamps_bf16_mode.log
 # round 5: the fused MP layer and the node update's own kernel against the separate launches / the tile kernel
 timeout 600 python scripts/mp_layer_check.py --time 2>&1 | grep -v "^ok\|amdgpu.ids" > $A/${TAG}_mp_layer_check_and_ab.log
-timeout 600 python scripts/node_check.py --time 2>&1 | grep -v "^ok\|amdgpu.ids" > $A/${TAG}_node_check_and_ab.log
 { for f in 0 1; do for wl in "--workload c2" "--nodes 12500 --steps 100 --no-side-configs"; do
     echo "G4C_FUSE_LAYER=$f bench.py $wl: $(G4C_FUSE_LAYER=$f timeout 300 python bench.py $wl --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys;print(round(json.loads(sys.stdin.read())['value'],1))") steps/s"
   done; done; } > $A/${TAG}_ab_fused_layer.log 2>&1

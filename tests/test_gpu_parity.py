@@ -1787,39 +1787,6 @@ def test_fused_mp_layer_matches_the_separate_launches(layers):
         ops.set_mlp_precision(old)
 
 
-def test_node_kernel_matches_the_tile_kernel():
-    """mlp_node_kernel (g4c_mlp_node_enable: the node update [aggregate | v] -> MLP -> LayerNorm -> activation + heads on one persistent
-    pair-pipelined workgroup per CU; the code the fused MP layer runs behind its message phase) against the 32-row tile kernel, over
-    row counts that leave every kind of remainder (one row, < 32, 33 - 64, an odd number of tiles per workgroup), two / three layers,
-    with / without LayerNorm and heads, every activation.  Same arithmetic per element, another association of the sums over k: 2e-5."""
-    lib = _lib.load()
-    H = 128
-    old = ops.set_mlp_precision("f16x3")
-    was = lib.g4c_mlp_node_enable(-1)
-    try:
-        for layers, ln in ((3, True), (2, True), (3, False)):
-            torch.manual_seed(7 * layers + ln)
-            node = B.MLP(2 * H, (H,) * layers, ln).to(DEV)
-            nxt = B.MLP(3 * H, (H,) * layers, True).to(DEV)
-            for rows in (40000, 12511, 97, 65, 33, 31, 1):
-                agg, v = torch.randn(rows, H, device=DEV), torch.randn(rows, H, device=DEV)
-                for act in (_lib.ACT_SELU, _lib.ACT_TANH, _lib.ACT_NONE):
-                    res = []
-                    with torch.no_grad():
-                        for mode in (0, 2):
-                            lib.g4c_mlp_node_enable(mode)
-                            y, hs = node.run_with_heads([ops.Source(agg), ops.Source(v)], rows, act, nxt, H, [H, H])
-                            k1 = int(lib.g4c_mlp_last_kernel())
-                            z = node.run_coded([ops.Source(agg), ops.Source(v)], rows, act)
-                            assert k1 == (5 if mode else 2) and int(lib.g4c_mlp_last_kernel()) == k1
-                            res.append((y, hs[0], hs[1], z))
-                    for a_, b_ in zip(*res):
-                        torch.testing.assert_close(b_, a_, rtol=0, atol=2e-5, msg=lambda m: f"{(layers, ln, rows, act)}: {m}")
-    finally:
-        lib.g4c_mlp_node_enable(was)
-        ops.set_mlp_precision(old)
-
-
 # ------------------------------------------------------------------ per-mesh constants are cached across rollout steps (round 4)
 def _manual_rollout(model, g, field, n_out):
     """solve() spelled out with bare forward() calls (which never use the cache); n_in = 1: the next input is the prediction.
