@@ -2,8 +2,8 @@
 # Round artifacts, produced on the GPU box into gpurun_out/artifacts_<tag>/ (copy them into profiles/ afterwards):
 #   pytest -m gpu tail, bench lines of every named workload, rocprofv3 kernel stats of the headline and REMuS benches, PMC HBM
 #   traffic of both, MFMA ceiling, training benches.
-# Usage: gpurun --timeout 3000 -- 'bash scripts/refresh_artifacts.sh r05'
-TAG=${1:-r05}
+# Usage: gpurun --timeout 3000 -- 'bash scripts/refresh_artifacts.sh r06'
+TAG=${1:-r06}
 cd "$GRAFT_REPO_ROOT"
 A=gpurun_out/artifacts_$TAG; rm -rf $A; mkdir -p $A
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $A/${TAG}_pytest_gpu.log
@@ -42,6 +42,11 @@ for wl in headline c3; do
   G4C_BENCH_SAME_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
       bench.py --gpus 2 --workload $wl --steps 20 --warmup 3 2> $A/bench_${wl}_2rank_stderr.log | tail -1 > $A/${TAG}_bench_${wl}_2rank_samegpu.json
 done
+# the driver's command shape: bench.py --gpus N as a PLAIN command starts its own ranks
+for n in 2 4; do
+  G4C_BENCH_SAME_GPU=1 timeout 900 python bench.py --gpus $n --steps 5 --warmup 2 2> $A/bench_${n}rank_plain_stderr.log | tail -1 > $A/${TAG}_bench_headline_${n}rank_plain_cmd.json
+done
+bash scripts/size_sweep.sh > $A/${TAG}_size_sweep.log 2>&1
 timeout 300 python scripts/step_breakdown.py > $A/${TAG}_step_breakdown.log 2>&1
 timeout 300 python scripts/step_breakdown.py --workload c3 > $A/${TAG}_step_breakdown_c3.log 2>&1
 timeout 300 python scripts/bench_segment_reduce.py 2>&1 | grep -v amdgpu.ids > $A/${TAG}_segment_reduce_rotating.log
@@ -81,5 +86,13 @@ bash scripts/build_variant.sh "$GRAFT_REPO_ROOT/graphs4cfd_amd/lib/libg4c_timing
 rm -f graphs4cfd_amd/lib/libg4c_timing.so
 ( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $A/trace_small -o t -- \
     python bench.py --nodes 12500 --steps 60 --warmup 5 --no-side-configs --no-cpu-baseline --no-strict-range --no-roofline --no-partition-check > /dev/null 2>&1 )
-python scripts/trace_gaps.py $A/trace_small > $A/${TAG}_trace_gaps_12k5.log 2>&1; rm -rf $A/trace_small
+python scripts/trace_gaps.py $A/trace_small > $A/${TAG}_trace_gaps_12k5.log 2>&1
+python scripts/trace_step_positions.py $A/trace_small > $A/${TAG}_step_positions_12k5.log 2>&1; rm -rf $A/trace_small
+# where a replayed step goes, launch by launch (headline and config 2)
+for wl in headline c2; do
+  ( cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $A/trace_$wl -o t -- \
+      python bench.py --workload $wl --steps 20 --warmup 3 --no-side-configs --no-cpu-baseline --no-strict-range --no-roofline > /dev/null 2>&1 )
+  sfx=""; [ "$wl" != headline ] && sfx="_$wl"
+  python scripts/trace_step_positions.py $A/trace_$wl > $A/${TAG}_step_positions$sfx.log 2>&1; rm -rf $A/trace_$wl
+done
 ls -la $A
