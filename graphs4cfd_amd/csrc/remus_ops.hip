@@ -70,9 +70,12 @@ __global__ __launch_bounds__(256) void rollout_advance_kernel(
     }
     // *step = t + 1 by the LAST workgroup to get here (step[1]: a ticket counter, zero between launches): every workgroup has read
     // the step index before it takes its ticket, so nobody can see the new value — no trailing single-thread launch (4 us per step)
+    // (round 6: no __threadfence() in front of the ticket — nothing this workgroup WROTE has to be visible to the others, only its read
+    // of the step index has to have completed, which the wait below says; 391 workgroups each writing back and invalidating their XCD's
+    // L2 was most of the launch's 16 us)
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (atomicAdd(step + 1, 1) == (int)gridDim.x - 1) { step[1] = 0; step[0] = t + 1; }
     }
 }
