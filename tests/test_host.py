@@ -266,3 +266,33 @@ def test_bench_starts_its_own_ranks_when_not_under_torchrun(monkeypatch):
     with pytest.raises(SystemExit) as exc:
         bench.main()
     assert exc.value.code == 7 and seen == {"gpus": 2, "argv": ["--gpus", "2", "--steps", "2", "--warmup", "1"]}
+
+
+def test_range_watch_hands_every_hit_to_all_live_consumers_before_clearing():
+    """ops.RangeWatch / f16_range_poll (host logic; the flag array stands on the CPU here): whoever reads the shared per-site flags
+    distributes each hit to every live consumer that named the site, keeps what nobody asked for for f16_range_report, and only
+    then clears — a second consumer of the same model, or a report in between, cannot erase the first one's evidence."""
+    from graphs4cfd_amd import ops
+    dev = torch.device("cpu")
+    saved = (dict(ops._range_bufs), set(ops._range_unclaimed))
+    try:
+        ops._range_bufs.clear(); ops._range_unclaimed.clear()
+        buf = ops._range_buffer(dev)
+        sa, sb, so = ops._range_slot("T.model_a.mlp"), ops._range_slot("T.model_b.mlp"), ops._range_slot("T.orphan.mlp")
+        wa1 = ops.RangeWatch(dev, ["T.model_a.mlp"])
+        buf[sa] = 1                                   # a launch of model A clipped
+        wa2 = ops.RangeWatch(dev, ["T.model_a.mlp"])  # a second rollout of A is built: its entry drain must not eat wa1's hit
+        assert wa2.hits == set() and wa1.hits == {"T.model_a.mlp"} and int(buf.sum()) == 0
+        buf[sb] = 1; buf[so] = 1
+        assert ops.f16_range_report(dev, sites=["T.model_b.mlp"]) == ["T.model_b.mlp"]          # nobody watches B: reported, cleared
+        assert ops.f16_range_report(dev, clear=False) == ["T.orphan.mlp"]
+        assert wa1.take() == ["T.model_a.mlp"] and wa1.take() == [] and wa2.take() == []
+        buf[sa] = 1                                   # indistinguishable: both live consumers of the site get it
+        assert wa2.take() == ["T.model_a.mlp"] and wa1.take() == ["T.model_a.mlp"]
+        wa1.close(); wa2.close()
+        buf[sa] = 1
+        assert sorted(ops.f16_range_report(dev)) == ["T.model_a.mlp", "T.orphan.mlp"]          # no live watch: unclaimed again
+        assert ops.f16_range_report(dev) == []
+    finally:
+        ops._range_bufs.clear(); ops._range_bufs.update(saved[0])
+        ops._range_unclaimed.clear(); ops._range_unclaimed.update(saved[1])
