@@ -627,6 +627,26 @@ def test_solve_list_of_graphs(golden):
     assert torch.equal(model.solve([gfd.Graph(**cu(d)) for d in c["graphs"]], 4, capture=True)[:, :9], out)
 
 
+def test_rollout_advance_layouts_agree():
+    """g4c_rollout_advance (nn/model.py:316-327: outputs[:, nf t : nf (t + 1)] = pred, field window shifted): the step-major output
+    buffer [steps, N, nf] (out_ld = 0, what Rollout uses) holds the same values as the reference's row-major [N, nf * steps]."""
+    torch.manual_seed(3)
+    N, nf, n_in, steps = 1234, 3, 2, 5
+    f_row, f_step = torch.randn(N, nf * n_in, device=DEV), None
+    f_step = f_row.clone()
+    out_row = torch.zeros(N, nf * steps, device=DEV)
+    out_step = torch.zeros(steps, N, nf, device=DEV)
+    c_row, c_step = torch.zeros(2, dtype=torch.int32, device=DEV), torch.zeros(2, dtype=torch.int32, device=DEV)
+    ref_field = f_row.clone().cpu()
+    for t in range(steps):
+        pred = torch.randn(N, nf, device=DEV)
+        ops.rollout_advance(f_row, pred, out_row, c_row, nf)
+        ops.rollout_advance(f_step, pred, out_step, c_step, nf)
+        ref_field = torch.cat([ref_field[:, nf:], pred.cpu()], 1)
+    assert torch.equal(ops.steps_to_columns(out_step), out_row) and torch.equal(f_row, f_step)
+    assert torch.equal(f_row.cpu(), ref_field) and c_row.tolist() == [steps, 0] and c_step.tolist() == [steps, 0]
+
+
 def test_rollout_on_the_renumbered_mesh(golden):
     """Rollout(reorder=True) (the default from 50k nodes): same result rows, in the caller's numbering, up to the summation order
     inside clusters / coarse edges; captured == eager; the caller's Graph is untouched."""

@@ -296,3 +296,15 @@ def test_range_watch_hands_every_hit_to_all_live_consumers_before_clearing():
     finally:
         ops._range_bufs.clear(); ops._range_bufs.update(saved[0])
         ops._range_unclaimed.clear(); ops._range_unclaimed.update(saved[1])
+
+
+def test_csr_plan_knows_a_uniform_in_degree():
+    """CsrPlan.uniform_deg (what G4C_AGG_UNIFORM is fed with): k when EVERY segment has exactly k rows, else 0 (one shorter or
+    one empty segment is enough)."""
+    dev = torch.device("cpu")
+    assert plan.build_csr(torch.arange(50).repeat_interleave(6), 50, dev).uniform_deg == 6
+    assert plan.build_csr(torch.arange(7).repeat_interleave(5), 7, dev).uniform_deg == 5
+    ragged = torch.cat([torch.arange(49).repeat_interleave(6), torch.full((5,), 49)])
+    assert plan.build_csr(ragged, 50, dev).uniform_deg == 0
+    assert plan.build_csr(torch.arange(49).repeat_interleave(6), 50, dev).uniform_deg == 0          # the last target is empty
+    assert plan.build_csr(torch.arange(3).repeat_interleave(40), 3, dev).uniform_deg == 0           # beyond 32 rows: not offered
