@@ -312,6 +312,10 @@ bool ws_eligible(const Params &p, bool round1, bool agg, bool save, bool f16x2, 
 int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st, const NodeParams *node = nullptr);
 
 
+// row-split persistent kernel (mlp_rs.hip, round 6): f16x3 stream, hoisted three-layer message form
+bool rs_eligible(const Params &p, bool agg, long long row_count);
+int rs_launch(const Params &p, bool agg, hipStream_t st);
+
 // four bf16 values (two dwords as loaded) widened to fp32: a shift / a mask each — exact
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 widen_bf16x4(u32x2 w) {

@@ -1413,9 +1413,10 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     if (force_tiles) tile_rows -= 1;
     const bool round1 = (tile_rows == 3216);     // operands rounded to bf16: only the leading plane of the stream is used
     const bool bx6 = (tile_rows == 3248) || round1;   // weights: the three-plane stream of g4c_mlp_pack_layer_bx6
+    const bool rs_fmt = round1 && mlp && mlp->w_format == G4C_WFMT_BF16_RS;     // the rounded-bf16 stream in the row-split kernel's k order: that kernel only
     const bool f16x2 = bx6 && mlp && mlp->w_format == G4C_WFMT_F16X2;     // the stream holds the two-way fp16 split (g4c_mlp_pack_layer_f16x3)
     G4C_REQUIRE(!(f16x2 && round1), G4C_EINVAL, "g4c_mlp_forward_bf16: the weights were packed by g4c_mlp_pack_layer_f16x3 (fp16 planes)");
-    G4C_REQUIRE(!mlp || mlp->w_format == 0 || f16x2, G4C_EINVAL, "g4c_mlp_forward: w_format %d does not match this entry point", mlp->w_format);
+    G4C_REQUIRE(!mlp || mlp->w_format == 0 || f16x2 || rs_fmt, G4C_EINVAL, "g4c_mlp_forward: w_format %d does not match this entry point", mlp->w_format);
     const bool bf16 = bx6;                       // input blocks padded to 128 k
     const int wbytes = bx6 ? 6 : 4;
     if (bf16) tile_rows = 324;
@@ -1619,6 +1620,15 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         if (p.n_tiles == 0) return G4C_OK;
         g_last_kernel = G4C_KERNEL_MLP_WS;
         return ws_launch(p, true, false, st, &q);
+    }
+    if (rs_fmt) {
+        // row-split persistent kernel (mlp_rs.hip): a wave owns 16 rows through all layers, the weights stay in LDS, bf16 rows in its
+        // own column order.  A stream in its k order can run on no other kernel: outside its envelope the call fails instead of
+        // computing something else.
+        G4C_REQUIRE(!save && !node && !force_tiles && rs_eligible(p, agg != nullptr, row_count), G4C_EUNSUPPORTED,
+                    "g4c_mlp_forward_bf16: weights packed for the row-split kernel (G4C_WFMT_BF16_RS), launch outside its envelope");
+        g_last_kernel = G4C_KERNEL_MLP_RS;
+        return rs_launch(p, agg != nullptr, st);
     }
     if (bx6 && !force_tiles && ws_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
         // weight-stationary persistent kernel (mlp_ws.hip): pairs of 32-row tiles (whole segments with aggregation), one workgroup per CU

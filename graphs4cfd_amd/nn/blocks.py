@@ -281,13 +281,15 @@ class MLP(nn.Module):
 
     def run_with_heads(self, sources: Sequence[Source], n_rows: int, act_code: int, consumer: "MLP", k_cols: int,
                        widths: Sequence[int], out: Optional[Tensor] = None,
-                       head_outs: Optional[Sequence[Optional[Tensor]]] = None) -> Optional[Tuple[Tensor, List[Tensor]]]:
+                       head_outs: Optional[Sequence[Optional[Tensor]]] = None, rs_rows: bool = False) -> Optional[Tuple[Tensor, List[Tensor]]]:
         """This MLP on `sources`, plus — from the same launch — the first-layer products `consumer` will need from
         this MLP's output y: [W1c[:, a:b] y for consecutive column blocks [a, b) of `widths` after the first `k_cols`
         columns of consumer's first layer] (see MLP.run_hoisted; g4c_mlp_forward_heads).
         Returns None when the launch cannot carry heads (shape envelope / kernel variant): the caller then lets the
         consumer compute its products itself.  `out` / `head_outs` (entries may be None): caller-provided [n_rows, 128]
-        destinations (row-sliced views of wider buffers are fine)."""
+        destinations (row-sliced views of wider buffers are fine).  `rs_rows` (rounded-bf16 mode, bf16 products: the consumer's message
+        launch will run on the row-split kernel, MLP.rs1_ready): the products come back as ops.RsOrderedRows, their columns in that
+        kernel's order — the heads' weight rows are permuted, nothing else changes."""
         if self.output_size != 128 or any(int(w) != 128 for w in widths) or not 1 <= len(widths) <= _lib.MAX_HEADS:
             return None
         if not self.fits_one_launch():
@@ -299,13 +301,16 @@ class MLP(nn.Module):
         if prec == "bf16" and not HOIST_BF16:
             return None
         narrow = tuple(_narrow_flags(sources)) if prec != "fp32" else (False,) * len(sources)
-        key = ("heads", id(consumer), k_cols, tuple(widths), tuple(s.width for s in sources), tuple(s.negate for s in sources), prec, narrow)
+        rs_rows = bool(rs_rows and prec == "bf16" and PRODUCTS_BF16 and not any(t is not None for t in (head_outs or ())))
+        key = ("heads", id(consumer), k_cols, tuple(widths), tuple(s.width for s in sources), tuple(s.negate for s in sources), prec, narrow, rs_rows)
         sig = (self._signature(), consumer._signature())
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
             lin = self._linears()
             ln = getattr(self.MLP, "layer_norm", None)
             w1 = consumer._linears()[0].weight.detach()
+            if rs_rows and int(w1.size(0)) == 128:
+                w1 = w1[ops._rs_k_order(w1.device)]
             heads, off = [], k_cols
             for w in widths:
                 heads.append(w1[:, off:off + w].contiguous())
@@ -327,11 +332,14 @@ class MLP(nn.Module):
         if any(_ld_of(t) != _ld_of(outs[0]) or t.dtype != hdt for t in outs):        # one leading dimension / type for all heads (g4c_mlp_forward_heads)
             return None
         ops.mlp_forward(pk, sources, n_rows, act_code, out=y, head_outs=outs)
-        return y, outs
+        return y, ([ops.RsOrderedRows.tag(t) for t in outs] if rs_rows else outs)
 
     # -- first-layer hoisting ------------------------------------------------------------------
-    def _packed_cols(self, tag: str, a: int, b: int, seg_widths, seg_negate, first_only: bool) -> ops.PackedMLP:
-        """Packed variant using only columns [a, b) of the first Linear layer (`first_only`: that layer alone, no bias)."""
+    def _packed_cols(self, tag: str, a: int, b: int, seg_widths, seg_negate, first_only: bool, rs_order: bool = False,
+                     rs_rows: bool = False) -> ops.PackedMLP:
+        """Packed variant using only columns [a, b) of the first Linear layer (`first_only`: that layer alone, no bias).
+        `rs_order`: the stream of the row-split kernel (ops.PackedMLP); `rs_rows` (with `first_only`): the product's output columns in that
+        kernel's order (ops.RsOrderedRows) — the weight's rows permuted."""
         prec = ops.effective_precision(seg_widths)
         key = (tag, a, b, tuple(seg_widths), tuple(bool(x) for x in seg_negate), prec)
         sig = self._signature()
@@ -339,12 +347,15 @@ class MLP(nn.Module):
         if hit is None or hit[0] != sig:
             lin = self._linears()
             w1 = lin[0].weight.detach()[:, a:b].contiguous()
+            if rs_rows:
+                w1 = w1[ops._rs_k_order(w1.device)].contiguous()
             if first_only:
                 pk = ops.PackedMLP([w1], [None], None, key[3], key[4], precision=prec, site=self._site)
             else:
                 ln = getattr(self.MLP, "layer_norm", None)
                 pk = ops.PackedMLP([w1] + [l.weight for l in lin[1:]], [l.bias for l in lin],
-                                   None if ln is None else (ln.weight, ln.bias, ln.eps), key[3], key[4], precision=prec, site=self._site)
+                                   None if ln is None else (ln.weight, ln.bias, ln.eps), key[3], key[4], precision=prec, site=self._site,
+                                   rs_order=rs_order)
             self._packed[key] = (sig, pk)
             hit = self._packed[key]
         return hit[1]
@@ -357,6 +368,8 @@ class MLP(nn.Module):
         Below HOIST_MIN_ROWS the launch is latency-bound and the extra product launches cost more than the MFMA
         work they save (measured crossover ~25k rows, scripts/sweep_tile_modes.py): one plain fused launch then.
         `products` (from the producer's launch, MLP.run_with_heads): the per-node terms, already multiplied."""
+        if self._rs1_takes(k_sources, gathered, n_rows, act_code, products, kw):
+            return self._run_rs1(k_sources[0], gathered, n_rows, products, kw)
         plain = list(k_sources) + [Source(t, index=idx) for t, idx in gathered]
         if not self.fits_one_launch():          # (a chain of launches: nothing to hoist into)
             return self.run_coded(plain, n_rows, act_code, **kw)
@@ -385,6 +398,56 @@ class MLP(nn.Module):
             raise ValueError(f"MLP expects {self.input_size} input columns, got {off}")
         pk = self._packed_cols("hoist", 0, sum(kw_widths), kw_widths, [s.negate for s in k_sources], False)
         return ops.mlp_forward(pk, list(k_sources) + adds, n_rows, act_code, **kw)
+
+    # -- rounded-bf16 mode: uniform-degree message launches on the row-split kernel ------------------------------------------
+    def rs1_ready(self, n_rows: int, csr) -> bool:
+        """Whether a message launch of this MLP over `csr` (its rows grouped by receiver) is one the row-split kernel takes in the
+        rounded-bf16 mode (mlp_rs.hip: mlp_rs1_kernel): [e | s[row] | r[col]] with three 128-wide blocks, two or three 128 x 128 layers
+        behind the first, LayerNorm, receivers of one uniform in-degree 4 .. 8, the aggregation fused.  The launch that produces
+        this MLP's hoisted products asks the same question (MLP.run_with_heads `rs_rows`): products and compact message rows of such
+        launches are bf16 rows in that kernel's column order (ops.RsOrderedRows)."""
+        if not (ROW_SPLIT_BF16 and HOIST_BF16 and PRODUCTS_BF16 and ops.FUSE_AGG) or ops.mlp_precision() != "bf16" or ops.grad_mode():
+            return False
+        lin = self._linears()
+        if (len(lin) not in (2, 3) or tuple(lin[0].weight.shape) != (128, 384) or any(tuple(l.weight.shape) != (128, 128) for l in lin[1:])
+                or getattr(self.MLP, "layer_norm", None) is None or not self.fits_one_launch()):
+            return False
+        return n_rows >= RS1_MIN_ROWS and n_rows == csr.n and 4 <= csr.uniform_deg <= 8 and csr.tiles() is not None
+
+    def _rs1_takes(self, k_sources, gathered, n_rows, act_code, products, kw) -> bool:
+        agg = kw.get("agg")
+        if agg is None or act_code != _lib.ACT_NONE or not set(kw) <= {"agg", "store_rows", "rows_dtype", "rows_act"}:
+            return False
+        if not self.rs1_ready(n_rows, agg[0]) or len(k_sources) != 1 or len(gathered) != 2:
+            return False
+        x = k_sources[0]
+        if (x.width != 128 or x.col0 != 0 or x.negate or x.index is not None or x.segments is not None or x.additive
+                or x.pre_act not in (_lib.ACT_NONE, _lib.ACT_SELU)):
+            return False
+        if x.tensor.dtype == torch.bfloat16 and not (isinstance(x.tensor, ops.RsOrderedRows) and x.pre_act == _lib.ACT_NONE):
+            return False
+        if any(int(t.size(1)) != 128 or t.dtype != torch.float32 for t, _ in gathered):
+            return False
+        if products is not None and not (len(products) == 2 and all(isinstance(t, ops.RsOrderedRows) for t in products)):
+            return False
+        if kw.get("rows_dtype") == torch.bfloat16 and kw.get("store_rows", True) and kw.get("rows_act", _lib.ACT_NONE) != _lib.ACT_SELU:
+            return False
+        return agg[1].dtype == torch.float32 and agg[1].stride(1) == 1 and agg[1].stride(0) % 4 == 0 and agg[1].data_ptr() % 16 == 0
+
+    def _run_rs1(self, x: Source, gathered, n_rows: int, products, kw) -> Optional[Tensor]:
+        adds = []
+        for j, (t, idx) in enumerate(gathered):
+            if products is not None:
+                part = products[j]
+            else:        # this block's product W1[:, 128 (j + 1) : 128 (j + 2)] t, bf16 rows in the kernel's column order
+                pk1 = self._packed_cols("hoist1_rs", 128 * (j + 1), 128 * (j + 2), [128], [False], True, rs_rows=True)
+                part = torch.empty((int(t.size(0)), 128), dtype=torch.bfloat16, device=t.device)
+                ops.mlp_forward(pk1, [Source(t)], int(t.size(0)), out=part)
+                part = ops.RsOrderedRows.tag(part)
+            adds.append(Source(part, index=idx, additive=True))
+        pk = self._packed_cols("hoist_rs", 0, 128, [128], [False], False, rs_order=True)
+        y = ops.mlp_forward(pk, [x] + adds, n_rows, _lib.ACT_NONE, **kw)
+        return ops.RsOrderedRows.tag(y) if (y is not None and y.dtype == torch.bfloat16) else y
 
     def forward(self, x: Tensor) -> Tensor:
         lead = x.shape[:-1]
@@ -477,6 +540,14 @@ HOIST_BF16 = True
 # largest stream — at half the bytes.  One more rounding (relative 2^-9) of a pre-activation term whose operands were rounded to
 # bf16 already; error against the fp32 reference restatement: scripts/remus_bf16_err.py and the 20k-node REMuS parity test.
 PRODUCTS_BF16 = True
+# Round 6, rounded-bf16 mode: message launches over receivers of one uniform in-degree (REMuS-GNN's angle launches: every edge of a
+# k-nearest-neighbour graph receives k angles) run on the row-split kernel (mlp_rs.hip, mlp_rs1_kernel): a wave owns 16 rows through all
+# layers, the weights stay in LDS, the aggregation is a segmented scan over the lanes of a row group.  Its bf16 rows — compact messages
+# and hoisted products — are in its own column order (ops.RsOrderedRows), 16 contiguous bytes per lane: the level-1 angle launch of
+# config 3 is bound by the NUMBER of memory instructions and 32-byte pieces, not by HBM bytes (2.5 M rows: 655 us on
+# mlp_ws_kernel<SP = 1>, 622 us on this kernel with natural-order 8-byte pieces, 520 us with 16-byte pieces).
+ROW_SPLIT_BF16 = __import__('os').environ.get('G4C_ROW_SPLIT_BF16', '1') != '0'      # (A/B switch while the path is measured)
+RS1_MIN_ROWS = 20000
 
 
 # One launch per MP layer (round 5, ops.mp_layer_forward / g4c_mp_layer_forward_bx6): message MLP + aggregation + node MLP (+ the next
@@ -597,7 +668,7 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
         if ep.n_edges >= HOIST_MIN_ROWS:     # the consumer will hoist: give it its node-side terms from this launch
             w = upd_mlp.output_size          # (width of v', the node input of the next layer's message MLP)
             nxt = upd_mlp.run_with_heads([agg_src, Source(v)], int(v.size(0)), act_code, next_msg,
-                                         next_msg.input_size - 2 * w, [w, w])
+                                         next_msg.input_size - 2 * w, [w, w], rs_rows=next_msg.rs1_ready(ep.n_edges, csr))
         if nxt is None:
             return upd_mlp.run_coded([agg_src, Source(v)], int(v.size(0)), act_code), e_new, None
         return nxt[0], e_new, nxt[1]

@@ -543,12 +543,39 @@ def set_mlp_precision(precision: str) -> str:
     return old
 
 
+def _rs_k_order(dev) -> Tensor:
+    """Column order of the row-split kernel's stream and of its bf16 rows (G4C_ROWS_RS_ORDER): position 32 j + 8 g + 4 h + e holds
+    feature 32 j + 16 h + 4 g + e — the eight values a lane of a 16x16x32 MFMA holds of a 32-feature step, side by side."""
+    pos = torch.arange(128, device=dev)
+    j, g, h, e = pos // 32, (pos % 32) // 8, (pos % 8) // 4, pos % 4
+    return 32 * j + 16 * h + 4 * g + e
+
+
+class RsOrderedRows(Tensor):
+    """bf16 [n, 128] rows whose columns are in the row-split kernel's order (`_rs_k_order`): the compact message rows and the hoisted
+    product tables its launches exchange (mlp_rs.hip, rounded-bf16 mode).  The subclass is only a tag that travels with the tensor
+    (row slices and views keep it): `mlp_forward` hands such rows to that kernel as they are and restores the natural column order
+    for every other reader."""
+
+    @staticmethod
+    def tag(t: Tensor) -> Tensor:
+        if t.dtype != torch.bfloat16 or t.dim() != 2 or t.size(1) != 128:
+            raise ValueError("RsOrderedRows: bf16 [n, 128] rows only")
+        return t.as_subclass(RsOrderedRows)
+
+
+def rs_rows_to_natural(t: Tensor) -> Tensor:
+    """The rows of an RsOrderedRows tensor with their columns in feature order (a copy, plain Tensor)."""
+    inv = torch.argsort(_rs_k_order(t.device))
+    return t.as_subclass(Tensor).index_select(1, inv)
+
+
 class PackedMLP:
     """Device-side packed weights of one MLP for a given input block structure."""
 
     def __init__(self, weights: Sequence[Tensor], biases: Sequence[Tensor], ln: Optional[Tuple[Tensor, Tensor, float]],
                  seg_widths: Sequence[int], seg_negate: Sequence[bool], heads: Sequence[Tensor] = (),
-                 precision: str = "fp32", narrow: Optional[Sequence[bool]] = None, site: Optional[str] = None):
+                 precision: str = "fp32", narrow: Optional[Sequence[bool]] = None, site: Optional[str] = None, rs_order: bool = False):
         """`heads`: bias-free [128, 128] weights applied to the MLP's final output row (g4c_mlp_forward_heads); their
         packed images continue the weight stream after the last layer.  `precision` "bf16": the bf16 stream of
         g4c_mlp_pack_layer_bx6 (every input block padded to 128 k; "bf16" uses the same stream, leading plane only).
@@ -578,7 +605,15 @@ class PackedMLP:
             raise NotImplementedError(f"MLP input concatenated from {len(seg_widths)} blocks (max {_lib.MAX_SRC})")
         self.desc = _lib.g4c_mlp_t()
         self.desc.n_layers = n_layers
-        self.desc.w_format = 1 if self.split == "f16x2" else 0
+        # `rs_order` (rounded-bf16 mode, every layer 128 x 128 over ONE 128-wide input block): the stream is written for the row-split
+        # kernel (mlp_rs.hip, G4C_WFMT_BF16_RS) — the columns of every layer in the order `_rs_k_order`, the order in which a 16x16x32
+        # MFMA leaves a layer's output in the lane that needs it as the next layer's operand.  No other kernel can read such a stream:
+        # the library fails a launch outside that kernel's envelope.
+        self.rs_order = bool(rs_order)
+        if self.rs_order and (precision != "bf16" or heads or len(seg_widths) != 1 or seg_widths[0] != 128 or any(narrow or ())
+                              or any(tuple(W.shape) != (128, 128) for W in weights)):
+            raise NotImplementedError("rs_order: rounded-bf16 mode, one 128-wide input block, 128 x 128 layers, no heads")
+        self.desc.w_format = 1 if self.split == "f16x2" else (3 if self.rs_order else 0)
         # (`site`: the name a clipped value is reported under — f16_range_report)
         self.site = site or "an MLP created outside a model"
         if self.split == "f16x2":
@@ -637,6 +672,8 @@ class PackedMLP:
             wptr = stream_buf.data_ptr() + esz * off
             if W is not None:            # (None: every input block of the first layer is narrow, nothing to stream)
                 Wc = W.detach().to(torch.float32).contiguous()
+                if self.rs_order:
+                    Wc = Wc[:, _rs_k_order(dev)].contiguous()
                 seg_arr = (C.c_int32 * len(segs))(*segs)
                 neg_arr = (C.c_int32 * len(segs))(*negs)
                 _lib.check(pack(_lib.ptr(Wc), n_out, k_in, seg_arr, neg_arr, len(segs), wptr, k_pads[l], NP, stream))
@@ -756,6 +793,14 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                                           "call under torch.no_grad() or use the plain form")
             return _ag.mlp(packed, sources, n_rows, act, resid, resid_col0)
     lib = _lib.load()
+    if packed.rs_order and packed.precision == "bf16":
+        # (the row-split kernel's rounded-bf16 stream: its bf16 rows are in ITS column order, nobody else's)
+        if any(s.tensor.dtype == torch.bfloat16 and not isinstance(s.tensor, RsOrderedRows) for s in sources):
+            raise ValueError("weights packed for the row-split kernel: bf16 rows must be RsOrderedRows (its column order)")
+    elif any(isinstance(s.tensor, RsOrderedRows) for s in sources):
+        sources = [s if not isinstance(s.tensor, RsOrderedRows) else
+                   Source(rs_rows_to_natural(s.tensor), s.index, s.col0, s.width, s.negate, s.pre_act, s.additive, s.segments, s.seg_mean)
+                   for s in sources]
     dev = _lib.require_hip(*[s.tensor for s in sources], *[s.index for s in sources], out, out_idx32, resid)
     if dev != packed.device:
         raise RuntimeError(f"MLP weights on {packed.device}, inputs on {dev}")

@@ -156,6 +156,8 @@ typedef struct {
     int32_t range_slot;
 } g4c_mlp_t;
 #define G4C_WFMT_F16X2 1
+#define G4C_WFMT_BF16_RS 3       /* the bf16 stream of g4c_mlp_pack_layer_bx6 (rounded-bf16 mode: its leading plane) with the row-split
+                                  * kernel's k order, see "row-split order" at g4c_mlp_forward_bf16 */
 
 /* Packs one nn.Linear weight W[n_out, k_in] (row-major, device) for the kernel.  The input
  * dimension is the concatenation of `n_seg` column blocks of widths seg_width[] (each padded
@@ -259,6 +261,7 @@ int g4c_debug_mean_div(const float *a, const int32_t *count, float *out, int64_t
 #define G4C_KERNEL_MLP_BX6 2
 #define G4C_KERNEL_MLP_BX6I 3
 #define G4C_KERNEL_MLP_WS 4
+#define G4C_KERNEL_MLP_RS 5      /* mlp_rs1_kernel: row-split persistent kernel of the rounded-bf16 mode (round 6) */
 int g4c_mlp_last_kernel(void);
 
 /* Rounded-bf16 variant (opt-in only; BASELINE config 3 "bf16 edge-MLP MFMA"): the same stream and kernel structure, but
@@ -294,6 +297,17 @@ int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs
  * the model applies to the messages after the aggregation (nn/blocks.py:331-333, nn/remus_gnn.py:150-190), which their one reader
  * would otherwise apply on load (g4c_src_t.pre_act) BEFORE rounding to bf16: stored this way the reader gets bit for bit the operand
  * it would have formed from fp32 rows (one rounding, after the activation), the aggregate still sees the un-activated fp32 rows. */
+/* Row-split order (round 6; g4c_mlp_t.w_format = G4C_WFMT_BF16_RS, with g4c_mlp_forward_bf16 / _bf16_agg only).  The message launch
+ * of an MP layer whose receivers all have the same in-degree k, 4 <= k <= 8 (agg_mean | G4C_AGG_UNIFORM(k); REMuS-GNN: every edge of
+ * a k-nearest-neighbour graph receives k angles) — ONE weighted 128-wide direct block (fp32, optional SELU on load, or bf16), two
+ * additive 128-wide blocks through indices, two or three 128-wide layers, LayerNorm, no output activation — runs on a kernel in which a
+ * wave owns 16 rows through all layers (csrc/mlp_rs.hip).  Its caller packs the weights with the COLUMNS of every layer permuted:
+ * position 32 j + 8 g + 4 h + e (j < 4, g < 4, h < 2, e < 4) of the 128 input columns takes column 32 j + 16 h + 4 g + e, and every
+ * bf16 row of such a launch — the bf16 weighted block, bf16 additive tables, the rows it stores with out_dtype G4C_DTYPE_BF16 /
+ * _BF16_SELU — has its 128 values in the SAME order (position -> feature): producers of the additive tables permute the ROWS of the
+ * weight that makes them (g4c_mlp_forward_bf16_out / _heads_bf16_out), readers other than this kernel must undo the order.  fp32
+ * rows, the bias / LayerNorm vectors and the aggregate are in feature order.  The aggregate is a fixed-order segmented scan, not the
+ * sequential order of g4c_segment_reduce: last-bit differences.  A launch outside this envelope fails with G4C_EUNSUPPORTED. */
 int g4c_mlp_forward_bf16_agg(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
                              int64_t n_rows, void *out, int32_t out_ld, int32_t out_dtype, int32_t act,
                              const int32_t *tile_rows, const int32_t *tile_seg, const int32_t *seg_off, int32_t n_tiles,

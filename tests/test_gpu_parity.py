@@ -1685,6 +1685,118 @@ def test_remus_bf16_compact_messages_are_bit_identical():
         ops.set_mlp_precision(old)
 
 
+@pytest.mark.parametrize("layers", [2, 3])
+def test_row_split_kernel_matches_the_weight_stationary_path(layers):
+    """Rounded-bf16 mode, round 6 (blocks.ROW_SPLIT_BF16; csrc/mlp_rs.hip): message launches over receivers of one uniform in-degree
+    4 .. 8 run on the row-split kernel — a wave owns 16 rows through all layers, bf16 rows in its own column order
+    (ops.RsOrderedRows), the aggregation a segmented scan.  Against the weight-stationary / tile path of the same mode on the same
+    inputs: rows and aggregates agree to the mode's rounding (a hidden activation that rounds to the neighbouring bf16 under the other
+    summation order moves an output by ~1e-3: mean difference < 2e-5); the aggregate is the fixed-order sum of the kernel's OWN fp32
+    rows to 1e-6; compact rows come back tagged, and a reader outside the kernel sees them in feature order."""
+    lib = _lib.load()
+    old = ops.set_mlp_precision("bf16")
+    was = B.ROW_SPLIT_BF16
+    H = 128
+    try:
+        for n, K in ((5001, 5), (6200, 4), (3100, 8), (3601, 7), (4200, 6)):
+            torch.manual_seed(1000 * layers + K)
+            E = n * K
+            assert E >= max(B.RS1_MIN_ROWS, B.HOIST_MIN_ROWS)          # (both paths hoist the first layer: bf16 products either way)
+            blk = B.GNBlock((3 * H, (H,) * layers, True), (2 * H, (H,) * layers, True)).to(DEV)
+            a32, e_send, e_recv = torch.randn(E, H, device=DEV), torch.randn(n, H, device=DEV), torch.randn(n, H, device=DEV)
+            ei = torch.stack([torch.randint(0, n, (E,)), torch.arange(n).repeat_interleave(K)]).to(DEV)
+            ep, csr = plan.edge_csr(ei, n)
+            assert csr.uniform_deg == K
+
+            def launch(x_src, **kw):
+                agg = torch.full((n, H), float("nan"), device=DEV)
+                with torch.no_grad():
+                    y = blk.edge_mlp.run_hoisted([x_src], [(e_send, ep.row), (e_recv, ep.col)], E, agg=(csr, agg, True), **kw)
+                return y, agg, int(lib.g4c_mlp_last_kernel())
+
+            compact = dict(rows_dtype=torch.bfloat16, rows_act=_lib.ACT_SELU)
+            res = {}
+            for on in (False, True):
+                B.ROW_SPLIT_BF16 = on
+                res[on, "fp32"] = launch(ops.Source(a32, pre_act=_lib.ACT_SELU))
+                res[on, "compact"] = launch(ops.Source(a32, pre_act=_lib.ACT_SELU), **compact)
+                # compact rows as the next launch's input (already activated; the same rows for both paths, in each one's column order)
+                x16 = res[False, "compact"][0]
+                res[on, "chained"] = launch(ops.Source(ops.RsOrderedRows.tag(x16[:, ops._rs_k_order(DEV)].contiguous()) if on else x16), **compact)
+                res[on, "no rows"] = launch(ops.Source(a32, pre_act=_lib.ACT_SELU), store_rows=False)
+            for form in ("fp32", "compact", "chained", "no rows"):
+                (y0, g0, k0), (y1, g1, k1) = res[False, form], res[True, form]
+                assert k1 == _lib.KERNEL_MLP_RS and k0 != _lib.KERNEL_MLP_RS, (form, k0, k1)
+                assert torch.isfinite(g1).all()
+                d = (g1 - g0).abs()
+                assert d.mean().item() < 2e-5 and d.max().item() < 2e-2, (form, K, d.mean().item(), d.max().item())
+                if form == "no rows":
+                    assert y0 is None and y1 is None
+                    continue
+                if y1.dtype == torch.bfloat16:
+                    assert isinstance(y1, ops.RsOrderedRows) and not isinstance(y0, ops.RsOrderedRows)
+                    y1 = ops.rs_rows_to_natural(y1)
+                d = (y1.float() - y0.float()).abs()
+                assert d.mean().item() < 2e-5 and d.max().item() < 4e-2, (form, K, d.mean().item(), d.max().item())
+            # the scan: the aggregate is the mean of the kernel's own fp32 rows
+            y1, g1, _ = res[True, "fp32"]
+            torch.testing.assert_close(g1, ops.segment_reduce(y1, csr, True), rtol=0, atol=1e-6)
+            # "no rows" and "compact" aggregate the same fp32 rows
+            assert torch.equal(res[True, "no rows"][1], res[True, "compact"][1])
+            # a reader outside the kernel (here: the tile kernel, forced) sees tagged rows in feature order
+            tagged = res[True, "compact"][0]
+            pk = blk.edge_mlp._packed_cols("hoist", 0, H, [H], [False], False)
+            with torch.no_grad():
+                pr = ops.mlp_forward(blk.edge_mlp._packed_cols("hoist1", H, 2 * H, [H], [False], True), [ops.Source(e_send)], n)
+                pc = ops.mlp_forward(blk.edge_mlp._packed_cols("hoist1", 2 * H, 3 * H, [H], [False], True), [ops.Source(e_recv)], n)
+                adds = [ops.Source(pr, index=ep.row, additive=True), ops.Source(pc, index=ep.col, additive=True)]
+                via_guard = ops.mlp_forward(pk, [ops.Source(tagged)] + adds, E)
+                by_hand = ops.mlp_forward(pk, [ops.Source(ops.rs_rows_to_natural(tagged))] + adds, E)
+            assert torch.equal(via_guard, by_hand)
+    finally:
+        B.ROW_SPLIT_BF16 = was
+        ops.set_mlp_precision(old)
+
+
+def test_row_split_path_in_the_remus_model():
+    """BASELINE config 3's model at 20k nodes in the rounded-bf16 mode with and without the row-split kernel: the level-1 and level-2
+    angle launches take it (k = 5 angles per edge), products and compact messages travel in its column order between consecutive
+    EdgeMPs, and the forward agrees with the weight-stationary path to the mode's rounding; a captured rollout replays it."""
+    lib = _lib.load()
+    old = ops.set_mlp_precision("bf16")
+    was = B.ROW_SPLIT_BF16
+    try:
+        g = S.remus_graph(20_000, k=5, seed=31).to(DEV)
+        torch.manual_seed(32)
+        model = gfd.nn.NsRotEquiTreeScaleGNN(arch=S.remus_arch(128), device=DEV)
+        outs, used = {}, {}
+        for on in (False, True):
+            B.ROW_SPLIT_BF16 = on
+            seen = set()
+            orig = ops.mlp_forward
+
+            def spy(*a, **kw):
+                r = orig(*a, **kw)
+                seen.add(int(lib.g4c_mlp_last_kernel()))
+                return r
+            ops.mlp_forward = spy
+            try:
+                with torch.no_grad():
+                    outs[on] = model.forward(g.clone()).clone()
+            finally:
+                ops.mlp_forward = orig
+            used[on] = seen
+        assert _lib.KERNEL_MLP_RS in used[True] and _lib.KERNEL_MLP_RS not in used[False], used
+        d = (outs[True] - outs[False]).abs()
+        assert torch.isfinite(outs[True]).all() and d.max().item() < 3e-2 and d.mean().item() < 2e-3, (d.max().item(), d.mean().item())
+        B.ROW_SPLIT_BF16 = True
+        cap, eag = model.solve(g.clone(), 3, capture=True), model.solve(g.clone(), 3, capture=False)
+        assert torch.equal(cap, eag) and torch.isfinite(cap).all()
+    finally:
+        B.ROW_SPLIT_BF16 = was
+        ops.set_mlp_precision(old)
+
+
 def test_bf16_product_rows_are_exact_copies():
     """Rounded-bf16 mode, round 5 (blocks.PRODUCTS_BF16): the hoisted first-layer products are stored as bf16.  The kernels only
     change representation — (a) head rows / plain output rows stored as bf16 are the round-to-nearest bf16 of the fp32 rows the same

@@ -308,3 +308,25 @@ def test_csr_plan_knows_a_uniform_in_degree():
     assert plan.build_csr(ragged, 50, dev).uniform_deg == 0
     assert plan.build_csr(torch.arange(49).repeat_interleave(6), 50, dev).uniform_deg == 0          # the last target is empty
     assert plan.build_csr(torch.arange(3).repeat_interleave(40), 3, dev).uniform_deg == 0           # beyond 32 rows: not offered
+
+
+def test_row_split_column_order_is_the_mfma_lane_order():
+    """ops._rs_k_order (include/g4c.h "row-split order"): position 32 j + 8 g + 4 h + e holds feature 32 j + 16 h + 4 g + e — the eight
+    values lane (n, g) of a 16x16x32 MFMA holds of 32-feature step j are 16 contiguous bytes; rs_rows_to_natural undoes it; the tag
+    survives row slices and is refused for anything but bf16 [n, 128] rows."""
+    import torch
+    from graphs4cfd_amd import ops
+    order = ops._rs_k_order(torch.device("cpu")).tolist()
+    assert sorted(order) == list(range(128))
+    for j in range(4):
+        for g in range(4):
+            got = order[32 * j + 8 * g: 32 * j + 8 * g + 8]
+            # a C-layout lane holds features 16 b + 4 g + e of feature blocks b = 2 j and 2 j + 1
+            assert got == [16 * (2 * j) + 4 * g + e for e in range(4)] + [16 * (2 * j + 1) + 4 * g + e for e in range(4)]
+    rows = torch.arange(3 * 128, dtype=torch.float32).reshape(3, 128).to(torch.bfloat16)
+    tagged = ops.RsOrderedRows.tag(rows[:, order].contiguous())
+    assert isinstance(tagged[1:], ops.RsOrderedRows)
+    back = ops.rs_rows_to_natural(tagged)
+    assert type(back) is torch.Tensor and torch.equal(back, rows)
+    with pytest.raises(ValueError):
+        ops.RsOrderedRows.tag(rows.float())
