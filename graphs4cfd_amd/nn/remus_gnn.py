@@ -71,6 +71,18 @@ class NsRotEquiTreeScaleGNN(GNN):
         enc = getattr(self, name)
         return ops.static_launch(name, [att], lambda: enc.run_coded([Source(att)], int(att.size(0)), SELU))
 
+    def _compact_static_angles(self, lvl: int, name: str, att: torch.Tensor, a: torch.Tensor, angle_index: torch.Tensor, n_edges: int):
+        """Inside a rollout, rounded-bf16 mode: when the level's first EdgeMP runs its angle launch on the row-split kernel
+        (MLP.rs1_ready), the cached (static, already activated) angle latents are kept as the bf16 rows in that kernel's column order it
+        would form from them on load — bit for bit the same operand, half the bytes of the step's one launch that read them as fp32."""
+        if ops.StaticCache.active is None or torch.is_grad_enabled():
+            return a
+        first = next((getattr(self, nm) for o, nm, l in self._PROGRAM if o == "mp" and l == lvl), None)
+        if first is None or not first.angle_mlp.rs1_ready(int(a.size(0)), plan.edge_csr(angle_index, n_edges)[1]):
+            return a
+        return ops.static_launch(name + "/rs16", [att], lambda: ops.RsOrderedRows.tag(
+            a.to(torch.bfloat16)[:, ops._rs_k_order(a.device)].contiguous()))
+
     def forward(self, graph: Graph, t: Optional[int] = None) -> torch.Tensor:
         g = graph
         sfx = {1: "", 2: "2", 3: "3"}
@@ -87,6 +99,7 @@ class NsRotEquiTreeScaleGNN(GNN):
             # reference nn/remus_gnn.py:136-140)
             a[lvl] = self._angle_latents(f"angle_encoder{s}", getattr(g, f"angle_attr{s}"))
             aidx[lvl] = getattr(g, f"angle_index{s}")
+            a[lvl] = self._compact_static_angles(lvl, f"angle_encoder{s}", getattr(g, f"angle_attr{s}"), a[lvl], aidx[lvl], ep.n_edges)
         a12 = self._angle_latents("angle_encoder12", g.angle_attr12)
         a23 = self._angle_latents("angle_encoder23", g.angle_attr23)
         a_pending = {1: NONE, 2: NONE, 3: NONE}
