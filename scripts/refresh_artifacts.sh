@@ -66,6 +66,9 @@ timeout 600 python scripts/mp_layer_check.py --time 2>&1 | grep -v "^ok\|amdgpu.
     echo "G4C_FUSE_LAYER=$f bench.py $wl: $(G4C_FUSE_LAYER=$f timeout 300 python bench.py $wl --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys;print(round(json.loads(sys.stdin.read())['value'],1))") steps/s"
   done; done; } > $A/${TAG}_ab_fused_layer.log 2>&1
 timeout 300 python scripts/remus_bf16_err.py 2>&1 | grep -v amdgpu.ids > $A/${TAG}_remus_bf16_products_err.log
+# round 6: the row-split kernel of the rounded-bf16 mode against mlp_ws_kernel<SP = 1> (parity + time, every row format), sender locality
+timeout 300 python scripts/rs1_check.py 2>&1 | grep -v amdgpu.ids > $A/${TAG}_rs1_check.log
+timeout 200 python scripts/rs1_gather_locality.py 2>&1 | grep -v amdgpu.ids > $A/${TAG}_rs1_gather_locality.log
 # co-issue microbenchmarks (what hides behind one MFMA, by shape, waves per SIMD and instruction kind)
 hipcc -w --offload-arch=gfx950 -O3 -o /tmp/mfma_fillers scripts/micro/mfma_fillers.hip 2>/dev/null && /tmp/mfma_fillers > $A/${TAG}_mfma_fillers.log 2>&1
 for m in mfma_gap_patterns mfma_chain_probe mfma_lds_probe; do

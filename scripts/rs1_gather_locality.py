@@ -5,6 +5,8 @@ from graphs4cfd_amd.nn import blocks as B
 torch.set_grad_enabled(False)
 lib = _lib.load(); dev = torch.device("cuda", 0); H = 128
 ops.set_mlp_precision("bf16")
+def rs(t):          # the same bf16 rows in the row-split kernel's column order
+    return ops.RsOrderedRows.tag(t[:, ops._rs_k_order(t.device)].contiguous())
 def bench(fn, reps=10):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -28,13 +30,16 @@ for name, snd in (("random senders", torch.randint(0, n, (E,))), ("senders withi
                   ("senders within +-4096 rows", (tgt + torch.randint(-4096, 4097, (E,))).clamp(0, n - 1)), ("senders = receivers", tgt.clone())):
     ei = torch.stack([snd, tgt]).to(dev)
     ep, csr = plan.edge_csr(ei, n)
-    src = [ops.Source(e16), ops.Source(pr16, index=ep.row, additive=True), ops.Source(pc16, index=ep.col, additive=True)]
+    srcs = {"ws": [ops.Source(e16), ops.Source(pr16, index=ep.row, additive=True), ops.Source(pc16, index=ep.col, additive=True)],
+            "rs1": [ops.Source(rs(e16)), ops.Source(rs(pr16), index=ep.row, additive=True), ops.Source(rs(pc16), index=ep.col, additive=True)]}
     for tag, pack in (("ws", pk), ("rs1", pk_rs)):
+        src = srcs[tag]
         agg = torch.empty((n, H), device=dev)
         t = bench(lambda: ops.mlp_forward(pack, src, E, agg=(csr, agg, True), rows_dtype=torch.bfloat16, rows_act=_lib.ACT_SELU))
         print(f"{name:28s} {tag:4s} kernel {int(lib.g4c_mlp_last_kernel())}: {t:7.1f} us   {1536e6 / t / 1e6:.2f} TB/s algorithmic")
     # no stores of rows (aggregate only)
     for tag, pack in (("ws", pk), ("rs1", pk_rs)):
+        src = srcs[tag]
         agg = torch.empty((n, H), device=dev)
         t = bench(lambda: ops.mlp_forward(pack, src, E, agg=(csr, agg, True), store_rows=False))
         print(f"{name:28s} {tag:4s} rows not stored: {t:7.1f} us")

@@ -5,6 +5,8 @@ from graphs4cfd_amd.nn import blocks as B
 torch.set_grad_enabled(False)
 lib = _lib.load(); dev = torch.device("cuda", 0); H = 128
 ops.set_mlp_precision("bf16")
+def rs(t):          # the same bf16 rows in the row-split kernel's column order
+    return ops.RsOrderedRows.tag(t[:, ops._rs_k_order(t.device)].contiguous())
 n, K, layers = 500000, 5, 2
 E = K * n
 torch.manual_seed(0)
@@ -14,7 +16,7 @@ pr16, pc16 = torch.randn(n, H, device=dev).to(torch.bfloat16), torch.randn(n, H,
 tgt = torch.arange(n).repeat_interleave(K)
 ei = torch.stack([(tgt + torch.randint(-4096, 4097, (E,))).clamp(0, n - 1), tgt]).to(dev)
 ep, csr = plan.edge_csr(ei, n)
-src = [ops.Source(e16), ops.Source(pr16, index=ep.row, additive=True), ops.Source(pc16, index=ep.col, additive=True)]
+src = [ops.Source(rs(e16)), ops.Source(rs(pr16), index=ep.row, additive=True), ops.Source(rs(pc16), index=ep.col, additive=True)]
 pk_rs = blk.edge_mlp._packed_cols("hoist_rs", 0, H, [H], [False], False, rs_order=True)
 agg = torch.empty((n, H), device=dev)
 fn = lambda: ops.mlp_forward(pk_rs, src, E, agg=(csr, agg, True), rows_dtype=torch.bfloat16, rows_act=_lib.ACT_SELU)
