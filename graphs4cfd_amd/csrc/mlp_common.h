@@ -79,6 +79,7 @@ struct Params {
     float *agg;
     int agg_ld, agg_mean;
     int agg_deg;              // > 0: every segment has exactly this many rows (G4C_AGG_UNIFORM)
+    int agg_bf16;             // the aggregate is stored as bf16 rows in the row-split order (G4C_AGG_OUT_BF16; mlp_rs1_kernel only)
     // narrow input blocks of the first layer, multiplied in fp32 on the vector ALUs (bf16x6 kernel)
     NarSrc nar[G4C_MAX_SRC];
     int n_nar;

@@ -1519,12 +1519,12 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
         p.out_bf16 = g_out_dtype;
     }
     p.resid = resid; p.resid_ld = resid_ld; p.resid_col0 = resid_col0;
-    p.tile_rows = p.tile_seg = p.seg_off = nullptr; p.agg = nullptr; p.agg_ld = 0; p.agg_mean = 0; p.agg_deg = 0;
+    p.tile_rows = p.tile_seg = p.seg_off = nullptr; p.agg = nullptr; p.agg_ld = 0; p.agg_mean = 0; p.agg_deg = 0; p.agg_bf16 = 0;
     if (agg) {
         G4C_REQUIRE(bx6 && mlp->n_out == NP && !out_idx && !resid, G4C_EUNSUPPORTED, "g4c_mlp_forward_bx6_agg: needs the bf16x6 kernel and a plain 128-wide output");
         p.tile_rows = agg->tile_rows; p.tile_seg = agg->tile_seg; p.seg_off = agg->seg_off;
-        p.agg = agg->out; p.agg_ld = agg->out_ld; p.agg_mean = agg->mean & 1; p.agg_deg = (agg->mean >> 8) & 0xff;
-        G4C_REQUIRE((agg->mean >> 16) == 0 && p.agg_deg <= 32 && (p.agg_deg == 0 || row_count % p.agg_deg == 0), G4C_EINVAL,
+        p.agg = agg->out; p.agg_ld = agg->out_ld; p.agg_mean = agg->mean & 1; p.agg_deg = (agg->mean >> 8) & 0xff; p.agg_bf16 = (agg->mean >> 16) & 1;
+        G4C_REQUIRE((agg->mean >> 17) == 0 && (!p.agg_bf16 || rs_fmt) && p.agg_deg <= 32 && (p.agg_deg == 0 || row_count % p.agg_deg == 0), G4C_EINVAL,
                     "fused aggregation: agg_mean = %d is not 0 / 1 [| G4C_AGG_UNIFORM(k), 1 <= k <= 32, k dividing the %lld rows]", agg->mean,
                     (long long)row_count);
         if (agg->rows_bf16) {

@@ -34,6 +34,8 @@
 //         inclusive scan over the 16 lanes of a row group (v_fmac_f32 with DPP row_shr 1 / 2 / 4 and per-row masks; a segment cut by the
 //         chunk's end continues with the previous chunk's running sum), and the lanes that hold a segment's last row store its sum /
 //         mean.  Fixed order, deterministic; NOT the sequential order of g4c_segment_reduce (last-bit differences: tests allow 1e-6).
+//         AGG = 2 (G4C_AGG_OUT_BF16): the aggregate is stored as bf16 rows in the same column order — what its one reader, the update
+//         MLP of the layer, rounds it to on load anyway (same operand, half the bytes of two launches).
 // Envelope (rs_eligible): rounded-bf16 stream in this kernel's k order, ONE weighted 128-wide direct block (fp32 with optional SELU on
 // load, or bf16), two additive 128-wide blocks through indices, two or three 128-wide layers, LayerNorm, no output activation / residual /
 // heads / output index.  A stream in this k order runs on no other kernel: outside the envelope the call fails.
@@ -74,7 +76,7 @@ __device__ __forceinline__ float sum_over_g(float v) {
 __device__ __forceinline__ f32x4 rs1_selu4(f32x4 v) { if (RS1_ABLATE & 1) return v; return selu4(v); }
 __device__ __forceinline__ f32x4 mfma16b(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
-template <int NL, bool XB16, bool AB16, int OUT, bool AGG>
+template <int NL, bool XB16, bool AB16, int OUT, int AGG>
 __global__ __launch_bounds__(RS_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_rs1_kernel(const Params p) {
     __shared__ __attribute__((aligned(1024))) char sW1[NL * 32 * 1024];
     __shared__ __attribute__((aligned(16))) float sBias[3 * NP];
@@ -182,8 +184,10 @@ __global__ __launch_bounds__(RS_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
     // kept in LDS — wave-private, 128 floats
     f32x4 *const carry = reinterpret_cast<f32x4 *>(sCarry1) + (wave * 4 + g) * 8;
     // the wave's segments of the aggregate as a raw buffer (offsets past its end are dropped)
+    constexpr int AGB = AGG == 2 ? 2 : 4;          // bytes per value of the aggregate
     const __amdgpu_buffer_rsrc_t agg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        AGG ? (void *)(p.agg + (long long)(R0 / K) * p.agg_ld) : nullptr, 0, AGG ? (int)(((R1 - R0) / K) * p.agg_ld * 4) : 0, 0x00020000);
+        AGG ? (void *)(reinterpret_cast<char *>(p.agg) + (long long)(R0 / K) * p.agg_ld * AGB) : nullptr, 0,
+        AGG ? (int)(((R1 - R0) / K) * p.agg_ld * AGB) : 0, 0x00020000);
     if constexpr (AGG) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) carry[b] = f32x4{0.f, 0.f, 0.f, 0.f};          // (multiplied by 0 in chunk 0: must be finite)
@@ -321,20 +325,27 @@ __global__ __launch_bounds__(RS_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
             // the lanes that hold a segment's last row store its sum / mean: a buffer store whose offset is out of range in every other
             // lane (dropped by the bounds check) — no branch around the stores, so the waits on later loads need not drain them
             const bool last = real && dist == K - 1;
-            const unsigned aoff = last ? (unsigned)((qd * p.agg_ld + 4 * g) * 4) : 0x7ffffff0u;
+            const unsigned aoff = last ? (unsigned)((qd * p.agg_ld + (AGG == 2 ? 8 : 4) * g) * AGB) : 0x7ffffff0u;
             const float km = p.agg_mean ? (float)K : 1.f, ikm = p.agg_mean ? inv_k : 1.f;
+            f32x4 a[8];
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const f32x4 pv = carry[b];
                 if (!(RS1_ABLATE & 2)) scan4(y[b]);
-                f32x4 a;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     y[b][e] = fmaf(pv[e], mc, y[b][e]);                     // the segment's rows in the previous chunk (mc = 0 in chunk 0)
                     const float q0 = y[b][e] * ikm;                         // sum / K, correctly rounded (q0 = the sum itself when km = 1)
-                    a[e] = fmaf(fmaf(-km, q0, y[b][e]), ikm, q0);
+                    a[b][e] = fmaf(fmaf(-km, q0, y[b][e]), ikm, q0);
                 }
-                if (!(RS1_ABLATE & 32)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, a), agg_rsrc, aoff + 64u * b, 0, 0);
+                if constexpr (AGG == 1) {
+                    if (!(RS1_ABLATE & 32)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, a[b]), agg_rsrc, aoff + 64u * b, 0, 0);
+                } else if (b & 1) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = (__bf16)a[b - 1][e]; o[4 + e] = (__bf16)a[b][e]; }
+                    if (!(RS1_ABLATE & 32)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), agg_rsrc, aoff + 32u * (b - 1), 0, 0);
+                }
             }
             if (n == 15) {
 #pragma unroll
@@ -356,7 +367,7 @@ bool rs_eligible(const Params &p, bool agg, long long row_count) {
     for (int a = 0; a < 2; ++a)
         if (p.add[a].width != NP || (p.add[a].ld & 7) || ((uintptr_t)p.add[a].ptr & 15) || !p.add[a].idx || p.add[a].bf16 != p.add[0].bf16) return false;
     if (!p.out && !agg) return false;
-    if (agg && (!p.agg || (p.agg_ld & 3) || ((uintptr_t)p.agg & 15) || p.M % p.agg_deg != 0)) return false;
+    if (agg && (!p.agg || (p.agg_ld & (p.agg_bf16 ? 7 : 3)) || ((uintptr_t)p.agg & 15) || p.M % p.agg_deg != 0)) return false;
     if (p.out && ((p.out_ld & 7) || ((uintptr_t)p.out & 15))) return false;
     if (!p.gamma || p.act != G4C_ACT_NONE || ((uintptr_t)p.gamma & 15) || ((uintptr_t)p.beta & 15) || ((uintptr_t)p.b & 15)) return false;
     return p.M < (1LL << 31) && p.row_base == 0 && row_count == p.M;
@@ -369,11 +380,11 @@ int rs_launch(const Params &p, bool agg, hipStream_t st) {
     const bool xb = p.src[0].bf16 != 0, ab = p.add[0].bf16 != 0;
     const dim3 grid((unsigned)(want < n_cu ? want : n_cu)), blk(RS_WAVES * 64);
     const int od = p.out ? p.out_bf16 : 3;
-#define G4C_RS1(NL, XB, AB, OD) do { if (agg) mlp_rs1_kernel<NL, XB, AB, OD, true><<<grid, blk, 0, st>>>(p); \
-                                     else if constexpr (!(XB)) mlp_rs1_kernel<NL, XB, AB, OD, false><<<grid, blk, 0, st>>>(p); \
+#define G4C_RS1(NL, XB, AB, OD) do { if (agg && p.agg_bf16) mlp_rs1_kernel<NL, XB, AB, OD, 2><<<grid, blk, 0, st>>>(p); \
+                                     else if (agg) mlp_rs1_kernel<NL, XB, AB, OD, 1><<<grid, blk, 0, st>>>(p); \
+                                     else if constexpr (!(XB) && (OD) != 3) mlp_rs1_kernel<NL, XB, AB, OD, 0><<<grid, blk, 0, st>>>(p); \
                                      else { g4c::set_error("rs: bf16 input rows without an aggregation are not built"); return G4C_EUNSUPPORTED; } } while (0)
-#define G4C_RS1_XA(NL, XB, AB) do { if (od == 0) G4C_RS1(NL, XB, AB, 0); else if (od == 2) G4C_RS1(NL, XB, AB, 2); \
-                                  else if (od == 3 && agg) mlp_rs1_kernel<NL, XB, AB, 3, true><<<grid, blk, 0, st>>>(p); \
+#define G4C_RS1_XA(NL, XB, AB) do { if (od == 0) G4C_RS1(NL, XB, AB, 0); else if (od == 2) G4C_RS1(NL, XB, AB, 2); else if (od == 3 && agg) G4C_RS1(NL, XB, AB, 3); \
                                   else { g4c::set_error("rs: this combination of row formats is not built"); return G4C_EUNSUPPORTED; } } while (0)
 #define G4C_RS1_NL(NL) do { if (!xb && !ab && od == 0) G4C_RS1(NL, false, false, 0); else if (!xb && ab) G4C_RS1_XA(NL, false, true); \
                             else if (xb && ab) G4C_RS1_XA(NL, true, true); else { g4c::set_error("rs: this combination of row formats is not built"); return G4C_EUNSUPPORTED; } } while (0)

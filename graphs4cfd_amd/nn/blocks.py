@@ -99,10 +99,12 @@ class MLP(nn.Module):
     def _signature(self):
         return (ops.weights_epoch(),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def packed(self, seg_widths: Sequence[int], seg_negate: Sequence[bool], narrow: Optional[Sequence[bool]] = None) -> ops.PackedMLP:
+    def packed(self, seg_widths: Sequence[int], seg_negate: Sequence[bool], narrow: Optional[Sequence[bool]] = None,
+               rs_blocks: Optional[Sequence[bool]] = None) -> ops.PackedMLP:
         prec = ops.effective_precision(seg_widths)
         narrow = tuple(bool(x) for x in narrow) if (narrow is not None and prec != "fp32") else (False,) * len(seg_widths)
-        key = (tuple(seg_widths), tuple(bool(x) for x in seg_negate), prec, narrow)
+        rs_blocks = tuple(bool(x) for x in rs_blocks) if (rs_blocks is not None and prec == "bf16") else (False,) * len(seg_widths)
+        key = (tuple(seg_widths), tuple(bool(x) for x in seg_negate), prec, narrow, rs_blocks)
         sig = self._signature()
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
@@ -112,7 +114,7 @@ class MLP(nn.Module):
             ln = getattr(self.MLP, "layer_norm", None)
             pk = ops.PackedMLP([l.weight for l in lin], [l.bias for l in lin],
                                None if ln is None else (ln.weight, ln.bias, ln.eps), key[0], key[1], precision=prec, narrow=narrow,
-                               site=self._site)
+                               site=self._site, rs_blocks=rs_blocks if any(rs_blocks) else None)
             self._packed[key] = (sig, pk)
             hit = self._packed[key]
         return hit[1]
@@ -241,7 +243,7 @@ class MLP(nn.Module):
                                  resid_col0=resid_col0)
             return _finish(y, activation, code)
         sources = _split_wide(sources)
-        pk = self.packed([s.width for s in sources], [s.negate for s in sources], _narrow_flags(sources))
+        pk = self.packed([s.width for s in sources], [s.negate for s in sources], _narrow_flags(sources), _rs_blocks(sources))
         y = ops.mlp_forward(pk, sources, n_rows, _lib.ACT_NONE if code is None else code, out, out_idx32, resid, resid_col0)
         return _finish(y, activation, code)
 
@@ -249,7 +251,7 @@ class MLP(nn.Module):
         if not self.fits_one_launch():
             return self._run_stages(sources, n_rows, act_code, **kw)
         sources = _split_wide(sources)
-        pk = self.packed([s.width for s in sources], [s.negate for s in sources], _narrow_flags(sources))
+        pk = self.packed([s.width for s in sources], [s.negate for s in sources], _narrow_flags(sources), _rs_blocks(sources))
         return ops.mlp_forward(pk, sources, n_rows, act_code, **kw)
 
     def _heads_packed(self, seg_widths: Sequence[int], consumer: "MLP", k_cols: int, widths: Sequence[int]) -> Optional[ops.PackedMLP]:
@@ -259,7 +261,8 @@ class MLP(nn.Module):
             return None
         prec = ops.effective_precision(seg_widths)
         narrow = (False,) * len(seg_widths)
-        key = ("heads", id(consumer), k_cols, tuple(widths), tuple(seg_widths), (False,) * len(seg_widths), prec, narrow)
+        key = ("heads", id(consumer), k_cols, tuple(widths), tuple(seg_widths), (False,) * len(seg_widths), prec, narrow, False,
+               (False,) * len(seg_widths))
         sig = (self._signature(), consumer._signature())
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
@@ -302,7 +305,9 @@ class MLP(nn.Module):
             return None
         narrow = tuple(_narrow_flags(sources)) if prec != "fp32" else (False,) * len(sources)
         rs_rows = bool(rs_rows and prec == "bf16" and PRODUCTS_BF16 and not any(t is not None for t in (head_outs or ())))
-        key = ("heads", id(consumer), k_cols, tuple(widths), tuple(s.width for s in sources), tuple(s.negate for s in sources), prec, narrow, rs_rows)
+        rs_blocks = _rs_blocks(sources) if prec == "bf16" else (False,) * len(sources)
+        key = ("heads", id(consumer), k_cols, tuple(widths), tuple(s.width for s in sources), tuple(s.negate for s in sources), prec, narrow, rs_rows,
+               rs_blocks)
         sig = (self._signature(), consumer._signature())
         hit = self._packed.get(key)
         if hit is None or hit[0] != sig:
@@ -319,7 +324,7 @@ class MLP(nn.Module):
                 return None
             pk = ops.PackedMLP([l.weight for l in lin], [l.bias for l in lin],
                                None if ln is None else (ln.weight, ln.bias, ln.eps), key[4], key[5], heads=heads, precision=prec,
-                               narrow=narrow, site=self._site)
+                               narrow=narrow, site=self._site, rs_blocks=rs_blocks if any(rs_blocks) else None)
             self._packed[key] = (sig, pk)
             hit = self._packed[key]
         pk = hit[1]
@@ -432,7 +437,8 @@ class MLP(nn.Module):
             return False
         if kw.get("rows_dtype") == torch.bfloat16 and kw.get("store_rows", True) and kw.get("rows_act", _lib.ACT_NONE) != _lib.ACT_SELU:
             return False
-        return agg[1].dtype == torch.float32 and agg[1].stride(1) == 1 and agg[1].stride(0) % 4 == 0 and agg[1].data_ptr() % 16 == 0
+        return (agg[1].dtype in (torch.float32, torch.bfloat16) and agg[1].stride(1) == 1 and agg[1].data_ptr() % 16 == 0
+                and agg[1].stride(0) % (8 if agg[1].dtype == torch.bfloat16 else 4) == 0)
 
     def _run_rs1(self, x: Source, gathered, n_rows: int, products, kw) -> Optional[Tensor]:
         adds = []
@@ -457,6 +463,13 @@ class MLP(nn.Module):
 
 
 # ------------------------------------------------------------------------------------- helpers
+def _rs_blocks(sources: Sequence[Source]) -> Tuple[bool, ...]:
+    """Per weighted input block: its rows are ops.RsOrderedRows (128 wide, whole) — the pack then takes that block's weight columns in the
+    same order (ops.PackedMLP rs_blocks) instead of the rows being copied back to feature order."""
+    return tuple(isinstance(s.tensor, ops.RsOrderedRows) and s.width == 128 and s.col0 == 0 and s.segments is None
+                 for s in sources if not s.additive)
+
+
 def scatter(src: Tensor, index: Tensor, dim: int = 0, dim_size: Optional[int] = None, reduce: str = "sum") -> Tensor:
     """Drop-in for `torch_geometric.utils.scatter(src, index, dim=0, dim_size, reduce)` as the
     reference uses it (nn/blocks.py:46-47,183,231,330,378): a CSR segmented reduction on a cached plan."""
@@ -546,7 +559,11 @@ PRODUCTS_BF16 = True
 # and hoisted products — are in its own column order (ops.RsOrderedRows), 16 contiguous bytes per lane: the level-1 angle launch of
 # config 3 is bound by the NUMBER of memory instructions and 32-byte pieces, not by HBM bytes (2.5 M rows: 655 us on
 # mlp_ws_kernel<SP = 1>, 622 us on this kernel with natural-order 8-byte pieces, 520 us with 16-byte pieces).
-ROW_SPLIT_BF16 = __import__('os').environ.get('G4C_ROW_SPLIT_BF16', '1') != '0'      # (A/B switch while the path is measured)
+ROW_SPLIT_BF16 = __import__('os').environ.get('G4C_ROW_SPLIT_BF16', '1') != '0'      # (environment: same-box A/B runs)
+# ... and the aggregate of such a launch is stored as bf16 rows in the same order (G4C_AGG_OUT_BF16) when its reader is the layer's update
+# MLP in one launch: that reader rounds it to bf16 on load, so the operand is the same and two launches move half its bytes (2.5M-row
+# angle launch 521 -> 493 us, the 500k-row edge update 284 -> 254 us).
+AGGREGATE_BF16 = __import__('os').environ.get('G4C_AGGREGATE_BF16', '1') != '0'
 RS1_MIN_ROWS = 20000
 
 
@@ -644,12 +661,22 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
         # the edge launch reduces the rows it has just computed (whole CSR segments per row tile, g4c_mlp_forward_bx6_agg):
         # no second pass over the messages; with keep_e=False (the model discards e', nn/mus_gnn.py:199-200) they are not
         # even written
-        agg = torch.empty((csr.n_seg, msg_mlp.output_size), dtype=torch.float32, device=v.device)
-        e_new = msg_mlp.run_hoisted([e_src], [(senders, ep.row), (v, ep.col)], ep.n_edges,
-                                    products=products, agg=(csr, agg, mean), store_rows=keep_e,
-                                    rows_dtype=torch.bfloat16 if compact_messages and COMPACT_MESSAGES else None,
-                                    rows_act=_lib.ACT_SELU if compact_messages and COMPACT_MESSAGES else _lib.ACT_NONE)
-        agg_src = Source(agg)
+        kw = dict(store_rows=keep_e, rows_dtype=torch.bfloat16 if compact_messages and COMPACT_MESSAGES else None,
+                  rows_act=_lib.ACT_SELU if compact_messages and COMPACT_MESSAGES else _lib.ACT_NONE)
+        gathered = [(senders, ep.row), (v, ep.col)]
+        agg = None
+        if (AGGREGATE_BF16 and ops.mlp_precision() == "bf16" and msg_mlp.output_size == 128 and int(v.size(1)) == 128
+                and upd_mlp.fits_one_launch() and ops.effective_precision([128, 128]) == "bf16"):
+            # rounded-bf16 mode, message launch on the row-split kernel: the aggregate's one reader — this layer's update MLP — rounds it
+            # to bf16 on load, so it is stored that way (in the kernel's column order; the update MLP's pack takes the block's columns in
+            # the same order): the same operand, half the bytes in both launches
+            agg16 = torch.empty((csr.n_seg, 128), dtype=torch.bfloat16, device=v.device)
+            if msg_mlp._rs1_takes([e_src], gathered, ep.n_edges, _lib.ACT_NONE, products, dict(kw, agg=(csr, agg16, mean))):
+                agg = agg16
+        if agg is None:
+            agg = torch.empty((csr.n_seg, msg_mlp.output_size), dtype=torch.float32, device=v.device)
+        e_new = msg_mlp.run_hoisted([e_src], gathered, ep.n_edges, products=products, agg=(csr, agg, mean), **kw)
+        agg_src = Source(ops.RsOrderedRows.tag(agg) if agg.dtype == torch.bfloat16 else agg)
     elif ops.can_aggregate_on_load(csr, msg_mlp.output_size, [msg_mlp.output_size, int(v.size(1))]):
         # the node launch averages each target's messages while it gathers its input (g4c_src_t.seg_off): no separate
         # aggregation pass, no aggregate written to / re-read from HBM

@@ -575,7 +575,8 @@ class PackedMLP:
 
     def __init__(self, weights: Sequence[Tensor], biases: Sequence[Tensor], ln: Optional[Tuple[Tensor, Tensor, float]],
                  seg_widths: Sequence[int], seg_negate: Sequence[bool], heads: Sequence[Tensor] = (),
-                 precision: str = "fp32", narrow: Optional[Sequence[bool]] = None, site: Optional[str] = None, rs_order: bool = False):
+                 precision: str = "fp32", narrow: Optional[Sequence[bool]] = None, site: Optional[str] = None, rs_order: bool = False,
+                 rs_blocks: Optional[Sequence[bool]] = None):
         """`heads`: bias-free [128, 128] weights applied to the MLP's final output row (g4c_mlp_forward_heads); their
         packed images continue the weight stream after the last layer.  `precision` "bf16": the bf16 stream of
         g4c_mlp_pack_layer_bx6 (every input block padded to 128 k; "bf16" uses the same stream, leading plane only).
@@ -614,6 +615,13 @@ class PackedMLP:
                               or any(tuple(W.shape) != (128, 128) for W in weights)):
             raise NotImplementedError("rs_order: rounded-bf16 mode, one 128-wide input block, 128 x 128 layers, no heads")
         self.desc.w_format = 1 if self.split == "f16x2" else (3 if self.rs_order else 0)
+        # `rs_blocks[j]` (rounded-bf16 mode): input block j arrives as RsOrderedRows — bf16 rows in the row-split kernel's column order
+        # (its aggregate, G4C_AGG_OUT_BF16) — and is read by a kernel that knows nothing of that order: the COLUMNS of the first layer's
+        # block j are packed in the same order instead, the product is the same sum in another order.
+        self.rs_blocks = tuple(bool(x) for x in rs_blocks) if rs_blocks is not None else (False,) * len(seg_widths)
+        if any(self.rs_blocks) and (self.rs_order or precision != "bf16" or any(narrow) or len(self.rs_blocks) != len(seg_widths)
+                                    or any(r and w != 128 for r, w in zip(self.rs_blocks, seg_widths))):
+            raise NotImplementedError("rs_blocks: rounded-bf16 mode, 128-wide blocks, no narrow blocks")
         # (`site`: the name a clipped value is reported under — f16_range_report)
         self.site = site or "an MLP created outside a model"
         if self.split == "f16x2":
@@ -674,6 +682,13 @@ class PackedMLP:
                 Wc = W.detach().to(torch.float32).contiguous()
                 if self.rs_order:
                     Wc = Wc[:, _rs_k_order(dev)].contiguous()
+                if l == 0 and any(self.rs_blocks):
+                    cols = torch.arange(k_in, device=dev)
+                    for j, r in enumerate(self.rs_blocks):
+                        if r:
+                            c0 = sum(seg_widths[:j])
+                            cols[c0:c0 + 128] = c0 + _rs_k_order(dev)
+                    Wc = Wc[:, cols].contiguous()
                 seg_arr = (C.c_int32 * len(segs))(*segs)
                 neg_arr = (C.c_int32 * len(segs))(*negs)
                 _lib.check(pack(_lib.ptr(Wc), n_out, k_in, seg_arr, neg_arr, len(segs), wptr, k_pads[l], NP, stream))
@@ -797,10 +812,20 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
         # (the row-split kernel's rounded-bf16 stream: its bf16 rows are in ITS column order, nobody else's)
         if any(s.tensor.dtype == torch.bfloat16 and not isinstance(s.tensor, RsOrderedRows) for s in sources):
             raise ValueError("weights packed for the row-split kernel: bf16 rows must be RsOrderedRows (its column order)")
-    elif any(isinstance(s.tensor, RsOrderedRows) for s in sources):
-        sources = [s if not isinstance(s.tensor, RsOrderedRows) else
-                   Source(rs_rows_to_natural(s.tensor), s.index, s.col0, s.width, s.negate, s.pre_act, s.additive, s.segments, s.seg_mean)
-                   for s in sources]
+    elif any(isinstance(s.tensor, RsOrderedRows) for s in sources) or any(packed.rs_blocks):
+        # tagged rows reach a kernel that reads feature order: fine where the pack has that block's columns in the same order
+        # (`rs_blocks`), restored to feature order (a copy) anywhere else
+        fixed, j = [], 0
+        for s in sources:
+            tagged = isinstance(s.tensor, RsOrderedRows)
+            ok = (not s.additive) and j < len(packed.rs_blocks) and packed.rs_blocks[j] and s.col0 == 0 and s.width == 128
+            if not s.additive:
+                if j < len(packed.rs_blocks) and packed.rs_blocks[j] and not tagged:
+                    raise ValueError(f"input block {j}: the weights expect rows in the row-split order (ops.RsOrderedRows)")
+                j += 1
+            fixed.append(s if (not tagged or ok) else
+                         Source(rs_rows_to_natural(s.tensor), s.index, s.col0, s.width, s.negate, s.pre_act, s.additive, s.segments, s.seg_mean))
+        sources = fixed
     dev = _lib.require_hip(*[s.tensor for s in sources], *[s.index for s in sources], out, out_idx32, resid)
     if dev != packed.device:
         raise RuntimeError(f"MLP weights on {packed.device}, inputs on {dev}")
@@ -839,7 +864,14 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
             return y
         _lib.require_hip(agg_out)
         t_rows, t_seg, nt = tiles
-        tail = (_lib.ptr(t_rows), _lib.ptr(t_seg), _lib.ptr(csr.off), nt, _lib.ptr(agg_out), _ld(agg_out), _agg_mode(agg_mean, csr),
+        mode = _agg_mode(agg_mean, csr)
+        if agg_out.dtype == torch.bfloat16:          # (G4C_AGG_OUT_BF16: bf16 aggregate rows in the row-split kernel's column order)
+            if not (packed.rs_order and packed.precision == "bf16"):
+                raise ValueError("a bf16 aggregate needs weights packed for the row-split kernel (rounded-bf16 mode)")
+            mode |= 1 << 16
+        elif agg_out.dtype != torch.float32:
+            raise TypeError(f"aggregate: expected float32 (or bfloat16 on the row-split kernel), got {agg_out.dtype}")
+        tail = (_lib.ptr(t_rows), _lib.ptr(t_seg), _lib.ptr(csr.off), nt, _lib.ptr(agg_out), _ld(agg_out), mode,
                 _lib.stream_handle(dev))
         o_ld = _ld(out) if out is not None else 128
         if packed.precision == "bf16x6":

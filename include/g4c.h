@@ -284,6 +284,10 @@ int g4c_mlp_forward_bf16(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*
  * offsets (same sums in the same order; the mean as the correctly rounded quotient by Markstein's correction, which differs from
  * the IEEE division only below 2^-100). */
 #define G4C_AGG_UNIFORM(k) ((int32_t)(k) << 8)
+/* OR-ed into agg_mean (g4c_mlp_forward_bf16_agg with a G4C_WFMT_BF16_RS stream only): `agg` points to bf16 rows (agg_ld in elements, a
+ * multiple of 8) and the aggregate is stored rounded to bf16, its 128 values in the row-split order — what the layer's update MLP, its
+ * one reader in the rounded-bf16 mode, rounds it to on load anyway. */
+#define G4C_AGG_OUT_BF16 ((int32_t)1 << 16)
 int64_t g4c_plan_tiles(const int32_t *off /*host*/, int32_t n_seg, int32_t max_rows, int32_t *tile_rows /*host, out*/,
                        int32_t *tile_seg /*host, out*/, int64_t capacity);
 int g4c_mlp_forward_bx6_agg(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,

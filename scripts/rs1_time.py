@@ -18,7 +18,7 @@ ei = torch.stack([(tgt + torch.randint(-4096, 4097, (E,))).clamp(0, n - 1), tgt]
 ep, csr = plan.edge_csr(ei, n)
 src = [ops.Source(rs(e16)), ops.Source(rs(pr16), index=ep.row, additive=True), ops.Source(rs(pc16), index=ep.col, additive=True)]
 pk_rs = blk.edge_mlp._packed_cols("hoist_rs", 0, H, [H], [False], False, rs_order=True)
-agg = torch.empty((n, H), device=dev)
+agg = torch.empty((n, H), device=dev, dtype=torch.bfloat16 if os.environ.get('AGG16') == '1' else torch.float32)
 fn = lambda: ops.mlp_forward(pk_rs, src, E, agg=(csr, agg, True), rows_dtype=torch.bfloat16, rows_act=_lib.ACT_SELU)
 for _ in range(3): fn()
 torch.cuda.synchronize()

@@ -1758,6 +1758,56 @@ def test_row_split_kernel_matches_the_weight_stationary_path(layers):
         ops.set_mlp_precision(old)
 
 
+def test_bf16_aggregate_of_the_row_split_kernel_is_the_operand_its_reader_forms():
+    """Rounded-bf16 mode (blocks.AGGREGATE_BF16, G4C_AGG_OUT_BF16): the row-split kernel stores the per-receiver mean as bf16 rows in its
+    column order when the layer's update MLP reads it — (a) bit for bit the round-to-nearest bf16 of the fp32 aggregate it stores
+    otherwise; (b) the update MLP, packed with that block's weight columns in the same order, gives the result of the fp32 aggregate
+    up to the summation order of its first layer (1e-5), with and without the next layer's product heads."""
+    lib = _lib.load()
+    old = ops.set_mlp_precision("bf16")
+    was = B.AGGREGATE_BF16
+    H = 128
+    try:
+        torch.manual_seed(77)
+        n, K = 6000, 5
+        E = n * K
+        blk = B.GNBlock((3 * H, (H, H), True), (2 * H, (H, H), True)).to(DEV)
+        nxt = B.GNBlock((3 * H, (H, H), True), (2 * H, (H, H), True)).to(DEV)
+        a, v = torch.randn(E, H, device=DEV), torch.randn(n, H, device=DEV)
+        ei = torch.stack([torch.randint(0, n, (E,)), torch.arange(n).repeat_interleave(K)]).to(DEV)
+        ep, csr = plan.edge_csr(ei, n)
+        order = ops._rs_k_order(DEV)
+        # (a) the launch alone
+        aggs = {}
+        for dt in (torch.float32, torch.bfloat16):
+            g = torch.empty(n, H, dtype=dt, device=DEV)
+            with torch.no_grad():
+                blk.edge_mlp.run_hoisted([ops.Source(a, pre_act=_lib.ACT_SELU)], [(v, ep.row), (v, ep.col)], E, agg=(csr, g, True), store_rows=False)
+            assert int(lib.g4c_mlp_last_kernel()) == _lib.KERNEL_MLP_RS
+            aggs[dt] = g
+        assert torch.equal(aggs[torch.bfloat16], aggs[torch.float32].to(torch.bfloat16)[:, order])
+        # (b) the whole layer
+        res = {}
+        for on in (False, True):
+            B.AGGREGATE_BF16 = on
+            with torch.no_grad():
+                res[on, "heads"] = B._mp_step(blk.edge_mlp, blk.node_mlp, v, a, ei, "mean", _lib.ACT_SELU, e_pre_act=_lib.ACT_SELU,
+                                              next_msg=nxt.edge_mlp, compact_messages=True)
+                res[on, "plain"] = B._mp_step(blk.edge_mlp, blk.node_mlp, v, a, ei, "mean", _lib.ACT_SELU, e_pre_act=_lib.ACT_SELU, compact_messages=True)
+        for form in ("heads", "plain"):
+            (v0, e0, *p0), (v1, e1, *p1) = res[False, form], res[True, form]
+            assert torch.equal(e0, e1)                                    # (the message rows do not depend on how the aggregate is stored)
+            torch.testing.assert_close(v1, v0, rtol=0, atol=1e-5)
+            if form == "heads":
+                assert p0[0] is not None and p1[0] is not None
+                for h0, h1 in zip(p0[0], p1[0]):
+                    d = (h1.float() - h0.float()).abs()
+                    assert d.mean().item() < 1e-5 and d.max().item() < 4e-2          # (bf16 rows: a rare one-ulp flip)
+    finally:
+        B.AGGREGATE_BF16 = was
+        ops.set_mlp_precision(old)
+
+
 def test_row_split_path_in_the_remus_model():
     """BASELINE config 3's model at 20k nodes in the rounded-bf16 mode with and without the row-split kernel: the level-1 and level-2
     angle launches take it (k = 5 angles per edge), products and compact messages travel in its column order between consecutive
@@ -1788,7 +1838,7 @@ def test_row_split_path_in_the_remus_model():
             used[on] = seen
         assert _lib.KERNEL_MLP_RS in used[True] and _lib.KERNEL_MLP_RS not in used[False], used
         d = (outs[True] - outs[False]).abs()
-        assert torch.isfinite(outs[True]).all() and d.max().item() < 3e-2 and d.mean().item() < 2e-3, (d.max().item(), d.mean().item())
+        assert torch.isfinite(outs[True]).all() and d.max().item() < 6e-2 and d.mean().item() < 2e-3, (d.max().item(), d.mean().item())      # (the mode's own tolerance against the fp32 oracle: 6e-2 / 1e-2)
         B.ROW_SPLIT_BF16 = True
         cap, eag = model.solve(g.clone(), 3, capture=True), model.solve(g.clone(), 3, capture=False)
         assert torch.equal(cap, eag) and torch.isfinite(cap).all()
