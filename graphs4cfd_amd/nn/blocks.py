@@ -628,7 +628,8 @@ def _fused_layer(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e_src: Source, ep, csr, 
 def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, aggr: str, act_code: int,
              e_pre_act: int = _lib.ACT_NONE, v_src: Optional[Tensor] = None,
              products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None, keep_e: bool = True,
-             n_targets: Optional[int] = None, v_out: Optional[Tensor] = None, compact_messages: bool = False):
+             n_targets: Optional[int] = None, v_out: Optional[Tensor] = None, compact_messages: bool = False,
+             next_graph: Optional[Tuple[int, "plan.CsrPlan"]] = None):
     """Shared body of GNBlock / EdgeMP / DownEdgeMP (nn/blocks.py:175-186,322-333,360-381):
         e' = msg_mlp([e | s[row] | v[col]]);  agg = reduce(e' -> col);  v' = act(upd_mlp([agg | v])).
     Returns (v', e') where e' is stored WITHOUT the activation: the aggregation consumes the raw
@@ -643,6 +644,8 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
     the launch that fuses the aggregation stores bf16(SELU(e')) (ops.mlp_forward rows_dtype / rows_act) — exactly the operand that
     reader forms; REMuS-GNN's angle launches are HBM-bound on these rows.  A bf16 result is ALREADY ACTIVATED: its reader passes
     `e_pre_act = ACT_NONE` (see `pending_act`).
+    `next_graph` = (rows, receiver CSR) of the launch `next_msg` will run when it is NOT over this step's graph (DownEdgeMP: the
+    consumer is the coarse level's first EdgeMP): decides whether the consumer hoists and which column order its products take.
     `n_targets` / `v_out` (partitioned sub-meshes, partition_remus.py): only the first `n_targets` rows of `v` are targets (the
     rows behind them are halo rows, read as senders only); v' for those rows is written into `v_out`."""
     if aggr not in ("mean", "sum", "add"):
@@ -654,7 +657,7 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
     senders = v if v_src is None else v_src
     mean = aggr == "mean"
     e_src = e if isinstance(e, Source) else Source(e, pre_act=e_pre_act)
-    if _can_fuse_layer(msg_mlp, upd_mlp, v, e, index, csr, v_src, n_targets, v_out, compact_messages):
+    if next_graph is None and _can_fuse_layer(msg_mlp, upd_mlp, v, e, index, csr, v_src, n_targets, v_out, compact_messages):
         v_new, e_new, nxt = _fused_layer(msg_mlp, upd_mlp, v, e_src, ep, csr, mean, act_code, products, next_msg, keep_e)
         return (v_new, e_new, nxt) if next_msg is not None else (v_new, e_new)
     if ops.can_fuse_aggregation(csr, msg_mlp.output_size):
@@ -692,10 +695,11 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
         agg_src = Source(agg)
     if next_msg is not None:
         nxt = None
-        if ep.n_edges >= HOIST_MIN_ROWS:     # the consumer will hoist: give it its node-side terms from this launch
+        nx_rows, nx_csr = (ep.n_edges, csr) if next_graph is None else next_graph
+        if nx_rows >= HOIST_MIN_ROWS:        # the consumer will hoist: give it its node-side terms from this launch
             w = upd_mlp.output_size          # (width of v', the node input of the next layer's message MLP)
             nxt = upd_mlp.run_with_heads([agg_src, Source(v)], int(v.size(0)), act_code, next_msg,
-                                         next_msg.input_size - 2 * w, [w, w], rs_rows=next_msg.rs1_ready(ep.n_edges, csr))
+                                         next_msg.input_size - 2 * w, [w, w], rs_rows=next_msg.rs1_ready(nx_rows, nx_csr))
         if nxt is None:
             return upd_mlp.run_coded([agg_src, Source(v)], int(v.size(0)), act_code), e_new, None
         return nxt[0], e_new, nxt[1]
@@ -879,10 +883,20 @@ class DownEdgeMP(nn.Module):
                 item.reset_parameters()
 
     def forward(self, e1: Tensor, e2: Tensor, a12: Tensor, angle_index12: Tensor, *, activation=None) -> Tensor:
+        return self.step(e1, e2, a12, angle_index12, activation)[0]
+
+    def step(self, e1: Tensor, e2: Tensor, a12: Tensor, angle_index12: Tensor, activation=None, next_msg: Optional[MLP] = None,
+             next_graph=None) -> Tuple[Tensor, Optional[Sequence[Tensor]]]:
+        """Internal form: (e2', products) — `next_msg` = the angle MLP of the coarse level's EdgeMP that reads e2' next, `next_graph` its
+        (angle rows, receiver CSR): its hoisted first-layer products then come out of this block's edge launch (see GNBlock.step)."""
         code = _lib.act_code(activation)
-        e2_new, _ = _mp_step(self.angle_mlp, self.edge_mlp, e2, a12, angle_index12, "mean",
-                             _lib.ACT_NONE if code is None else code, v_src=e1)
-        return _finish(e2_new, activation, code)
+        if next_msg is None or code is None:
+            e2_new, _ = _mp_step(self.angle_mlp, self.edge_mlp, e2, a12, angle_index12, "mean",
+                                 _lib.ACT_NONE if code is None else code, v_src=e1)
+            return _finish(e2_new, activation, code), None
+        e2_new, _, prods = _mp_step(self.angle_mlp, self.edge_mlp, e2, a12, angle_index12, "mean", code, v_src=e1,
+                                    next_msg=next_msg, next_graph=next_graph)
+        return e2_new, prods
 
 
 class UpEdgeMP(nn.Module):
@@ -901,6 +915,15 @@ class UpEdgeMP(nn.Module):
     def forward(self, pos: Tensor, y_idx_21: Tensor, x_idx_21: Tensor, weights_21: Tensor, edge_attr2: Tensor,
                 edge_index2: Tensor, edgeUnitVectorInverse2: Tensor, coarse_mask2: Tensor, edge_attr1: Tensor,
                 edge_index1: Tensor, edgeUnitVector1: Tensor, coarse_mask1=None, *, activation=None) -> Tensor:
+        return self.step(pos, y_idx_21, x_idx_21, weights_21, edge_attr2, edge_index2, edgeUnitVectorInverse2, coarse_mask2, edge_attr1,
+                         edge_index1, edgeUnitVector1, coarse_mask1, activation=activation)[0]
+
+    def step(self, pos: Tensor, y_idx_21: Tensor, x_idx_21: Tensor, weights_21: Tensor, edge_attr2: Tensor,
+             edge_index2: Tensor, edgeUnitVectorInverse2: Tensor, coarse_mask2: Tensor, edge_attr1: Tensor,
+             edge_index1: Tensor, edgeUnitVector1: Tensor, coarse_mask1=None, *, activation=None, next_msg: Optional[MLP] = None,
+             next_graph=None) -> Tuple[Tensor, Optional[Sequence[Tensor]]]:
+        """Internal form: (e1', products) — with `next_msg` / `next_graph` (the fine level's next EdgeMP, see DownEdgeMP.step) the
+        per-edge launch also emits that EdgeMP's hoisted first-layer products."""
         n_total, nfeat = int(pos.size(0)), int(edge_attr2.size(1))
         # 1- edge scalars of level 2 -> node vectors [|V_2|, 2F]
         v2 = edgeScalarToNodeVector(edge_attr2, edge_index2, edgeUnitVectorInverse=edgeUnitVectorInverse2,
@@ -920,4 +943,11 @@ class UpEdgeMP(nn.Module):
         ep = plan.edge_plan(edge_index1)
         e1 = ops.project_to_edges(v1, ep.col, edgeUnitVector1, ep.n_edges, nfeat)
         # 4- skip connection + per-edge MLP
-        return self.up_mlp.run([Source(e1), Source(edge_attr1)], ep.n_edges, activation=activation)
+        code = _lib.act_code(activation)
+        if next_msg is not None and code is not None and next_graph is not None and next_graph[0] >= HOIST_MIN_ROWS:
+            w = self.up_mlp.output_size
+            got = self.up_mlp.run_with_heads([Source(e1), Source(edge_attr1)], ep.n_edges, code, next_msg, next_msg.input_size - 2 * w, [w, w],
+                                             rs_rows=next_msg.rs1_ready(*next_graph))
+            if got is not None:
+                return got
+        return self.up_mlp.run([Source(e1), Source(edge_attr1)], ep.n_edges, activation=activation), None

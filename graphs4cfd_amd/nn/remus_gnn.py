@@ -21,6 +21,12 @@ from .model import GNN
 SELU, NONE = _lib.ACT_SELU, _lib.ACT_NONE
 
 
+# Round 6: the hoisted first-layer products of the FIRST EdgeMP of a run on a level (after the edge encoder, a DownEdgeMP, an UpEdgeMP)
+# come out of that producer's own launch as two heads, like the products between consecutive EdgeMPs — instead of two product launches
+# per entry (config 3: 10 launches, 0.49 ms of an 8.3 ms step).
+ENTRY_PRODUCTS = __import__("os").environ.get("G4C_ENTRY_PRODUCTS", "1") != "0"
+
+
 class NsRotEquiTreeScaleGNN(GNN):
     """The three-scale REMuS-GNN for incompressible flow inference from Lino et al. (2022)
     (https://doi.org/10.1063/5.0097679); reference: nn/remus_gnn.py:11-199.
@@ -83,17 +89,38 @@ class NsRotEquiTreeScaleGNN(GNN):
         return ops.static_launch(name + "/rs16", [att], lambda: ops.RsOrderedRows.tag(
             a.to(torch.bfloat16)[:, ops._rs_k_order(a.device)].contiguous()))
 
+    def _entry_of(self, prog, k: int, lvl: int, aidx, e):
+        """(angle MLP, (angle rows, receiver CSR)) of the EdgeMP that follows program step k on level `lvl` — whose hoisted first-layer
+        products the inter-level block at step k can emit with its own edge launch — or (None, None)."""
+        nxt = prog[k + 1] if k + 1 < len(prog) else None
+        if not ENTRY_PRODUCTS or nxt is None or nxt[0] != "mp" or nxt[2] != lvl or ops.grad_mode():
+            return None, None
+        return getattr(self, nxt[1]).angle_mlp, (int(aidx[lvl].size(1)), plan.edge_csr(aidx[lvl], int(e[lvl].size(0)))[1])
+
     def forward(self, graph: Graph, t: Optional[int] = None) -> torch.Tensor:
         g = graph
         sfx = {1: "", 2: "2", 3: "3"}
         nfeat = int(g.field.size(1)) // 2
         e, a, aidx = {}, {}, {}
+        entry_products = None
         for lvl, s in sfx.items():
             ep = plan.edge_plan(getattr(g, f"edge_index{s}"))
             # project the node vectors along the edges, then [proj | glob[col] | omega[col]] -> encoder
             proj = ops.project_to_edges(g.field, ep.col, getattr(g, f"edgeUnitVector{s}"), ep.n_edges, nfeat)
-            e[lvl] = getattr(self, f"edge_encoder{s}").run_coded(
-                [Source(proj), Source(g.glob, ep.col), Source(g.omega, ep.col)], ep.n_edges, SELU)
+            enc_src = [Source(proj), Source(g.glob, ep.col), Source(g.omega, ep.col)]
+            e[lvl] = None
+            if ENTRY_PRODUCTS and lvl == 1 and self._PROGRAM[0][0] == "mp" and not ops.grad_mode():
+                # the level's first EdgeMP reads e next: its hoisted first-layer products come out of the encoder's launch
+                first = getattr(self, self._PROGRAM[0][1]).angle_mlp
+                n_ang = int(getattr(g, f"angle_index{s}").size(1))
+                if n_ang >= _blocks.HOIST_MIN_ROWS:
+                    enc = getattr(self, f"edge_encoder{s}")
+                    got = enc.run_with_heads(enc_src, ep.n_edges, SELU, first, first.input_size - 2 * enc.output_size,
+                                             [enc.output_size] * 2, rs_rows=first.rs1_ready(n_ang, plan.edge_csr(getattr(g, f"angle_index{s}"), ep.n_edges)[1]))
+                    if got is not None:
+                        e[lvl], entry_products = got
+            if e[lvl] is None:
+                e[lvl] = getattr(self, f"edge_encoder{s}").run_coded(enc_src, ep.n_edges, SELU)
             # (the angle attributes are static inside a rollout — nn/model.py:316-320 replaces graph.field only — so a Rollout
             # runs the five angle encoders once per mesh and weights, ops.StaticCache; a bare forward() launches them, like the
             # reference nn/remus_gnn.py:136-140)
@@ -103,7 +130,7 @@ class NsRotEquiTreeScaleGNN(GNN):
         a12 = self._angle_latents("angle_encoder12", g.angle_attr12)
         a23 = self._angle_latents("angle_encoder23", g.angle_attr23)
         a_pending = {1: NONE, 2: NONE, 3: NONE}
-        products = {1: None, 2: None, 3: None}   # first-layer edge-side terms of the next EdgeMP of a level, if already made
+        products = {1: entry_products, 2: None, 3: None}   # first-layer edge-side terms of the next EdgeMP of a level, if already made
         prog = self._PROGRAM
         for k, (op, name, lvl) in enumerate(prog):
             block = getattr(self, name)
@@ -123,16 +150,16 @@ class NsRotEquiTreeScaleGNN(GNN):
                 a_pending[lvl] = _blocks.pending_act(a[lvl])       # (SELU; none when the rows came back compact and activated)
             elif op == "down":
                 a_x, idx_x = (a12, g.angle_index12) if lvl == 1 else (a23, g.angle_index23)
-                e[lvl + 1] = block(e[lvl], e[lvl + 1], a_x, idx_x, activation="selu")
-                products[lvl + 1] = None
+                e[lvl + 1], products[lvl + 1] = block.step(e[lvl], e[lvl + 1], a_x, idx_x, "selu", *self._entry_of(prog, k, lvl + 1, aidx, e))
             else:
                 lo, hi = lvl, lvl - 1
-                products[hi] = None
-                e[hi] = block(g.pos, getattr(g, f"y_idx_{lo}{hi}"), getattr(g, f"x_idx_{lo}{hi}"),
-                              getattr(g, f"weights_{lo}{hi}"), e[lo], getattr(g, f"edge_index{sfx[lo]}"),
-                              getattr(g, f"edgeUnitVectorInverse{sfx[lo]}"), getattr(g, f"coarse_mask{sfx[lo]}"),
-                              e[hi], getattr(g, f"edge_index{sfx[hi]}"), getattr(g, f"edgeUnitVector{sfx[hi]}"),
-                              getattr(g, f"coarse_mask{sfx[hi]}") if hi > 1 else None, activation="selu")
+                nm, ng = self._entry_of(prog, k, hi, aidx, e)
+                e[hi], products[hi] = block.step(g.pos, getattr(g, f"y_idx_{lo}{hi}"), getattr(g, f"x_idx_{lo}{hi}"),
+                                                 getattr(g, f"weights_{lo}{hi}"), e[lo], getattr(g, f"edge_index{sfx[lo]}"),
+                                                 getattr(g, f"edgeUnitVectorInverse{sfx[lo]}"), getattr(g, f"coarse_mask{sfx[lo]}"),
+                                                 e[hi], getattr(g, f"edge_index{sfx[hi]}"), getattr(g, f"edgeUnitVector{sfx[hi]}"),
+                                                 getattr(g, f"coarse_mask{sfx[hi]}") if hi > 1 else None, activation="selu",
+                                                 next_msg=nm, next_graph=ng)
         s = self.edge_decoder.run_coded([Source(e[1])], int(e[1].size(0)), NONE)
         out = edgeScalarToNodeVector(s, g.edge_index, edgeUnitVectorInverse=g.edgeUnitVectorInverse)
         # time step: field[:, -2:] + output (nn/remus_gnn.py:199)

@@ -1849,6 +1849,29 @@ def test_row_split_path_in_the_remus_model():
         ops.set_mlp_precision(old)
 
 
+@pytest.mark.parametrize("prec", ["f16x3", "bf16"])
+def test_remus_entry_products_come_from_the_producer_launch(prec):
+    """remus_gnn.ENTRY_PRODUCTS (round 6): the hoisted first-layer products of the first EdgeMP of a run on a level are two heads of the
+    launch that produces its edge latents (edge encoder, DownEdgeMP, UpEdgeMP) instead of two product launches — the same products
+    (same operand rounding, same weights, same summation order): the forward is bit-identical."""
+    from graphs4cfd_amd.nn import remus_gnn as R
+    old = ops.set_mlp_precision(prec)
+    was = R.ENTRY_PRODUCTS
+    try:
+        g = S.remus_graph(20_000, k=5, seed=41).to(DEV)
+        torch.manual_seed(42)
+        model = gfd.nn.NsRotEquiTreeScaleGNN(arch=S.remus_arch(128), device=DEV)
+        outs = {}
+        for on in (False, True):
+            R.ENTRY_PRODUCTS = on
+            with torch.no_grad():
+                outs[on] = model.forward(g.clone()).clone()
+        assert torch.equal(outs[True], outs[False]), (outs[True] - outs[False]).abs().max().item()
+    finally:
+        R.ENTRY_PRODUCTS = was
+        ops.set_mlp_precision(old)
+
+
 def test_bf16_product_rows_are_exact_copies():
     """Rounded-bf16 mode, round 5 (blocks.PRODUCTS_BF16): the hoisted first-layer products are stored as bf16.  The kernels only
     change representation — (a) head rows / plain output rows stored as bf16 are the round-to-nearest bf16 of the fp32 rows the same
