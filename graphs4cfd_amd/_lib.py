@@ -82,6 +82,8 @@ _SIGNATURES = {
                                             C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "g4c_mlp_forward_heads_bf16_out": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
                                                  C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
+    "g4c_mlp_forward_heads_bf16_rows": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
+                                                  C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
     "g4c_mp_layer_forward_bx6": (C.c_int, [C.POINTER(g4c_mlp_t), C.POINTER(g4c_src_t), C.c_int32, C.c_int64, C.c_void_p, C.c_int32,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                            C.POINTER(g4c_mlp_t), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,

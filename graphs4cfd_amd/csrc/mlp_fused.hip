@@ -1328,6 +1328,20 @@ extern "C" int g4c_mlp_forward_heads_bf16_out(const g4c_mlp_t *mlp, const g4c_sr
     return rc;
 }
 
+extern "C" int g4c_mlp_forward_heads_bf16_rows(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
+                                               void *out, int32_t out_ld, int32_t out_dtype, int32_t act,
+                                               const void *head_w, int32_t n_heads, void *const *head_out, int32_t head_ld, int32_t head_dtype,
+                                               void *stream) {
+    G4C_REQUIRE(n_heads >= 1 && n_heads <= G4C_MAX_HEADS && head_w && head_out, G4C_EINVAL, "g4c_mlp_forward_heads_bf16_rows: bad heads (n=%d)", n_heads);
+    G4C_REQUIRE((head_dtype == G4C_DTYPE_F32 || head_dtype == G4C_DTYPE_BF16) && (out_dtype == G4C_DTYPE_F32 || out_dtype == G4C_DTYPE_BF16), G4C_EINVAL,
+                "g4c_mlp_forward_heads_bf16_rows: unknown dtype (out %d, heads %d)", out_dtype, head_dtype);
+    g_head_dtype = head_dtype; g_out_dtype = out_dtype;
+    const int rc = mlp_launch(mlp, srcs, n_src, n_rows, 0, n_rows, 3216, (float *)out, out_ld, nullptr, act, nullptr, 0, 0,
+                              (const float *)head_w, n_heads, (float *const *)head_out, head_ld, stream);
+    g_head_dtype = 0; g_out_dtype = 0;
+    return rc;
+}
+
 extern "C" int g4c_mlp_forward_bf16_out(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src, int64_t n_rows,
                                         void *out, int32_t out_ld, int32_t out_dtype, int32_t act, void *stream) {
     G4C_REQUIRE(out_dtype == G4C_DTYPE_F32 || out_dtype == G4C_DTYPE_BF16, G4C_EINVAL, "g4c_mlp_forward_bf16_out: unknown out_dtype %d", out_dtype);

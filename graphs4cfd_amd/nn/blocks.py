@@ -431,7 +431,7 @@ class MLP(nn.Module):
             return False
         if x.tensor.dtype == torch.bfloat16 and not (isinstance(x.tensor, ops.RsOrderedRows) and x.pre_act == _lib.ACT_NONE):
             return False
-        if any(int(t.size(1)) != 128 or t.dtype != torch.float32 for t, _ in gathered):
+        if any(int(t.size(1)) != 128 or t.dtype not in (torch.float32, torch.bfloat16) or isinstance(t, ops.RsOrderedRows) for t, _ in gathered):
             return False
         if products is not None and not (len(products) == 2 and all(isinstance(t, ops.RsOrderedRows) for t in products)):
             return False
@@ -564,6 +564,9 @@ ROW_SPLIT_BF16 = __import__('os').environ.get('G4C_ROW_SPLIT_BF16', '1') != '0' 
 # MLP in one launch: that reader rounds it to bf16 on load, so the operand is the same and two launches move half its bytes (2.5M-row
 # angle launch 521 -> 493 us, the 500k-row edge update 284 -> 254 us).
 AGGREGATE_BF16 = __import__('os').environ.get('G4C_AGGREGATE_BF16', '1') != '0'
+# ... and the edge latents BETWEEN consecutive EdgeMPs of a level — read only by the next update MLP, which rounds them to bf16 on load —
+# are stored as bf16 rows by the update launch (g4c_mlp_forward_heads_bf16_rows): the same operand, half the bytes in both launches.
+COMPACT_LATENTS = __import__('os').environ.get('G4C_COMPACT_LATENTS', '1') != '0'
 RS1_MIN_ROWS = 20000
 
 
@@ -629,7 +632,7 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
              e_pre_act: int = _lib.ACT_NONE, v_src: Optional[Tensor] = None,
              products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None, keep_e: bool = True,
              n_targets: Optional[int] = None, v_out: Optional[Tensor] = None, compact_messages: bool = False,
-             next_graph: Optional[Tuple[int, "plan.CsrPlan"]] = None):
+             next_graph: Optional[Tuple[int, "plan.CsrPlan"]] = None, compact_v: bool = False):
     """Shared body of GNBlock / EdgeMP / DownEdgeMP (nn/blocks.py:175-186,322-333,360-381):
         e' = msg_mlp([e | s[row] | v[col]]);  agg = reduce(e' -> col);  v' = act(upd_mlp([agg | v])).
     Returns (v', e') where e' is stored WITHOUT the activation: the aggregation consumes the raw
@@ -646,6 +649,9 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
     `e_pre_act = ACT_NONE` (see `pending_act`).
     `next_graph` = (rows, receiver CSR) of the launch `next_msg` will run when it is NOT over this step's graph (DownEdgeMP: the
     consumer is the coarse level's first EdgeMP): decides whether the consumer hoists and which column order its products take.
+    `compact_v` (rounded-bf16 mode; the caller guarantees that v' is only ever read as an input block of the next layer's update MLP, which
+    rounds it to bf16 on load — EdgeMP's edge latents between consecutive EdgeMPs of a level): v' comes back as bf16 rows (feature order),
+    the same operand at half the bytes in both launches.
     `n_targets` / `v_out` (partitioned sub-meshes, partition_remus.py): only the first `n_targets` rows of `v` are targets (the
     rows behind them are halo rows, read as senders only); v' for those rows is written into `v_out`."""
     if aggr not in ("mean", "sum", "add"):
@@ -693,17 +699,22 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
         e_new = msg_mlp.run_hoisted([e_src], [(senders, ep.row), (v, ep.col)], ep.n_edges,
                                     products=products, agg=(csr, agg, mean))
         agg_src = Source(agg)
+    v16 = (compact_v and COMPACT_LATENTS and ops.mlp_precision() == "bf16" and upd_mlp.output_size == 128 and upd_mlp.fits_one_launch()
+           and n_targets is None and v_out is None and not ops.grad_mode() and ops.effective_precision([128, int(v.size(1))]) == "bf16")
     if next_msg is not None:
         nxt = None
         nx_rows, nx_csr = (ep.n_edges, csr) if next_graph is None else next_graph
         if nx_rows >= HOIST_MIN_ROWS:        # the consumer will hoist: give it its node-side terms from this launch
             w = upd_mlp.output_size          # (width of v', the node input of the next layer's message MLP)
             nxt = upd_mlp.run_with_heads([agg_src, Source(v)], int(v.size(0)), act_code, next_msg,
-                                         next_msg.input_size - 2 * w, [w, w], rs_rows=next_msg.rs1_ready(nx_rows, nx_csr))
+                                         next_msg.input_size - 2 * w, [w, w], rs_rows=next_msg.rs1_ready(nx_rows, nx_csr),
+                                         out=torch.empty((int(v.size(0)), 128), dtype=torch.bfloat16, device=v.device) if v16 else None)
         if nxt is None:
-            return upd_mlp.run_coded([agg_src, Source(v)], int(v.size(0)), act_code), e_new, None
+            out16 = torch.empty((int(v.size(0)), 128), dtype=torch.bfloat16, device=v.device) if v16 else None
+            return upd_mlp.run_coded([agg_src, Source(v)], int(v.size(0)), act_code, out=out16), e_new, None
         return nxt[0], e_new, nxt[1]
-    v_new = upd_mlp.run_coded([agg_src, Source(v)], n_t, act_code, out=v_out)
+    v_new = upd_mlp.run_coded([agg_src, Source(v)], n_t, act_code,
+                              out=torch.empty((n_t, 128), dtype=torch.bfloat16, device=v.device) if v16 else v_out)
     return v_new, e_new
 
 
@@ -857,12 +868,13 @@ class EdgeMP(nn.Module):
                 item.reset_parameters()
 
     def step(self, e: Tensor, a: Tensor, angle_index: Tensor, act_code: int, a_pre_act: int = _lib.ACT_NONE,
-             products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None, keep_e: bool = True):
+             products: Optional[Sequence[Tensor]] = None, next_msg: Optional[MLP] = None, keep_e: bool = True, compact_e: bool = False):
         """Internal form: returns (act(e'), raw a') (+ the next EdgeMP's `products` when `next_msg` is given, see GNBlock.step).
+        `compact_e`: e' is read by nothing but the next EdgeMP.step of the level (_mp_step compact_v).
         The model feeds a' only to the next EdgeMP.step of the level, so it may come back as bf16 in the rounded-bf16 mode
         (_mp_step compact_messages); the public forward always returns fp32."""
         return _mp_step(self.angle_mlp, self.edge_mlp, e, a, angle_index, self.aggr, act_code, a_pre_act,
-                        products=products, next_msg=next_msg, keep_e=keep_e, compact_messages=True)
+                        products=products, next_msg=next_msg, keep_e=keep_e, compact_messages=True, compact_v=compact_e)
 
     def forward(self, e: Tensor, a: Tensor, angle_index: Tensor, *, activation=None) -> Tuple[Tensor, Tensor]:
         return _public_mp(self.angle_mlp, self.edge_mlp, e, a, angle_index, self.aggr, activation)

@@ -138,7 +138,8 @@ class NsRotEquiTreeScaleGNN(GNN):
                 nxt = prog[k + 1] if k + 1 < len(prog) else None
                 if nxt is not None and nxt[0] == "mp" and nxt[2] == lvl:   # same level, consecutive: products ride along
                     e[lvl], a[lvl], products[lvl] = block.step(e[lvl], a[lvl], aidx[lvl], SELU, a_pre_act=a_pending[lvl],
-                                                               products=products[lvl], next_msg=getattr(self, nxt[1]).angle_mlp)
+                                                               products=products[lvl], next_msg=getattr(self, nxt[1]).angle_mlp,
+                                                               compact_e=True)     # (e' of this EdgeMP is read by the next one only)
                 else:
                     # the angle latents of a level are read again by its next EdgeMP — on the way up as well (a1 after mp114 feeds
                     # mp121, nn/remus_gnn.py:150-190); after the level's LAST EdgeMP of the step nothing reads them: not stored

@@ -930,9 +930,10 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                 # rounded-bf16 mode: the head rows (the next message MLP's first-layer products) stored as bf16 (g4c_mlp_forward_heads_bf16_out)
                 if packed.precision != "bf16" or any(h.dtype != torch.bfloat16 for h in head_outs):
                     raise TypeError("bf16 head outputs need the rounded-bf16 mode, and every head in bf16")
-                call = lambda: _lib.check(lib.g4c_mlp_forward_heads_bf16_out(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out),
-                                                                             _ld(out), act, packed.head_w, len(head_outs), ho,
-                                                                             _ld(head_outs[0]), 1, _lib.stream_handle(dev)))
+                # (a bf16 `out` as well: the launch's own rows stored as bf16 — g4c_mlp_forward_heads_bf16_rows)
+                call = lambda: _lib.check(lib.g4c_mlp_forward_heads_bf16_rows(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out),
+                                                                              _ld(out), 1 if out.dtype == torch.bfloat16 else 0, act, packed.head_w,
+                                                                              len(head_outs), ho, _ld(head_outs[0]), 1, _lib.stream_handle(dev)))
             else:
                 heads_fn = lib.g4c_mlp_forward_heads_bf16 if packed.precision == "bf16" else lib.g4c_mlp_forward_heads_bx6
                 call = lambda: _lib.check(heads_fn(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out),

@@ -359,6 +359,14 @@ int g4c_mlp_forward_heads_bf16_out(const g4c_mlp_t *mlp /*host*/, const g4c_src_
                                    int64_t n_rows, float *out, int32_t out_ld, int32_t act,
                                    const void *head_w, int32_t n_heads, void *const *head_out /*host*/, int32_t head_ld,
                                    int32_t head_dtype, void *stream);
+/* Round 6: g4c_mlp_forward_heads_bf16_out with out_dtype as well — G4C_DTYPE_BF16 stores the launch's own output rows (after LayerNorm
+ * and the activation) as bf16 (out is then a bf16 pointer, out_ld in elements, a multiple of 4): the edge latents between consecutive
+ * EdgeMPs of a level, whose only reader is the next update MLP — which rounds them to bf16 on load (same operand, half the bytes in
+ * both launches).  The heads are computed from the fp32 rows either way. */
+int g4c_mlp_forward_heads_bf16_rows(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
+                                    int64_t n_rows, void *out, int32_t out_ld, int32_t out_dtype, int32_t act,
+                                    const void *head_w, int32_t n_heads, void *const *head_out /*host*/, int32_t head_ld,
+                                    int32_t head_dtype, void *stream);
 int g4c_mlp_forward_bf16_out(const g4c_mlp_t *mlp /*host*/, const g4c_src_t *srcs /*host*/, int32_t n_src,
                              int64_t n_rows, void *out, int32_t out_ld, int32_t out_dtype, int32_t act, void *stream);
 

@@ -1872,6 +1872,27 @@ def test_remus_entry_products_come_from_the_producer_launch(prec):
         ops.set_mlp_precision(old)
 
 
+def test_remus_compact_edge_latents_are_the_same_operand():
+    """blocks.COMPACT_LATENTS (round 6, rounded-bf16 mode): the edge latents between consecutive EdgeMPs of a level are stored as bf16
+    rows by the update launch (g4c_mlp_forward_heads_bf16_rows) — their only reader, the next update MLP, rounds them to bf16 on load:
+    the forward is bit-identical."""
+    old = ops.set_mlp_precision("bf16")
+    was = B.COMPACT_LATENTS
+    try:
+        g = S.remus_graph(20_000, k=5, seed=51).to(DEV)
+        torch.manual_seed(52)
+        model = gfd.nn.NsRotEquiTreeScaleGNN(arch=S.remus_arch(128), device=DEV)
+        outs = {}
+        for on in (False, True):
+            B.COMPACT_LATENTS = on
+            with torch.no_grad():
+                outs[on] = model.forward(g.clone()).clone()
+        assert torch.equal(outs[True], outs[False]), (outs[True] - outs[False]).abs().max().item()
+    finally:
+        B.COMPACT_LATENTS = was
+        ops.set_mlp_precision(old)
+
+
 def test_bf16_product_rows_are_exact_copies():
     """Rounded-bf16 mode, round 5 (blocks.PRODUCTS_BF16): the hoisted first-layer products are stored as bf16.  The kernels only
     change representation — (a) head rows / plain output rows stored as bf16 are the round-to-nearest bf16 of the fp32 rows the same
