@@ -718,6 +718,12 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
     return v_new, e_new
 
 
+def compact_latents_now(width: int = 128) -> bool:
+    """Whether a launch whose output rows are read by nothing but the next update MLP may store them as bf16 (COMPACT_LATENTS)."""
+    return bool(COMPACT_LATENTS and ops.mlp_precision() == "bf16" and width == 128 and not ops.grad_mode()
+                and ops.effective_precision([128, 128]) == "bf16")
+
+
 def pending_act(e: Optional[Tensor]) -> int:
     """Activation still to be applied to the messages `_mp_step` returned: SELU for fp32 rows (stored raw, the aggregation needed them
     so), none for compact bf16 rows (stored activated)."""
@@ -907,7 +913,7 @@ class DownEdgeMP(nn.Module):
                                  _lib.ACT_NONE if code is None else code, v_src=e1)
             return _finish(e2_new, activation, code), None
         e2_new, _, prods = _mp_step(self.angle_mlp, self.edge_mlp, e2, a12, angle_index12, "mean", code, v_src=e1,
-                                    next_msg=next_msg, next_graph=next_graph)
+                                    next_msg=next_msg, next_graph=next_graph, compact_v=True)      # (e2' is read by that EdgeMP only)
         return e2_new, prods
 
 
@@ -958,8 +964,9 @@ class UpEdgeMP(nn.Module):
         code = _lib.act_code(activation)
         if next_msg is not None and code is not None and next_graph is not None and next_graph[0] >= HOIST_MIN_ROWS:
             w = self.up_mlp.output_size
+            out16 = torch.empty((ep.n_edges, 128), dtype=torch.bfloat16, device=pos.device) if compact_latents_now(w) else None
             got = self.up_mlp.run_with_heads([Source(e1), Source(edge_attr1)], ep.n_edges, code, next_msg, next_msg.input_size - 2 * w, [w, w],
-                                             rs_rows=next_msg.rs1_ready(*next_graph))
+                                             rs_rows=next_msg.rs1_ready(*next_graph), out=out16)      # (e1' is read by that EdgeMP only)
             if got is not None:
                 return got
         return self.up_mlp.run([Source(e1), Source(edge_attr1)], ep.n_edges, activation=activation), None

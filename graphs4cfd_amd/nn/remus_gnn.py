@@ -115,8 +115,10 @@ class NsRotEquiTreeScaleGNN(GNN):
                 n_ang = int(getattr(g, f"angle_index{s}").size(1))
                 if n_ang >= _blocks.HOIST_MIN_ROWS:
                     enc = getattr(self, f"edge_encoder{s}")
+                    out16 = (torch.empty((ep.n_edges, 128), dtype=torch.bfloat16, device=proj.device)
+                             if _blocks.compact_latents_now(enc.output_size) else None)       # (e is read by that EdgeMP's update MLP only)
                     got = enc.run_with_heads(enc_src, ep.n_edges, SELU, first, first.input_size - 2 * enc.output_size,
-                                             [enc.output_size] * 2, rs_rows=first.rs1_ready(n_ang, plan.edge_csr(getattr(g, f"angle_index{s}"), ep.n_edges)[1]))
+                                             [enc.output_size] * 2, out=out16, rs_rows=first.rs1_ready(n_ang, plan.edge_csr(getattr(g, f"angle_index{s}"), ep.n_edges)[1]))
                     if got is not None:
                         e[lvl], entry_products = got
             if e[lvl] is None:
