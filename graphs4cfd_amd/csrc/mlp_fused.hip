@@ -648,8 +648,8 @@ constexpr int G4C_F16_MINW = 4;
 // no column masks anywhere.
 template <int RT, bool VEC, bool FULL, int SP, bool SAVE = false, int RD6 = 2>
 __global__ __launch_bounds__(256, RD6 > 2 ? 2 : (SP == 2 ? G4C_F16_MINW : G4C_BX6_MINW)) void mlp_bx6_kernel(const Params p) {
-    static_assert(RT == 1, "64-row tiles (RT = 2) measured slower in every arithmetic (480 against 446 us, two / three workgroups per CU) and cannot "
-                           "take the fused aggregation: not instantiated since round 3");
+    static_assert(RT == 1, "64-row tiles (RT = 2) measured slower in every arithmetic (split streams, round 3: 480 against 446 us; rounded-bf16 mode, round 6, "
+                           "500k-row edge update with heads: 288 against 255 us) and cannot take the fused aggregation: not instantiated");
     constexpr int ROWS = 32 * RT, NW = 4;
     constexpr int PLN = ROWS * HB;              // one bf16 operand plane [ROWS][136]
     // three operand planes; the fp32 final tile [ROWS][132] aliases them
