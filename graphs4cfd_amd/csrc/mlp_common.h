@@ -316,6 +316,8 @@ int ws_launch(const Params &p, bool agg, bool round1, hipStream_t st, const Node
 // row-split persistent kernel (mlp_rs.hip, round 6): f16x3 stream, hoisted three-layer message form
 bool rs_eligible(const Params &p, bool agg, long long row_count);
 int rs_launch(const Params &p, bool agg, hipStream_t st);
+bool rs2_eligible(const Params &p, long long row_count);
+int rs2_launch(const Params &p, bool e_natural, hipStream_t st);
 
 // four bf16 values (two dwords as loaded) widened to fp32: a shift / a mask each — exact
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));

@@ -1428,9 +1428,10 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     const bool round1 = (tile_rows == 3216);     // operands rounded to bf16: only the leading plane of the stream is used
     const bool bx6 = (tile_rows == 3248) || round1;   // weights: the three-plane stream of g4c_mlp_pack_layer_bx6
     const bool rs_fmt = round1 && mlp && mlp->w_format == G4C_WFMT_BF16_RS;     // the rounded-bf16 stream in the row-split kernel's k order: that kernel only
+    const bool rs2_fmt = round1 && mlp && (mlp->w_format == G4C_WFMT_BF16_RS2 || mlp->w_format == G4C_WFMT_BF16_RS2N);     // ... its update-MLP form
     const bool f16x2 = bx6 && mlp && mlp->w_format == G4C_WFMT_F16X2;     // the stream holds the two-way fp16 split (g4c_mlp_pack_layer_f16x3)
     G4C_REQUIRE(!(f16x2 && round1), G4C_EINVAL, "g4c_mlp_forward_bf16: the weights were packed by g4c_mlp_pack_layer_f16x3 (fp16 planes)");
-    G4C_REQUIRE(!mlp || mlp->w_format == 0 || f16x2 || rs_fmt, G4C_EINVAL, "g4c_mlp_forward: w_format %d does not match this entry point", mlp->w_format);
+    G4C_REQUIRE(!mlp || mlp->w_format == 0 || f16x2 || rs_fmt || rs2_fmt, G4C_EINVAL, "g4c_mlp_forward: w_format %d does not match this entry point", mlp->w_format);
     const bool bf16 = bx6;                       // input blocks padded to 128 k
     const int wbytes = bx6 ? 6 : 4;
     if (bf16) tile_rows = 324;
@@ -1643,6 +1644,12 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
                     "g4c_mlp_forward_bf16: weights packed for the row-split kernel (G4C_WFMT_BF16_RS), launch outside its envelope");
         g_last_kernel = G4C_KERNEL_MLP_RS;
         return rs_launch(p, agg != nullptr, st);
+    }
+    if (rs2_fmt) {
+        G4C_REQUIRE(!save && !node && !force_tiles && !agg && rs2_eligible(p, row_count), G4C_EUNSUPPORTED,
+                    "g4c_mlp_forward_bf16: weights packed for the row-split update kernel (G4C_WFMT_BF16_RS2), launch outside its envelope");
+        g_last_kernel = G4C_KERNEL_MLP_RS;
+        return rs2_launch(p, mlp->w_format == G4C_WFMT_BF16_RS2N, st);
     }
     if (bx6 && !force_tiles && ws_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {
         // weight-stationary persistent kernel (mlp_ws.hip): pairs of 32-row tiles (whole segments with aggregation), one workgroup per CU

@@ -355,6 +355,205 @@ __global__ __launch_bounds__(RS_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The update MLP of such a layer in the same form ("rs2"): [aggregate | e] -> Linear (256 -> 128) -> SELU -> Linear -> LayerNorm -> SELU
+// -> e' (+ the next layer's two hoisted products W1s e', W1r e' as heads) for REMuS-GNN's edge update (graphs4cfd/nn/blocks.py:331-333
+// with the next EdgeMP's nn/blocks.py:327).  Both input blocks are bf16 rows in the row-split order (the aggregate of mlp_rs1_kernel,
+// G4C_AGG_OUT_BF16; the compact edge latents of the previous launch of this kernel), every stored bf16 row is in that order too.
+// The five 128 x 128 weight blocks (two of the first layer, the second layer, two heads) are 160 KB of bf16 — ALL of a CU's LDS — so
+// the bias / LayerNorm vectors live in registers (128 per lane: the four values of each of the eight feature blocks a lane owns).
+//   OUT16  e' is stored as bf16 rows in the row-split order (its one reader: the next launch of this kernel) / as fp32 rows in feature order
+//   HEADS  the two heads are computed and stored (bf16, row-split order)
+//   ENAT   the e block's bf16 rows are in FEATURE order (G4C_WFMT_BF16_RS2N: rows a tile-kernel launch stored — the first update of a
+//          run of EdgeMPs): two 8-byte loads per 32-feature step instead of one 16-byte load
+template <bool OUT16, bool HEADS, bool ENAT>
+__global__ __launch_bounds__(RS_WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_rs2_kernel(const Params p) {
+    constexpr int NB = HEADS ? 5 : 3;          // weight blocks: L0 (aggregate), L0 (e), L1, head 0, head 1
+    __shared__ __attribute__((aligned(1024))) char sW2[NB * 32 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    int R0, R1;
+    {
+        const int G = gridDim.x, b = blockIdx.x;
+        const int slot = (G & 7) ? b : (b & 7) * (G >> 3) + (b >> 3);
+        const long long chunks = (p.M + 15) >> 4, gw = (long long)slot * RS_WAVES + wave, nw = (long long)G * RS_WAVES;
+        R0 = __builtin_amdgcn_readfirstlane((int)((gw * chunks) / nw) * 16);
+        const long long r1 = ((gw + 1) * chunks) / nw * 16;
+        R1 = __builtin_amdgcn_readfirstlane((int)(r1 < p.M ? r1 : p.M));
+    }
+    {
+        const unsigned lds_w = (unsigned)reinterpret_cast<uintptr_t>(sW2);
+#pragma unroll
+        for (int l = 0; l < NB; ++l) {
+            const char *src = reinterpret_cast<const char *>(p.w) + (size_t)l * (2u * BLOCK6);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = wave * 4 + j;          // = ct * 8 + st
+                rs_dma16(src + (size_t)q * 3072 + lane * 16, lds_w + (unsigned)(l * 32768 + q * 1024));
+            }
+        }
+        rs_vm_wait0();
+    }
+    // the lane's bias / LayerNorm values (features 16 b + 4 g + e)
+    f32x4 cb0[8], cb1[8], cg[8], cbe[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        cb0[b] = *reinterpret_cast<const f32x4 *>(p.b + 16 * b + 4 * g);
+        cb1[b] = *reinterpret_cast<const f32x4 *>(p.b + NP + 16 * b + 4 * g);
+        cg[b] = *reinterpret_cast<const f32x4 *>(p.gamma + 16 * b + 4 * g);
+        cbe[b] = *reinterpret_cast<const f32x4 *>(p.beta + 16 * b + 4 * g);
+    }
+    __syncthreads();
+    if (R1 <= R0) return;
+    const unsigned frag_lane = (unsigned)((g >> 1) * 1024 + ((g & 1) * 32 + n) * 16);
+    auto wfrag = [&](int l, int b, int ks) __attribute__((always_inline)) {
+        return *reinterpret_cast<const bf16x8 *>(sW2 + (unsigned)(l * 32768 + ((b >> 1) * 8 + 2 * ks) * 1024 + (b & 1) * 256) + frag_lane);
+    };
+    auto row_of = [&](int rd) __attribute__((always_inline)) { const int r = R0 + 16 * rd + n; return r < R1 ? r : R1 - 1; };
+    auto to_op = [&](f32x4 y, bf16x8 &o, int half) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[4 * half + e] = (__bf16)y[e];
+    };
+    u32x4v xin[2][4];          // the chunk's two input blocks, 16 bytes per 32-feature step: the MFMA operands as they are
+    auto request_x = [&](int rd) __attribute__((always_inline)) {
+        const int row = row_of(rd);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (ENAT && s2 == 1) {
+                const __bf16 *xr = reinterpret_cast<const __bf16 *>(p.src[1].ptr) + (long long)row * p.src[1].ld + p.src[1].col0 + 4 * g;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const u32x2 lo = *reinterpret_cast<const u32x2 *>(xr + 32 * ks), hi = *reinterpret_cast<const u32x2 *>(xr + 32 * ks + 16);
+                    xin[1][ks][0] = lo[0]; xin[1][ks][1] = lo[1]; xin[1][ks][2] = hi[0]; xin[1][ks][3] = hi[1];
+                }
+            } else {
+                const __bf16 *xr = reinterpret_cast<const __bf16 *>(p.src[s2].ptr) + (long long)row * p.src[s2].ld + p.src[s2].col0 + 8 * g;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) xin[s2][ks] = *reinterpret_cast<const u32x4v *>(xr + 32 * ks);
+            }
+        }
+    };
+    const int rounds = (R1 - R0 + 15) >> 4;
+    const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000);
+    request_x(0);
+    // (stores the bounds check drops: the loop is entered the way its back edge enters it — see mlp_rs1_kernel)
+#pragma unroll
+    for (int b = 0; b < (HEADS ? 8 : 0) + (OUT16 ? 4 : 8); ++b)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4v{0u, 0u, 0u, 0u}, none, 0x7ffff000u + 16u * b, 0, 0);
+    for (int rd = 0; rd < rounds; ++rd) {
+        asm volatile("" ::: "memory");          // (the weights in LDS are loop-invariant: without this hipcc hoists their reads and spills)
+        bf16x8 in[2][4], out[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) in[s2][ks] = __builtin_bit_cast(bf16x8, xin[s2][ks]);
+        // ---- layer 0: eight feature blocks x (two input blocks x four 32-k steps)
+        {
+            bf16x8 f[4];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) f[q] = wfrag(q >> 2 & 1, 0, q & 3);
+            f32x4 acc[2], v;
+            auto epilogue = [&](int eb, int k) __attribute__((always_inline)) {
+                if (k == 0) v = acc[eb & 1];
+                else if (k == 1) v = rs1_selu4(v);
+                else if (k == 2) to_op(v, out[eb >> 1], eb & 1);
+            };
+#pragma unroll
+            for (int st = 0; st < 64; ++st) {          // st = 8 b + 4 blk + ks
+                const int b = st >> 3, blk = (st >> 2) & 1, ks = st & 3;
+                if (st + 3 < 64) { const int t = st + 3; f[t % 4] = wfrag((t >> 2) & 1, t >> 3, t & 3); }
+                if ((st & 7) == 0) acc[b & 1] = cb0[b];
+                if (b > 0 && (st & 7) < 3) epilogue(b - 1, st & 7);
+                acc[b & 1] = mfma16b(f[st % 4], in[blk][ks], acc[b & 1]);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) epilogue(7, k);
+        }
+        // ---- the next chunk's rows (into the registers layer 0 has just released), in front of this chunk's stores
+        request_x(rd + 1 < rounds ? rd + 1 : rd);
+        // ---- layer 1
+        f32x4 y[8];
+        {
+            bf16x8 f[4];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) f[q] = wfrag(2, 0, q);
+            f32x4 acc[2];
+#pragma unroll
+            for (int st = 0; st < 32; ++st) {
+                const int b = st >> 2, ks = st & 3;
+                if (st + 3 < 32) f[(st + 3) % 4] = wfrag(2, (st + 3) >> 2, (st + 3) & 3);
+                if (ks == 0) acc[b & 1] = cb1[b];
+                if (b > 0 && ks == 0) y[b - 1] = acc[(b - 1) & 1];
+                acc[b & 1] = mfma16b(f[st % 4], out[ks], acc[b & 1]);
+            }
+            y[7] = acc[1];
+        }
+        // ---- LayerNorm, activation
+        {
+            float s = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) s += (y[b][0] + y[b][1]) + (y[b][2] + y[b][3]);
+            const float mean = sum_over_g(s) * (1.0f / NP);
+            float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const float d0 = y[b][0] - mean, d1 = y[b][1] - mean, d2 = y[b][2] - mean, d3 = y[b][3] - mean;
+                q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1); q0 = fmaf(d2, d2, q0); q1 = fmaf(d3, d3, q1);
+            }
+            const float rstd = rsqrtf(sum_over_g(q0 + q1) * (1.0f / NP) + p.eps);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[b][e] = fmaf((y[b][e] - mean) * rstd, cg[b][e], cbe[b][e]);
+                if (p.act == G4C_ACT_SELU) y[b] = rs1_selu4(y[b]);
+            }
+        }
+        const int row_st = row_of(rd);
+        // ---- e'
+        if constexpr (OUT16) {
+            __bf16 *op = reinterpret_cast<__bf16 *>(p.out) + (long long)row_st * p.out_ld + 8 * g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o[e] = (__bf16)y[2 * j][e]; o[4 + e] = (__bf16)y[2 * j + 1][e]; }
+                *reinterpret_cast<bf16x8 *>(op + 32 * j) = o;
+            }
+        } else {
+            float *op = p.out + (long long)row_st * p.out_ld + 4 * g;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) *reinterpret_cast<f32x4 *>(op + 16 * b) = y[b];
+        }
+        // ---- the heads: 128 x 128 products of the activated row, stored as bf16 rows in the row-split order
+        if constexpr (HEADS) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) to_op(y[b], out[b >> 1], b & 1);
+#pragma unroll
+            for (int hd = 0; hd < 2; ++hd) {
+                __bf16 *hp = reinterpret_cast<__bf16 *>(p.head_out[hd]) + (long long)row_st * p.head_ld + 8 * g;
+                bf16x8 f[4];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) f[q] = wfrag(3 + hd, 0, q);
+                f32x4 acc[2];
+#pragma unroll
+                for (int st = 0; st < 32; ++st) {
+                    const int b = st >> 2, ks = st & 3;
+                    if (st + 3 < 32) f[(st + 3) % 4] = wfrag(3 + hd, (st + 3) >> 2, (st + 3) & 3);
+                    if (ks == 0) acc[b & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc[b & 1] = mfma16b(f[st % 4], out[ks], acc[b & 1]);
+                    if (ks == 3 && (b & 1)) {
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { o[e] = (__bf16)acc[0][e]; o[4 + e] = (__bf16)acc[1][e]; }
+                        *reinterpret_cast<bf16x8 *>(hp + 16 * (b - 1)) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 namespace g4cm {
@@ -393,6 +592,30 @@ int rs_launch(const Params &p, bool agg, hipStream_t st) {
 #undef G4C_RS1_XA
 #undef G4C_RS1
     return g4c::check_launch("g4c_mlp_forward_bf16 (rs)");
+}
+
+bool rs2_eligible(const Params &p, long long row_count) {
+    if (p.n_src != 2 || p.n_nar != 0 || p.n_add != 0 || p.n_layers != 2 || p.n_out != NP || p.resid || p.out_idx || p.agg || !p.out) return false;
+    if (p.n_heads != 0 && (p.n_heads != 2 || !p.head_bf16 || (p.head_ld & 7) || ((uintptr_t)p.head_out[0] & 15) || ((uintptr_t)p.head_out[1] & 15))) return false;
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const Src &s = p.src[s2];
+        if (s.width != NP || !s.vec || s.seg_off || s.idx || !s.bf16 || s.pre_act || (s.ld & 7) || (s.col0 & 7) || ((uintptr_t)s.ptr & 15)) return false;
+    }
+    if ((p.out_ld & (p.out_bf16 ? 7 : 3)) || ((uintptr_t)p.out & 15) || p.out_bf16 > 1) return false;
+    if (!p.gamma || (p.act != G4C_ACT_NONE && p.act != G4C_ACT_SELU) || ((uintptr_t)p.gamma & 15) || ((uintptr_t)p.beta & 15) || ((uintptr_t)p.b & 15)) return false;
+    return p.M < (1LL << 31) && p.row_base == 0 && row_count == p.M;
+}
+
+int rs2_launch(const Params &p, bool e_natural, hipStream_t st) {
+    if (p.M == 0) return G4C_OK;
+    const int n_cu = g4c::cu_count();
+    const long long chunks = (p.M + 15) / 16, want = (chunks + RS_WAVES - 1) / RS_WAVES;
+    const dim3 grid((unsigned)(want < n_cu ? want : n_cu)), blk(RS_WAVES * 64);
+#define G4C_RS2(O16, HD) do { if (e_natural) mlp_rs2_kernel<O16, HD, true><<<grid, blk, 0, st>>>(p); else mlp_rs2_kernel<O16, HD, false><<<grid, blk, 0, st>>>(p); } while (0)
+    if (p.n_heads) { if (p.out_bf16) G4C_RS2(true, true); else G4C_RS2(false, true); }
+    else { if (p.out_bf16) G4C_RS2(true, false); else G4C_RS2(false, false); }
+#undef G4C_RS2
+    return g4c::check_launch("g4c_mlp_forward_bf16 (rs2)");
 }
 
 }  // namespace g4cm

@@ -250,6 +250,10 @@ class MLP(nn.Module):
     def run_coded(self, sources: Sequence[Source], n_rows: int, act_code: int = _lib.ACT_NONE, **kw) -> Tensor:
         if not self.fits_one_launch():
             return self._run_stages(sources, n_rows, act_code, **kw)
+        fmt = self._rs2_format(sources, n_rows, act_code, kw)
+        if fmt:
+            y = ops.mlp_forward(self._rs2_packed(fmt, None, 0, ()), sources, n_rows, act_code, **kw)
+            return ops.RsOrderedRows.tag(y) if y.dtype == torch.bfloat16 else y
         sources = _split_wide(sources)
         pk = self.packed([s.width for s in sources], [s.negate for s in sources], _narrow_flags(sources), _rs_blocks(sources))
         return ops.mlp_forward(pk, sources, n_rows, act_code, **kw)
@@ -299,6 +303,15 @@ class MLP(nn.Module):
             return None
         if ops.grad_mode():          # recorded for autograd: the plain launches are the differentiable ones
             return None
+        if not any(t is not None for t in (head_outs or ())) and PRODUCTS_BF16 and HOIST_BF16:
+            fmt = self._rs2_format(sources, n_rows, act_code, {} if out is None else {"out": out}, rs_rows)
+            pk2 = self._rs2_packed(fmt, consumer, k_cols, widths) if fmt else None
+            if pk2 is not None:          # the row-split update kernel: e' (+ the consumer's products) from rows in its own order
+                dev = sources[0].tensor.device
+                y = out if out is not None else torch.empty((n_rows, 128), dtype=torch.float32, device=dev)
+                outs = [torch.empty((n_rows, 128), dtype=torch.bfloat16, device=dev) for _ in range(2)]
+                ops.mlp_forward(pk2, sources, n_rows, act_code, out=y, head_outs=outs)
+                return (ops.RsOrderedRows.tag(y) if y.dtype == torch.bfloat16 else y), [ops.RsOrderedRows.tag(t) for t in outs]
         sources = _split_wide(sources)
         prec = ops.effective_precision([s.width for s in sources])
         if prec == "bf16" and not HOIST_BF16:
@@ -404,6 +417,50 @@ class MLP(nn.Module):
         pk = self._packed_cols("hoist", 0, sum(kw_widths), kw_widths, [s.negate for s in k_sources], False)
         return ops.mlp_forward(pk, list(k_sources) + adds, n_rows, act_code, **kw)
 
+    # -- rounded-bf16 mode: the update MLP of such a layer on the row-split update kernel -------------------------------------
+    def _rs2_format(self, sources: Sequence[Source], n_rows: int, act_code: int, kw: dict, rs_rows: bool = True) -> int:
+        """0, or the stream format (ops.PackedMLP rs2: 4 / 5) of mlp_rs2_kernel when this launch fits it: [aggregate | e] as two whole
+        128-wide bf16 blocks — the aggregate in the row-split order (blocks.AGGREGATE_BF16), e in that order (4) or in feature order (5) —
+        two layers 256 -> 128 -> 128, LayerNorm, activation none / SELU, plain fp32 or bf16 output rows."""
+        if not (ROW_SPLIT_BF16 and UPDATE_ROW_SPLIT) or ops.mlp_precision() != "bf16" or ops.grad_mode() or n_rows < RS1_MIN_ROWS:
+            return 0
+        if len(sources) != 2 or act_code not in (_lib.ACT_NONE, _lib.ACT_SELU) or not rs_rows or not set(kw) <= {"out"}:
+            return 0
+        for s_ in sources:
+            if (s_.width != 128 or s_.col0 != 0 or s_.negate or s_.index is not None or s_.segments is not None or s_.additive
+                    or s_.pre_act != _lib.ACT_NONE or s_.tensor.dtype != torch.bfloat16 or s_.tensor.stride(0) % 8 or s_.tensor.data_ptr() % 16):
+                return 0
+        if not isinstance(sources[0].tensor, ops.RsOrderedRows):
+            return 0
+        lin = self._linears()
+        if (len(lin) != 2 or tuple(lin[0].weight.shape) != (128, 256) or tuple(lin[1].weight.shape) != (128, 128)
+                or getattr(self.MLP, "layer_norm", None) is None):
+            return 0
+        out = kw.get("out")
+        if out is not None and (out.dtype not in (torch.float32, torch.bfloat16) or out.stride(1) != 1 or out.data_ptr() % 16
+                                or out.stride(0) % (8 if out.dtype == torch.bfloat16 else 4)):
+            return 0
+        return 4 if isinstance(sources[1].tensor, ops.RsOrderedRows) else 5
+
+    def _rs2_packed(self, fmt: int, consumer: Optional["MLP"], k_cols: int, widths) -> Optional[ops.PackedMLP]:
+        key = ("rs2", fmt, None if consumer is None else id(consumer), k_cols, tuple(widths))
+        sig = (self._signature(), None if consumer is None else consumer._signature())
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != sig:
+            lin = self._linears()
+            ln = self.MLP.layer_norm
+            heads = []
+            if consumer is not None:
+                w1 = consumer._linears()[0].weight.detach()
+                if int(w1.size(0)) != 128 or tuple(int(w) for w in widths) != (128, 128):
+                    return None
+                heads = [w1[:, k_cols + 128 * j: k_cols + 128 * (j + 1)].contiguous() for j in range(2)]      # (rows in feature order: the kernel's stores order them)
+            pk = ops.PackedMLP([l.weight for l in lin], [l.bias for l in lin], (ln.weight, ln.bias, ln.eps), [128, 128], [False, False],
+                               heads=heads, precision="bf16", site=self._site, rs2=fmt)
+            self._packed[key] = (sig, pk)
+            hit = self._packed[key]
+        return hit[1]
+
     # -- rounded-bf16 mode: uniform-degree message launches on the row-split kernel ------------------------------------------
     def rs1_ready(self, n_rows: int, csr) -> bool:
         """Whether a message launch of this MLP over `csr` (its rows grouped by receiver) is one the row-split kernel takes in the
@@ -431,8 +488,10 @@ class MLP(nn.Module):
             return False
         if x.tensor.dtype == torch.bfloat16 and not (isinstance(x.tensor, ops.RsOrderedRows) and x.pre_act == _lib.ACT_NONE):
             return False
-        if any(int(t.size(1)) != 128 or t.dtype not in (torch.float32, torch.bfloat16) or isinstance(t, ops.RsOrderedRows) for t, _ in gathered):
+        if any(int(t.size(1)) != 128 for t, _ in gathered):
             return False
+        if products is None and any(t.dtype not in (torch.float32, torch.bfloat16) for t, _ in gathered):
+            return False          # (the product launches read them; tagged rows are restored to feature order there)
         if products is not None and not (len(products) == 2 and all(isinstance(t, ops.RsOrderedRows) for t in products)):
             return False
         if kw.get("rows_dtype") == torch.bfloat16 and kw.get("store_rows", True) and kw.get("rows_act", _lib.ACT_NONE) != _lib.ACT_SELU:
@@ -567,6 +626,10 @@ AGGREGATE_BF16 = __import__('os').environ.get('G4C_AGGREGATE_BF16', '1') != '0'
 # ... and the edge latents BETWEEN consecutive EdgeMPs of a level — read only by the next update MLP, which rounds them to bf16 on load —
 # are stored as bf16 rows by the update launch (g4c_mlp_forward_heads_bf16_rows): the same operand, half the bytes in both launches.
 COMPACT_LATENTS = __import__('os').environ.get('G4C_COMPACT_LATENTS', '1') != '0'
+# ... and the update MLP of such a layer — [bf16 aggregate | bf16 e] -> two layers -> LayerNorm -> SELU -> e' (+ the next layer's two
+# product heads) — runs on the row-split UPDATE kernel (mlp_rs.hip, mlp_rs2_kernel: the five 128 x 128 weight blocks are all of a CU's
+# LDS, the bias / LayerNorm vectors live in registers), e' as bf16 rows in the kernel's order between consecutive EdgeMPs.
+UPDATE_ROW_SPLIT = __import__('os').environ.get('G4C_UPDATE_ROW_SPLIT', '1') != '0'
 RS1_MIN_ROWS = 20000
 
 

@@ -576,7 +576,7 @@ class PackedMLP:
     def __init__(self, weights: Sequence[Tensor], biases: Sequence[Tensor], ln: Optional[Tuple[Tensor, Tensor, float]],
                  seg_widths: Sequence[int], seg_negate: Sequence[bool], heads: Sequence[Tensor] = (),
                  precision: str = "fp32", narrow: Optional[Sequence[bool]] = None, site: Optional[str] = None, rs_order: bool = False,
-                 rs_blocks: Optional[Sequence[bool]] = None):
+                 rs_blocks: Optional[Sequence[bool]] = None, rs2: int = 0):
         """`heads`: bias-free [128, 128] weights applied to the MLP's final output row (g4c_mlp_forward_heads); their
         packed images continue the weight stream after the last layer.  `precision` "bf16": the bf16 stream of
         g4c_mlp_pack_layer_bx6 (every input block padded to 128 k; "bf16" uses the same stream, leading plane only).
@@ -614,7 +614,14 @@ class PackedMLP:
         if self.rs_order and (precision != "bf16" or heads or len(seg_widths) != 1 or seg_widths[0] != 128 or any(narrow or ())
                               or any(tuple(W.shape) != (128, 128) for W in weights)):
             raise NotImplementedError("rs_order: rounded-bf16 mode, one 128-wide input block, 128 x 128 layers, no heads")
-        self.desc.w_format = 1 if self.split == "f16x2" else (3 if self.rs_order else 0)
+        # `rs2` (4 / 5 = G4C_WFMT_BF16_RS2 / _RS2N): the stream of the row-split UPDATE kernel (mlp_rs2_kernel): two 128-wide input
+        # blocks, two layers, optional heads — the columns of every 128-wide block of every layer and head in the order `_rs_k_order`
+        self.rs2 = int(rs2)
+        if self.rs2 and (self.rs2 not in (4, 5) or precision != "bf16" or self.rs_order or tuple(seg_widths) != (128, 128) or any(narrow or ())
+                         or len(weights) != 2 or tuple(weights[0].shape) != (128, 256) or tuple(weights[1].shape) != (128, 128)
+                         or len(heads) not in (0, 2) or any(tuple(h.shape) != (128, 128) for h in heads) or any(seg_negate)):
+            raise NotImplementedError("rs2: rounded-bf16 mode, [128 | 128] -> 128 -> 128, no or two 128 x 128 heads")
+        self.desc.w_format = 1 if self.split == "f16x2" else (3 if self.rs_order else (self.rs2 if self.rs2 else 0))
         # `rs_blocks[j]` (rounded-bf16 mode): input block j arrives as RsOrderedRows — bf16 rows in the row-split kernel's column order
         # (its aggregate, G4C_AGG_OUT_BF16) — and is read by a kernel that knows nothing of that order: the COLUMNS of the first layer's
         # block j are packed in the same order instead, the product is the same sum in another order.
@@ -682,6 +689,9 @@ class PackedMLP:
                 Wc = W.detach().to(torch.float32).contiguous()
                 if self.rs_order:
                     Wc = Wc[:, _rs_k_order(dev)].contiguous()
+                if self.rs2:
+                    o = _rs_k_order(dev)
+                    Wc = Wc[:, torch.cat([c0 + o for c0 in range(0, k_in, 128)])].contiguous()
                 if l == 0 and any(self.rs_blocks):
                     cols = torch.arange(k_in, device=dev)
                     for j, r in enumerate(self.rs_blocks):
@@ -703,6 +713,8 @@ class PackedMLP:
         zero = (C.c_int32 * 1)(0)
         for W in heads:
             Wc = W.detach().to(torch.float32).contiguous()
+            if self.rs2:
+                Wc = Wc[:, _rs_k_order(dev)].contiguous()
             _lib.check(pack(_lib.ptr(Wc), NP, NP, one, zero, 1, stream_buf.data_ptr() + esz * off, NP, NP, stream))
             off += NP * NP
         self.n_out = int(weights[-1].size(0))
@@ -808,7 +820,11 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                                           "call under torch.no_grad() or use the plain form")
             return _ag.mlp(packed, sources, n_rows, act, resid, resid_col0)
     lib = _lib.load()
-    if packed.rs_order and packed.precision == "bf16":
+    if packed.rs2:
+        ok = [isinstance(s.tensor, RsOrderedRows) for s in sources]
+        if len(sources) != 2 or not ok[0] or ok[1] != (packed.rs2 == 4) or any(s.tensor.dtype != torch.bfloat16 for s in sources):
+            raise ValueError("weights packed for the row-split update kernel: [aggregate | e] as bf16 rows, the aggregate (and, format 4, e) RsOrderedRows")
+    elif packed.rs_order and packed.precision == "bf16":
         # (the row-split kernel's rounded-bf16 stream: its bf16 rows are in ITS column order, nobody else's)
         if any(s.tensor.dtype == torch.bfloat16 and not isinstance(s.tensor, RsOrderedRows) for s in sources):
             raise ValueError("weights packed for the row-split kernel: bf16 rows must be RsOrderedRows (its column order)")

@@ -158,6 +158,13 @@ typedef struct {
 #define G4C_WFMT_F16X2 1
 #define G4C_WFMT_BF16_RS 3       /* the bf16 stream of g4c_mlp_pack_layer_bx6 (rounded-bf16 mode: its leading plane) with the row-split
                                   * kernel's k order, see "row-split order" at g4c_mlp_forward_bf16 */
+#define G4C_WFMT_BF16_RS2 4      /* ... the update MLP of such a layer on the row-split update kernel (csrc/mlp_rs.hip, mlp_rs2_kernel;
+                                  * g4c_mlp_forward_bf16_out / g4c_mlp_forward_heads_bf16_rows): TWO weighted 128-wide bf16 blocks
+                                  * [aggregate | e] in the row-split order, two layers (256 -> 128 -> 128), LayerNorm, activation none /
+                                  * SELU, no heads or two bf16 heads; the columns of every 128-wide block of every layer AND of the heads
+                                  * are packed in the row-split order (the heads' ROWS are not permuted: the kernel's stores put them in
+                                  * that order); bf16 output rows and head rows come out in the row-split order, fp32 rows in feature order */
+#define G4C_WFMT_BF16_RS2N 5     /* the same with the e block's rows in FEATURE order (rows a launch of another kernel stored) */
 
 /* Packs one nn.Linear weight W[n_out, k_in] (row-major, device) for the kernel.  The input
  * dimension is the concatenation of `n_seg` column blocks of widths seg_width[] (each padded
