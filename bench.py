@@ -236,7 +236,7 @@ def reference_flop_per_step(model, g):
 
 KERNEL_SOURCES = {"mlp_ws_kernel": ("mlp_ws.hip", "mlp_common.h"), "mlp_bx6_kernel": ("mlp_fused.hip", "mlp_common.h"),
                   "mlp_bx6i_kernel": ("mlp_bx6i.hip", "mlp_common.h"), "mlp_split_kernel": ("mlp_fused.hip", "mlp_common.h"),
-                  "mlp_rs1_kernel": ("mlp_rs.hip", "mlp_common.h")}
+                  "mlp_rs1_kernel": ("mlp_rs.hip", "mlp_common.h"), "mlp_rs2_kernel": ("mlp_rs.hip", "mlp_common.h")}
 
 
 def source_sha16(kernel):
@@ -299,12 +299,14 @@ def roofline_blocks(args, result, model, graph_cpu, dev, ops, Rollout):
     summ = kt.summary()
     remus = args.model == "NsRotEquiTreeScaleGNN"
 
-    SPLIT_FAMILY = ("mlp_bx6_kernel", "mlp_bx6i_kernel", "mlp_ws_kernel", "mlp_rs1_kernel")      # kernels on the bf16 / f16 matrix pipe
+    SPLIT_FAMILY = ("mlp_bx6_kernel", "mlp_bx6i_kernel", "mlp_ws_kernel", "mlp_rs1_kernel", "mlp_rs2_kernel")      # kernels on the bf16 / f16 matrix pipe
     WHAT = {"mlp_ws_kernel": "weight-stationary persistent kernel (mlp_ws.hip): message launches of >= 20k rows in the f16x3 stream / rounded-bf16 mode",
             "mlp_bx6_kernel": "split-operand 32-row tile kernel (mlp_fused.hip): node / encoder / pool / unpool / decoder launches, heads, small launches",
             "mlp_bx6i_kernel": "dual-tile kernel (mlp_bx6i.hip): message launches of >= 400k rows in the bf16x6 stream",
             "mlp_rs1_kernel": "row-split persistent kernel (mlp_rs.hip): rounded-bf16 message launches of >= 20k rows over receivers of one in-degree 4..8 "
                               "(REMuS-GNN's angle launches); a wave owns 16 rows through all layers, weights resident in LDS, aggregation a segmented scan",
+            "mlp_rs2_kernel": "row-split update kernel (mlp_rs.hip): the update MLP behind such a message launch — [bf16 aggregate | bf16 e] -> two layers -> "
+                              "LayerNorm -> SELU -> e' + two product heads, the five weight blocks = all 160 KB of LDS",
             "mlp_split_kernel": "fp32-MFMA kernel (mlp_fused.hip: g4c_mlp_forward)"}
 
     def price(kind, flops, seconds):

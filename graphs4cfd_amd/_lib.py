@@ -20,7 +20,8 @@ MAX_SRC, MAX_LAYERS = 4, 4
 MAX_HEADS = 2
 NARROW_MAX = 8
 KERNEL_MLP_RS = 5
-KERNEL_NAMES = {0: "none", 1: "mlp_split_kernel", 2: "mlp_bx6_kernel", 3: "mlp_bx6i_kernel", 4: "mlp_ws_kernel", 5: "mlp_rs1_kernel"}   # g4c_mlp_last_kernel
+KERNEL_MLP_RS2 = 6
+KERNEL_NAMES = {0: "none", 1: "mlp_split_kernel", 2: "mlp_bx6_kernel", 3: "mlp_bx6i_kernel", 4: "mlp_ws_kernel", 5: "mlp_rs1_kernel", 6: "mlp_rs2_kernel"}   # g4c_mlp_last_kernel
 
 _ACT_CODES = {None: ACT_NONE, "none": ACT_NONE, "selu": ACT_SELU, "tanh": ACT_TANH}
 

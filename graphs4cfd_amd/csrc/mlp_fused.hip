@@ -1648,7 +1648,7 @@ static int mlp_launch(const g4c_mlp_t *mlp, const g4c_src_t *srcs, int32_t n_src
     if (rs2_fmt) {
         G4C_REQUIRE(!save && !node && !force_tiles && !agg && rs2_eligible(p, row_count), G4C_EUNSUPPORTED,
                     "g4c_mlp_forward_bf16: weights packed for the row-split update kernel (G4C_WFMT_BF16_RS2), launch outside its envelope");
-        g_last_kernel = G4C_KERNEL_MLP_RS;
+        g_last_kernel = G4C_KERNEL_MLP_RS2;
         return rs2_launch(p, mlp->w_format == G4C_WFMT_BF16_RS2N, st);
     }
     if (bx6 && !force_tiles && ws_eligible(p, round1, agg != nullptr, save != nullptr, f16x2, row_count)) {

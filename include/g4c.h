@@ -269,6 +269,7 @@ int g4c_debug_mean_div(const float *a, const int32_t *count, float *out, int64_t
 #define G4C_KERNEL_MLP_BX6I 3
 #define G4C_KERNEL_MLP_WS 4
 #define G4C_KERNEL_MLP_RS 5      /* mlp_rs1_kernel: row-split persistent kernel of the rounded-bf16 mode (round 6) */
+#define G4C_KERNEL_MLP_RS2 6     /* mlp_rs2_kernel: its update-MLP form (G4C_WFMT_BF16_RS2) */
 int g4c_mlp_last_kernel(void);
 
 /* Rounded-bf16 variant (opt-in only; BASELINE config 3 "bf16 edge-MLP MFMA"): the same stream and kernel structure, but

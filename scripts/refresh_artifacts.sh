@@ -69,6 +69,7 @@ timeout 300 python scripts/remus_bf16_err.py 2>&1 | grep -v amdgpu.ids > $A/${TA
 # round 6: the row-split kernel of the rounded-bf16 mode against mlp_ws_kernel<SP = 1> (parity + time, every row format), sender locality
 timeout 300 python scripts/rs1_check.py 2>&1 | grep -v amdgpu.ids > $A/${TAG}_rs1_check.log
 timeout 200 python scripts/rs1_gather_locality.py 2>&1 | grep -v amdgpu.ids > $A/${TAG}_rs1_gather_locality.log
+timeout 300 python scripts/rs2_check.py 2>&1 | grep -v amdgpu.ids > $A/${TAG}_rs2_check.log
 # co-issue microbenchmarks (what hides behind one MFMA, by shape, waves per SIMD and instruction kind)
 hipcc -w --offload-arch=gfx950 -O3 -o /tmp/mfma_fillers scripts/micro/mfma_fillers.hip 2>/dev/null && /tmp/mfma_fillers > $A/${TAG}_mfma_fillers.log 2>&1
 for m in mfma_gap_patterns mfma_chain_probe mfma_lds_probe; do

@@ -1844,7 +1844,7 @@ def test_row_split_update_kernel_matches_the_tile_kernel():
                                 else:
                                     y, hs = blk.node_mlp.run_coded(src, n, _lib.ACT_SELU, out=out), []
                             k = int(lib.g4c_mlp_last_kernel())
-                            assert (k == _lib.KERNEL_MLP_RS) == on, (k, on)
+                            assert (k == _lib.KERNEL_MLP_RS2) == on, (k, on)
                             if on:
                                 assert isinstance(y, ops.RsOrderedRows) == out16 and all(isinstance(h, ops.RsOrderedRows) for h in hs)
                             res[on] = (nat(y).float().clone(), [nat(h).float().clone() for h in hs])
