@@ -586,9 +586,20 @@ def partition_check(args, runner, model, graph_cpu, dev, rank, world, Rollout):
         single = Rollout(model, graph_cpu.clone().to(dev), 2, capture=False)
         single.run(2)
         torch.cuda.synchronize(dev)
-        diff = (full[:, : 2 * nf] - single.result()[:, : 2 * nf]).abs().max().item()
+        dev_abs = (full[:, : 2 * nf] - single.result()[:, : 2 * nf]).abs()
+        diff = dev_abs.max().item()
         out["max_abs_diff_vs_single_rank"] = diff
-        out["ok"] = bool(diff <= out["tol"])
+        if args.precision == "bf16":
+            # rounded-bf16 mode (config 3): which kernel takes a launch depends on its row count (the row-split kernels from 20k rows),
+            # so a sub-mesh and the whole mesh sum in different orders and round different hidden activations to the neighbouring bf16 —
+            # the two results agree to the mode's noise floor (the one its oracle test bounds: tests/test_gpu_parity.py
+            # test_remus_20k_vs_oracle), not to fp32 round-off
+            p999 = dev_abs.flatten().kthvalue(max(1, int(0.999 * dev_abs.numel()))).values.item()
+            out.update({"tol": None, "criterion": "rounded-bf16 mode: mean < 1e-2, 99.9th percentile < 3e-2, max < 1e-1",
+                        "mean_abs_diff_vs_single_rank": dev_abs.mean().item(), "p999_abs_diff_vs_single_rank": p999})
+            out["ok"] = bool(dev_abs.mean().item() < 1e-2 and p999 < 3e-2 and diff < 1e-1)
+        else:
+            out["ok"] = bool(diff <= out["tol"])
         single.close()
         del single
     ok = torch.tensor([1 if out.get("ok", True) else 0], dtype=torch.int32, device=dev)
