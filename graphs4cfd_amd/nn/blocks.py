@@ -973,9 +973,9 @@ class DownEdgeMP(nn.Module):
         code = _lib.act_code(activation)
         if next_msg is None or code is None:
             e2_new, _ = _mp_step(self.angle_mlp, self.edge_mlp, e2, a12, angle_index12, "mean",
-                                 _lib.ACT_NONE if code is None else code, v_src=e1)
+                                 _lib.ACT_NONE if code is None else code, v_src=e1, keep_e=False)          # (a12' is read by nobody)
             return _finish(e2_new, activation, code), None
-        e2_new, _, prods = _mp_step(self.angle_mlp, self.edge_mlp, e2, a12, angle_index12, "mean", code, v_src=e1,
+        e2_new, _, prods = _mp_step(self.angle_mlp, self.edge_mlp, e2, a12, angle_index12, "mean", code, v_src=e1, keep_e=False,
                                     next_msg=next_msg, next_graph=next_graph, compact_v=True)      # (e2' is read by that EdgeMP only)
         return e2_new, prods
 

@@ -25,6 +25,9 @@ SELU, NONE = _lib.ACT_SELU, _lib.ACT_NONE
 # come out of that producer's own launch as two heads, like the products between consecutive EdgeMPs — instead of two product launches
 # per entry (config 3: 10 launches, 0.49 ms of an 8.3 ms step).
 ENTRY_PRODUCTS = __import__("os").environ.get("G4C_ENTRY_PRODUCTS", "1") != "0"
+# Round 6, rounded-bf16 mode: the (static) angle latents of a DownEdgeMP regrouped by receiver once, so that its angle launch runs on the
+# row-split kernel with the aggregation fused and no rows stored, instead of mlp_ws_kernel + a segment_reduce over the stored rows.
+GROUP_DOWN_ANGLES = __import__("os").environ.get("G4C_GROUP_DOWN_ANGLES", "1") != "0"
 
 
 class NsRotEquiTreeScaleGNN(GNN):
@@ -89,6 +92,17 @@ class NsRotEquiTreeScaleGNN(GNN):
         return ops.static_launch(name + "/rs16", [att], lambda: ops.RsOrderedRows.tag(
             a.to(torch.bfloat16)[:, ops._rs_k_order(a.device)].contiguous()))
 
+    def _grouped_static_angles(self, name: str, att: torch.Tensor, a: torch.Tensor, index: torch.Tensor, n_targets: int, block):
+        """(angle latents, angle index) of a DownEdgeMP with the angles grouped by receiver, when that makes its angle launch one the
+        row-split kernel takes (uniform in-degree, rounded-bf16 mode, MLP.rs1_ready); unchanged otherwise.  The latents are static: inside a
+        rollout the regrouped copy is cached with them."""
+        if not GROUP_DOWN_ANGLES or ops.grad_mode() or ops.mlp_precision() != "bf16":
+            return a, index
+        grouped, perm = plan.grouped_by_target(index, n_targets)
+        if perm is None or not block.angle_mlp.rs1_ready(int(a.size(0)), plan.edge_csr(grouped, n_targets)[1]):
+            return a, index
+        return ops.static_launch(name + "/grouped", [att], lambda: a.index_select(0, perm)), grouped
+
     def _entry_of(self, prog, k: int, lvl: int, aidx, e):
         """(angle MLP, (angle rows, receiver CSR)) of the EdgeMP that follows program step k on level `lvl` — whose hoisted first-layer
         products the inter-level block at step k can emit with its own edge launch — or (None, None)."""
@@ -131,6 +145,10 @@ class NsRotEquiTreeScaleGNN(GNN):
             a[lvl] = self._compact_static_angles(lvl, f"angle_encoder{s}", getattr(g, f"angle_attr{s}"), a[lvl], aidx[lvl], ep.n_edges)
         a12 = self._angle_latents("angle_encoder12", g.angle_attr12)
         a23 = self._angle_latents("angle_encoder23", g.angle_attr23)
+        # (the inter-level angles come in no receiver order; where the DownEdgeMP's angle launch can run on the row-split kernel their
+        # — static — latents and the index are regrouped by receiver once: the launch then reduces its own rows and stores none)
+        a12, idx12 = self._grouped_static_angles("angle_encoder12", g.angle_attr12, a12, g.angle_index12, int(e[2].size(0)), self.down_mp12)
+        a23, idx23 = self._grouped_static_angles("angle_encoder23", g.angle_attr23, a23, g.angle_index23, int(e[3].size(0)), self.down_mp23)
         a_pending = {1: NONE, 2: NONE, 3: NONE}
         products = {1: entry_products, 2: None, 3: None}   # first-layer edge-side terms of the next EdgeMP of a level, if already made
         prog = self._PROGRAM
@@ -152,7 +170,7 @@ class NsRotEquiTreeScaleGNN(GNN):
                     products[lvl] = None
                 a_pending[lvl] = _blocks.pending_act(a[lvl])       # (SELU; none when the rows came back compact and activated)
             elif op == "down":
-                a_x, idx_x = (a12, g.angle_index12) if lvl == 1 else (a23, g.angle_index23)
+                a_x, idx_x = (a12, idx12) if lvl == 1 else (a23, idx23)
                 e[lvl + 1], products[lvl + 1] = block.step(e[lvl], e[lvl + 1], a_x, idx_x, "selu", *self._entry_of(prog, k, lvl + 1, aidx, e))
             else:
                 lo, hi = lvl, lvl - 1

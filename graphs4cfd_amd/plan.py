@@ -241,6 +241,22 @@ def edge_csr(edge_index: torch.Tensor, n_targets: int) -> Tuple[EdgePlan, CsrPla
     return plan, csr
 
 
+def grouped_by_target(edge_index: torch.Tensor, n_targets: int) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """(edge_index with its columns stably grouped by target, the int64 permutation that does it) — cached like the plans, so that
+    the grouped tensor has a stable identity of its own (its EdgePlan / CsrPlan are built once).  (edge_index, None) when the columns
+    are grouped already.  For launches that want their rows in receiver order (the row-split kernels' fused aggregation) where the
+    caller can reorder the row tensor once: REMuS-GNN's static inter-level angle latents (DownEdgeMP)."""
+    _, csr = edge_csr(edge_index, n_targets)
+    if csr.perm is None:
+        return edge_index, None
+    key = _Cache.key(edge_index) + (("grouped", n_targets),)
+    out = _index_plans.get(key)
+    if out is None:
+        perm = csr.perm.to(torch.int64)
+        out = _index_plans.put(key, (edge_index,), (edge_index.index_select(1, perm).contiguous(), perm))
+    return out
+
+
 def index32(index: torch.Tensor) -> torch.Tensor:
     """Cached int32 copy of an int64 gather index (idx{h}_to_idx{l}, x_idx, col, ...)."""
     if index.dtype == torch.int32:

@@ -1949,6 +1949,34 @@ def test_remus_compact_edge_latents_are_the_same_operand():
         ops.set_mlp_precision(old)
 
 
+def test_remus_down_angles_grouped_by_receiver():
+    """remus_gnn.GROUP_DOWN_ANGLES (round 6, rounded-bf16 mode): the static inter-level angle latents and their index regrouped by
+    receiver, so that DownEdgeMP's angle launch runs on the row-split kernel (aggregation fused, no rows stored) instead of
+    mlp_ws_kernel + segment_reduce over rows in no receiver order: the same sums in another order — the forward agrees to the mode's
+    rounding; plan.grouped_by_target is a stable grouping with an identity of its own."""
+    from graphs4cfd_amd.nn import remus_gnn as R
+    old = ops.set_mlp_precision("bf16")
+    was = R.GROUP_DOWN_ANGLES
+    try:
+        g = S.remus_graph(20_000, k=5, seed=61).to(DEV)
+        n2 = int(g.edge_index2.size(1))
+        grouped, perm = plan.grouped_by_target(g.angle_index12, n2)
+        assert perm is not None and torch.equal(grouped, g.angle_index12[:, perm]) and bool((grouped[1][1:] >= grouped[1][:-1]).all())
+        assert plan.grouped_by_target(g.angle_index12, n2)[0] is grouped and plan.edge_csr(grouped, n2)[1].perm is None
+        torch.manual_seed(62)
+        model = gfd.nn.NsRotEquiTreeScaleGNN(arch=S.remus_arch(128), device=DEV)
+        outs = {}
+        for on in (False, True):
+            R.GROUP_DOWN_ANGLES = on
+            with torch.no_grad():
+                outs[on] = model.forward(g.clone()).clone()
+        d = (outs[True] - outs[False]).abs()
+        assert torch.isfinite(outs[True]).all() and d.mean().item() < 1e-2 and d.max().item() < 1e-1, (d.mean().item(), d.max().item())      # (two results of the mode: its noise floor)
+    finally:
+        R.GROUP_DOWN_ANGLES = was
+        ops.set_mlp_precision(old)
+
+
 def test_bf16_product_rows_are_exact_copies():
     """Rounded-bf16 mode, round 5 (blocks.PRODUCTS_BF16): the hoisted first-layer products are stored as bf16.  The kernels only
     change representation — (a) head rows / plain output rows stored as bf16 are the round-to-nearest bf16 of the fp32 rows the same
