@@ -354,7 +354,7 @@ class MLP(nn.Module):
 
     # -- first-layer hoisting ------------------------------------------------------------------
     def _packed_cols(self, tag: str, a: int, b: int, seg_widths, seg_negate, first_only: bool, rs_order: bool = False,
-                     rs_rows: bool = False) -> ops.PackedMLP:
+                     rs_rows: bool = False, rs_in: bool = False) -> ops.PackedMLP:
         """Packed variant using only columns [a, b) of the first Linear layer (`first_only`: that layer alone, no bias).
         `rs_order`: the stream of the row-split kernel (ops.PackedMLP); `rs_rows` (with `first_only`): the product's output columns in that
         kernel's order (ops.RsOrderedRows) — the weight's rows permuted."""
@@ -368,7 +368,9 @@ class MLP(nn.Module):
             if rs_rows:
                 w1 = w1[ops._rs_k_order(w1.device)].contiguous()
             if first_only:
-                pk = ops.PackedMLP([w1], [None], None, key[3], key[4], precision=prec, site=self._site)
+                # (`rs_in`: the one input block arrives as ops.RsOrderedRows — its weight columns are packed in that order)
+                pk = ops.PackedMLP([w1], [None], None, key[3], key[4], precision=prec, site=self._site,
+                                   rs_blocks=[True] if (rs_in and prec == "bf16") else None)
             else:
                 ln = getattr(self.MLP, "layer_norm", None)
                 pk = ops.PackedMLP([w1] + [l.weight for l in lin[1:]], [l.bias for l in lin],
@@ -505,7 +507,9 @@ class MLP(nn.Module):
             if products is not None:
                 part = products[j]
             else:        # this block's product W1[:, 128 (j + 1) : 128 (j + 2)] t, bf16 rows in the kernel's column order
-                pk1 = self._packed_cols("hoist1_rs", 128 * (j + 1), 128 * (j + 2), [128], [False], True, rs_rows=True)
+                tagged = isinstance(t, ops.RsOrderedRows)
+                pk1 = self._packed_cols("hoist1_rs" + ("/rs_in" if tagged else ""), 128 * (j + 1), 128 * (j + 2), [128], [False], True,
+                                        rs_rows=True, rs_in=tagged)
                 part = torch.empty((int(t.size(0)), 128), dtype=torch.bfloat16, device=t.device)
                 ops.mlp_forward(pk1, [Source(t)], int(t.size(0)), out=part)
                 part = ops.RsOrderedRows.tag(part)

@@ -28,6 +28,9 @@ ENTRY_PRODUCTS = __import__("os").environ.get("G4C_ENTRY_PRODUCTS", "1") != "0"
 # Round 6, rounded-bf16 mode: the (static) angle latents of a DownEdgeMP regrouped by receiver once, so that its angle launch runs on the
 # row-split kernel with the aggregation fused and no rows stored, instead of mlp_ws_kernel + a segment_reduce over the stored rows.
 GROUP_DOWN_ANGLES = __import__("os").environ.get("G4C_GROUP_DOWN_ANGLES", "1") != "0"
+# ... and the edge latents a run of EdgeMPs leaves behind are stored compact too (blocks.COMPACT_LATENTS) where only MLP launches read them
+# until the level's next run (a DownEdgeMP from the level, an UpEdgeMP into it, the decoder) — not where an UpEdgeMP projects them in fp32.
+LAST_COMPACT = __import__("os").environ.get("G4C_LAST_COMPACT", "1") != "0"
 
 
 class NsRotEquiTreeScaleGNN(GNN):
@@ -103,6 +106,21 @@ class NsRotEquiTreeScaleGNN(GNN):
             return a, index
         return ops.static_launch(name + "/grouped", [att], lambda: a.index_select(0, perm)), grouped
 
+    @staticmethod
+    def _mlp_readers_only(prog, k: int, lvl: int) -> bool:
+        """Whether the edge latents of level `lvl` produced at program step k are read, until the level's next EdgeMP replaces them, by
+        nothing but MLP launches (as an input block or through hoisted products): a DownEdgeMP from this level, an UpEdgeMP INTO this
+        level (its skip input), the decoder.  An UpEdgeMP FROM this level projects them with fp32 arithmetic (edgeScalarToNodeVector):
+        not compact then.  (blocks._mp_step compact_v: such latents may be stored as the bf16 rows their readers round them to.)"""
+        if not LAST_COMPACT:
+            return False
+        for o, _, l in prog[k + 1:]:
+            if o == "mp" and l == lvl:
+                return True
+            if o == "up" and l == lvl:          # (op level = the coarse side: this level is being projected)
+                return False
+        return True
+
     def _entry_of(self, prog, k: int, lvl: int, aidx, e):
         """(angle MLP, (angle rows, receiver CSR)) of the EdgeMP that follows program step k on level `lvl` — whose hoisted first-layer
         products the inter-level block at step k can emit with its own edge launch — or (None, None)."""
@@ -166,7 +184,7 @@ class NsRotEquiTreeScaleGNN(GNN):
                     # then, when the launch can reduce its own rows (_mp_step keep_e)
                     last_use = not any(o == "mp" and l == lvl for o, _, l in prog[k + 1:])
                     e[lvl], a[lvl] = block.step(e[lvl], a[lvl], aidx[lvl], SELU, a_pre_act=a_pending[lvl], products=products[lvl],
-                                                keep_e=not last_use)
+                                                keep_e=not last_use, compact_e=self._mlp_readers_only(prog, k, lvl))
                     products[lvl] = None
                 a_pending[lvl] = _blocks.pending_act(a[lvl])       # (SELU; none when the rows came back compact and activated)
             elif op == "down":
