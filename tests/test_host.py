@@ -330,3 +330,17 @@ def test_row_split_column_order_is_the_mfma_lane_order():
     assert type(back) is torch.Tensor and torch.equal(back, rows)
     with pytest.raises(ValueError):
         ops.RsOrderedRows.tag(rows.float())
+
+
+def test_remus_program_knows_which_run_outputs_only_mlps_read():
+    """remus_gnn._mlp_readers_only: the edge latents a run of EdgeMPs leaves behind may be stored as the bf16 rows their readers round
+    them to (rounded-bf16 mode) exactly where no UpEdgeMP projects them with fp32 arithmetic (edgeScalarToNodeVector, nn/blocks.py:420-430)
+    before the level's next run replaces them."""
+    from graphs4cfd_amd.nn.remus_gnn import NsRotEquiTreeScaleGNN as M
+    prog = M._PROGRAM
+    at = {name: k for k, (_, name, _) in enumerate(prog)}
+    lvl = {name: l for _, name, l in prog}
+    got = {name: M._mlp_readers_only(prog, at[name], lvl[name]) for name in ("mp114", "mp212", "mp34", "mp222", "mp124")}
+    # mp114 -> down_mp12 (products) and up_mp21 (skip input); mp212 -> down_mp23, up_mp32 (skip); mp124 -> decoder: MLP operands only.
+    # mp34 -> up_mp32 and mp222 -> up_mp21 project the latents of the coarse side: fp32 readers.
+    assert got == {"mp114": True, "mp212": True, "mp34": False, "mp222": False, "mp124": True}, got
