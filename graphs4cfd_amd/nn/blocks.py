@@ -766,7 +766,7 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
         e_new = msg_mlp.run_hoisted([e_src], [(senders, ep.row), (v, ep.col)], ep.n_edges,
                                     products=products, agg=(csr, agg, mean))
         agg_src = Source(agg)
-    v16 = (compact_v and COMPACT_LATENTS and ops.mlp_precision() == "bf16" and upd_mlp.output_size == 128 and upd_mlp.fits_one_launch()
+    v16 = (compact_v and COMPACT_LATENTS and PRODUCTS_BF16 and HOIST_BF16 and ops.mlp_precision() == "bf16" and upd_mlp.output_size == 128 and upd_mlp.fits_one_launch()
            and n_targets is None and v_out is None and not ops.grad_mode() and ops.effective_precision([128, int(v.size(1))]) == "bf16")
     if next_msg is not None:
         nxt = None
@@ -787,7 +787,7 @@ def _mp_step(msg_mlp: MLP, upd_mlp: MLP, v: Tensor, e: Tensor, index: Tensor, ag
 
 def compact_latents_now(width: int = 128) -> bool:
     """Whether a launch whose output rows are read by nothing but the next update MLP may store them as bf16 (COMPACT_LATENTS)."""
-    return bool(COMPACT_LATENTS and ops.mlp_precision() == "bf16" and width == 128 and not ops.grad_mode()
+    return bool(COMPACT_LATENTS and PRODUCTS_BF16 and HOIST_BF16 and ops.mlp_precision() == "bf16" and width == 128 and not ops.grad_mode()
                 and ops.effective_precision([128, 128]) == "bf16")
 
 

@@ -951,6 +951,8 @@ def mlp_forward(packed: PackedMLP, sources: Sequence[Source], n_rows: int, act: 
                                                                               _ld(out), 1 if out.dtype == torch.bfloat16 else 0, act, packed.head_w,
                                                                               len(head_outs), ho, _ld(head_outs[0]), 1, _lib.stream_handle(dev)))
             else:
+                if out is not None and out.dtype != torch.float32:
+                    raise TypeError("heads stored as fp32 need fp32 output rows (bf16 rows: bf16 heads, g4c_mlp_forward_heads_bf16_rows)")
                 heads_fn = lib.g4c_mlp_forward_heads_bf16 if packed.precision == "bf16" else lib.g4c_mlp_forward_heads_bx6
                 call = lambda: _lib.check(heads_fn(C.byref(packed.desc), arr, len(sources), n_rows, _lib.ptr(out),
                                                    _ld(out), act, packed.head_w, len(head_outs), ho,

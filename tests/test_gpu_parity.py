@@ -1977,6 +1977,33 @@ def test_remus_down_angles_grouped_by_receiver():
         ops.set_mlp_precision(old)
 
 
+def test_remus_bf16_mode_switches_one_at_a_time():
+    """Every switch of the rounded-bf16 mode's REMuS path turned off alone (the combinations a user can reach through the module
+    attributes / G4C_* environment variables): the forward runs, and agrees with the default path to the mode's noise floor."""
+    from graphs4cfd_amd.nn import remus_gnn as R
+    old = ops.set_mlp_precision("bf16")
+    switches = [(B, "COMPACT_MESSAGES"), (B, "HOIST_BF16"), (B, "PRODUCTS_BF16"), (B, "ROW_SPLIT_BF16"), (B, "AGGREGATE_BF16"),
+                (B, "COMPACT_LATENTS"), (B, "UPDATE_ROW_SPLIT"), (R, "ENTRY_PRODUCTS"), (R, "GROUP_DOWN_ANGLES"), (R, "LAST_COMPACT")]
+    try:
+        g = S.remus_graph(20_000, k=5, seed=81).to(DEV)
+        torch.manual_seed(82)
+        model = gfd.nn.NsRotEquiTreeScaleGNN(arch=S.remus_arch(128), device=DEV)
+        with torch.no_grad():
+            ref = model.forward(g.clone()).clone()
+        for mod, name in switches:
+            was = getattr(mod, name)
+            setattr(mod, name, False)
+            try:
+                with torch.no_grad():
+                    y = model.forward(g.clone())
+                d = (y - ref).abs()
+                assert torch.isfinite(y).all() and d.mean().item() < 1e-2 and d.max().item() < 1e-1, (name, d.mean().item(), d.max().item())
+            finally:
+                setattr(mod, name, was)
+    finally:
+        ops.set_mlp_precision(old)
+
+
 def test_bf16_product_rows_are_exact_copies():
     """Rounded-bf16 mode, round 5 (blocks.PRODUCTS_BF16): the hoisted first-layer products are stored as bf16.  The kernels only
     change representation — (a) head rows / plain output rows stored as bf16 are the round-to-nearest bf16 of the fp32 rows the same
